@@ -1,0 +1,204 @@
+/*
+ * kraken_amd.h -- C ABI of the MI355X (gfx950) line-recognition hot path.
+ *
+ * The reference (mittagessen/kraken) is 100 % Python and has no FFI: its
+ * arithmetic is delegated to torch.nn modules.  This header is therefore the
+ * boundary a kraken maintainer would bind (ctypes stub in INTEGRATION.md) to
+ * replace exactly these reference call sites (paths relative to the
+ * reference root):
+ *
+ *   krk_plan_create   <- TorchVGSLModel._parse / build_* (kraken/lib/vgsl/model.py:202-243,
+ *                        570-817): the parsed layer list + state-dict tensors
+ *   krk_plan_olens    <- per-layer seq_len arithmetic (kraken/lib/vgsl/layers.py:387,
+ *                        858-859, 334)
+ *   krk_forward       <- MultiParamSequential.forward, i.e. `nn(x, seq_lens)`
+ *                        (kraken/lib/vgsl/layers.py:44-53; model.py:488-489)
+ *   krk_greedy_decode <- greedy_decoder (kraken/lib/ctc_decoder.py:35-72), optionally
+ *                        fused with `(logits / T).softmax(1)`
+ *                        (kraken/lib/vgsl/rpred.py:226, kraken/lib/models.py:115)
+ *   krk_recognize     <- VGSLRecognitionInference._rec_predict up to the label tuples
+ *                        (kraken/lib/vgsl/rpred.py:210-229)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross the boundary;
+ *   - every entry point returns KRK_OK (0) or a negative error code and never
+ *     throws; krk_last_error() returns a thread-local message for the last failure;
+ *   - `*_dev` pointers are HIP device pointers owned by the caller, `*_host`
+ *     pointers are host memory owned by the caller;
+ *   - all device work is enqueued on the caller's `stream` (a hipStream_t passed as
+ *     void*); no entry point synchronises the device except where stated;
+ *   - a plan is bound to one device and may be used from one stream at a time;
+ *     different plans are independent.
+ *
+ * Semantics: masked-padding.  A batch is right-padded to a common width W; per
+ * line only the first lens[n] columns are valid.  After every layer activations at
+ * positions >= that line's propagated valid width are zero, GroupNorm statistics
+ * cover the valid width only, and the LSTM is packed by length -- which reproduces
+ * the reference's per-line (batch = 1, lens = None) result for every line of a
+ * ragged batch (SURVEY.md section 8a note) and equals the reference's batched
+ * result when all lines have the same width.
+ */
+#ifndef KRAKEN_AMD_H
+#define KRAKEN_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KRK_ABI_VERSION 1
+
+/* error codes */
+#define KRK_OK            0
+#define KRK_E_INVALID    -1   /* bad argument / unsupported layer configuration */
+#define KRK_E_HIP        -2   /* a HIP runtime call failed */
+#define KRK_E_NOMEM      -3
+#define KRK_E_UNSUPPORTED -4  /* valid VGSL, but not implemented by the HIP executor */
+
+/* layer kinds (one per reference layer wrapper in kraken/lib/vgsl/layers.py) */
+#define KRK_OP_CONV       1   /* ActConv2D  layers.py:785  */
+#define KRK_OP_MAXPOOL    2   /* MaxPool    layers.py:367  */
+#define KRK_OP_GROUPNORM  3   /* GroupNorm  layers.py:955  */
+#define KRK_OP_RESHAPE_HC 4   /* Reshape S1(1x0)1,3: fold height into channels, layers.py:285 */
+#define KRK_OP_LSTM       5   /* TransposedSummarizingRNN (L{f,r,b}x) layers.py:462 */
+#define KRK_OP_LINEAR     6   /* LinSoftmax (logits, no softmax) layers.py:679 */
+
+/* activations of ActConv2D (layers.py:808-825).  'sigmoid' is skipped in the
+ * reference's forward (layers.py:850-852) and is therefore identical to LINEAR. */
+#define KRK_ACT_LINEAR    0
+#define KRK_ACT_RELU      1
+#define KRK_ACT_TANH      2
+#define KRK_ACT_LEAKY     3   /* torch.nn.LeakyReLU() default slope 0.01 */
+#define KRK_ACT_SIGMOID   4   /* == LINEAR in forward */
+
+/* LSTM directions */
+#define KRK_DIR_FWD       0
+#define KRK_DIR_REV       1
+#define KRK_DIR_BIDI      2
+
+/* arithmetic modes */
+#define KRK_PREC_F32      0   /* exact f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4) */
+#define KRK_PREC_BF16     1   /* bf16 operands, f32 accumulate */
+
+typedef struct krk_plan krk_plan;
+
+/*
+ * One VGSL layer.  Weight pointers are HOST pointers to contiguous f32 arrays in
+ * the layout of the reference's state dict; they are only
+ * read during krk_plan_create (packed into MFMA fragment order and uploaded).
+ *
+ *  CONV      cout=filters, kh,kw,sh,sw,dh,dw, act;  w[0]=co.weight (cout,cin,kh,kw), w[1]=co.bias (cout)
+ *            padding is the reference's ((dh*(kh-1))/2, (dw*(kw-1))/2)   (layers.py:803)
+ *  MAXPOOL   kh,kw,sh,sw (no padding, floor)
+ *  GROUPNORM cout=num_groups; w[0]=layer.weight (C), w[1]=layer.bias (C); eps 1e-5
+ *  RESHAPE_HC no parameters: (N,C,H,W) -> (N,H*C,1,W), feature index h*C + c
+ *  LSTM      cout=hidden, direction; per direction d (0 = forward / the only one, 1 = reverse):
+ *            w[4d+0]=weight_ih (4H,In)  w[4d+1]=weight_hh (4H,H)  w[4d+2]=bias_ih (4H)  w[4d+3]=bias_hh (4H)
+ *            gate row order i,f,g,o (torch.nn.LSTM)
+ *  LINEAR    cout=out features; w[0]=lin.weight (cout,In), w[1]=lin.bias (cout)
+ */
+typedef struct krk_layer {
+    int op;
+    int cout;
+    int kh, kw, sh, sw, dh, dw;
+    int act;
+    int direction;
+    const float* w[8];
+} krk_layer;
+
+/* Result buffers of the greedy decode, all caller-owned DEVICE memory.
+ * Per line n the kernel writes counts[n] tuples into the first counts[n] slots of
+ * row n of labels/starts/ends/confs (row stride = t_stride elements):
+ * (label, first timestep, last timestep INCLUSIVE, max confidence in the run),
+ * exactly the tuples of greedy_decoder (ctc_decoder.py:66-71). */
+typedef struct krk_decode_out {
+    int*   labels;    /* [N][t_stride] */
+    int*   starts;    /* [N][t_stride] */
+    int*   ends;      /* [N][t_stride] */
+    float* confs;     /* [N][t_stride] */
+    int*   counts;    /* [N]           */
+    int    t_stride;  /* >= T          */
+} krk_decode_out;
+
+int         krk_abi_version(void);
+const char* krk_last_error(void);
+
+/* number of visible HIP devices (0 if none); never fails */
+int krk_device_count(void);
+
+/*
+ * Builds an execution plan for `n_layers` layers applied to an input of
+ * `in_channels` x `in_height` x (variable width).  Dropout/Identity layers are
+ * elided by the caller.  `precision` is KRK_PREC_*.  Synchronises the device once
+ * (weight upload).
+ */
+int krk_plan_create(const krk_layer* layers, int n_layers,
+                    int in_channels, int in_height,
+                    int precision, int device, krk_plan** out);
+void krk_plan_destroy(krk_plan* plan);
+
+/* Output geometry for an input batch of width W: channels, height, width of the
+ * final layer's (N, C, H, W') output.  For a recogniser H == 1. */
+int krk_plan_out_shape(const krk_plan* plan, int W, int* C, int* H, int* Wout);
+
+/* Host-side length propagation: olens_host[n] = valid output width of line n. */
+int krk_plan_olens(const krk_plan* plan, const int* lens_host, int N, int* olens_host);
+
+/*
+ * nn(x, lens): x_dev is (N, in_channels, in_height, W) f32 NCHW, right-padded;
+ * lens_host[n] in [1, W] or NULL (all lines W wide).
+ * out_dev receives the final activations:
+ *   - final layer LINEAR/LSTM/RESHAPE_HC (sequence output): time-major
+ *     [N][T][C] f32 (the (N,C,1,T) tensor of the reference is the permuted view);
+ *   - otherwise NCHW (N, C, H', W').
+ */
+int krk_forward(krk_plan* plan, const float* x_dev, const int* lens_host,
+                int N, int W, void* stream, float* out_dev);
+
+/*
+ * CTC best-path decode of a score tensor with element strides (sn, sc, st), i.e.
+ * score(n,c,t) = scores_dev[n*sn + c*sc + t*st], N lines, C classes, T steps,
+ * valid steps olens_host[n] (NULL: T).
+ *   softmax == 0: confidences are the raw maxima of the input (what greedy_decoder
+ *                 does with whatever it is given -- probabilities or logits);
+ *   softmax == 1: the input are logits; confidences are max softmax(logits / temperature)
+ *                 and ties are resolved on the probabilities like the reference.
+ * If probs_dev != NULL (softmax == 1 only) the full softmax is also written there with
+ * the same strides.  Argmax ties resolve to the lowest class index.
+ */
+int krk_greedy_decode(const float* scores_dev, long sn, long sc, long st,
+                      int N, int C, int T, const int* olens_host,
+                      int softmax, float temperature, float* probs_dev,
+                      void* stream, const krk_decode_out* out);
+
+/*
+ * Fused nn(x, lens) -> softmax(logits / temperature) -> greedy decode for a plan
+ * that ends in a LINEAR layer.  logits_dev ([N][T][C]) may be NULL if the caller
+ * does not need the logits; probs_dev likewise.  olens_host (may be NULL) receives
+ * the valid output widths.
+ */
+int krk_recognize(krk_plan* plan, const float* x_dev, const int* lens_host,
+                  int N, int W, float temperature, void* stream,
+                  float* logits_dev, float* probs_dev, int* olens_host,
+                  const krk_decode_out* out);
+
+/* Bytes of device workspace currently held by the plan (diagnostics). */
+long krk_plan_workspace_bytes(const krk_plan* plan);
+
+/*
+ * Per-kernel-group timing of the last krk_forward/krk_recognize call when profiling is
+ * enabled on the plan (krk_plan_set_profiling(plan, 1)).  Profiling records hipEvents
+ * around each layer on the caller's stream; krk_plan_layer_ms synchronises those events.
+ * Returns the number of layers written (<= cap).
+ */
+int krk_plan_set_profiling(krk_plan* plan, int enable);
+int krk_plan_layer_ms(krk_plan* plan, float* ms_host, int cap);
+/* short static name of layer i's kernel group ("conv", "lstm_xproj", ...) or NULL */
+const char* krk_plan_layer_name(const krk_plan* plan, int i);
+/* algorithmic FLOPs of layer i for the last call's shapes (2 * MACs over valid+padded extent) */
+double krk_plan_layer_flops(const krk_plan* plan, int i);
+int krk_plan_num_steps(const krk_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KRAKEN_AMD_H */

@@ -1,0 +1,118 @@
+"""
+ctypes binding of ``libkraken_amd.so`` (C ABI declared in ``include/kraken_amd.h``).
+
+There is deliberately NO fallback: if the shared library is missing or a HIP
+device is absent, the product path raises.  Only ``oracle/`` (test
+infrastructure) computes this path on a CPU.
+"""
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libkraken_amd.so')
+
+KRK_OK = 0
+KRK_E_INVALID, KRK_E_HIP, KRK_E_NOMEM, KRK_E_UNSUPPORTED = -1, -2, -3, -4
+
+OP_CONV, OP_MAXPOOL, OP_GROUPNORM, OP_RESHAPE_HC, OP_LSTM, OP_LINEAR = 1, 2, 3, 4, 5, 6
+ACT_LINEAR, ACT_RELU, ACT_TANH, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3, 4
+DIR_FWD, DIR_REV, DIR_BIDI = 0, 1, 2
+PREC_F32, PREC_BF16 = 0, 1
+
+# every symbol include/kraken_amd.h declares (checked by the CPU test-suite)
+EXPORTS = ['krk_abi_version', 'krk_last_error', 'krk_device_count', 'krk_plan_create', 'krk_plan_destroy',
+           'krk_plan_out_shape', 'krk_plan_olens', 'krk_forward', 'krk_greedy_decode', 'krk_recognize',
+           'krk_plan_workspace_bytes', 'krk_plan_set_profiling', 'krk_plan_layer_ms', 'krk_plan_layer_name',
+           'krk_plan_layer_flops', 'krk_plan_num_steps']
+
+
+class KrkLayer(C.Structure):
+    _fields_ = [('op', C.c_int), ('cout', C.c_int),
+                ('kh', C.c_int), ('kw', C.c_int), ('sh', C.c_int), ('sw', C.c_int), ('dh', C.c_int), ('dw', C.c_int),
+                ('act', C.c_int), ('direction', C.c_int),
+                ('w', C.c_void_p * 8)]
+
+
+class KrkDecodeOut(C.Structure):
+    _fields_ = [('labels', C.c_void_p), ('starts', C.c_void_p), ('ends', C.c_void_p), ('confs', C.c_void_p),
+                ('counts', C.c_void_p), ('t_stride', C.c_int)]
+
+
+class KrakenAmdError(RuntimeError):
+    """Raised when an entry point of libkraken_amd.so reports a failure."""
+
+    def __init__(self, code, msg):
+        super().__init__(f'libkraken_amd error {code}: {msg}')
+        self.code = code
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Loads the shared library (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f'{LIB_PATH} is missing: build the HIP extension first '
+                              '(python -m kraken_amd.build, or __graft_entry__.build()). '
+                              'kraken_amd has no CPU fallback.')
+        lib = C.CDLL(LIB_PATH)
+        vp, i32, f32, lng = C.c_void_p, C.c_int, C.c_float, C.c_long
+        lib.krk_abi_version.restype = i32
+        lib.krk_last_error.restype = C.c_char_p
+        lib.krk_device_count.restype = i32
+        lib.krk_plan_create.argtypes = [C.POINTER(KrkLayer), i32, i32, i32, i32, i32, C.POINTER(vp)]
+        lib.krk_plan_create.restype = i32
+        lib.krk_plan_destroy.argtypes = [vp]
+        lib.krk_plan_destroy.restype = None
+        lib.krk_plan_out_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        lib.krk_plan_out_shape.restype = i32
+        lib.krk_plan_olens.argtypes = [vp, vp, i32, vp]
+        lib.krk_plan_olens.restype = i32
+        lib.krk_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+        lib.krk_forward.restype = i32
+        lib.krk_greedy_decode.argtypes = [vp, lng, lng, lng, i32, i32, i32, vp, i32, f32, vp, vp,
+                                          C.POINTER(KrkDecodeOut)]
+        lib.krk_greedy_decode.restype = i32
+        lib.krk_recognize.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, C.POINTER(KrkDecodeOut)]
+        lib.krk_recognize.restype = i32
+        lib.krk_plan_workspace_bytes.argtypes = [vp]
+        lib.krk_plan_workspace_bytes.restype = lng
+        lib.krk_plan_set_profiling.argtypes = [vp, i32]
+        lib.krk_plan_set_profiling.restype = i32
+        lib.krk_plan_layer_ms.argtypes = [vp, vp, i32]
+        lib.krk_plan_layer_ms.restype = i32
+        lib.krk_plan_layer_name.argtypes = [vp, i32]
+        lib.krk_plan_layer_name.restype = C.c_char_p
+        lib.krk_plan_layer_flops.argtypes = [vp, i32]
+        lib.krk_plan_layer_flops.restype = C.c_double
+        lib.krk_plan_num_steps.argtypes = [vp]
+        lib.krk_plan_num_steps.restype = i32
+        if lib.krk_abi_version() != 1:
+            raise ImportError('libkraken_amd.so ABI version mismatch; rebuild the extension')
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != KRK_OK:
+        msg = load().krk_last_error()
+        raise KrakenAmdError(rc, msg.decode('utf-8', 'replace') if msg else '')
+
+
+def device_count() -> int:
+    return int(load().krk_device_count())
+
+
+def require_gpu():
+    """The product path needs a HIP device; fail loudly otherwise."""
+    if device_count() <= 0:
+        raise KrakenAmdError(KRK_E_HIP, 'no HIP device visible: the kraken_amd recognition path runs only on '
+                                        'MI355X-class GPUs and has no CPU fallback')

@@ -1,0 +1,68 @@
+"""
+In-tree build of the gfx950 shared library ``kraken_amd/libkraken_amd.so``.
+
+hipcc cross-compiles without a GPU, so this runs in the authoring container, on
+the GPU box and from ``__graft_entry__.build()``.  Objects are cached under
+``kraken_amd/csrc/_build`` keyed on source mtimes.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+BUILD = os.path.join(CSRC, '_build')
+LIB = os.path.join(HERE, 'libkraken_amd.so')
+SOURCES = ['conv_mfma.hip', 'lstm_rec.hip', 'misc_kernels.hip', 'capi.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'),
+           os.path.join(os.path.dirname(HERE), 'include', 'kraken_amd.h')]
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function',
+         '-fno-gpu-rdc', '-DNDEBUG']
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found; the HIP extension cannot be built')
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compiles every HIP source for gfx950 and links the C-ABI library. Returns its path."""
+    os.makedirs(BUILD, exist_ok=True)
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(BUILD, src.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or _stale(obj, [sp] + HEADERS + [os.path.abspath(__file__)]):
+            jobs.append([hipcc, *FLAGS, '-c', sp, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f'hipcc failed: {" ".join(cmd)}\n{r.stdout}\n{r.stderr}')
+        return r
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', LIB])
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

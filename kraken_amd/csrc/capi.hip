@@ -1,0 +1,812 @@
+// C ABI + plan executor of the MI355X recognition path (see include/kraken_amd.h).
+//
+// krk_plan_create plays the role of TorchVGSLModel._parse (reference
+// kraken/lib/vgsl/model.py:202-243): it turns the layer list into a fused kernel
+// schedule and repacks the state-dict tensors into MFMA fragment order.
+// krk_forward plays the role of MultiParamSequential.forward (layers.py:44-53).
+#include "common.h"
+#include "../../include/kraken_amd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(KRK_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR };
+const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear"};
+
+constexpr size_t kLdsBudget = 72 * 1024;  // two workgroups per CU inside the 160 KiB LDS
+
+// Python-style floor division (the reference does float division + floor).
+inline int floordiv(int a, int b) {
+    int q = a / b, r = a % b;
+    return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) {
+            if (hipDeviceSynchronize() != hipSuccess) return -1;
+            (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + bytes / 8;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            return -1;
+        }
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Geometry + packed weights of one implicit-GEMM (conv / projection) launch.
+struct ConvGeom {
+    int Cin = 0, H = 1, Cout = 0;
+    int kh = 1, kw = 1, sh = 1, sw = 1, dh = 1, dw = 1, ph = 0, pw = 0;
+    int act = 0;
+    bool in_seq = false, out_seq = false, pool = false;
+    int Ho = 1, Hy = 1;
+    int SR = 8, TH = 1, TW = 256, IH = 1, IW = 256, RS = 256, PS = 257;
+    int cchunk = 1, nchunks = 1, Kc = 1, KS = 1, CB = 1, CBpad = 1, otab_floats = 4;
+    float* d_w = nullptr;
+    float* d_b = nullptr;
+};
+
+int conv_out(int L, int k, int s, int d, int p) { return floordiv(L + 2 * p - d * (k - 1) - 1, s) + 1; }
+
+// Chooses the tile shape / channel chunking for a conv whose input height is known.
+void plan_conv_geom(ConvGeom& g) {
+    g.CB = (g.Cout + 31) / 32;
+    const int cbw = g.CB >= 4 ? 4 : (g.CB >= 2 ? 2 : 1);
+    g.CBpad = (g.CB + cbw - 1) / cbw * cbw;
+    if (g.in_seq) {
+        g.SR = 8;
+        g.TH = 1;
+        g.TW = 256;
+        g.IH = 1;
+        g.IW = g.TW;
+        g.RS = g.TW + 1;
+        g.PS = g.TW + 1;
+        g.Ho = g.Hy = 1;
+    } else {
+        g.Ho = conv_out(g.H, g.kh, g.sh, g.dh, g.ph);
+        g.Hy = g.pool ? floordiv(g.Ho - 2, 2) + 1 : g.Ho;
+        if (g.Ho >= 3) g.SR = 2;
+        else if (g.Ho == 2 || g.pool) g.SR = 4;
+        else g.SR = 8;
+        g.TH = 8 / g.SR;
+        g.TW = 32 * g.SR;
+        g.IH = (g.TH - 1) * g.sh + (g.kh - 1) * g.dh + 1;
+        g.IW = (g.TW - 1) * g.sw + (g.kw - 1) * g.dw + 1;
+        g.RS = g.IW;
+        g.PS = g.IH * g.IW;
+    }
+    const int kk = g.kh * g.kw;
+    // largest channel chunk whose tile (+ offset table) fits the LDS budget
+    int cmax = (int)((kLdsBudget - 64) / ((size_t)g.PS * 4 + (size_t)kk * 4));
+    cmax = std::max(1, std::min(cmax, g.Cin));
+    g.nchunks = (g.Cin + cmax - 1) / cmax;
+    g.cchunk = (g.Cin + g.nchunks - 1) / g.nchunks;
+    g.Kc = g.cchunk * kk;
+    g.KS = (g.Kc + 1) / 2;
+    g.otab_floats = (2 * g.KS + 3) / 4 * 4;
+}
+
+// wpack[chunk][ks][cb][lane] = W[cout = cb*32 + (lane&31)][k = 2*ks + (lane>>5)], k -> (c, dy, dx)
+// `rowmap` (optional) maps packed output column -> source row of `w` (or -1 for a zero column).
+int upload_conv_weights(ConvGeom& g, const float* w, const float* bias, const std::vector<int>* rowmap,
+                        const std::vector<float>* bias_override) {
+    const int kk = g.kh * g.kw;
+    std::vector<float> pack((size_t)g.nchunks * g.KS * g.CBpad * 64, 0.f);
+    for (int ci = 0; ci < g.nchunks; ++ci)
+        for (int ks = 0; ks < g.KS; ++ks)
+            for (int cb = 0; cb < g.CB; ++cb)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = cb * 32 + (lane & 31);
+                    const int k = 2 * ks + (lane >> 5);
+                    if (co >= g.Cout || k >= g.Kc) continue;
+                    const int cl = k / kk, rem = k % kk;
+                    const int c = ci * g.cchunk + cl;
+                    if (c >= g.Cin) continue;
+                    int src = co;
+                    if (rowmap) {
+                        src = (*rowmap)[co];
+                        if (src < 0) continue;
+                    }
+                    pack[(((size_t)ci * g.KS + ks) * g.CBpad + cb) * 64 + lane] =
+                        w[((size_t)src * g.Cin + c) * kk + rem];
+                }
+    std::vector<float> b((size_t)g.CBpad * 32, 0.f);
+    for (int co = 0; co < g.Cout; ++co) {
+        if (bias_override) b[co] = (*bias_override)[co];
+        else if (bias) b[co] = bias[rowmap ? std::max((*rowmap)[co], 0) : co];
+    }
+    HIPCHK(hipMalloc((void**)&g.d_w, pack.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(g.d_w, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&g.d_b, b.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(g.d_b, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
+struct Step {
+    StepKind kind = S_CONV;
+    ConvGeom cg;              // CONV / LINEAR / the LSTM input projection
+    // shape of the step's input: NCHW (C,H) or sequence (C = features, H = 1)
+    int C = 0, H = 1;
+    // MAXPOOL
+    int kh = 1, kw = 1, sh = 1, sw = 1, Ho = 1;
+    // GROUPNORM
+    int groups = 1;
+    float* d_gamma = nullptr;
+    float* d_beta = nullptr;
+    // LSTM
+    int hidden = 0, Hp = 0, ndir = 1, dirmode = 0;
+    float* d_wrec32 = nullptr;  // recurrent weights, 32x32x2 fragment order
+    float* d_wrec16 = nullptr;  // recurrent weights, 16x16x4 fragment order
+    // output description
+    bool out_is_seq = false;
+    int outC = 0, outH = 1;     // NCHW: channels,height; seq: features,1
+    int len_in = 0, len_out = 0;  // indices into the per-stage length table
+    // per-call
+    DevBuf out, aux;
+    double flops = 0.0;
+};
+
+}  // namespace
+
+struct krk_plan {
+    int device = 0;
+    int in_c = 1, in_h = 1;
+    int precision = KRK_PREC_F32;
+    std::vector<Step> steps;
+    int nstages = 1;  // length-table rows: 0 = input widths
+    // how lengths evolve: stage s+1 = f(stage s) for the steps that change the width
+    struct LenOp { int kind; int k, s, d, p; };  // kind 0: conv (clamp min 1), 1: pool
+    std::vector<LenOp> lenops;                     // lenops[i] produces stage i+1 from stage i
+    DevBuf d_lens;
+    int* h_lens_pinned = nullptr;
+    size_t h_lens_cap = 0;
+    hipEvent_t lens_ev = nullptr;
+    bool lens_ev_pending = false;
+    DevBuf d_labels, d_confs, d_final;
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    int last_N = 0, last_W = 0;
+};
+
+namespace {
+
+int width_after(const krk_plan::LenOp& op, int L) {
+    if (op.kind == 0) return std::max(conv_out(L, op.k, op.s, op.d, op.p), 1);
+    return floordiv(L - (op.k - 1) - 1, op.s) + 1;
+}
+// tensor width (not clamped: shapes follow torch's conv/pool arithmetic)
+int shape_after(const krk_plan::LenOp& op, int W) {
+    if (op.kind == 0) return conv_out(W, op.k, op.s, op.d, op.p);
+    return floordiv(W - (op.k - 1) - 1, op.s) + 1;
+}
+
+void pack_lstm_recurrent(const Step& st, const float* const* whh, int M, std::vector<float>& pack) {
+    const int H = st.hidden, Hp = st.Hp, G = 4 * Hp;
+    const int KPI = (M == 32) ? 2 : 4;
+    const int KS = Hp / KPI, NB = G / M;
+    pack.assign((size_t)st.ndir * KS * NB * 64, 0.f);
+    for (int d = 0; d < st.ndir; ++d)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int b = 0; b < NB; ++b)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int k = KPI * ks + ((M == 32) ? (lane >> 5) : (lane >> 4));
+                    const int col = b * M + (lane & (M - 1));
+                    const int u = col >> 2, gt = col & 3;
+                    if (u >= H || k >= H) continue;
+                    pack[(((size_t)d * KS + ks) * NB + b) * 64 + lane] = whh[d][((size_t)gt * H + u) * H + k];
+                }
+}
+
+int upload(float** dst, const std::vector<float>& v) {
+    HIPCHK(hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * sizeof(float)));
+    if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
+void free_step(Step& s) {
+    if (s.cg.d_w) (void)hipFree(s.cg.d_w);
+    if (s.cg.d_b) (void)hipFree(s.cg.d_b);
+    if (s.d_gamma) (void)hipFree(s.d_gamma);
+    if (s.d_beta) (void)hipFree(s.d_beta);
+    if (s.d_wrec32) (void)hipFree(s.d_wrec32);
+    if (s.d_wrec16) (void)hipFree(s.d_wrec16);
+    s.out.release();
+    s.aux.release();
+}
+
+bool monotone_act(int act) { return act >= 0 && act <= KRK_ACT_SIGMOID; }
+
+int map_act(int act) { return act == KRK_ACT_SIGMOID ? ACT_LINEAR : act; }
+
+}  // namespace
+
+extern "C" {
+
+int krk_abi_version(void) { return KRK_ABI_VERSION; }
+
+const char* krk_last_error(void) { return g_err.c_str(); }
+
+int krk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void krk_plan_destroy(krk_plan* plan) {
+    if (!plan) return;
+    (void)hipSetDevice(plan->device);
+    (void)hipDeviceSynchronize();
+    for (auto& s : plan->steps) free_step(s);
+    plan->d_lens.release();
+    plan->d_labels.release();
+    plan->d_confs.release();
+    plan->d_final.release();
+    if (plan->h_lens_pinned) (void)hipHostFree(plan->h_lens_pinned);
+    if (plan->lens_ev) (void)hipEventDestroy(plan->lens_ev);
+    for (auto e : plan->events) (void)hipEventDestroy(e);
+    delete plan;
+}
+
+int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int in_height, int precision,
+                    int device, krk_plan** out) {
+    if (!layers || n_layers <= 0 || !out) return fail(KRK_E_INVALID, "krk_plan_create: null/empty layer list");
+    if (in_channels <= 0 || in_height <= 0)
+        return fail(KRK_E_UNSUPPORTED, "krk_plan_create: input channels/height must be fixed and positive");
+    if (precision != KRK_PREC_F32)
+        return fail(KRK_E_UNSUPPORTED, "krk_plan_create: only KRK_PREC_F32 is implemented in this build");
+    if (krk_device_count() <= device)
+        return fail(KRK_E_HIP, "krk_plan_create: no HIP device " + std::to_string(device));
+    HIPCHK(hipSetDevice(device));
+
+    krk_plan* p = new krk_plan();
+    p->device = device;
+    p->in_c = in_channels;
+    p->in_h = in_height;
+    p->precision = precision;
+    auto bail = [&](int code, const std::string& msg) {
+        krk_plan_destroy(p);
+        return fail(code, msg);
+    };
+
+    bool seq = false;
+    int C = in_channels, H = in_height;
+    int stage = 0;
+    auto push_toseq = [&]() {
+        Step s;
+        s.kind = S_TOSEQ;
+        s.C = C;
+        s.H = H;
+        s.out_is_seq = true;
+        s.outC = C * H;
+        s.outH = 1;
+        s.len_in = s.len_out = stage;
+        p->steps.push_back(std::move(s));
+        seq = true;
+        C = C * H;
+        H = 1;
+    };
+
+    for (int i = 0; i < n_layers; ++i) {
+        const krk_layer& L = layers[i];
+        const std::string where = "layer " + std::to_string(i);
+        switch (L.op) {
+            case KRK_OP_CONV: {
+                if (seq) return bail(KRK_E_UNSUPPORTED, where + ": convolution after a sequence layer");
+                if (!L.w[0] || !L.w[1]) return bail(KRK_E_INVALID, where + ": conv weights missing");
+                if (L.cout <= 0 || L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0 || L.dh <= 0 || L.dw <= 0)
+                    return bail(KRK_E_INVALID, where + ": bad conv geometry");
+                if (L.act < 0 || L.act > KRK_ACT_SIGMOID) return bail(KRK_E_UNSUPPORTED, where + ": activation");
+                Step s;
+                s.kind = S_CONV;
+                s.C = C;
+                s.H = H;
+                ConvGeom& g = s.cg;
+                g.Cin = C;
+                g.H = H;
+                g.Cout = L.cout;
+                g.kh = L.kh; g.kw = L.kw; g.sh = L.sh; g.sw = L.sw; g.dh = L.dh; g.dw = L.dw;
+                g.ph = (L.dh * (L.kh - 1)) / 2;
+                g.pw = (L.dw * (L.kw - 1)) / 2;
+                g.act = map_act(L.act);
+                s.len_in = stage;
+                p->lenops.push_back({0, L.kw, L.sw, L.dw, g.pw});
+                ++stage;
+                const int Ho = conv_out(H, L.kh, L.sh, L.dh, g.ph);
+                if (Ho <= 0) return bail(KRK_E_INVALID, where + ": conv output height <= 0");
+                // fuse a directly following 2x2/2 max-pool, or the height->channel reshape
+                if (i + 1 < n_layers && layers[i + 1].op == KRK_OP_MAXPOOL && layers[i + 1].kh == 2 &&
+                    layers[i + 1].kw == 2 && layers[i + 1].sh == 2 && layers[i + 1].sw == 2 && Ho >= 2 &&
+                    monotone_act(L.act)) {
+                    g.pool = true;
+                    p->lenops.push_back({1, 2, 2, 1, 0});
+                    ++stage;
+                    ++i;
+                } else if (i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
+                    g.out_seq = true;
+                    ++i;
+                }
+                plan_conv_geom(g);
+                if (upload_conv_weights(g, L.w[0], L.w[1], nullptr, nullptr) != KRK_OK) {
+                    krk_plan_destroy(p);
+                    return KRK_E_HIP;
+                }
+                s.len_out = stage;
+                if (g.out_seq) {
+                    s.out_is_seq = true;
+                    s.outC = g.Ho * g.Cout;
+                    s.outH = 1;
+                    seq = true;
+                    C = s.outC;
+                    H = 1;
+                } else {
+                    s.outC = g.Cout;
+                    s.outH = g.Hy;
+                    C = g.Cout;
+                    H = g.Hy;
+                }
+                p->steps.push_back(std::move(s));
+                break;
+            }
+            case KRK_OP_MAXPOOL: {
+                if (seq) return bail(KRK_E_UNSUPPORTED, where + ": max-pool after a sequence layer");
+                if (L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0) return bail(KRK_E_INVALID, where + ": bad pool");
+                Step s;
+                s.kind = S_MAXPOOL;
+                s.C = C;
+                s.H = H;
+                s.kh = L.kh; s.kw = L.kw; s.sh = L.sh; s.sw = L.sw;
+                s.Ho = floordiv(H - (L.kh - 1) - 1, L.sh) + 1;
+                if (s.Ho <= 0) return bail(KRK_E_INVALID, where + ": pool output height <= 0");
+                s.len_in = stage;
+                p->lenops.push_back({1, L.kw, L.sw, 1, 0});
+                ++stage;
+                s.len_out = stage;
+                s.outC = C;
+                s.outH = s.Ho;
+                H = s.Ho;
+                p->steps.push_back(std::move(s));
+                break;
+            }
+            case KRK_OP_GROUPNORM: {
+                if (seq) return bail(KRK_E_UNSUPPORTED, where + ": group norm after a sequence layer");
+                if (L.cout <= 0 || C % L.cout) return bail(KRK_E_INVALID, where + ": groups must divide channels");
+                if (!L.w[0] || !L.w[1]) return bail(KRK_E_INVALID, where + ": group norm weights missing");
+                Step s;
+                s.kind = S_GN;
+                s.C = C;
+                s.H = H;
+                s.groups = L.cout;
+                std::vector<float> ga(L.w[0], L.w[0] + C), be(L.w[1], L.w[1] + C);
+                if (upload(&s.d_gamma, ga) != KRK_OK || upload(&s.d_beta, be) != KRK_OK) {
+                    krk_plan_destroy(p);
+                    return KRK_E_HIP;
+                }
+                s.len_in = s.len_out = stage;
+                s.outC = C;
+                s.outH = H;
+                p->steps.push_back(std::move(s));
+                break;
+            }
+            case KRK_OP_RESHAPE_HC: {
+                if (seq) return bail(KRK_E_UNSUPPORTED, where + ": reshape after a sequence layer");
+                push_toseq();
+                break;
+            }
+            case KRK_OP_LSTM:
+            case KRK_OP_LINEAR: {
+                if (!seq) {
+                    if (H != 1)
+                        return bail(KRK_E_UNSUPPORTED, where + ": recurrent/linear layer on an input of height " +
+                                                           std::to_string(H) + " (only height 1 is implemented)");
+                    push_toseq();
+                }
+                Step s;
+                s.C = C;
+                s.H = 1;
+                s.out_is_seq = true;
+                s.outH = 1;
+                s.len_in = s.len_out = stage;
+                ConvGeom& g = s.cg;
+                g.Cin = C;
+                g.H = 1;
+                g.in_seq = g.out_seq = true;
+                g.act = ACT_LINEAR;
+                if (L.op == KRK_OP_LINEAR) {
+                    if (L.cout <= 0 || !L.w[0] || !L.w[1]) return bail(KRK_E_INVALID, where + ": linear weights missing");
+                    s.kind = S_LINEAR;
+                    g.Cout = L.cout;
+                    plan_conv_geom(g);
+                    if (upload_conv_weights(g, L.w[0], L.w[1], nullptr, nullptr) != KRK_OK) {
+                        krk_plan_destroy(p);
+                        return KRK_E_HIP;
+                    }
+                    s.outC = L.cout;
+                    C = L.cout;
+                } else {
+                    s.kind = S_LSTM;
+                    s.hidden = L.cout;
+                    s.dirmode = L.direction;
+                    if (L.cout <= 0 || L.direction < 0 || L.direction > 2) return bail(KRK_E_INVALID, where + ": bad LSTM");
+                    s.ndir = (L.direction == KRK_DIR_BIDI) ? 2 : 1;
+                    for (int k = 0; k < 4 * s.ndir; ++k)
+                        if (!L.w[k]) return bail(KRK_E_INVALID, where + ": LSTM weights missing");
+                    s.Hp = (s.hidden + 7) / 8 * 8;
+                    if (s.Hp > 256)
+                        return bail(KRK_E_UNSUPPORTED, where + ": hidden size > 256 not implemented by the recurrent kernel");
+                    const int H_ = s.hidden, G = 4 * s.Hp;
+                    g.Cout = s.ndir * G;
+                    plan_conv_geom(g);
+                    // packed projection column d*G + 4*u + gate  <-  torch row gate*H + u of direction d
+                    std::vector<float> wih((size_t)g.Cout * C, 0.f), bsum(g.Cout, 0.f);
+                    std::vector<int> rowmap(g.Cout, -1);
+                    for (int d = 0; d < s.ndir; ++d)
+                        for (int u = 0; u < H_; ++u)
+                            for (int gt = 0; gt < 4; ++gt) {
+                                const int col = d * G + 4 * u + gt, row = gt * H_ + u;
+                                rowmap[col] = col;  // identity on the staged matrix below
+                                std::memcpy(&wih[(size_t)col * C], L.w[4 * d + 0] + (size_t)row * C, (size_t)C * sizeof(float));
+                                bsum[col] = L.w[4 * d + 2][row] + L.w[4 * d + 3][row];
+                            }
+                    if (upload_conv_weights(g, wih.data(), nullptr, &rowmap, &bsum) != KRK_OK) {
+                        krk_plan_destroy(p);
+                        return KRK_E_HIP;
+                    }
+                    const float* whh[2] = {L.w[1], s.ndir == 2 ? L.w[5] : nullptr};
+                    std::vector<float> pk;
+                    pack_lstm_recurrent(s, whh, 32, pk);
+                    if (upload(&s.d_wrec32, pk) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
+                    pack_lstm_recurrent(s, whh, 16, pk);
+                    if (upload(&s.d_wrec16, pk) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
+                    s.outC = s.ndir * s.hidden;
+                    C = s.outC;
+                }
+                p->steps.push_back(std::move(s));
+                break;
+            }
+            default:
+                return bail(KRK_E_UNSUPPORTED, where + ": unknown op " + std::to_string(L.op));
+        }
+    }
+    p->nstages = stage + 1;
+    if (hipEventCreateWithFlags(&p->lens_ev, hipEventDisableTiming) != hipSuccess)
+        return bail(KRK_E_HIP, "hipEventCreate failed");
+    HIPCHK(hipDeviceSynchronize());
+    *out = p;
+    return KRK_OK;
+}
+
+int krk_plan_out_shape(const krk_plan* plan, int W, int* C, int* H, int* Wout) {
+    if (!plan || plan->steps.empty()) return fail(KRK_E_INVALID, "krk_plan_out_shape: null plan");
+    int w = W;
+    for (const auto& op : plan->lenops) w = shape_after(op, w);
+    const Step& last = plan->steps.back();
+    if (C) *C = last.outC;
+    if (H) *H = last.outH;
+    if (Wout) *Wout = w;
+    return KRK_OK;
+}
+
+int krk_plan_olens(const krk_plan* plan, const int* lens_host, int N, int* olens_host) {
+    if (!plan || !lens_host || !olens_host || N < 0) return fail(KRK_E_INVALID, "krk_plan_olens: bad argument");
+    for (int n = 0; n < N; ++n) {
+        int l = lens_host[n];
+        for (const auto& op : plan->lenops) l = width_after(op, l);
+        olens_host[n] = l;
+    }
+    return KRK_OK;
+}
+
+long krk_plan_workspace_bytes(const krk_plan* plan) {
+    if (!plan) return 0;
+    size_t t = plan->d_lens.cap + plan->d_labels.cap + plan->d_confs.cap + plan->d_final.cap;
+    for (const auto& s : plan->steps) t += s.out.cap + s.aux.cap;
+    return (long)t;
+}
+
+int krk_plan_set_profiling(krk_plan* plan, int enable) {
+    if (!plan) return fail(KRK_E_INVALID, "null plan");
+    plan->profiling = enable != 0;
+    if (plan->profiling && plan->events.empty()) {
+        plan->events.resize(plan->steps.size() + 1);
+        for (auto& e : plan->events)
+            if (hipEventCreate(&e) != hipSuccess) return fail(KRK_E_HIP, "hipEventCreate failed");
+    }
+    return KRK_OK;
+}
+
+int krk_plan_num_steps(const krk_plan* plan) { return plan ? (int)plan->steps.size() : 0; }
+
+const char* krk_plan_layer_name(const krk_plan* plan, int i) {
+    if (!plan || i < 0 || i >= (int)plan->steps.size()) return nullptr;
+    return kStepNames[plan->steps[i].kind];
+}
+
+double krk_plan_layer_flops(const krk_plan* plan, int i) {
+    if (!plan || i < 0 || i >= (int)plan->steps.size()) return 0.0;
+    return plan->steps[i].flops;
+}
+
+int krk_plan_layer_ms(krk_plan* plan, float* ms_host, int cap) {
+    if (!plan || !ms_host) return fail(KRK_E_INVALID, "bad argument");
+    if (!plan->profiling || plan->events.empty()) return fail(KRK_E_INVALID, "profiling not enabled");
+    HIPCHK(hipEventSynchronize(plan->events.back()));
+    const int n = std::min<int>(cap, (int)plan->steps.size());
+    for (int i = 0; i < n; ++i) HIPCHK(hipEventElapsedTime(&ms_host[i], plan->events[i], plan->events[i + 1]));
+    return n;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Runs the schedule.  `final_out` (may be null) receives the last step's output.
+// On return *final_ptr points at the last step's output buffer and *d_olens at the
+// device copy of the final valid widths (or null when lens_host is null).
+int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W, hipStream_t stream,
+             float* final_out, const float** final_ptr, const int** d_olens, int* T_out) {
+    if (!p || !x_dev) return fail(KRK_E_INVALID, "forward: null plan or input");
+    if (N <= 0 || W <= 0) return fail(KRK_E_INVALID, "forward: N and W must be positive");
+    HIPCHK(hipSetDevice(p->device));
+    p->last_N = N;
+    p->last_W = W;
+
+    // ---- per-stage widths (tensor extents) and per-line valid widths
+    std::vector<int> Ws(p->nstages);
+    Ws[0] = W;
+    for (int s = 0; s + 1 < p->nstages; ++s) {
+        Ws[s + 1] = shape_after(p->lenops[s], Ws[s]);
+        if (Ws[s + 1] <= 0) return fail(KRK_E_INVALID, "forward: input width " + std::to_string(W) + " too small for this network");
+    }
+    const int* d_lens = nullptr;
+    if (lens_host) {
+        const size_t cnt = (size_t)p->nstages * N;
+        if (cnt > p->h_lens_cap) {
+            if (p->lens_ev_pending) { HIPCHK(hipEventSynchronize(p->lens_ev)); p->lens_ev_pending = false; }
+            if (p->h_lens_pinned) (void)hipHostFree(p->h_lens_pinned);
+            p->h_lens_pinned = nullptr;
+            HIPCHK(hipHostMalloc((void**)&p->h_lens_pinned, cnt * sizeof(int) * 2, hipHostMallocDefault));
+            p->h_lens_cap = cnt * 2;
+        }
+        if (p->d_lens.ensure(cnt * sizeof(int))) return fail(KRK_E_NOMEM, "forward: length table allocation failed");
+        // the pinned staging buffer may still be in flight from the previous call
+        if (p->lens_ev_pending) { HIPCHK(hipEventSynchronize(p->lens_ev)); p->lens_ev_pending = false; }
+        int* hl = p->h_lens_pinned;
+        for (int n = 0; n < N; ++n) {
+            int l = lens_host[n];
+            if (l < 1 || l > W) return fail(KRK_E_INVALID, "forward: lens[" + std::to_string(n) + "] outside [1, W]");
+            hl[n] = l;
+            for (int s = 0; s + 1 < p->nstages; ++s) {
+                l = width_after(p->lenops[s], l);
+                hl[(size_t)(s + 1) * N + n] = std::max(0, std::min(l, Ws[s + 1]));
+            }
+        }
+        HIPCHK(hipMemcpyAsync(p->d_lens.p, hl, cnt * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(p->lens_ev, stream));
+        p->lens_ev_pending = true;
+        d_lens = (const int*)p->d_lens.p;
+    }
+    auto lens_at = [&](int stage) -> const int* { return d_lens ? d_lens + (size_t)stage * N : nullptr; };
+
+    const float* cur = x_dev;
+    const size_t nsteps = p->steps.size();
+    for (size_t si = 0; si < nsteps; ++si) {
+        Step& s = p->steps[si];
+        if (p->profiling) HIPCHK(hipEventRecord(p->events[si], stream));
+        const int Win = Ws[s.len_in], Wout = Ws[s.len_out];
+        const bool is_last = (si + 1 == nsteps);
+        size_t out_elems = (size_t)N * s.outC * s.outH * Wout;
+        float* outp;
+        if (is_last && final_out) outp = final_out;
+        else {
+            if (s.out.ensure(out_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
+            outp = (float*)s.out.p;
+        }
+        auto fill_conv = [&](const ConvGeom& g, ConvArgs& a, const float* xin, float* yout, int Nn, int Wn,
+                             const int* li, const int* lo) {
+            a.x = xin; a.y = yout; a.wpack = g.d_w; a.bias = g.d_b;
+            a.len_in = li; a.len_out = lo;
+            a.N = Nn; a.Cin = g.Cin; a.H = g.H; a.W = Wn;
+            a.Cout = g.Cout; a.CBpad = g.CBpad;
+            a.kh = g.kh; a.kw = g.kw; a.sh = g.sh; a.sw = g.sw; a.dh = g.dh; a.dw = g.dw; a.ph = g.ph; a.pw = g.pw;
+            a.Ho = g.Ho;
+            a.Wo = g.in_seq ? Wn : conv_out(Wn, g.kw, g.sw, g.dw, g.pw);
+            a.Hy = g.Hy;
+            a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
+            a.act = g.act;
+            a.cchunk = g.cchunk; a.nchunks = g.nchunks; a.KS = g.KS; a.Kc = g.Kc;
+            a.IH = g.IH; a.IW = g.IW; a.RS = g.RS; a.PS = g.PS; a.SR = g.SR;
+            a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
+            a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
+            a.otab_floats = g.otab_floats;
+        };
+        int rc = 0;
+        switch (s.kind) {
+            case S_CONV: {
+                ConvArgs a;
+                fill_conv(s.cg, a, cur, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));
+                s.flops = 2.0 * N * (double)s.cg.Ho * a.Wo * s.cg.Cout * s.cg.Cin * s.cg.kh * s.cg.kw;
+                rc = krk_launch_conv(a, false, s.cg.out_seq, s.cg.pool, stream);
+                break;
+            }
+            case S_MAXPOOL:
+                s.flops = 0;
+                rc = krk_launch_maxpool(cur, outp, lens_at(s.len_out), N, s.C, s.H, Win, s.kh, s.kw, s.sh, s.sw, s.Ho,
+                                        Wout, stream);
+                break;
+            case S_GN:
+                s.flops = 0;
+                rc = krk_launch_groupnorm(cur, outp, s.d_gamma, s.d_beta, lens_at(s.len_in), N, s.C, s.H, Win, s.groups,
+                                          1e-5f, stream);
+                break;
+            case S_TOSEQ:
+                s.flops = 0;
+                rc = krk_launch_to_seq(cur, outp, N, s.C, s.H, Win, stream);
+                break;
+            case S_LINEAR: {
+                ConvArgs a;
+                fill_conv(s.cg, a, cur, outp, 1, N * Win, nullptr, nullptr);
+                s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
+                rc = krk_launch_conv(a, true, true, false, stream);
+                break;
+            }
+            case S_LSTM: {
+                const int T = Win;
+                const int G = 4 * s.Hp;
+                const size_t xp_elems = (size_t)N * T * s.ndir * G;
+                if (s.aux.ensure(xp_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
+                ConvArgs a;
+                fill_conv(s.cg, a, cur, (float*)s.aux.p, 1, N * T, nullptr, nullptr);
+                rc = krk_launch_conv(a, true, true, false, stream);
+                if (rc) break;
+                if (lens_host) HIPCHK(hipMemsetAsync(outp, 0, out_elems * sizeof(float), stream));
+                LstmArgs l;
+                l.xp = (const float*)s.aux.p;
+                l.out = outp;
+                l.lens = lens_at(s.len_in);
+                l.N = N; l.T = T; l.H = s.hidden; l.Hp = s.Hp; l.G = G;
+                l.ndir = s.ndir; l.dirmode = s.dirmode;
+                l.xstride = s.ndir * G;
+                l.ostride = s.ndir * s.hidden;
+                // 32-line tiles once they fill most of the 256 CUs, 16-line tiles below that
+                const int tiles32 = (N + 31) / 32 * s.ndir;
+                const int M = tiles32 >= 192 ? 32 : 16;
+                l.wp = (M == 32) ? s.d_wrec32 : s.d_wrec16;
+                l.KS = s.Hp / ((M == 32) ? 2 : 4);
+                l.NB = G / M;
+                s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
+                rc = krk_launch_lstm(l, M, stream);
+                break;
+            }
+        }
+        if (rc == -4) return fail(KRK_E_UNSUPPORTED, std::string("forward: unsupported kernel configuration in ") + kStepNames[s.kind]);
+        if (rc) return fail(KRK_E_HIP, std::string("forward: launch of ") + kStepNames[s.kind] + " failed: " +
+                                           hipGetErrorString(hipGetLastError()));
+        cur = outp;
+    }
+    if (p->profiling) HIPCHK(hipEventRecord(p->events[nsteps], stream));
+    if (final_ptr) *final_ptr = cur;
+    if (d_olens) *d_olens = lens_at(p->nstages - 1);
+    if (T_out) *T_out = Ws[p->nstages - 1];
+    return KRK_OK;
+}
+
+int decode_on_device(const float* scores, long sn, long sc, long st, int N, int C, int T, const int* d_olens,
+                     int softmax, float temperature, float* probs, int* d_labels, float* d_confs,
+                     hipStream_t stream, const krk_decode_out* out) {
+    if (!out || !out->labels || !out->starts || !out->ends || !out->confs || !out->counts)
+        return fail(KRK_E_INVALID, "decode: null output buffers");
+    if (out->t_stride < T) return fail(KRK_E_INVALID, "decode: t_stride < T");
+    if (softmax && !(temperature > 0.f)) return fail(KRK_E_INVALID, "decode: temperature must be > 0");
+    if ((size_t)T * 2 * sizeof(float) > 60 * 1024) return fail(KRK_E_UNSUPPORTED, "decode: more than 7680 time steps");
+    int rc = krk_launch_rowmax(scores, sn, sc, st, N, C, T, softmax, temperature, probs, d_labels, d_confs, stream);
+    if (!rc)
+        rc = krk_launch_collapse(d_labels, d_confs, d_olens, N, T, out->labels, out->starts, out->ends, out->confs,
+                                 out->counts, out->t_stride, stream);
+    if (rc) return fail(KRK_E_HIP, std::string("decode: kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return KRK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int krk_forward(krk_plan* plan, const float* x_dev, const int* lens_host, int N, int W, void* stream,
+                float* out_dev) {
+    if (!out_dev) return fail(KRK_E_INVALID, "krk_forward: out_dev is null");
+    return run_plan(plan, x_dev, lens_host, N, W, (hipStream_t)stream, out_dev, nullptr, nullptr, nullptr);
+}
+
+int krk_greedy_decode(const float* scores_dev, long sn, long sc, long st, int N, int C, int T,
+                      const int* olens_host, int softmax, float temperature, float* probs_dev, void* stream,
+                      const krk_decode_out* out) {
+    if (!scores_dev || N <= 0 || C <= 0 || T <= 0) return fail(KRK_E_INVALID, "krk_greedy_decode: bad argument");
+    if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_greedy_decode: no HIP device");
+    hipStream_t s = (hipStream_t)stream;
+    int* d_labels = nullptr;
+    float* d_confs = nullptr;
+    int* d_olens = nullptr;
+    const size_t rows = (size_t)N * T;
+    HIPCHK(hipMallocAsync((void**)&d_labels, rows * sizeof(int), s));
+    HIPCHK(hipMallocAsync((void**)&d_confs, rows * sizeof(float), s));
+    if (olens_host) {
+        for (int n = 0; n < N; ++n)
+            if (olens_host[n] < 0 || olens_host[n] > T) {
+                (void)hipFreeAsync(d_labels, s);
+                (void)hipFreeAsync(d_confs, s);
+                return fail(KRK_E_INVALID, "krk_greedy_decode: olens outside [0, T]");
+            }
+        HIPCHK(hipMallocAsync((void**)&d_olens, (size_t)N * sizeof(int), s));
+        HIPCHK(hipMemcpyAsync(d_olens, olens_host, (size_t)N * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    const int rc = decode_on_device(scores_dev, sn, sc, st, N, C, T, d_olens, softmax, temperature, probs_dev,
+                                    d_labels, d_confs, s, out);
+    (void)hipFreeAsync(d_labels, s);
+    (void)hipFreeAsync(d_confs, s);
+    if (d_olens) (void)hipFreeAsync(d_olens, s);
+    return rc;
+}
+
+int krk_recognize(krk_plan* plan, const float* x_dev, const int* lens_host, int N, int W, float temperature,
+                  void* stream, float* logits_dev, float* probs_dev, int* olens_host,
+                  const krk_decode_out* out) {
+    if (!plan || plan->steps.empty()) return fail(KRK_E_INVALID, "krk_recognize: null plan");
+    const Step& last = plan->steps.back();
+    if (last.kind != S_LINEAR) return fail(KRK_E_UNSUPPORTED, "krk_recognize: the network must end in a linear (O1) layer");
+    hipStream_t s = (hipStream_t)stream;
+    const float* logits = nullptr;
+    const int* d_olens = nullptr;
+    int T = 0;
+    int rc = run_plan(plan, x_dev, lens_host, N, W, s, logits_dev, &logits, &d_olens, &T);
+    if (rc) return rc;
+    const int C = last.outC;
+    const size_t rows = (size_t)N * T;
+    if (plan->d_labels.ensure(rows * sizeof(int)) || plan->d_confs.ensure(rows * sizeof(float)))
+        return fail(KRK_E_NOMEM, "krk_recognize: workspace allocation failed");
+    rc = decode_on_device(logits, (long)T * C, 1, C, N, C, T, d_olens, 1, temperature, probs_dev,
+                          (int*)plan->d_labels.p, (float*)plan->d_confs.p, s, out);
+    if (rc) return rc;
+    if (olens_host) {
+        if (lens_host) krk_plan_olens(plan, lens_host, N, olens_host);
+        else for (int n = 0; n < N; ++n) olens_host[n] = T;
+    }
+    return KRK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Shared declarations of the gfx950 line-recognition kernels (host + device).
+// Written for CDNA4 only: 64-wide wavefronts, v_mfma_f32_32x32x2_f32 /
+// v_mfma_f32_16x16x4_f32 (exact f32 matrix cores), 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- activations
+#define ACT_LINEAR 0
+#define ACT_RELU 1
+#define ACT_TANH 2
+#define ACT_LEAKY 3
+
+__device__ __forceinline__ float krk_sigmoid(float x) {
+    // 1 / (1 + e^-x); e^-x = 2^(-x log2 e) on v_exp_f32, v_rcp_f32 for the reciprocal
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float krk_tanh(float x) {
+    // tanh x = 2 sigma(2x) - 1; saturates cleanly to +-1 (e^-2x -> inf / 0)
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f;
+}
+__device__ __forceinline__ float krk_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_TANH: return tanhf(v);
+        case ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+        default: return v;
+    }
+}
+
+// ------------------------------------------------------------------ conv/GEMM
+// One kernel covers ActConv2D, the LSTM input projection and LinSoftmax: an
+// implicit GEMM whose K axis enumerates (channel, dy, dx) through an LDS offset
+// table, so any kernel size / stride / dilation / channel count runs on the
+// matrix cores without materialising im2col.
+struct ConvArgs {
+    const float* x;       // IN_SEQ=0: (N,Cin,H,W) planes; IN_SEQ=1: [W][Cin] rows (N=1,H=1)
+    float* y;             // see epilogues in conv_mfma.hip
+    const float* wpack;   // [nchunks][KS][CBpad][64] fragment order
+    const float* bias;    // [CBpad*32]
+    const int* len_in;    // [N] valid input width per line or nullptr
+    const int* len_out;   // [N] valid stored-output width per line or nullptr
+    int N, Cin, H, W;
+    int Cout, CBpad;
+    int kh, kw, sh, sw, dh, dw, ph, pw;
+    int Ho, Wo;           // conv output extent (before pooling)
+    int Hy, Wy;           // stored extent (after the fused 2x2/2 max-pool, else == Ho,Wo)
+    int act;
+    int cchunk, nchunks, KS, Kc;   // channels per LDS chunk, #chunks, K-steps (of 2) and K per chunk
+    int IH, IW, RS, PS;   // staged tile rows/cols, row stride, plane stride (floats)
+    int SR;               // 32-pixel segments per tile row: tile = (8/SR) rows x (32*SR) cols
+    int tiles_h, tiles_w;
+    int otab_floats;      // LDS floats reserved for the K-offset table
+};
+
+// ----------------------------------------------------------------------- LSTM
+struct LstmArgs {
+    const float* xp;      // [N*T][xstride] input projections (+ both biases), gate-interleaved columns
+    const float* wp;      // [ndir][KS][NB][64] recurrent weights in B-fragment order
+    float* out;           // [N][T][ostride]
+    const int* lens;      // [N] valid steps per line or nullptr
+    int N, T, H, Hp;      // hidden size and hidden size padded to the column-block granule
+    int KS, NB, G;        // K-steps per time step, column blocks, G = 4*Hp gate columns per direction
+    int ndir, dirmode;    // 1|2 directions; 0 fwd, 1 rev, 2 bidi
+    int xstride, ostride;
+};
+
+// host-side launchers (implemented in the .hip files)
+int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);
+int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);
+int krk_launch_maxpool(const float* x, float* y, const int* len_out, int N, int C, int H, int W,
+                       int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);
+int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta,
+                         const int* lens, int N, int C, int H, int W, int G, float eps, hipStream_t s);
+int krk_launch_to_seq(const float* x, float* y, int N, int C, int H, int W, hipStream_t s);
+int krk_launch_rowmax(const float* scores, long sn, long sc, long st, int N, int C, int T,
+                      int softmax, float temp, float* probs, int* labels, float* confs,
+                      hipStream_t s);
+int krk_launch_collapse(const int* labels, const float* confs, const int* olens, int N, int T,
+                        int* o_labels, int* o_starts, int* o_ends, float* o_confs, int* o_counts,
+                        int t_stride, hipStream_t s);

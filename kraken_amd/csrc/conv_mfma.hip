@@ -1,0 +1,247 @@
+// Implicit-GEMM convolution / projection on the gfx950 f32 matrix cores.
+//
+// Replaces (reference, kraken/lib/vgsl/layers.py): ActConv2D.forward :842-860
+// (torch.nn.Conv2d + bias + activation), the directly following MaxPool 2x2/2
+// (:381-388, fused), the height->channel Reshape (:313-335, fused as the
+// channels-last epilogue), the input projection of nn.LSTM (:507-511) and the
+// Linear of LinSoftmax (:708-722).
+//
+// Work decomposition (one 256-thread workgroup = 4 waves):
+//   tile      = (8/SR) output rows x (32*SR) output columns of ONE line, CBW blocks of 32 filters
+//   wave      = 2 segments of 32 consecutive output pixels (for the fused pool: the two rows of a
+//               pooling pair), all CBW filter blocks -> 2*CBW accumulators of 32x32 f32
+//   K axis    = (channel, dy, dx) of one LDS-resident channel chunk, two K per v_mfma_f32_32x32x2_f32;
+//               the LDS offset of each K is looked up in a table so that kernel size, stride and
+//               dilation are data, not code
+//   operands  = input pixels from the LDS tile (lanes 0-31 read 32 consecutive floats: conflict-free),
+//               weights straight from global memory in fragment order (one coalesced 256-B load per
+//               fragment; the 0.2-1.3 MB of weights stay L2-resident)
+// Masked-padding semantics: input columns >= len_in[n] read as zero, stored columns >= len_out[n]
+// are written as zero (see include/kraken_amd.h).
+#include "common.h"
+
+namespace {
+
+template <int IN_SEQ, int OUT_SEQ, int POOL, int CBW>
+__global__ void __launch_bounds__(256) conv_f32_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* otab = reinterpret_cast<int*>(smem);
+    float* tile = smem + a.otab_floats;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, px = lane & 31;
+
+    int bt = blockIdx.x;
+    const int tw = bt % a.tiles_w;
+    bt /= a.tiles_w;
+    const int th = bt % a.tiles_h;
+    const int n = bt / a.tiles_h;
+    const int SR = a.SR;
+    const int TH = 8 / SR, TW = 32 * SR;
+    const int h0 = th * TH, w0 = tw * TW;
+    const int cb0 = blockIdx.y * CBW;
+
+    const int len_in = a.len_in ? a.len_in[n] : a.W;
+    const int len_out = a.len_out ? a.len_out[n] : a.Wy;
+    // conv-output columns that still carry data after masking
+    const int wlim = POOL ? min(a.Wo, 2 * len_out) : min(a.Wo, len_out);
+
+    int srow[2], scol[2];
+    bool inb[2], live[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (POOL) {
+            srow[s] = 2 * (wave / SR) + s;
+            scol[s] = 32 * (wave % SR);
+        } else {
+            const int g = wave * 2 + s;
+            srow[s] = g / SR;
+            scol[s] = 32 * (g % SR);
+        }
+        inb[s] = (h0 + srow[s] < a.Ho) && (w0 + scol[s] < a.Wo);
+        live[s] = inb[s] && (w0 + scol[s] < wlim);
+    }
+
+    // K -> LDS offset table (identical for every channel chunk)
+    for (int k = tid; k < 2 * a.KS; k += 256) {
+        int off = 0;
+        if (k < a.Kc) {
+            const int kk = a.kh * a.kw;
+            const int c = k / kk, rem = k - c * kk;
+            const int dy = rem / a.kw, dx = rem - dy * a.kw;
+            off = c * a.PS + dy * a.dh * a.RS + dx * a.dw;
+        }
+        otab[k] = off;
+    }
+
+    f32x16 acc[CBW][2];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][s][r] = 0.f;
+
+    int boff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) boff[s] = srow[s] * a.sh * a.RS + (scol[s] + px) * a.sw;
+
+    const bool any_live = live[0] || live[1];
+
+    for (int ci = 0; ci < a.nchunks; ++ci) {
+        __syncthreads();  // previous chunk fully consumed (and otab visible on the first pass)
+        if (IN_SEQ) {
+            // rows of [W][Cin]: a pixel's channel chunk is contiguous -> coalesced reads,
+            // transposed into tile[c][p] (odd plane stride: conflict-free writes)
+            const int cc = a.cchunk;
+            const int total = TW * cc;
+            for (int e = tid; e < total; e += 256) {
+                const int p = e / cc, c = e - p * cc;
+                const int gp = w0 + p, gc = ci * cc + c;
+                float v = 0.f;
+                if (gp < a.W && gc < a.Cin) v = a.x[(size_t)gp * a.Cin + gc];
+                tile[c * a.PS + p] = v;
+            }
+        } else {
+            const int gh0 = h0 * a.sh - a.ph, gw0 = w0 * a.sw - a.pw;
+            const int per_c = a.IH * a.IW;
+            const int total = a.cchunk * per_c;
+            const float* xn = a.x + (size_t)n * a.Cin * a.H * a.W;
+            for (int e = tid; e < total; e += 256) {
+                const int c = e / per_c, r = e - c * per_c;
+                const int ih = r / a.IW, iw = r - ih * a.IW;
+                const int gc = ci * a.cchunk + c, gh = gh0 + ih, gw = gw0 + iw;
+                float v = 0.f;
+                if (gc < a.Cin && gh >= 0 && gh < a.H && gw >= 0 && gw < len_in)
+                    v = xn[((size_t)gc * a.H + gh) * a.W + gw];
+                tile[c * a.PS + ih * a.RS + iw] = v;
+            }
+        }
+        __syncthreads();
+        if (!any_live) continue;
+
+        const float* wp = a.wpack + ((size_t)ci * a.KS * a.CBpad + cb0) * 64 + lane;
+        const size_t wstep = (size_t)a.CBpad * 64;
+#pragma unroll 2
+        for (int ks = 0; ks < a.KS; ++ks) {
+            const int off = otab[2 * ks + half];
+            float b[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) b[s] = tile[off + boff[s]];
+            float w[CBW];
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) w[cb] = wp[(size_t)ks * wstep + cb * 64];
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (live[s]) {
+                        if (OUT_SEQ)  // D[pixel][filter]
+                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], w[cb], acc[cb][s], 0, 0, 0);
+                        else          // D[filter][pixel]
+                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cb], b[s], acc[cb][s], 0, 0, 0);
+                    }
+        }
+    }
+
+    // ------------------------------------------------------------- epilogues
+    if (POOL) {
+        // rows srow[0], srow[1] form one pooling pair; adjacent lanes form the column pair
+        if (!inb[0]) return;
+        const int pr = (h0 + srow[0]) >> 1;
+        const int pc = (w0 + scol[0] + px) >> 1;
+        const bool st = !(px & 1) && pr < a.Hy && pc < a.Wy;
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (cb0 + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = fmaxf(acc[cb][0][r], acc[cb][1][r]);
+                v = fmaxf(v, __shfl_xor(v, 1));
+                if (st && co < a.Cout) {
+                    v = krk_act(v + a.bias[co], a.act);  // monotone activations commute with max
+                    if (pc >= len_out) v = 0.f;
+                    a.y[(((size_t)n * a.Cout + co) * a.Hy + pr) * a.Wy + pc] = v;
+                }
+            }
+        }
+    } else if (OUT_SEQ) {
+        // channels-last: y[n][col][row*Cout + filter]  (row*Cout+filter == the reference's h*C+c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (!inb[s]) continue;
+            const int row = h0 + srow[s];
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                const int co = (cb0 + cb) * 32 + px;
+                if (co >= a.Cout) continue;
+                const float bv = a.bias[co];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = w0 + scol[s] + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (col < a.Wo) {
+                        float v = krk_act(acc[cb][s][r] + bv, a.act);
+                        if (col >= len_out) v = 0.f;
+                        a.y[(((size_t)n * a.Wo + col) * a.Ho + row) * a.Cout + co] = v;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (!inb[s]) continue;
+            const int row = h0 + srow[s];
+            const int col = w0 + scol[s] + px;
+            if (col >= a.Wo) continue;
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = (cb0 + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < a.Cout) {
+                        float v = krk_act(acc[cb][s][r] + a.bias[co], a.act);
+                        if (col >= len_out) v = 0.f;
+                        a.y[(((size_t)n * a.Cout + co) * a.Ho + row) * a.Wo + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int IN_SEQ, int OUT_SEQ, int POOL>
+int launch_cbw(const ConvArgs& a, int cbw, dim3 grid, size_t lds, hipStream_t s) {
+#define KRK_LAUNCH(CBW_)                                                                        \
+    do {                                                                                        \
+        auto kfn = conv_f32_kernel<IN_SEQ, OUT_SEQ, POOL, CBW_>;                                \
+        if (lds > 48 * 1024)                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);                                    \
+    } while (0)
+    switch (cbw) {
+        case 1: KRK_LAUNCH(1); break;
+        case 2: KRK_LAUNCH(2); break;
+        default: KRK_LAUNCH(4); break;
+    }
+#undef KRK_LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s) {
+    const int CB = (a.Cout + 31) / 32;
+    const int cbw = CB >= 4 ? 4 : (CB >= 2 ? 2 : 1);
+    dim3 grid((unsigned)(a.tiles_w * a.tiles_h * a.N), (unsigned)((CB + cbw - 1) / cbw));
+    const size_t lds = ((size_t)a.otab_floats + (size_t)a.cchunk * a.PS) * sizeof(float);
+    if (in_seq) {
+        if (pool) return -1;
+        return out_seq ? launch_cbw<1, 1, 0>(a, cbw, grid, lds, s) : launch_cbw<1, 0, 0>(a, cbw, grid, lds, s);
+    }
+    if (pool) return out_seq ? -1 : launch_cbw<0, 0, 1>(a, cbw, grid, lds, s);
+    return out_seq ? launch_cbw<0, 1, 0>(a, cbw, grid, lds, s) : launch_cbw<0, 0, 0>(a, cbw, grid, lds, s);
+}

@@ -1,0 +1,303 @@
+// HBM-bound helper kernels of the recognition path: max-pool, masked GroupNorm,
+// NCHW -> time-major transpose, per-timestep softmax/argmax and the CTC run-length
+// collapse.  All are plain coalesced streaming kernels with wave-shuffle reductions;
+// none of them is reshaped into a GEMM.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------- MaxPool
+// reference: MaxPool.forward kraken/lib/vgsl/layers.py:381-388 (torch.nn.MaxPool2d(k, s),
+// no padding, floor).  Columns >= len_out[n] are written as zero (masked padding).
+__global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const int* __restrict__ len_out, int C, int H, int W,
+                                                      int kh, int kw, int sh, int sw, int Ho, int Wo,
+                                                      size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int wo = (int)(e % Wo);
+        size_t r = e / Wo;
+        const int ho = (int)(r % Ho);
+        r /= Ho;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        float m = 0.f;
+        if (!len_out || wo < len_out[n]) {
+            const float* xp = x + (((size_t)n * C + c) * H + (size_t)ho * sh) * W + (size_t)wo * sw;
+            m = -INFINITY;
+            for (int i = 0; i < kh; ++i)
+                for (int j = 0; j < kw; ++j) m = fmaxf(m, xp[(size_t)i * W + j]);
+        }
+        y[e] = m;
+    }
+}
+
+// ----------------------------------------------------------------- GroupNorm
+// reference: GroupNorm.forward kraken/lib/vgsl/layers.py:967-984: fp32, eps 1e-5, affine,
+// statistics per (line, group) over (C/G, H, valid width only); positions past the valid
+// width are zero.  One workgroup per (line, group); mean, then centred variance, then apply.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) groupnorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const int* __restrict__ lens, int C, int H, int W, int G,
+                                                        float eps) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, g = blockIdx.y;
+    const int Cg = C / G;
+    int L = lens ? lens[n] : W;
+    L = min(max(L, 1), W);   // the reference clamps to [1, W] (layers.py:982)
+    const size_t base = ((size_t)n * C + (size_t)g * Cg) * H * W;
+    const int rows = Cg * H;
+    const int cnt = rows * L;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const int r = e / L, w = e - r * L;
+        s += x[base + (size_t)r * W + w];
+    }
+    const float mean = block_sum(s, red) / (float)cnt;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const int r = e / L, w = e - r * L;
+        const float d = x[base + (size_t)r * W + w] - mean;
+        q += d * d;
+    }
+    const float var = block_sum(q, red) / (float)cnt;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const int tot = rows * W;
+    for (int e = threadIdx.x; e < tot; e += 256) {
+        const int r = e / W, w = e - r * W;
+        const int c = g * Cg + r / H;
+        float v = 0.f;
+        if (w < L) v = (x[base + e] - mean) * rstd * gamma[c] + beta[c];
+        y[base + e] = v;
+    }
+}
+
+// ---------------------------------------------------- NCHW -> [N][W][H*C] rows
+// reference: Reshape.forward kraken/lib/vgsl/layers.py:313-335 for S1(1x0)1,3 (feature
+// index h*C + c) followed by the NCHW->NWC permute of TransposedSummarizingRNN (:519) /
+// LinSoftmax (:716).  32x32 LDS transpose tiles: reads coalesced along w, writes along f.
+__global__ void __launch_bounds__(256) to_seq_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     int C, int H, int W) {
+    __shared__ float t[32][33];
+    const int n = blockIdx.z;
+    const int F = C * H;
+    const int f0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int f = f0 + i, w = w0 + tx;
+        float v = 0.f;
+        if (f < F && w < W) {
+            const int h = f / C, c = f - h * C;
+            v = x[(((size_t)n * C + c) * H + h) * W + w];
+        }
+        t[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int w = w0 + i, f = f0 + tx;
+        if (w < W && f < F) y[((size_t)n * W + w) * F + f] = t[tx][i];
+    }
+}
+
+// ----------------------------------------------------- softmax / argmax per step
+// reference: `(logits / T).softmax(1)` (kraken/lib/vgsl/rpred.py:226, lib/models.py:115) and
+// `seq[..., :L].max(dim=0)` (kraken/lib/ctc_decoder.py:65): per (line, timestep) the maximum
+// class score and its lowest index.  softmax=1: the confidence is the softmax maximum
+// 1/sum(exp(z - zmax)) and the tie rule is evaluated on the probabilities (exp(..) == 1).
+// Contiguous class axis: one wave per (n,t) row, 64 classes per pass, shuffle reductions.
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+__global__ void __launch_bounds__(256) rowmax_rows_kernel(const float* __restrict__ sc, long sn, long st, int C,
+                                                          int T, long rows, int softmax, float temp,
+                                                          float* __restrict__ probs, int* __restrict__ labels,
+                                                          float* __restrict__ confs) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long n = row / T, t = row - n * T;
+    const float* p = sc + n * sn + t * st;
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = p[c];
+        if (v > m) { m = v; mi = c; }   // ascending c: first maximum kept
+    }
+    wave_argmax(m, mi);
+    if (mi == 0x7fffffff) mi = 0;
+    if (!softmax) {
+        if (lane == 0) { labels[row] = mi; confs[row] = m; }
+        return;
+    }
+    const float zmax = m / temp;
+    float sum = 0.f;
+    int first1 = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float e = expf(p[c] / temp - zmax);
+        sum += e;
+        if (e == 1.0f && c < first1) first1 = c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o);
+        first1 = min(first1, __shfl_xor(first1, o));
+    }
+    if (probs) {
+        float* q = probs + n * sn + t * st;
+        for (int c = lane; c < C; c += 64) q[c] = expf(p[c] / temp - zmax) / sum;
+    }
+    if (lane == 0) { labels[row] = first1; confs[row] = 1.0f / sum; }
+}
+
+// Arbitrary strides (e.g. a contiguous (N,C,T) probability tensor handed to the decoder
+// operator): one thread per (n,t), lanes run along t.
+__global__ void __launch_bounds__(256) rowmax_strided_kernel(const float* __restrict__ sc, long sn, long scs,
+                                                             long st, int C, int T, long rows, int softmax,
+                                                             float temp, float* __restrict__ probs,
+                                                             int* __restrict__ labels,
+                                                             float* __restrict__ confs) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const long n = row / T, t = row - n * T;
+    const float* p = sc + n * sn + t * st;
+    float m = -INFINITY;
+    int mi = 0;
+    for (int c = 0; c < C; ++c) {
+        const float v = p[(long)c * scs];
+        if (v > m) { m = v; mi = c; }
+    }
+    if (!softmax) {
+        labels[row] = mi;
+        confs[row] = m;
+        return;
+    }
+    const float zmax = m / temp;
+    float sum = 0.f;
+    int first1 = -1;
+    for (int c = 0; c < C; ++c) {
+        const float e = expf(p[(long)c * scs] / temp - zmax);
+        sum += e;
+        if (e == 1.0f && first1 < 0) first1 = c;
+    }
+    if (probs) {
+        float* q = probs + n * sn + t * st;
+        for (int c = 0; c < C; ++c) q[(long)c * scs] = expf(p[(long)c * scs] / temp - zmax) / sum;
+    }
+    labels[row] = first1 < 0 ? mi : first1;
+    confs[row] = 1.0f / sum;
+}
+
+// ------------------------------------------------------------- CTC collapse
+// reference: greedy_decoder kraken/lib/ctc_decoder.py:66-71 -- itertools.groupby over the
+// per-step labels; every run of a non-blank (!= 0) label yields
+// (label, first step, last step inclusive, max confidence in the run).
+// One wave per line; run starts are found in parallel, compacted with ballot/popcount.
+__global__ void __launch_bounds__(64) collapse_kernel(const int* __restrict__ labels,
+                                                      const float* __restrict__ confs,
+                                                      const int* __restrict__ olens, int T,
+                                                      int* __restrict__ o_labels, int* __restrict__ o_starts,
+                                                      int* __restrict__ o_ends, float* __restrict__ o_confs,
+                                                      int* __restrict__ o_counts, int t_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* lab = reinterpret_cast<int*>(smem);
+    float* cf = smem + T;
+    const int n = blockIdx.x, lane = threadIdx.x;
+    int L = olens ? olens[n] : T;
+    L = min(max(L, 0), T);
+    for (int t = lane; t < L; t += 64) {
+        lab[t] = labels[(size_t)n * T + t];
+        cf[t] = confs[(size_t)n * T + t];
+    }
+    __syncthreads();
+    int count = 0;
+    for (int base = 0; base < L; base += 64) {
+        const int t = base + lane;
+        const bool valid = t < L;
+        const int l = valid ? lab[t] : 0;
+        const int prev = (valid && t > 0) ? lab[t - 1] : -1;
+        const bool start = valid && l != 0 && l != prev;
+        const unsigned long long mask = __ballot(start);
+        if (start) {
+            const int idx = count + __popcll(mask & ((1ull << lane) - 1ull));
+            int e = t;
+            float m = cf[t];
+            while (e + 1 < L && lab[e + 1] == l) {
+                ++e;
+                m = fmaxf(m, cf[e]);
+            }
+            const size_t o = (size_t)n * t_stride + idx;
+            o_labels[o] = l;
+            o_starts[o] = t;
+            o_ends[o] = e;
+            o_confs[o] = m;
+        }
+        count += __popcll(mask);
+    }
+    if (lane == 0) o_counts[n] = count;
+}
+
+}  // namespace
+
+static inline int last_ok() { return hipGetLastError() == hipSuccess ? 0 : -2; }
+
+int krk_launch_maxpool(const float* x, float* y, const int* len_out, int N, int C, int H, int W, int kh,
+                       int kw, int sh, int sw, int Ho, int Wo, hipStream_t s) {
+    const size_t total = (size_t)N * C * Ho * Wo;
+    if (!total) return 0;
+    const unsigned blocks = (unsigned)min((size_t)8192, (total + 255) / 256);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, s, x, y, len_out, C, H, W, kh, kw, sh, sw,
+                       Ho, Wo, total);
+    return last_ok();
+}
+
+int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const int* lens,
+                         int N, int C, int H, int W, int G, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(groupnorm_kernel, dim3(N, G), dim3(256), 0, s, x, y, gamma, beta, lens, C, H, W, G, eps);
+    return last_ok();
+}
+
+int krk_launch_to_seq(const float* x, float* y, int N, int C, int H, int W, hipStream_t s) {
+    dim3 grid((W + 31) / 32, (C * H + 31) / 32, N);
+    hipLaunchKernelGGL(to_seq_kernel, grid, dim3(256), 0, s, x, y, C, H, W);
+    return last_ok();
+}
+
+int krk_launch_rowmax(const float* scores, long sn, long sc, long st, int N, int C, int T, int softmax,
+                      float temp, float* probs, int* labels, float* confs, hipStream_t s) {
+    const long rows = (long)N * T;
+    if (!rows) return 0;
+    if (sc == 1) {
+        hipLaunchKernelGGL(rowmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, scores, sn, st,
+                           C, T, rows, softmax, temp, probs, labels, confs);
+    } else {
+        hipLaunchKernelGGL(rowmax_strided_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, scores,
+                           sn, sc, st, C, T, rows, softmax, temp, probs, labels, confs);
+    }
+    return last_ok();
+}
+
+int krk_launch_collapse(const int* labels, const float* confs, const int* olens, int N, int T, int* o_labels,
+                        int* o_starts, int* o_ends, float* o_confs, int* o_counts, int t_stride,
+                        hipStream_t s) {
+    if (!N) return 0;
+    const size_t lds = (size_t)2 * T * sizeof(float);
+    hipLaunchKernelGGL(collapse_kernel, dim3(N), dim3(64), lds, s, labels, confs, olens, T, o_labels, o_starts,
+                       o_ends, o_confs, o_counts, t_stride);
+    return last_ok();
+}

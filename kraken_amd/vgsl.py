@@ -1,0 +1,580 @@
+"""
+VGSL model object whose ``nn(x, seq_lens)`` operator runs on hand-written HIP
+kernels for gfx950 (MI355X).
+
+Mirrors the public surface of the reference's ``kraken.lib.vgsl.TorchVGSLModel``
+(kraken/lib/vgsl/model.py:78-568) for the recognition hot path:
+
+* constructor ``TorchVGSLModel(vgsl=spec, codec=..., **metadata)`` (model.py:109-200);
+* layer names ``C_0, Mp_2, L_12, O_18 ...`` with a global running index (model.py:53-64), which
+  are the state-dict keys ``nn.<name>.co.weight`` etc. -- reference
+  weight files load unchanged;
+* ``.nn(x, seq_lens) -> (logits (N,C,1,T), olens)`` (model.py:488-489, layers.py:44-53);
+* ``.input/.output/.codec/.user_metadata/.one_channel_mode/.seg_type/.model_type/
+  .use_legacy_polygons/.hyper_params`` (model.py:343-398);
+* ``init_weights`` (model.py:450-479), ``add_codec`` (:481-486), ``forward`` (:488-489).
+
+torch modules are used only as parameter containers (device memory, state dict); all
+arithmetic of the forward is in ``csrc/*.hip`` behind the C ABI of ``include/kraken_amd.h``.
+There is no CPU execution path: calling ``nn`` without a HIP device raises.
+"""
+import ctypes as C
+import json
+import math
+import re
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Any, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .codec import PytorchCodec
+
+__all__ = ['TorchVGSLModel', 'parse_vgsl', 'LayerSpec', 'HipSequential']
+
+
+# --------------------------------------------------------------------------- spec parsing
+@dataclass
+class LayerSpec:
+    kind: str                      # conv | maxpool | groupnorm | dropout | reshape | rnn | linear
+    name: str                      # state-dict name, e.g. 'C_0'
+    text: str                      # spec block with the {name} inserted (named_spec entry)
+    params: dict = field(default_factory=dict)
+    in_shape: tuple = ()           # (batch, channels, height, width); 0 = variable
+    out_shape: tuple = ()
+
+
+_RE_INPUT = re.compile(r'^(\d+),(\d+),(\d+),(\d+)$')
+_RE_NAME = r'(?:\{(?P<name>\w+)\})?'
+_GRAMMAR = [
+    ('conv', re.compile(r'^C(?P<trans>T)?(?P<nl>lr|s|t|r|l|m)' + _RE_NAME +
+                        r'(?P<ky>\d+),(?P<kx>\d+),(?P<out>\d+)(?:,(?P<sy>\d+),(?P<sx>\d+))?(?:,(?P<dy>\d+),(?P<dx>\d+))?$')),
+    ('maxpool', re.compile(r'^Mp' + _RE_NAME + r'(?P<ky>\d+),(?P<kx>\d+)(?:,(?P<sy>\d+),(?P<sx>\d+))?$')),
+    ('groupnorm', re.compile(r'^Gn' + _RE_NAME + r'(?P<groups>\d+)$')),
+    ('dropout', re.compile(r'^Do' + _RE_NAME + r'(?P<p>\d+(?:\.\d*)?|\.\d+)?(?:,(?P<dim>\d+))?$')),
+    ('reshape', re.compile(r'^S' + _RE_NAME + r'(?P<dim>\d+)\((?P<a>\d+)x(?P<b>\d+)\)(?P<high>\d+),(?P<low>\d+)$')),
+    ('rnn', re.compile(r'^(?P<cell>L|G)(?P<dir>f|r|b)(?P<axis>x|y)(?P<sum>s)?(?P<legacy>c|o)?' + _RE_NAME +
+                       r'(?P<out>\d+)$')),
+    ('output', re.compile(r'^O' + _RE_NAME + r'(?P<dim>[012])(?P<type>l|s|c)(?P<aug>a)?(?P<out>\d+)$')),
+]
+_TYPE_TAG = {'conv': 'C', 'maxpool': 'Mp', 'groupnorm': 'Gn', 'dropout': 'Do', 'reshape': 'S', 'output': 'O'}
+
+
+def _floor_out(size: int, k: int, s: int, d: int = 1, p: int = 0) -> int:
+    """Output extent of a conv / pool window along one axis (0 stays variable)."""
+    if size == 0:
+        return 0
+    return int(math.floor((size + 2 * p - d * (k - 1) - 1) / s + 1))
+
+
+def _named_block(block: str, name: str) -> str:
+    """'Cr3,13,32' + 'C_0' -> 'Cr{C_0}3,13,32' (what the reference stores in named_spec)."""
+    block = re.sub(r'\{.+\}', '', block)
+    m = re.match(r'^[^\d]+', block)
+    head = m.group(0) if m else ''
+    return f'{head}{{{name}}}{block[len(head):]}'
+
+
+def parse_vgsl(spec: str):
+    """
+    Parses a sequential VGSL spec into the input 4-tuple (batch, channels, height, width)
+    and a list of LayerSpec.  Grammar: SURVEY.md Appendix A (reference model.py:579-817).
+    Raises ValueError for malformed specs and NotImplementedError for valid VGSL the
+    HIP executor does not cover (parallel blocks, transposed conv, y-axis/summarising/legacy
+    RNNs, addition, wav2vec masking).
+    """
+    spec = spec.strip()
+    if not spec or spec[0] != '[' or spec[-1] != ']':
+        raise ValueError('Non-sequential models not supported')
+    blocks = spec[1:-1].split(' ')
+    m = _RE_INPUT.match(blocks[0])
+    if not m:
+        raise ValueError('Invalid input spec.')
+    batch, height, width, channels = (int(v) for v in m.groups())
+    shape = (batch, channels, height, width)
+    layers: list[LayerSpec] = []
+    idx = -1
+    for block in blocks[1:]:
+        if not block:
+            raise ValueError(' invalid layer definition')
+        if block[0] in '[(' or block[-1] in '])':
+            raise NotImplementedError(f'nested/parallel VGSL block "{block}" is not supported by the HIP executor')
+        hit = None
+        for kind, rx in _GRAMMAR:
+            mm = rx.match(block)
+            if mm:
+                hit = (kind, mm)
+                break
+        if hit is None:
+            if re.match(r'^(A|I|W)', block):
+                raise NotImplementedError(f'VGSL block "{block}" is not supported by the HIP executor')
+            raise ValueError(f'{block} invalid layer definition')
+        kind, mm = hit
+        idx += 1
+        g = mm.groupdict()
+        tag = g['cell'] if kind == 'rnn' else _TYPE_TAG[kind]
+        name = g.get('name') or f'{tag}_{idx}'
+        n, c, h, w = shape
+        p: dict[str, Any] = {}
+        if kind == 'conv':
+            if g['trans']:
+                raise NotImplementedError('transposed convolutions are not supported by the HIP executor')
+            if g['nl'] == 'm':
+                raise NotImplementedError('softmax-activated convolutions are not supported by the HIP executor')
+            ky, kx, out = int(g['ky']), int(g['kx']), int(g['out'])
+            sy, sx = (int(g['sy']), int(g['sx'])) if g['sx'] else (1, 1)
+            dy, dx = (int(g['dy']), int(g['dx'])) if g['dx'] else (1, 1)
+            p = dict(kernel=(ky, kx), out=out, stride=(sy, sx), dilation=(dy, dx), nl=g['nl'],
+                     padding=((dy * (ky - 1)) // 2, (dx * (kx - 1)) // 2))
+            oshape = (n, out, _floor_out(h, ky, sy, dy, p['padding'][0]), _floor_out(w, kx, sx, dx, p['padding'][1]))
+        elif kind == 'maxpool':
+            ky, kx = int(g['ky']), int(g['kx'])
+            sy, sx = (int(g['sy']), int(g['sx'])) if g['sx'] else (ky, kx)
+            p = dict(kernel=(ky, kx), stride=(sy, sx))
+            oshape = (n, c, _floor_out(h, ky, sy), _floor_out(w, kx, sx))
+        elif kind == 'groupnorm':
+            p = dict(groups=int(g['groups']))
+            oshape = shape
+        elif kind == 'dropout':
+            p = dict(p=float(g['p']) if g['p'] else 0.5, dim=int(g['dim']) if g['dim'] else 1)
+            oshape = shape
+        elif kind == 'reshape':
+            src, a, b, high, low = int(g['dim']), int(g['a']), int(g['b']), int(g['high']), int(g['low'])
+            if src != high and src != low:
+                raise ValueError(f'Either high ({high}) or low ({low}) must be source dimension ({src})')
+            if a == 0 and b == 0:
+                raise ValueError('Only one size may be -1')
+            # the only form on the recognition path: fold height into channels, S1(1x0)1,3
+            # (feature index h*C + c)
+            if not (src == 1 and high == 1 and low == 3 and b == 0 and a == 1) or h == 0:
+                raise NotImplementedError(f'reshape "{block}" is not supported by the HIP executor '
+                                          '(only the height->channel collapse S1(1x0)1,3)')
+            p = dict(src=src, a=a, b=b, high=high, low=low)
+            # the reference derives this shape from a dummy tensor with variable dims set to 1
+            oshape = (n or 1, c * h, 1, w or 1)
+        elif kind == 'rnn':
+            if g['axis'] == 'y' or g['sum'] or g['legacy']:
+                raise NotImplementedError(f'RNN variant "{block}" (y-axis / summarising / legacy) is not supported '
+                                          'by the HIP executor')
+            hidden = int(g['out'])
+            p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'])
+            oshape = (n, hidden * (2 if g['dir'] == 'b' else 1), h, w)
+        else:  # output
+            dim, typ, out = int(g['dim']), g['type'], int(g['out'])
+            if dim == 0:
+                raise ValueError('categorical output not supported, yet.')
+            if typ == 'c' and dim == 2:
+                raise ValueError('CTC not supported for heatmap output')
+            if g['aug']:
+                raise NotImplementedError('1-augmented output layers are not supported by the HIP executor')
+            if dim == 2:
+                if typ != 'l':
+                    raise NotImplementedError('softmax heatmap outputs are not supported by the HIP executor')
+                kind = 'conv'   # 1x1 ActConv2D with (skipped) sigmoid, reference model.py:806-811
+                p = dict(kernel=(1, 1), out=out, stride=(1, 1), dilation=(1, 1), nl='s', padding=(0, 0),
+                         output_type=typ)
+            else:
+                kind = 'linear'
+                p = dict(out=out, output_type=typ)
+            oshape = (n, out, h, w)
+        layers.append(LayerSpec(kind, name, _named_block(block, name), p, shape, oshape))
+        shape = oshape
+    return (batch, channels, height, width), layers
+
+
+# ------------------------------------------------------------------ parameter containers
+# Module/attribute names below are part of the on-disk format (state-dict keys).
+class _ConvHolder(nn.Module):
+    def __init__(self, spec: LayerSpec):
+        super().__init__()
+        p = spec.params
+        self.co = nn.Conv2d(spec.in_shape[1], p['out'], p['kernel'], stride=p['stride'],
+                            padding=p['padding'], dilation=p['dilation'])
+
+
+class _GroupNormHolder(nn.Module):
+    def __init__(self, spec: LayerSpec):
+        super().__init__()
+        self.layer = nn.GroupNorm(spec.params['groups'], spec.in_shape[1])
+
+
+class _RnnHolder(nn.Module):
+    def __init__(self, spec: LayerSpec):
+        super().__init__()
+        self.layer = nn.LSTM(spec.in_shape[1], spec.params['hidden'],
+                             bidirectional=spec.params['direction'] == 'b', batch_first=True, bias=True)
+
+
+class _LinearHolder(nn.Module):
+    def __init__(self, spec: LayerSpec):
+        super().__init__()
+        self.lin = nn.Linear(spec.in_shape[1], spec.params['out'])
+
+
+class _NoParams(nn.Module):
+    pass
+
+
+_HOLDERS = {'conv': _ConvHolder, 'groupnorm': _GroupNormHolder, 'rnn': _RnnHolder, 'linear': _LinearHolder}
+_ACTS = {'l': _lib.ACT_LINEAR, 'r': _lib.ACT_RELU, 't': _lib.ACT_TANH, 'lr': _lib.ACT_LEAKY, 's': _lib.ACT_SIGMOID}
+_DIRS = {'f': _lib.DIR_FWD, 'r': _lib.DIR_REV, 'b': _lib.DIR_BIDI}
+
+
+def _f32(t: torch.Tensor) -> np.ndarray:
+    return np.ascontiguousarray(t.detach().to('cpu', torch.float32).numpy())
+
+
+class _Plan:
+    """Owns one ``krk_plan`` handle (weights repacked + uploaded by the C library)."""
+
+    def __init__(self, specs: Sequence[LayerSpec], modules: 'HipSequential', in_channels: int, in_height: int,
+                 device: int, precision: int = _lib.PREC_F32):
+        lib = _lib.load()
+        _lib.require_gpu()
+        descs, keep = [], []
+        for spec in specs:
+            if spec.kind == 'dropout':
+                continue   # identity in eval mode (reference layers.py:433-437)
+            d = _lib.KrkLayer()
+            mod = getattr(modules, spec.name)
+            arrays: list[np.ndarray] = []
+            p = spec.params
+            if spec.kind == 'conv':
+                d.op = _lib.OP_CONV
+                d.cout = p['out']
+                d.kh, d.kw = p['kernel']
+                d.sh, d.sw = p['stride']
+                d.dh, d.dw = p['dilation']
+                d.act = _ACTS[p['nl']]
+                arrays = [_f32(mod.co.weight), _f32(mod.co.bias)]
+            elif spec.kind == 'maxpool':
+                d.op = _lib.OP_MAXPOOL
+                d.kh, d.kw = p['kernel']
+                d.sh, d.sw = p['stride']
+            elif spec.kind == 'groupnorm':
+                d.op = _lib.OP_GROUPNORM
+                d.cout = p['groups']
+                arrays = [_f32(mod.layer.weight), _f32(mod.layer.bias)]
+            elif spec.kind == 'reshape':
+                d.op = _lib.OP_RESHAPE_HC
+            elif spec.kind == 'rnn':
+                d.op = _lib.OP_LSTM
+                d.cout = p['hidden']
+                d.direction = _DIRS[p['direction']]
+                sfx = [''] + (['_reverse'] if p['direction'] == 'b' else [])
+                for s in sfx:
+                    arrays += [_f32(getattr(mod.layer, f'weight_ih_l0{s}')), _f32(getattr(mod.layer, f'weight_hh_l0{s}')),
+                               _f32(getattr(mod.layer, f'bias_ih_l0{s}')), _f32(getattr(mod.layer, f'bias_hh_l0{s}'))]
+            elif spec.kind == 'linear':
+                d.op = _lib.OP_LINEAR
+                d.cout = p['out']
+                arrays = [_f32(mod.lin.weight), _f32(mod.lin.bias)]
+            else:
+                raise NotImplementedError(f'layer kind {spec.kind} is not supported by the HIP executor')
+            for i, a in enumerate(arrays):
+                d.w[i] = a.ctypes.data
+            keep.append(arrays)
+            descs.append(d)
+        arr = (_lib.KrkLayer * len(descs))(*descs)
+        handle = C.c_void_p()
+        _lib.check(lib.krk_plan_create(arr, len(descs), in_channels, in_height, precision, device, C.byref(handle)))
+        self.handle = handle
+        self.device = device
+        self._lib = lib
+
+    def out_shape(self, W: int):
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._lib.krk_plan_out_shape(self.handle, W, C.byref(c), C.byref(h), C.byref(w)))
+        return c.value, h.value, w.value
+
+    def olens(self, lens: np.ndarray) -> np.ndarray:
+        out = np.empty_like(lens)
+        _lib.check(self._lib.krk_plan_olens(self.handle, lens.ctypes.data, len(lens), out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._lib.krk_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DecodedBatch:
+    """Host copy of the compact greedy-decode result of one batch (see krk_decode_out)."""
+
+    def __init__(self, labels, starts, ends, confs, counts):
+        self.labels, self.starts, self.ends, self.confs, self.counts = labels, starts, ends, confs, counts
+
+    def tuples(self) -> list[list[tuple[int, int, int, float]]]:
+        """The list-of-lists of (label, start, end, conf) that greedy_decoder returns."""
+        out = []
+        lab, st, en, cf = self.labels.tolist(), self.starts.tolist(), self.ends.tolist(), self.confs.tolist()
+        for n, k in enumerate(self.counts.tolist()):
+            out.append(list(zip(lab[n][:k], st[n][:k], en[n][:k], cf[n][:k])))
+        return out
+
+
+class HipSequential(nn.Module):
+    """
+    The ``nn`` operator: an ordered container of parameter holders (children named like the
+    reference's layers) whose ``forward(x, seq_lens)`` executes the HIP plan.
+    Counterpart of MultiParamSequential (reference layers.py:39-53).
+    """
+
+    def __init__(self, specs: Sequence[LayerSpec], input_shape):
+        super().__init__()
+        self._specs = list(specs)
+        self._input = tuple(input_shape)
+        for spec in specs:
+            self.add_module(spec.name, _HOLDERS[spec.kind](spec) if spec.kind in _HOLDERS else _NoParams())
+        self._plan: Optional[_Plan] = None
+        self._plan_key = None
+        self.precision = _lib.PREC_F32
+
+    # -- plan management -------------------------------------------------------------
+    def _weights_version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def invalidate(self):
+        if self._plan is not None:
+            self._plan.close()
+        self._plan = None
+        self._plan_key = None
+
+    def plan(self, device_index: int) -> _Plan:
+        key = (device_index, self.precision, self._weights_version())
+        if self._plan is None or self._plan_key != key:
+            self.invalidate()
+            # legacy [1,1,0,48]-style inputs keep the line height in the channel axis: C=48, H=1
+            _, c, h, _ = self._input
+            self._plan = _Plan(self._specs, self, c, h, device_index, self.precision)
+            self._plan_key = key
+        return self._plan
+
+    def _apply(self, fn, *args, **kwargs):
+        r = super()._apply(fn, *args, **kwargs)
+        self.invalidate()
+        return r
+
+    def __len__(self):
+        return len(self._specs)
+
+    # -- execution ---------------------------------------------------------------------
+    @staticmethod
+    def _device_index(x: Optional[torch.Tensor] = None) -> int:
+        _lib.require_gpu()
+        if x is not None and x.is_cuda:
+            return x.device.index if x.device.index is not None else torch.cuda.current_device()
+        return torch.cuda.current_device()
+
+    def _prep(self, x: torch.Tensor, seq_lens):
+        if x.dim() != 4:
+            raise ValueError(f'expected a (N, C, H, W) tensor, got shape {tuple(x.shape)}')
+        dev = self._device_index(x)
+        xd = x.detach().to(device=f'cuda:{dev}', dtype=torch.float32).contiguous()
+        lens = None
+        if seq_lens is not None:
+            lens = np.ascontiguousarray(torch.as_tensor(seq_lens).detach().cpu().numpy().astype(np.int32))
+            if lens.shape != (xd.shape[0],):
+                raise ValueError('seq_lens must have one entry per line')
+        return dev, xd, lens
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, seq_lens: Optional[torch.Tensor] = None, output_shape=None):
+        """
+        nn(x, seq_lens) -> (output, olens).  For a recogniser the output is the (N, C, 1, T)
+        logits tensor (a permuted view of the time-major buffer the kernels write) on the GPU.
+        """
+        dev, xd, lens = self._prep(x, seq_lens)
+        plan = self.plan(dev)
+        N, _, _, W = xd.shape
+        c, h, w = plan.out_shape(W)
+        seq_out = self._specs_out_is_seq()
+        with torch.cuda.device(dev):
+            out = torch.empty((N, w, c) if seq_out else (N, c, h, w), dtype=torch.float32, device=xd.device)
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(plan._lib.krk_forward(plan.handle, xd.data_ptr(), lens.ctypes.data if lens is not None else None,
+                                             N, W, stream, out.data_ptr()))
+        olens = None
+        if lens is not None:
+            olens = torch.from_numpy(plan.olens(lens))
+        if seq_out:
+            out = out.permute(0, 2, 1).unsqueeze(2)
+        return out, olens
+
+    def _specs_out_is_seq(self) -> bool:
+        for spec in reversed(self._specs):
+            if spec.kind == 'dropout':
+                continue
+            if spec.kind in ('rnn', 'linear', 'reshape'):
+                return True
+            return False
+        return False
+
+    @torch.no_grad()
+    def recognize(self, x: torch.Tensor, seq_lens=None, temperature: float = 1.0, want_logits: bool = False,
+                  want_probs: bool = False):
+        """
+        Fused forward + softmax + CTC best-path decode (krk_recognize).
+        Returns (DecodedBatch, olens ndarray, logits or None, probs or None); logits/probs are
+        (N, C, T) permuted views on the GPU.
+        """
+        dev, xd, lens = self._prep(x, seq_lens)
+        plan = self.plan(dev)
+        N, _, _, W = xd.shape
+        c, h, T = plan.out_shape(W)
+        with torch.cuda.device(dev):
+            d = xd.device
+            i32 = dict(dtype=torch.int32, device=d)
+            labels, starts, ends = (torch.empty((N, T), **i32) for _ in range(3))
+            confs = torch.empty((N, T), dtype=torch.float32, device=d)
+            counts = torch.empty((N,), **i32)
+            logits = torch.empty((N, T, c), dtype=torch.float32, device=d) if want_logits else None
+            probs = torch.empty((N, T, c), dtype=torch.float32, device=d) if want_probs else None
+            olens = np.empty((N,), dtype=np.int32)
+            dec = _lib.KrkDecodeOut(labels.data_ptr(), starts.data_ptr(), ends.data_ptr(), confs.data_ptr(),
+                                    counts.data_ptr(), T)
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(plan._lib.krk_recognize(plan.handle, xd.data_ptr(),
+                                               lens.ctypes.data if lens is not None else None, N, W,
+                                               float(temperature), stream,
+                                               logits.data_ptr() if want_logits else None,
+                                               probs.data_ptr() if want_probs else None,
+                                               olens.ctypes.data, C.byref(dec)))
+            packed = torch.stack([labels, starts, ends, confs.view(torch.int32)]).cpu().numpy()
+            cnt = counts.cpu().numpy()
+        batch = DecodedBatch(packed[0], packed[1], packed[2], packed[3].view(np.float32), cnt)
+        return (batch, olens,
+                logits.permute(0, 2, 1) if want_logits else None,
+                probs.permute(0, 2, 1) if want_probs else None)
+
+
+# ------------------------------------------------------------------------------ the model
+class TorchVGSLModel(nn.Module):
+    """
+    Drop-in counterpart of kraken.lib.vgsl.TorchVGSLModel for recognition inference.
+    See the module docstring for the mirrored surface.
+    """
+    _kraken_min_version = '5.0.0'
+
+    def __init__(self, **kwargs) -> None:
+        super().__init__()
+        if (vgsl := kwargs.pop('vgsl', None)) is None:
+            raise ValueError('vgsl specification argument is missing in args.')
+        self.spec = vgsl
+        self.user_metadata: dict[str, Any] = {'accuracy': [], 'metrics': [], 'seg_type': None,
+                                              'one_channel_mode': None, 'model_type': []}
+        codec = kwargs.get('codec', None)
+        self.user_metadata.update(**kwargs)
+        (batch, channels, height, width), specs = parse_vgsl(vgsl)
+        self.input = (batch, channels, height, width)
+        self.layer_specs = specs
+        self.nn = HipSequential(specs, self.input)
+        self.output = specs[-1].out_shape if specs else self.input
+        self.named_spec = [vgsl.strip()[1:-1].split(' ')[0]] + [s.text for s in specs]
+        self.user_metadata['vgsl'] = '[' + ' '.join(self.named_spec) + ']'
+        self.criterion = None
+        if specs and specs[-1].params.get('output_type') == 'c':
+            self.criterion = nn.CTCLoss(reduction='sum', zero_infinity=True)
+        if codec is not None:
+            self.add_codec(codec if isinstance(codec, PytorchCodec) else PytorchCodec(codec))
+        self.init_weights()
+        self.eval()
+
+    # -- initialisation (reference model.py:450-479) ------------------------------------
+    def init_weights(self) -> None:
+        """LSTM orthogonal (+ forget-gate bias 1), conv U(-0.1, 0.1), linear Xavier-uniform with zero
+        bias -- applied module by module in registration order like the reference's ``apply``."""
+        def _init(m):
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight.data)
+                nn.init.constant_(m.bias.data, 0)
+            elif isinstance(m, nn.LSTM):
+                for p in m.parameters():
+                    if p.data.dim() == 2:
+                        nn.init.orthogonal_(p.data)
+                    else:
+                        nn.init.constant_(p.data[len(p) // 4:len(p) // 2], 1.0)
+            elif isinstance(m, nn.Conv2d):
+                for p in m.parameters():
+                    nn.init.uniform_(p.data, -0.1, 0.1)
+        self.nn.apply(_init)
+        self.nn.invalidate()
+
+    def add_codec(self, codec: PytorchCodec) -> None:
+        self.codec = codec
+        self.user_metadata['codec'] = json.dumps(self.codec.c2l)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.nn.invalidate()
+        return r
+
+    def forward(self, x: torch.Tensor, seq_lens: Optional[torch.Tensor] = None):
+        return self.nn(x, seq_lens)
+
+    # -- metadata properties (reference model.py:343-398) -------------------------------
+    @property
+    def one_channel_mode(self):
+        return self.user_metadata['one_channel_mode']
+
+    @one_channel_mode.setter
+    def one_channel_mode(self, val):
+        if val not in ['1', 'L', None]:
+            raise ValueError('one_channel_mode {} is not one of [1, L, None]'.format(val))
+        self.user_metadata['one_channel_mode'] = val
+
+    @property
+    def model_type(self):
+        mt = self.user_metadata.get('model_type', [])
+        return [mt] if isinstance(mt, str) else mt
+
+    @model_type.setter
+    def model_type(self, val):
+        if isinstance(val, str):
+            val = [val]
+        for v in val:
+            if v not in ['recognition', 'segmentation']:
+                raise ValueError('model_type {} is not one of [recognition, segmentation]'.format(v))
+        self.user_metadata['model_type'] = val
+
+    @property
+    def seg_type(self):
+        return self.user_metadata.get('seg_type', None)
+
+    @seg_type.setter
+    def seg_type(self, val):
+        if val not in ['bbox', 'baselines', None]:
+            raise ValueError('segmentation type {} is not one of [bbox, baselines, None]'.format(val))
+        self.user_metadata['seg_type'] = val
+
+    @property
+    def hyper_params(self):
+        return self.user_metadata['hyper_params']
+
+    @hyper_params.setter
+    def hyper_params(self, val: dict):
+        self.user_metadata.setdefault('hyper_params', {}).update(val)
+
+    @property
+    def use_legacy_polygons(self):
+        return self.user_metadata.get('legacy_polygons', True)
+
+    @use_legacy_polygons.setter
+    def use_legacy_polygons(self, val: bool):
+        self.user_metadata['legacy_polygons'] = val
+
+    # -- model files ----------------------------------------------------------------------
+    @classmethod
+    def load_model(cls, path):
+        """Loads a CoreML (.mlmodel) or safetensors model file written by kraken."""
+        from .io import load_model_file
+        return load_model_file(path, cls)

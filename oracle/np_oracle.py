@@ -1,0 +1,265 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain numpy (fp32) restatement of the arithmetic of kraken's line-recognition hot path,
+written from the reference's semantics, one function per reference call site.  It exists only
+to check the HIP kernels: it may be imported by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` and by nothing else; the product package ``kraken_amd``
+never imports it and has no CPU path.
+
+Where the arithmetic lives: the reference delegates it to PyTorch (un-vendored dependency,
+``pyproject.toml:43`` ``torch>=2.4.0,<=2.12``; this image: torch 2.10.0) through the wrappers
+in ``kraken/lib/vgsl/layers.py``.  The published semantics of torch.nn.Conv2d / MaxPool2d /
+GroupNorm / LSTM / Linear / softmax are restated here.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function below against the golden vectors
+in ``tests/golden/*.npz``, which were produced by running the UNMODIFIED reference modules
+(``/root/reference/kraken``) on CPU -- generator committed as ``tests/golden/make_golden.py`` --
+including the reference's own known-answer strings of ``tests/test_rpred.py:352-462``.
+Parity status: pinned (fp32, tolerance 2e-4 on logits; identical label tuples).
+
+Semantics for ragged batches: masked padding (see include/kraken_amd.h) -- equal to the
+reference's per-line (batch = 1, lens = None) results, which is what the golden vectors hold.
+"""
+import math
+from itertools import groupby
+
+import numpy as np
+
+F32 = np.float32
+
+
+# ------------------------------------------------------------------ length propagation
+def conv_out_len(L, k, s, d, p):
+    """ActConv2D.forward seq_len update, kraken/lib/vgsl/layers.py:858-859 (clamp min 1)."""
+    return max(int(math.floor((L + 2 * p - d * (k - 1) - 1) / s + 1)), 1)
+
+
+def pool_out_len(L, k, s):
+    """MaxPool.forward seq_len update, kraken/lib/vgsl/layers.py:387."""
+    return int(math.floor((L - (k - 1) - 1) / s + 1))
+
+
+def _extent(size, k, s, d=1, p=0):
+    return int(math.floor((size + 2 * p - d * (k - 1) - 1) / s + 1))
+
+
+# ------------------------------------------------------------------------------ layers
+def conv2d(x, w, b, stride=(1, 1), dilation=(1, 1), act='l'):
+    """
+    ActConv2D.forward, kraken/lib/vgsl/layers.py:842-860: torch.nn.Conv2d (cross-correlation) with
+    padding ((dh*(kh-1))//2, (dw*(kw-1))//2) (:803) + bias + activation; 's' (sigmoid) is skipped
+    in forward (:850-852).  x (N,Cin,H,W), w (Cout,Cin,kh,kw).
+    """
+    x = np.asarray(x, F32)
+    N, Cin, H, W = x.shape
+    Cout, _, kh, kw = w.shape
+    sh, sw = stride
+    dh, dw = dilation
+    ph, pw = (dh * (kh - 1)) // 2, (dw * (kw - 1)) // 2
+    Ho, Wo = _extent(H, kh, sh, dh, ph), _extent(W, kw, sw, dw, pw)
+    xp = np.zeros((N, Cin, H + 2 * ph, W + 2 * pw), F32)
+    xp[:, :, ph:ph + H, pw:pw + W] = x
+    out = np.zeros((N, Cout, Ho, Wo), F32)
+    wmat = w.reshape(Cout, Cin, kh * kw).astype(F32)
+    for dy in range(kh):
+        for dx in range(kw):
+            patch = xp[:, :, dy * dh: dy * dh + (Ho - 1) * sh + 1: sh, dx * dw: dx * dw + (Wo - 1) * sw + 1: sw]
+            out += np.einsum('oc,nchw->nohw', wmat[:, :, dy * kw + dx], patch, optimize=True).astype(F32)
+    out += np.asarray(b, F32)[None, :, None, None]
+    if act == 'r':
+        out = np.maximum(out, 0)
+    elif act == 't':
+        out = np.tanh(out)
+    elif act == 'lr':
+        out = np.where(out > 0, out, F32(0.01) * out)
+    elif act not in ('l', 's'):
+        raise NotImplementedError(act)
+    return out.astype(F32)
+
+
+def maxpool2d(x, kernel, stride):
+    """MaxPool.forward, kraken/lib/vgsl/layers.py:381-388: torch.nn.MaxPool2d(k, s), no padding, floor."""
+    N, C, H, W = x.shape
+    kh, kw = kernel
+    sh, sw = stride
+    Ho, Wo = _extent(H, kh, sh), _extent(W, kw, sw)
+    out = np.full((N, C, Ho, Wo), -np.inf, F32)
+    for i in range(kh):
+        for j in range(kw):
+            out = np.maximum(out, x[:, :, i: i + (Ho - 1) * sh + 1: sh, j: j + (Wo - 1) * sw + 1: sw])
+    return out
+
+
+def groupnorm(x, gamma, beta, groups, lens=None, eps=1e-5):
+    """
+    GroupNorm.forward, kraken/lib/vgsl/layers.py:967-984: fp32, statistics per (sample, group);
+    with seq_len given and any len < W each sample is normalised over its first len columns only
+    and the rest stays zero (:979-984).
+    """
+    x = np.asarray(x, F32)
+    N, C, H, W = x.shape
+    out = np.zeros_like(x)
+    for n in range(N):
+        L = W if lens is None else min(max(int(lens[n]), 1), W)
+        xs = x[n, :, :, :L].reshape(groups, -1).astype(np.float64)
+        mean = xs.mean(axis=1, keepdims=True)
+        var = xs.var(axis=1, keepdims=True)
+        y = ((xs - mean) / np.sqrt(var + eps)).reshape(C, H, L)
+        out[n, :, :, :L] = (y * gamma[:, None, None] + beta[:, None, None]).astype(F32)
+    return out
+
+
+def reshape_hc(x):
+    """Reshape.forward for S1(1x0)1,3, kraken/lib/vgsl/layers.py:313-335: (N,C,H,W)->(N,H*C,1,W), feature h*C+c."""
+    N, C, H, W = x.shape
+    return np.ascontiguousarray(x.transpose(0, 2, 1, 3).reshape(N, H * C, 1, W))
+
+
+def _sigmoid(v):
+    return (1.0 / (1.0 + np.exp(-v))).astype(F32)
+
+
+def lstm(x, weights, hidden, direction='b', lens=None):
+    """
+    TransposedSummarizingRNN.forward, kraken/lib/vgsl/layers.py:513-547, for L{f,r,b}x on an input of
+    height 1: torch.nn.LSTM(batch_first, 1 layer) over the width axis with pack_padded_sequence /
+    pad_packed_sequence when lens is given.  Gates in torch order i,f,g,o;
+    c' = sig(f) c + sig(i) tanh(g); h' = sig(o) tanh(c'); the reverse direction starts at each
+    line's own last valid step; padded outputs are 0.
+    x (N,C,1,W) -> (N, D*hidden, 1, W).  weights: list per direction of (w_ih, w_hh, b_ih, b_hh).
+    """
+    N, Cin, Hh, W = x.shape
+    assert Hh == 1
+    seq = x[:, :, 0, :].transpose(0, 2, 1).astype(F32)   # (N, W, C)
+    dirs = {'f': [False], 'r': [True], 'b': [False, True]}[direction]
+    out = np.zeros((N, W, hidden * len(dirs)), F32)
+    for d, rev in enumerate(dirs):
+        w_ih, w_hh, b_ih, b_hh = (np.asarray(a, F32) for a in weights[d])
+        xp = (seq.reshape(-1, Cin) @ w_ih.T + b_ih).reshape(N, W, 4 * hidden).astype(F32)
+        for n in range(N):
+            L = W if lens is None else int(lens[n])
+            h = np.zeros(hidden, F32)
+            c = np.zeros(hidden, F32)
+            steps = range(L - 1, -1, -1) if rev else range(L)
+            for t in steps:
+                g = xp[n, t] + (w_hh @ h + b_hh).astype(F32)
+                i, f, gg, o = g[:hidden], g[hidden:2 * hidden], g[2 * hidden:3 * hidden], g[3 * hidden:]
+                c = _sigmoid(f) * c + _sigmoid(i) * np.tanh(gg).astype(F32)
+                h = _sigmoid(o) * np.tanh(c).astype(F32)
+                out[n, t, d * hidden:(d + 1) * hidden] = h
+    return np.ascontiguousarray(out.transpose(0, 2, 1))[:, :, None, :]
+
+
+def linear(x, w, b):
+    """LinSoftmax.forward, kraken/lib/vgsl/layers.py:710-722: Linear over the channel axis; logits, no softmax."""
+    N, C, H, W = x.shape
+    y = np.einsum('oc,nchw->nohw', np.asarray(w, F32), x.astype(F32), optimize=True) + np.asarray(b, F32)[None, :, None, None]
+    return y.astype(F32)
+
+
+def mask_width(x, lens):
+    """Masked-padding rule: zero every column >= the line's valid width."""
+    if lens is None:
+        return x
+    x = x.copy()
+    for n, L in enumerate(lens):
+        x[n, ..., max(int(L), 0):] = 0
+    return x
+
+
+# --------------------------------------------------------------------------- whole network
+def forward(specs, sd, x, lens=None):
+    """
+    MultiParamSequential.forward, kraken/lib/vgsl/layers.py:44-53, with masked-padding semantics.
+    `specs`: list of objects with .kind/.name/.params (kraken_amd.vgsl.parse_vgsl output);
+    `sd`: state dict {key: ndarray} with the reference's key names.
+    Returns (output (N,C,H,W') float32, olens list or None).
+    """
+    x = np.asarray(x, F32)
+    cur = None if lens is None else [int(v) for v in lens]
+    x = mask_width(x, cur)
+    for sp in specs:
+        k, p, nm = sp.kind, sp.params, sp.name
+        if k == 'dropout':
+            continue                                      # identity in eval, layers.py:433-437
+        if k == 'conv':
+            x = conv2d(x, sd[f'nn.{nm}.co.weight'], sd[f'nn.{nm}.co.bias'], p['stride'], p['dilation'], p['nl'])
+            if cur is not None:
+                cur = [conv_out_len(L, p['kernel'][1], p['stride'][1], p['dilation'][1], p['padding'][1]) for L in cur]
+        elif k == 'maxpool':
+            x = maxpool2d(x, p['kernel'], p['stride'])
+            if cur is not None:
+                cur = [pool_out_len(L, p['kernel'][1], p['stride'][1]) for L in cur]
+        elif k == 'groupnorm':
+            x = groupnorm(x, sd[f'nn.{nm}.layer.weight'], sd[f'nn.{nm}.layer.bias'], p['groups'], cur)
+        elif k == 'reshape':
+            x = reshape_hc(x)
+        elif k == 'rnn':
+            ws = []
+            for sfx in [''] + (['_reverse'] if p['direction'] == 'b' else []):
+                ws.append(tuple(sd[f'nn.{nm}.layer.{w}_l0{sfx}'] for w in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')))
+            x = lstm(x, ws, p['hidden'], p['direction'], cur)
+        elif k == 'linear':
+            x = linear(x, sd[f'nn.{nm}.lin.weight'], sd[f'nn.{nm}.lin.bias'])
+        else:
+            raise NotImplementedError(k)
+        if k not in ('linear',):
+            x = mask_width(x, cur)
+    return x, cur
+
+
+# ---------------------------------------------------------------------- softmax + decode
+def softmax_c(logits, temperature=1.0):
+    """`(logits / T).softmax(1)`, kraken/lib/vgsl/rpred.py:226 and kraken/lib/models.py:115. logits (N,C,T)."""
+    z = np.asarray(logits, F32) / F32(temperature)
+    z = z - z.max(axis=1, keepdims=True)
+    e = np.exp(z).astype(F32)
+    return (e / e.sum(axis=1, keepdims=True, dtype=F32)).astype(F32)
+
+
+def greedy_decode(outputs, seq_lens=None):
+    """
+    greedy_decoder, kraken/lib/ctc_decoder.py:35-72: per line argmax/max over classes for the valid
+    steps, runs of equal labels collapsed, blank (0) dropped; tuples (label, first step, last step
+    INCLUSIVE, max confidence of the run).  Ties resolve to the lowest class index.
+    """
+    outputs = np.asarray(outputs)
+    if outputs.ndim == 2:
+        outputs = outputs[None]
+    if seq_lens is None:
+        if outputs.shape[0] != 1:
+            raise ValueError('seq_lens need to be set for batch decoding.')
+        seq_lens = [outputs.shape[-1]]
+    dec = []
+    for seq, L in zip(outputs, seq_lens):
+        L = int(L)
+        labels = seq[:, :L].argmax(axis=0)
+        confs = seq[:, :L].max(axis=0)
+        line, t = [], 0
+        for lab, grp in groupby(labels.tolist()):
+            n = len(list(grp))
+            if lab != 0:
+                line.append((lab, t, t + n - 1, float(confs[t:t + n].max())))
+            t += n
+        dec.append(line)
+    return dec
+
+
+def codec_decode(l2c, tuples):
+    """PytorchCodec.decode, kraken/lib/codec.py:148-195, for `l2c` = {label tuple: string}."""
+    out, i = [], 0
+    labs = tuple(int(t[0]) for t in tuples)
+    while i < len(labs):
+        hit = False
+        for key, s in l2c.items():
+            if labs[i:i + len(key)] == tuple(key):
+                grp = tuples[i:i + len(key)]
+                conf = grp[0][3] if len(key) == 1 else float(np.mean([g[3] for g in grp]))
+                out.extend((ch, grp[0][1], grp[-1][2], conf) for ch in s)
+                i += len(key)
+                hit = True
+                break
+        if not hit:
+            i += 1
+    return out

@@ -1,0 +1,128 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+The reference's CPU path restated on the SAME library it uses: kraken's layer wrappers
+(``kraken/lib/vgsl/layers.py``) are thin shells around ``torch.nn`` modules, so this file calls
+the corresponding ``torch.nn.functional`` / ``torch.nn.LSTM`` operators (identical ATen CPU
+kernels, fp32) in the order ``MultiParamSequential.forward`` (layers.py:44-53) would, followed
+by ``(logits / T).softmax(1)`` (lib/models.py:115), the groupby best-path decode
+(lib/ctc_decoder.py:64-71) and the codec (lib/codec.py:148-195).
+
+It serves two purposes, both on the checker side only:
+  * the ``cpu_baseline`` of ``bench.py`` (kind "port": kraken's own PyTorch-CPU path cannot
+    travel to the GPU box because /root/reference does not exist there);
+  * a second, independent check of ``np_oracle``.
+It is pinned against the same golden vectors (``tests/test_oracle_golden.py``), bit-for-bit in
+the equal-width case because the operators are the reference's own.
+
+Two modes: ``reference_batched=True`` reproduces the reference's batched behaviour (padding is
+NOT masked between layers, exactly what kraken computes for a padded batch);
+``reference_batched=False`` applies the masked-padding rule (== per-line batch-1 results).
+"""
+from itertools import groupby
+
+import torch
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+_ACT = {'l': lambda v: v, 's': lambda v: v, 'r': torch.relu, 't': torch.tanh,
+        'lr': lambda v: F.leaky_relu(v, 0.01)}
+
+
+def _mask(x, lens):
+    if lens is None:
+        return x
+    W = x.shape[3]
+    keep = torch.arange(W)[None, :] < torch.as_tensor(lens)[:, None]
+    return x * keep[:, None, None, :].to(x.dtype)
+
+
+class CpuRecognizer:
+    """Executes a parsed VGSL layer list (kraken_amd.vgsl.parse_vgsl) with torch CPU operators."""
+
+    def __init__(self, specs, state_dict):
+        self.specs = [s for s in specs if s.kind != 'dropout']
+        self.sd = {k: torch.as_tensor(v).float() for k, v in state_dict.items()}
+        self.rnn = {}
+        for s in self.specs:
+            if s.kind == 'rnn':
+                m = torch.nn.LSTM(s.in_shape[1], s.params['hidden'], bidirectional=s.params['direction'] == 'b',
+                                  batch_first=True)
+                m.load_state_dict({k.split('.layer.')[1]: v for k, v in self.sd.items()
+                                   if k.startswith(f'nn.{s.name}.layer.')})
+                m.eval()
+                self.rnn[s.name] = m
+
+    @torch.inference_mode()
+    def forward(self, x, lens=None, reference_batched=False):
+        x = torch.as_tensor(x).float()
+        cur = None if lens is None else torch.as_tensor(lens).clone().int()
+        masked = cur is not None and not reference_batched
+        if masked:
+            x = _mask(x, cur)
+        for s in self.specs:
+            p, nm = s.params, s.name
+            if s.kind == 'conv':        # layers.py:842-860
+                x = _ACT[p['nl']](F.conv2d(x, self.sd[f'nn.{nm}.co.weight'], self.sd[f'nn.{nm}.co.bias'],
+                                           p['stride'], p['padding'], p['dilation']))
+                if cur is not None:
+                    cur = torch.clamp(torch.floor((cur + 2 * p['padding'][1] - p['dilation'][1] * (p['kernel'][1] - 1) - 1)
+                                                  .float() / p['stride'][1] + 1), min=1).int()
+            elif s.kind == 'maxpool':   # layers.py:381-388
+                x = F.max_pool2d(x, p['kernel'], p['stride'])
+                if cur is not None:
+                    cur = torch.floor((cur - (p['kernel'][1] - 1) - 1).float() / p['stride'][1] + 1).int()
+            elif s.kind == 'groupnorm':  # layers.py:967-984
+                g, b = self.sd[f'nn.{nm}.layer.weight'], self.sd[f'nn.{nm}.layer.bias']
+                W = x.shape[3]
+                if cur is None or bool((cur >= W).all()):
+                    x = F.group_norm(x, p['groups'], g, b, 1e-5)
+                else:
+                    o = torch.zeros_like(x)
+                    for i, L in enumerate(cur.clamp(min=1, max=W).tolist()):
+                        o[i, ..., :L] = F.group_norm(x[i:i + 1, ..., :L], p['groups'], g, b, 1e-5)[0]
+                    x = o
+            elif s.kind == 'reshape':   # layers.py:313-335, S1(1x0)1,3
+                n, c, h, w = x.shape
+                x = x.permute(0, 2, 1, 3).reshape(n, h * c, 1, w)
+            elif s.kind == 'rnn':       # layers.py:513-547
+                n, c, h, w = x.shape
+                seq = x.permute(2, 0, 3, 1).reshape(h * n, w, c)
+                if cur is not None:
+                    packed = pack_padded_sequence(seq, cur.cpu().clamp(min=1), batch_first=True, enforce_sorted=False)
+                    o, _ = self.rnn[nm](packed)
+                    o, _ = pad_packed_sequence(o, batch_first=True, total_length=w)
+                else:
+                    o, _ = self.rnn[nm](seq)
+                x = o.reshape(h, n, w, -1).permute(1, 3, 0, 2)
+            elif s.kind == 'linear':    # layers.py:710-722
+                x = F.linear(x.transpose(1, 3), self.sd[f'nn.{nm}.lin.weight'], self.sd[f'nn.{nm}.lin.bias']).transpose(1, 3)
+            else:
+                raise NotImplementedError(s.kind)
+            if masked and s.kind != 'linear':
+                x = _mask(x, cur)
+        return x, cur
+
+    @torch.inference_mode()
+    def predict_labels(self, x, lens=None, temperature=1.0, reference_batched=False):
+        """forward + softmax + greedy_decoder, i.e. TorchSeqRecognizer.predict_labels (lib/models.py:151-158)."""
+        logits, olens = self.forward(x, lens, reference_batched)
+        probs = (logits / temperature).softmax(1).squeeze(2)
+        if olens is None:
+            olens = [probs.shape[2]] * probs.shape[0]
+        return greedy_decode(probs, olens)
+
+
+def greedy_decode(outputs, seq_lens):
+    """kraken/lib/ctc_decoder.py:64-71 on a torch tensor (N,C,T)."""
+    dec = []
+    for seq, L in zip(outputs, seq_lens):
+        L = int(L)
+        confs, labels = seq[..., :L].max(dim=0)
+        line = []
+        for lab, grp in groupby(zip(range(L), labels.tolist(), confs.tolist()), key=lambda v: v[1]):
+            grp = list(grp)
+            if lab != 0:
+                line.append((lab, grp[0][0], grp[-1][0], max(v[2] for v in grp)))
+        dec.append(line)
+    return dec
