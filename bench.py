@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""
+Benchmark of the kraken line-recognition hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (VGSL conv stack + 3 BiLSTM + linear + softmax + CTC
+best-path decode, label tuples copied back to the host) over ONE batch of 256 synthetic
+1x48x1200 line images per GPU (BASELINE.json configs[1]; BENCH-A spec of SURVEY.md section 8d, random-init
+weights `torch.manual_seed(0)`).  Inputs are resident in HBM before the timed region.  Ranks
+shard lines (weak scaling: 256 lines per rank per step) and the decoded label sequences are
+gathered on all ranks over RCCL after the last step of the timed region.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     : dominant kernel (the f32-MFMA implicit-GEMM convolution) -- algorithmic FLOPs of one
+                 launch / its mean duration from HIP events on its own stream, vs the f32 MFMA peak
+  cpu_baseline : the reference's PyTorch-CPU path (oracle/torch_port.py, kind "port") timed on this
+                 box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256, help='lines per GPU per step')
+    ap.add_argument('--width', type=int, default=1200)
+    ap.add_argument('--slots', type=int, default=2, help='batches in flight per GPU (streams)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-lines', type=int, default=32, help='lines in the CPU baseline sample')
+    return ap.parse_args()
+
+
+def cpu_baseline(model, width, n_lines, reps=2):
+    """kraken's CPU path (torch CPU operators + Python greedy decode + codec), bounded sample."""
+    from oracle.torch_port import CpuRecognizer
+    ref = CpuRecognizer(model.layer_specs, {k: v.cpu() for k, v in model.state_dict().items()})
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(n_lines, 1, 48, width, generator=g)
+    lens = [width] * n_lines
+    ref.predict_labels(x[:2], lens[:2])   # warm-up
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        tuples = ref.predict_labels(x, lens)
+        _ = [''.join(c for c, *_ in model.codec.decode(t)) for t in tuples]
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {'value': round(n_lines / best, 2), 'unit': 'lines/s', 'cores': torch.get_num_threads(),
+            'host_cpus': os.cpu_count(), 'kind': 'port',
+            'sample': f'{n_lines} lines 1x48x{width}, fp32, best of {reps}: torch-CPU forward + softmax + '
+                      f'groupby greedy decode + codec (oracle/torch_port.py = kraken lib/models.py:138-149)'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    import kraken_amd
+    from kraken_amd import _lib, dist as kdist
+    from kraken_amd.engine import RecognitionEngine
+    from tests.specs import BENCH_A, bench_codec
+
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f'cuda:{local_rank}')
+    if world > 1:
+        kdist.init(backend='nccl')
+
+    torch.manual_seed(0)
+    model = kraken_amd.TorchVGSLModel(vgsl=BENCH_A, codec=bench_codec())
+    model.to(dev)
+    N, W = args.batch, args.width
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand(N, 1, 48, W, generator=g).to(dev)    # resident in HBM before timing
+    engine = RecognitionEngine(model, device=local_rank, max_batch=N, max_width=W, slots=args.slots)
+
+    def run(steps):
+        last = None
+        for _ in range(steps):
+            if engine.free_slots() == 0:
+                last = engine.collect()
+            engine.submit(x)
+        while engine.free_slots() < len(engine.slots):
+            last = engine.collect()
+        return last
+
+    run(args.warmup)
+    engine.set_profiling(True)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    batch, olens = run(args.steps)
+    gathered = kdist.gather_decoded(batch, olens) if world > 1 else [batch]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel-group timing from the HIP events recorded inside the timed region
+    per_layer = {}
+    for slot_times in engine.layer_times():
+        for i, (name, ms, flops) in enumerate(slot_times):
+            e = per_layer.setdefault(i, {'name': name, 'ms': [], 'flops': flops})
+            e['ms'].append(ms)
+    layers = [{'i': i, 'name': v['name'], 'ms': float(np.mean(v['ms'])), 'gflop': v['flops'] / 1e9}
+              for i, v in sorted(per_layer.items())]
+    convs = [l for l in layers if l['name'] == 'conv']
+    dom = max(convs, key=lambda l: l['ms'])
+    ach = dom['gflop'] / dom['ms']   # GFLOP/ms == TFLOP/s
+    roofline = {'bound': 'mfma', 'kernel': f'conv_f32_kernel (layer {dom["i"]})', 'achieved': round(ach, 2),
+                'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                'traffic': None}
+
+    lines = N * args.steps * world
+    value = lines / dt
+    out = {
+        'metric': 'text lines/sec (whole node) at 48x1200px, VGSL CNN+BiLSTM+CTC',
+        'value': round(value, 1), 'unit': 'lines/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'BENCH-A VGSL recogniser (3.17M params, random init seed 0), {N} lines 1x48x{W} per GPU '
+                               f'per step, greedy CTC decode, label tuples to host', 'lines_per_gpu_step': N, 'width': W,
+                   'slots': args.slots, 'parallelism': f'dp{world}', 'whole_path_tflops': round(value * 2.778e-3 *
+                                                                                                 (W / 1200.0), 2)},
+        'roofline': roofline,
+        'layers': [{'name': l['name'], 'ms': round(l['ms'], 3), 'tflops': round(l['gflop'] / l['ms'], 1) if l['ms'] > 0 else 0}
+                   for l in layers],
+        'gathered_lines': int(sum(len(b.counts) for b in gathered)),
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(model, W, args.cpu_lines)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

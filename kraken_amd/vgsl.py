@@ -220,7 +220,9 @@ class _NoParams(nn.Module):
 
 _HOLDERS = {'conv': _ConvHolder, 'groupnorm': _GroupNormHolder, 'rnn': _RnnHolder, 'linear': _LinearHolder}
 _ACTS = {'l': _lib.ACT_LINEAR, 'r': _lib.ACT_RELU, 't': _lib.ACT_TANH, 'lr': _lib.ACT_LEAKY, 's': _lib.ACT_SIGMOID}
-_DIRS = {'f': _lib.DIR_FWD, 'r': _lib.DIR_REV, 'b': _lib.DIR_BIDI}
+# The reference builds nn.LSTM(bidirectional = direction == 'b') and never flips the sequence, so an
+# 'r' layer runs forward like 'f' (kraken/lib/vgsl/layers.py:496-511); mirrored here on purpose.
+_DIRS = {'f': _lib.DIR_FWD, 'r': _lib.DIR_FWD, 'b': _lib.DIR_BIDI}
 
 
 def _f32(t: torch.Tensor) -> np.ndarray:

@@ -132,7 +132,9 @@ def lstm(x, weights, hidden, direction='b', lens=None):
     N, Cin, Hh, W = x.shape
     assert Hh == 1
     seq = x[:, :, 0, :].transpose(0, 2, 1).astype(F32)   # (N, W, C)
-    dirs = {'f': [False], 'r': [True], 'b': [False, True]}[direction]
+    # NB: the reference builds nn.LSTM(bidirectional = direction == 'b') and never flips the input, so
+    # 'r' ("reverse") runs FORWARD exactly like 'f' (layers.py:496-511) -- restated as is.
+    dirs = {'f': [False], 'r': [False], 'b': [False, True], 'rev': [True]}[direction]
     out = np.zeros((N, W, hidden * len(dirs)), F32)
     for d, rev in enumerate(dirs):
         w_ih, w_hh, b_ih, b_hh = (np.asarray(a, F32) for a in weights[d])

@@ -1,0 +1,331 @@
+#!/usr/bin/env python
+"""
+Generates the golden fixtures in this directory by running the UNMODIFIED reference
+(mittagessen/kraken mounted at /root/reference) on CPU, fp32.  Run in the authoring container:
+
+    python tests/golden/make_golden.py
+
+Nothing here runs on the GPU box; the fixtures travel instead.  What is pinned:
+
+  overfit.npz      the reference's own known-answer test (tests/test_rpred.py:352-358, :453-462):
+                   weights of tests/resources/overfit.mlmodel (read with kraken_amd.io, validated by
+                   reproducing the test's exact strings through the reference's TorchVGSLModel +
+                   TorchSeqRecognizer + rpred), the preprocessed line tensor, logits, softmax
+                   outputs, greedy_decoder tuples, codec output and the expected strings.
+  bench_a.npz      BENCH-A, torch.manual_seed(0) + TorchVGSLModel init: state-dict digests,
+  bench_b.npz      input digests, logits of selected lines, per-step argmax / max-prob and
+                   greedy_decoder tuples for equal-width batches, and per-line (batch = 1) results for
+                   the ragged widths {401, 613, 800} -- the parity target for masked padding.
+  layers.npz       single-layer networks through the reference's layer wrappers: odd/even kernels,
+                   strides, dilation (incl. the Cr4,2,*,4,2 form of tests/test_vgsl.py:71), max-pool
+                   floor cases, masked GroupNorm, the S1(1x0)1,3 reshape, f/r/b LSTMs with ragged lens.
+  codec.npz        PytorchCodec.decode / encode known answers incl. multi-label codes.
+  transforms.npz   ImageInputTransforms outputs (dewarp + fixed-height paths) for synthetic line images.
+"""
+import hashlib
+import json
+from collections import defaultdict
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _refshim  # noqa: E402
+
+_refshim.install()
+
+from kraken.lib import vgsl as ref_vgsl  # noqa: E402
+from kraken.lib.codec import PytorchCodec as RefCodec  # noqa: E402
+from kraken.lib.ctc_decoder import greedy_decoder as ref_greedy  # noqa: E402
+from kraken.lib.models import TorchSeqRecognizer as RefRecognizer  # noqa: E402
+
+from tests.specs import BENCH_A, BENCH_B, bench_codec  # noqa: E402
+
+RES = os.path.join(_refshim.REFERENCE_ROOT, 'tests', 'resources')
+
+
+def digest(t) -> str:
+    a = np.ascontiguousarray(t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def tuples_to_arr(dec):
+    """list of lists of (label,start,end,conf) -> (flat float64 [n,4], counts)"""
+    flat = [list(t) for line in dec for t in line]
+    return np.array(flat, dtype=np.float64).reshape(-1, 4), np.array([len(line) for line in dec], dtype=np.int32)
+
+
+def synth_input(n, w, seed=1234, h=48, c=1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(n, c, h, w, generator=g)
+
+
+@torch.inference_mode()
+def bench_fixture(spec, path, seed=0, cases=None):
+    torch.manual_seed(seed)
+    net = ref_vgsl.TorchVGSLModel(vgsl=spec, codec=bench_codec())
+    net.eval()
+    out = {'spec': spec, 'seed': seed,
+           'state_digest': json.dumps({k: digest(v) for k, v in net.state_dict().items()})}
+    rec = RefRecognizer(net, device='cpu')
+    # equal-width batches
+    for tag, n, w, keep in cases or (('n4w400', 4, 400, [0, 3]), ('n16w800', 16, 800, [0, 7]), ('n4w1200', 4, 1200, [1])):
+        x = synth_input(n, w)
+        lens = torch.tensor([w] * n)
+        logits, olens = net.nn(x, lens)
+        probs = logits.softmax(1).squeeze(2)
+        conf, lab = probs.max(dim=1)
+        dec = ref_greedy(probs, olens)
+        flat, counts = tuples_to_arr(dec)
+        out[f'{tag}_xdigest'] = digest(x)
+        out[f'{tag}_olens'] = olens.numpy().astype(np.int32)
+        out[f'{tag}_keep'] = np.array(keep)
+        out[f'{tag}_logits'] = logits[keep].squeeze(2).numpy()
+        out[f'{tag}_labels'] = lab.numpy().astype(np.int32)
+        out[f'{tag}_conf'] = conf.numpy()
+        out[f'{tag}_tuples'] = flat
+        out[f'{tag}_counts'] = counts
+        out[f'{tag}_logit_abs_sum'] = logits.abs().sum(dim=(1, 2, 3)).numpy()
+        strings = rec.predict_string(x, lens)
+        out[f'{tag}_strings'] = json.dumps(strings)
+    # ragged widths, each line on its own (batch = 1, lens = None): the reference's per-line result
+    widths = [800, 613, 401]
+    xr = synth_input(len(widths), 800, seed=4321)
+    out['ragged_widths'] = np.array(widths, dtype=np.int32)
+    out['ragged_xdigest'] = digest(xr)
+    for i, w in enumerate(widths):
+        xi = xr[i:i + 1, :, :, :w].contiguous()
+        logits, _ = net.nn(xi)
+        probs = logits.softmax(1).squeeze(2)
+        flat, counts = tuples_to_arr(ref_greedy(probs))
+        out[f'ragged{i}_logits'] = logits.squeeze(2)[0].numpy()
+        out[f'ragged{i}_tuples'] = flat
+        out[f'ragged{i}_counts'] = counts
+    # the same ragged lines through the reference's BATCHED path (padding not masked): documents
+    # that the reference itself is not batch-invariant (SURVEY.md 8a note)
+    xb = xr.clone()
+    for i, w in enumerate(widths):
+        xb[i, ..., w:] = 0
+    lb, ob = net.nn(xb, torch.tensor(widths))
+    out['ragged_batched_olens'] = ob.numpy().astype(np.int32)
+    out['ragged_batched_maxdiff'] = np.array([
+        float((lb[i, :, 0, :ob[i]] - torch.from_numpy(out[f'ragged{i}_logits'])[:, :ob[i]]).abs().max())
+        for i in range(len(widths))])
+    np.savez_compressed(path, **out)
+    print('wrote', path, {k: (v.shape if hasattr(v, 'shape') else '') for k, v in out.items() if 'logits' in k})
+
+
+@torch.inference_mode()
+def layer_fixture(path):
+    cases = {
+        'conv_odd':      ('[1,9,0,3 Cr3,5,7]', 2, 37, None),
+        'conv_even_str': ('[1,12,0,1 Cr4,2,5,4,2]', 2, 41, None),
+        'conv_stride2':  ('[1,30,0,1 Cr3,3,8,2,2]', 2, 45, [45, 31]),
+        'conv_dilated':  ('[1,10,0,2 Ct3,3,6,1,1,2,2]', 2, 33, None),
+        'conv_leaky':    ('[1,8,0,2 Clr3,3,4]', 1, 19, None),
+        'conv_linear':   ('[1,8,0,2 Cl1,1,40]', 1, 19, None),
+        'conv_sigmoid':  ('[1,8,0,2 Cs3,3,4]', 1, 19, None),
+        'conv_wide':     ('[1,6,0,4 Cr3,13,33]', 3, 70, [70, 53, 9]),
+        'pool_floor':    ('[1,9,0,2 Mp2,2]', 2, 37, [37, 20]),
+        'pool_3x2_s2x3': ('[1,11,0,2 Mp3,2,2,3]', 2, 40, None),
+        'conv_pool':     ('[1,16,0,1 Cr3,3,8 Mp2,2]', 3, 50, [50, 33, 17]),
+        'gn_full':       ('[1,6,0,8 Gn4]', 2, 21, None),
+        'gn_masked':     ('[1,6,0,8 Gn4]', 3, 21, [21, 13, 5]),
+        'conv_gn_pool':  ('[1,12,0,1 Cr3,3,16 Gn8 Mp2,2]', 3, 44, [44, 30, 21]),
+        'reshape':       ('[1,5,0,3 S1(1x0)1,3]', 2, 7, None),
+        'lstm_f':        ('[1,1,0,12 Lfx10]', 3, 17, [17, 9, 4]),
+        'lstm_r':        ('[1,1,0,12 Lrx10]', 3, 17, [17, 9, 4]),
+        'lstm_b':        ('[1,1,0,12 Lbx10]', 3, 17, [17, 9, 4]),
+        'lstm_b_h13':    ('[1,1,0,7 Lbx13]', 2, 11, None),
+        'lstm_stack':    ('[1,4,0,2 Cr3,3,4 S1(1x0)1,3 Lbx8 Lfx6 O1c5]', 3, 23, [23, 15, 8]),
+        'linear':        ('[1,1,0,20 O1c9]', 2, 13, None),
+        'two_linear':    ('[1,1,0,20 O1c16 O1c36]', 2, 13, None),
+    }
+    out = {'cases': json.dumps({k: {'spec': v[0], 'n': v[1], 'w': v[2], 'lens': v[3]} for k, v in cases.items()})}
+    for name, (spec, n, w, lens) in cases.items():
+        torch.manual_seed(hash(name) % 1000 if False else sum(map(ord, name)))
+        net = ref_vgsl.TorchVGSLModel(vgsl=spec)
+        net.eval()
+        # give GroupNorm a non-trivial affine and biases non-zero values
+        for k, v in net.state_dict().items():
+            if 'Gn' in k or k.endswith('bias'):
+                v.copy_(torch.randn(v.shape) * 0.5 + (1.0 if k.endswith('layer.weight') else 0.0))
+        _, c, h, _ = net.input
+        x = torch.randn(n, c, h, w)
+        for k, v in net.state_dict().items():
+            out[f'{name}/sd/{k}'] = v.numpy()
+        out[f'{name}/x'] = x.numpy()
+        if lens is None:
+            y, _ = net.nn(x, None)
+            out[f'{name}/y'] = y.numpy()
+        else:
+            # parity target for ragged batches = each line on its own (batch 1, lens None)
+            olens = []
+            for i, L in enumerate(lens):
+                y, _ = net.nn(x[i:i + 1, ..., :L].contiguous(), None)
+                out[f'{name}/y{i}'] = y.numpy()
+                olens.append(y.shape[3])
+            _, ol = net.nn(torch.nn.functional.pad(x, (0, 0)), torch.tensor(lens))
+            if ol is not None:
+                out[f'{name}/olens'] = ol.numpy().astype(np.int32)
+    np.savez_compressed(path, **out)
+    print('wrote', path, len(out), 'arrays')
+
+
+def codec_fixture(path):
+    c2l = {'a': [1], 'b': [2], 'c': [3, 4], 'de': [5], 'xyz': [6, 7, 8], 'ܐ': [9]}
+    codec = RefCodec(c2l)
+    seqs = [
+        [(1, 0, 1, 0.5), (2, 2, 3, 0.25), (3, 4, 5, 0.75), (4, 6, 9, 0.25), (5, 10, 12, 1.0)],
+        [(6, 0, 1, 0.3), (7, 2, 3, 0.6), (8, 4, 5, 0.9), (9, 6, 7, 0.1)],
+        [(3, 0, 1, 0.3), (1, 2, 3, 0.6)],          # dangling first half of a multi-label code
+        [(99, 0, 1, 0.3), (1, 2, 3, 0.6)],         # unknown label is skipped
+        [],
+    ]
+    out = {'c2l': json.dumps(c2l), 'seqs': json.dumps(seqs),
+           'decoded': json.dumps([[(c, int(s), int(e), float(u)) for c, s, e, u in codec.decode(s_)] for s_ in seqs]),
+           'encode_in': json.dumps(['abc', 'dexyzq', 'cdeܐ']),
+           'encode_out': json.dumps([codec.encode(s).tolist() for s in ['abc', 'dexyzq', 'cdeܐ']])}
+    np.savez_compressed(path, **out)
+    print('wrote', path)
+
+
+def _ref_transforms(batch, height, width, channels, pad, valid_norm):
+    """ImageInputTransforms (kraken/lib/dataset/utils.py:93-152) evaluated with the reference's own
+    lineest / resize code; torchvision is absent here, so the v2 ops it would call are spelled out with
+    PIL + numpy exactly as torchvision defines them (Grayscale = PIL convert('L'), Pad(fill=255),
+    PILToTensor, ToDtype(scale=True) = /255)."""
+    from PIL import Image, ImageOps
+    from kraken.lib import functional_im_transforms as F_t
+    from kraken.lib.lineest import CenterNormalizer
+
+    def run(im: Image.Image):
+        mode = 'RGB' if channels == 3 else 'L'
+        scale = (height, width)
+        center = valid_norm and channels == 1 and height > 1 and width == 0
+        im = im.convert(mode)
+        if scale != (0, 0):
+            if center:
+                im = F_t.pil_dewarp(im, lnorm=CenterNormalizer(scale[0]))
+                im = im.convert(mode)
+            else:
+                im = F_t.pil_fixed_resize(im, scale=scale)
+        if pad:
+            im = ImageOps.expand(im, border=(pad, 0), fill=255)
+        t = torch.from_numpy(np.array(im, dtype=np.uint8))
+        t = t[None] if t.dim() == 2 else t.permute(2, 0, 1)
+        t = t.to(torch.float32) / 255.0
+        return t.max() - t
+    return run
+
+
+@torch.inference_mode()
+def overfit_fixture(path):
+    from PIL import Image
+    from kraken_amd.io import read_coreml
+    import kraken.rpred as ref_rpred
+    from kraken.containers import BBoxLine, Segmentation
+
+    meta, sd = read_coreml(os.path.join(RES, 'overfit.mlmodel'))
+    kwargs = dict(meta)
+    net = ref_vgsl.TorchVGSLModel(**kwargs)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    net.eval()
+    rec = RefRecognizer(net, device='cpu')
+    rec.kind = 'vgsl'
+
+    # ---- reproduce the reference's known-answer test through its own rpred
+    class _TS:
+        def __init__(self, batch, height, width, channels, pad, valid_norm=True, **kw):
+            self.fn = _ref_transforms(batch, height, width, channels, pad[0] if isinstance(pad, tuple) else pad, valid_norm)
+
+        def __call__(self, im):
+            return self.fn(im)
+    ref_rpred.ImageInputTransforms = _TS
+    im = Image.open(os.path.join(RES, '000236.png'))
+    bbox = [0, 0, 2544, 156]
+    seg = Segmentation(type='bbox', text_direction='horizontal-lr', imagename='000236.png',
+                       lines=[BBoxLine(id='foo', bbox=bbox)], script_detection=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        # tests/test_rpred.py:352-358: rpred(model, im, seg, True) -- the 4th positional is `pad` (True == 1)
+        pred = list(ref_rpred.rpred(rec, im, seg, True))
+        # tests/test_rpred.py:453-462: mm_rpred(..., bidi_reordering=False), default pad 16
+        pred_nobidi = list(ref_rpred.mm_rpred(defaultdict(lambda: rec), im, seg, bidi_reordering=False))
+    print('rpred bbox pad=1 bidi  :', repr(pred[0].prediction))
+    print('rpred bbox pad=16 nobidi:', repr(pred_nobidi[0].prediction))
+    assert pred[0].prediction == 'ܡ ܘܡ ܗ ܡܕܐ ܐ ܐܐ ܡ ܗܗܐܐܐܕ', 'known answer tests/test_rpred.py:358 not reproduced'
+    assert pred_nobidi[0].prediction == 'ܕܗܣܐܕ ܪܝ .ܡܡ ܐܠܠ ܗܠ ܐܘܗ ܟܘܗܢ ܡܡ ܐܠ', 'known answer tests/test_rpred.py:462 not reproduced'
+
+    box = im.crop(bbox)
+    out = {'spec': meta['vgsl'], 'meta': json.dumps({k: v for k, v in meta.items() if k not in ('accuracy', 'metrics')}),
+           'string_rpred_pad1_bidi': pred[0].prediction, 'string_rpred_pad16_nobidi': pred_nobidi[0].prediction,
+           'cuts_rpred_pad16_nobidi': json.dumps(pred_nobidi[0].cuts),
+           'conf_rpred_pad16_nobidi': np.array(pred_nobidi[0].confidences),
+           'cuts_rpred_pad1_bidi': json.dumps(pred[0].cuts), 'conf_rpred_pad1_bidi': np.array(pred[0].confidences),
+           'bbox': np.array(bbox), 'box_size': np.array(box.size), 'page': np.array(im.convert('L'), dtype=np.uint8)}
+    for pad in (1, 16):
+        ts = _TS(1, 30, 0, 1, (pad, 0), True)(box)
+        logits, _ = net.nn(ts.unsqueeze(0))
+        probs = logits.softmax(1).squeeze(2)
+        dec = ref_greedy(probs)
+        flat, counts = tuples_to_arr(dec)
+        chars = net.codec.decode(dec[0])
+        out.update({f'pad{pad}_line': ts.numpy(), f'pad{pad}_logits': logits.squeeze(2).numpy(),
+                    f'pad{pad}_probs': probs.numpy(), f'pad{pad}_tuples': flat, f'pad{pad}_counts': counts,
+                    f'pad{pad}_decoded': json.dumps([(c, int(s), int(e), float(u)) for c, s, e, u in chars]),
+                    f'pad{pad}_string_display': ''.join(c for c, *_ in chars)})
+    for k, v in sd.items():
+        out[f'sd/{k}'] = v.numpy()
+    np.savez_compressed(path, **out)
+    print('wrote', path, 'line tensor', tuple(ts.shape), 'T', logits.shape[-1])
+
+
+def transforms_fixture(path):
+    from PIL import Image
+    rng = np.random.RandomState(7)
+    out = {}
+    cases = []
+    for i, (h, w, height, valid_norm, pad) in enumerate([(60, 400, 48, True, 16), (37, 250, 48, False, 16),
+                                                         (48, 300, 48, True, 0), (90, 333, 30, True, 16)]):
+        arr = np.full((h, w), 255, np.uint8)
+        # dark "strokes" on a light page with a wandering baseline
+        yc = (h / 2 + 0.15 * h * np.sin(np.arange(w) / 40.0)).astype(int)
+        for x in range(0, w, 3):
+            if rng.rand() < 0.6:
+                lo = max(yc[x] - rng.randint(2, h // 3), 0)
+                hi = min(yc[x] + rng.randint(2, h // 3), h)
+                arr[lo:hi, x:x + 2] = rng.randint(0, 90)
+        im = Image.fromarray(arr, 'L')
+        t = _ref_transforms(1, height, 0, 1, pad, valid_norm)(im)
+        out[f'im{i}'] = arr
+        out[f'out{i}'] = t.numpy()
+        cases.append({'height': height, 'valid_norm': valid_norm, 'pad': pad})
+    out['cases'] = json.dumps(cases)
+    np.savez_compressed(path, **out)
+    print('wrote', path)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['overfit', 'bench_a', 'bench_b', 'layers', 'codec', 'transforms']
+    if 'overfit' in which:
+        overfit_fixture(os.path.join(HERE, 'overfit.npz'))
+    if 'bench_a' in which:
+        bench_fixture(BENCH_A, os.path.join(HERE, 'bench_a.npz'))
+    if 'bench_b' in which:
+        bench_fixture(BENCH_B, os.path.join(HERE, 'bench_b.npz'),
+                      cases=(('n4w400', 4, 400, [0, 3]), ('n16w800', 16, 800, [7])))
+    if 'layers' in which:
+        layer_fixture(os.path.join(HERE, 'layers.npz'))
+    if 'codec' in which:
+        codec_fixture(os.path.join(HERE, 'codec.npz'))
+    if 'transforms' in which:
+        transforms_fixture(os.path.join(HERE, 'transforms.npz'))

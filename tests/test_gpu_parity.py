@@ -1,0 +1,350 @@
+"""
+Parity tests proper: the HIP path (through the C ABI of libkraken_amd.so) against
+  (1) golden vectors produced by the unmodified reference on CPU (tests/golden/*.npz),
+  (2) the CPU oracles on the same seeded inputs,
+  (3) at BASELINE.json's full size (256 x 1x48x1200) size-independent properties.
+
+Tolerances (fp32 plan): logits |d| <= 1e-3 (BASELINE.json north_star; observed ~2e-6), decode
+tuples (label, start, end) identical, confidences |d| <= 1e-4.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from kraken_amd.vgsl import parse_vgsl
+from oracle import np_oracle
+from oracle.torch_port import CpuRecognizer
+from tests.helpers import arr_to_tuples, build_model, layer_cases, load_golden, synth_input
+from tests.specs import BENCH_A, BENCH_B, bench_codec
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3
+CONF_TOL = 1e-4
+CASES = layer_cases()
+
+
+def _keys(tuples):
+    return [[t[:3] for t in line] for line in tuples]
+
+
+def _max_conf_diff(a, b):
+    return max([abs(x[3] - y[3]) for p, q in zip(a, b) for x, y in zip(p, q)] or [0.0])
+
+
+@pytest.fixture(scope='module')
+def bench_a():
+    return build_model(BENCH_A, codec=bench_codec(), seed=0).to('cuda')
+
+
+@pytest.fixture(scope='module')
+def bench_b():
+    return build_model(BENCH_B, codec=bench_codec(), seed=0).to('cuda')
+
+
+# --------------------------------------------------------------------- (1) golden: single layers
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_layers_against_reference_golden(name):
+    c = CASES[name]
+    m = build_model(c['spec'], c['sd']).to('cuda')
+    x = torch.from_numpy(c['x'])
+    if c['lens'] is None:
+        y, olens = m.nn(x.cuda())
+        assert olens is None
+        assert tuple(y.shape) == c['y'].shape
+        np.testing.assert_allclose(y.cpu().numpy(), c['y'], atol=2e-5, rtol=1e-4)
+    else:
+        for i, L in enumerate(c['lens']):
+            x[i, ..., L:] = 0
+        y, olens = m.nn(x.cuda(), torch.tensor(c['lens']))
+        y = y.cpu().numpy()
+        if c['olens'] is not None:
+            assert olens.tolist() == c['olens'].tolist()
+        for i, want in enumerate(c['ys']):
+            w = want.shape[3]
+            assert int(olens[i]) == w
+            np.testing.assert_allclose(y[i:i + 1, ..., :w], want, atol=2e-5, rtol=1e-4)
+            if not c['spec'].rstrip(']').split(' ')[-1].startswith('O'):
+                assert np.all(y[i, ..., w:] == 0), 'padding must be zero after every non-linear-output layer'
+
+
+# ------------------------------------------------------------- (1) golden: benchmark networks
+@pytest.mark.parametrize('which', ['a', 'b'])
+def test_bench_networks_against_reference_golden(which, bench_a, bench_b):
+    m = bench_a if which == 'a' else bench_b
+    z = load_golden(f'bench_{which}.npz')
+    tags = [t for t in ('n4w400', 'n16w800', 'n4w1200') if f'{t}_keep' in z.files]
+    for tag in tags:
+        n, w = int(tag[1:tag.index('w')]), int(tag[tag.index('w') + 1:])
+        x = synth_input(n, w).cuda()
+        logits, _ = m.nn(x)
+        logits = logits.squeeze(2).cpu().numpy()
+        keep = z[f'{tag}_keep'].tolist()
+        assert np.abs(logits[keep] - z[f'{tag}_logits']).max() < LOGIT_TOL
+        np.testing.assert_allclose(np.abs(logits).sum(axis=(1, 2)), z[f'{tag}_logit_abs_sum'], rtol=1e-4)
+        batch, olens, _, probs = m.nn.recognize(x, torch.tensor([w] * n), want_probs=True)
+        assert olens.tolist() == z[f'{tag}_olens'].tolist()
+        got, want = batch.tuples(), arr_to_tuples(z[f'{tag}_tuples'], z[f'{tag}_counts'])
+        assert _keys(got) == _keys(want)
+        assert _max_conf_diff(got, want) < CONF_TOL
+        conf, lab = probs.max(dim=1)
+        assert (lab.cpu().numpy() == z[f'{tag}_labels']).all()
+        np.testing.assert_allclose(conf.cpu().numpy(), z[f'{tag}_conf'], atol=CONF_TOL)
+        strings = [''.join(c for c, *_ in rec) for rec in m.codec.decode_batch(batch)]
+        assert strings == json.loads(str(z[f'{tag}_strings']))
+
+
+@pytest.mark.parametrize('which', ['a', 'b'])
+def test_ragged_batch_equals_reference_per_line(which, bench_a, bench_b):
+    """Masked padding: each line of a padded ragged batch == the reference's batch-1 result."""
+    m = bench_a if which == 'a' else bench_b
+    z = load_golden(f'bench_{which}.npz')
+    widths = z['ragged_widths'].tolist()
+    x = synth_input(len(widths), 800, seed=4321)
+    for i, w in enumerate(widths):
+        x[i, ..., w:] = 0
+    batch, olens, logits, _ = m.nn.recognize(x.cuda(), torch.tensor(widths), want_logits=True)
+    logits = logits.cpu().numpy()
+    got = batch.tuples()
+    for i in range(len(widths)):
+        want = z[f'ragged{i}_logits']
+        assert olens[i] == want.shape[1]
+        assert np.abs(logits[i, :, :olens[i]] - want).max() < LOGIT_TOL
+        wt = arr_to_tuples(z[f'ragged{i}_tuples'], z[f'ragged{i}_counts'])[0]
+        assert [t[:3] for t in got[i]] == [t[:3] for t in wt]
+    # garbage in the padding must not leak into the result (input columns >= len are masked)
+    x2 = x.clone()
+    for i, w in enumerate(widths):
+        x2[i, ..., w:] = 7.0
+    batch2, _, logits2, _ = m.nn.recognize(x2.cuda(), torch.tensor(widths), want_logits=True)
+    assert _keys(batch2.tuples()) == _keys(got)
+    for i in range(len(widths)):
+        assert np.array_equal(logits2.cpu().numpy()[i, :, :olens[i]], logits[i, :, :olens[i]])
+
+
+# ----------------------------------------------------- (1) golden: the reference's known answers
+def test_overfit_known_answer_strings():
+    """tests/test_rpred.py:352-358 / :453-462 of the reference, through the HIP path."""
+    z = load_golden('overfit.npz')
+    meta = json.loads(str(z['meta']))
+    sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
+    m = build_model(str(z['spec']), sd, codec=meta['codec']).to('cuda')
+    for pad in (1, 16):
+        line = torch.from_numpy(z[f'pad{pad}_line'])[None].cuda()
+        batch, olens, logits, probs = m.nn.recognize(line, None, want_logits=True, want_probs=True)
+        assert np.abs(logits.cpu().numpy() - z[f'pad{pad}_logits']).max() < LOGIT_TOL
+        assert np.abs(probs.cpu().numpy() - z[f'pad{pad}_probs']).max() < CONF_TOL
+        want = arr_to_tuples(z[f'pad{pad}_tuples'], z[f'pad{pad}_counts'])
+        assert _keys(batch.tuples()) == _keys(want)
+        assert _max_conf_diff(batch.tuples(), want) < CONF_TOL
+        chars = m.codec.decode(batch.tuples()[0])
+        assert ''.join(c for c, *_ in chars) == str(z[f'pad{pad}_string_display'])
+        wd = json.loads(str(z[f'pad{pad}_decoded']))
+        assert [(c, s, e) for c, s, e, _ in chars] == [(c, s, e) for c, s, e, _ in wd]
+    assert str(z['pad16_string_display']) == 'ܕܗܣܐܕ ܪܝ .ܡܡ ܐܠܠ ܗܠ ܐܘܗ ܟܘܗܢ ܡܡ ܐܠ'
+
+
+def test_rpred_mirror_reproduces_reference_record():
+    """Legacy generator API on the fixture page: string, cuts and confidences of the reference record."""
+    import warnings
+    from PIL import Image
+    from kraken_amd.containers import BBoxLine, Segmentation
+    from kraken_amd.models import TorchSeqRecognizer
+    from kraken_amd.rpred import mm_rpred, rpred
+    from collections import defaultdict
+    z = load_golden('overfit.npz')
+    meta = json.loads(str(z['meta']))
+    sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
+    m = build_model(str(z['spec']), sd, codec=meta['codec'])
+    m.seg_type, m.one_channel_mode, m.model_type = 'bbox', '1', ['recognition']
+    net = TorchSeqRecognizer(m, device='cuda')
+    page = Image.fromarray(z['page'], 'L')
+    bbox = z['bbox'].tolist()
+    seg = Segmentation(type='bbox', imagename='000236.png', text_direction='horizontal-lr', script_detection=False,
+                       lines=[BBoxLine(id='foo', bbox=bbox), BBoxLine(id='oob', bbox=[-1, -1, 10000, 10000]),
+                              BBoxLine(id='foo2', bbox=bbox)])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        it = mm_rpred(defaultdict(lambda: net), page, seg, bidi_reordering=False)
+        assert len(it) == 3
+        recs = list(it)
+    assert recs[0].prediction == str(z['string_rpred_pad16_nobidi']) == recs[2].prediction
+    assert len(recs[1]) == 0                                  # out-of-bounds line -> empty record, order kept
+    assert recs[0].cuts == json.loads(str(z['cuts_rpred_pad16_nobidi']))
+    np.testing.assert_allclose(recs[0].confidences, z['conf_rpred_pad16_nobidi'], atol=CONF_TOL)
+    # pad passed positionally as `True` like the reference's own test (pad == 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        seg1 = Segmentation(type='bbox', imagename='x', text_direction='horizontal-lr', script_detection=False,
+                            lines=[BBoxLine(id='foo', bbox=bbox)])
+        rec = next(rpred(net, page, seg1, True, bidi_reordering=False))
+    # display order of the pad=1 line; the reference's bidi (logical order) string holds the same code points
+    assert rec.prediction == str(z['pad1_string_display'])
+    assert sorted(rec.prediction) == sorted(str(z['string_rpred_pad1_bidi']))
+
+
+# --------------------------------------------------------------- (2) oracle on seeded inputs
+def test_decoder_operator_matches_oracle():
+    """The B4 plug point: greedy_decoder(outputs, seq_lens) on probabilities, logits, ndarray, (C,T)."""
+    from kraken_amd.ctc_decoder import greedy_decoder
+    rng = np.random.RandomState(3)
+    logits = rng.randn(5, 40, 77).astype(np.float32) * 3
+    logits[:, 0] += 2.0                                   # make blanks frequent
+    lens = [77, 50, 1, 0, 33]
+    probs = np_oracle.softmax_c(logits)
+    for arr in (probs, logits):
+        want = np_oracle.greedy_decode(arr, lens)
+        for inp in (arr, torch.from_numpy(arr), torch.from_numpy(arr).cuda(),
+                    torch.from_numpy(np.ascontiguousarray(arr.transpose(0, 2, 1))).cuda().permute(0, 2, 1)):
+            got = greedy_decoder(inp, torch.tensor(lens))
+            assert _keys(got) == _keys(want)
+            assert _max_conf_diff(got, want) < 1e-6
+    assert _keys(greedy_decoder(probs[0])) == _keys(np_oracle.greedy_decode(probs[0]))
+    with pytest.raises(ValueError):
+        greedy_decoder(probs)
+    # argmax ties -> lowest class index; a run of equal labels collapses; blank dropped
+    tie = np.zeros((1, 4, 6), np.float32)
+    tie[0, 2, :3] = 0.5
+    tie[0, 3, :3] = 0.5
+    tie[0, 1, 4:] = 0.9
+    assert greedy_decoder(tie) == [[(2, 0, 2, 0.5), (1, 4, 5, pytest.approx(0.9))]]
+
+
+def test_forward_then_decoder_equals_fused_recognize(bench_b):
+    x = synth_input(6, 300, seed=99)
+    lens = torch.tensor([300, 299, 150, 151, 64, 17])
+    for i, L in enumerate(lens.tolist()):
+        x[i, ..., L:] = 0
+    from kraken_amd.ctc_decoder import greedy_decoder
+    logits, olens = bench_b.nn(x.cuda(), lens)
+    probs = (logits / 1.7).softmax(1).squeeze(2)
+    unfused = greedy_decoder(probs, olens)
+    batch, olens2, _, probs2 = bench_b.nn.recognize(x.cuda(), lens, temperature=1.7, want_probs=True)
+    assert olens.tolist() == olens2.tolist()
+    assert _keys(unfused) == _keys(batch.tuples())
+    assert _max_conf_diff(unfused, batch.tuples()) < 1e-6
+    for i, L in enumerate(olens2.tolist()):
+        np.testing.assert_allclose(probs2[i, :, :L].cpu().numpy(), probs[i, :, :L].cpu().numpy(), atol=1e-6)
+
+
+def test_seq_recognizer_interface(bench_b):
+    """TorchSeqRecognizer.forward/predict/predict_string/predict_labels (lib/models.py:93-158)."""
+    from kraken_amd.models import TorchSeqRecognizer
+    rec = TorchSeqRecognizer(bench_b, device='cuda')
+    x = synth_input(3, 200, seed=5)
+    lens = torch.tensor([200, 120, 77])
+    for i, L in enumerate(lens.tolist()):
+        x[i, ..., L:] = 0
+    ref = CpuRecognizer(bench_b.layer_specs, {k: v.cpu() for k, v in bench_b.state_dict().items()})
+    want = ref.predict_labels(x, lens.tolist())
+    labels = rec.predict_labels(x, lens)
+    assert _keys(labels) == _keys(want)
+    o, olens = rec.forward(x, lens)
+    assert isinstance(o, np.ndarray) and o.shape == (3, 256, 50) and olens.tolist() == [50, 30, 19]
+    assert rec.outputs.shape[2] == 50
+    strings = rec.predict_string(x, lens)
+    assert strings == [''.join(chr(0x100 + t[0] - 1) for t in line) for line in want]
+    assert [len(p) for p in rec.predict(x, lens)] == [len(w) for w in want]
+    one = rec.predict(x[:1])                                   # batch 1, lens None: the legacy rpred shape
+    assert [(c, s, e) for c, s, e, _ in one[0]] == [(chr(0x100 + t[0] - 1), t[1], t[2]) for t in want[0]]
+
+
+def test_temperature_and_custom_plan_reuse(bench_b):
+    x = synth_input(2, 160, seed=8).cuda()
+    b1, _, lg, p1 = bench_b.nn.recognize(x, None, temperature=1.0, want_logits=True, want_probs=True)
+    b2, _, _, p2 = bench_b.nn.recognize(x, None, temperature=4.0, want_probs=True)
+    assert _keys(b1.tuples()) == _keys(b2.tuples())           # argmax is temperature invariant
+    want = (lg / 4.0).softmax(1)
+    np.testing.assert_allclose(p2.cpu().numpy(), want.cpu().numpy(), atol=1e-6)
+    assert float(p2.max()) < float(p1.max())
+
+
+def test_weight_update_invalidates_plan(bench_b):
+    x = synth_input(1, 128, seed=11).cuda()
+    m = build_model(BENCH_B, codec=bench_codec(), seed=0).to('cuda')
+    y0, _ = m.nn(x)
+    with torch.no_grad():
+        getattr(m.nn, m.layer_specs[-1].name).lin.bias.add_(1.0)
+    y1, _ = m.nn(x)
+    np.testing.assert_allclose((y1 - y0).cpu().numpy(), 1.0, atol=1e-5)
+
+
+# --------------------------------------------------- (3) full-size, size-independent properties
+def test_full_size_properties(bench_a):
+    """BASELINE.json configs[1]: 256 lines 1x48x1200 on one GPU."""
+    N, W = 256, 1200
+    x = synth_input(N, W, seed=2024).cuda()
+    batch, olens, logits, _ = bench_a.nn.recognize(x, None, want_logits=True)
+    assert olens.tolist() == [150] * N and tuple(logits.shape) == (N, 256, 150)
+    assert torch.isfinite(logits).all()
+    tuples = batch.tuples()
+    # decode invariants: sorted, non-overlapping runs of non-blank labels inside [0, T)
+    for line in tuples:
+        prev_end, prev_lab = -1, None
+        for lab, s, e, c in line:
+            assert 1 <= lab < 256 and 0 <= s <= e < 150 and 0.0 < c <= 1.0
+            assert s > prev_end and not (s == prev_end + 1 and lab == prev_lab)
+            prev_end, prev_lab = e, lab
+    # idempotence: same input, same bits
+    batch2, _, logits2, _ = bench_a.nn.recognize(x, None, want_logits=True)
+    assert torch.equal(logits, logits2) and _keys(batch2.tuples()) == _keys(tuples)
+    # permutation equivariance + batch invariance: a line's result does not depend on its batch mates
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1))
+    batch3, _, logits3, _ = bench_a.nn.recognize(x[perm.cuda()], None, want_logits=True)
+    assert (logits3 - logits[perm.cuda()]).abs().max().item() < 1e-5
+    assert _keys(batch3.tuples()) == [_keys(tuples)[i] for i in perm.tolist()]
+    sub = [3, 100, 255]
+    batch4, _, logits4, _ = bench_a.nn.recognize(x[sub], None, want_logits=True)
+    assert (logits4 - logits[sub]).abs().max().item() < 1e-5
+    # padding invariance: the same lines inside a wider zero-padded batch with lens
+    xp = torch.zeros(len(sub), 1, 48, 1400, device='cuda')
+    xp[..., :W] = x[sub]
+    batch5, olens5, logits5, _ = bench_a.nn.recognize(xp, torch.tensor([W] * len(sub)), want_logits=True)
+    assert olens5.tolist() == [150] * len(sub)
+    assert (logits5[:, :, :150] - logits[sub]).abs().max().item() < 1e-5
+    assert _keys(batch5.tuples()) == [_keys(tuples)[i] for i in sub]
+    # and against the CPU oracle on a bounded sample of the same batch
+    ref = CpuRecognizer(bench_a.layer_specs, {k: v.cpu() for k, v in bench_a.state_dict().items()})
+    want_logits, _ = ref.forward(x[sub].cpu())
+    assert (logits[sub].cpu() - want_logits.squeeze(2)).abs().max().item() < LOGIT_TOL
+    assert _keys(ref.predict_labels(x[sub].cpu())) == [_keys(tuples)[i] for i in sub]
+
+
+def test_config4_ragged_bucketed_batch(bench_a):
+    """BASELINE.json configs[3] (scaled to 96 lines for the test): widths U{400..2400}, width-sorted."""
+    rng = np.random.RandomState(4)
+    widths = np.sort(rng.randint(400, 2401, size=96))[::-1].copy()
+    xs = synth_input(96, 2400, seed=77)
+    for i, w in enumerate(widths):
+        xs[i, ..., w:] = 0
+    got, got_olens = [], []
+    for lo in range(0, 96, 32):                        # three buckets of 32 lines, padded to the bucket max
+        wmax = int(widths[lo:lo + 32].max())
+        b, ol, _, _ = bench_a.nn.recognize(xs[lo:lo + 32, ..., :wmax].contiguous().cuda(),
+                                           torch.from_numpy(widths[lo:lo + 32].astype(np.int64)))
+        got += b.tuples()
+        got_olens += ol.tolist()
+    ref = CpuRecognizer(bench_a.layer_specs, {k: v.cpu() for k, v in bench_a.state_dict().items()})
+    for i in (0, 17, 40, 63, 95):                      # per-line batch-1 reference on a sample
+        w = int(widths[i])
+        want = ref.predict_labels(xs[i:i + 1, ..., :w])
+        assert got_olens[i] == w // 8
+        assert [t[:3] for t in got[i]] == [t[:3] for t in want[0]]
+
+
+def test_engine_pipelined_results_identical(bench_b):
+    from kraken_amd.engine import RecognitionEngine
+    eng = RecognitionEngine(bench_b, device=0, max_batch=8, max_width=400, slots=2)
+    xs = [synth_input(8, 400, seed=s).cuda() for s in range(5)]
+    want = [_keys(bench_b.nn.recognize(x, None)[0].tuples()) for x in xs]
+    got = []
+    for x in xs:
+        if eng.free_slots() == 0:
+            got.append(_keys(eng.collect()[0].tuples()))
+        eng.submit(x)
+    while eng.free_slots() < 2:
+        got.append(_keys(eng.collect()[0].tuples()))
+    assert got == want
+    eng.close()

@@ -1,0 +1,152 @@
+"""
+Pins the CPU oracles (oracle/np_oracle.py, oracle/torch_port.py) against golden vectors produced by
+the UNMODIFIED reference (tests/golden/make_golden.py).  CPU only.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from kraken_amd.vgsl import parse_vgsl
+from oracle import np_oracle
+from oracle.torch_port import CpuRecognizer, greedy_decode as torch_greedy
+from tests.helpers import arr_to_tuples, layer_cases, load_golden, synth_input
+from tests.specs import BENCH_A, BENCH_B
+
+LAYER_TOL = 2e-5
+CASES = layer_cases()
+
+
+def _zero_pad_x(x, lens):
+    x = x.copy()
+    for i, L in enumerate(lens):
+        x[i, ..., L:] = 0
+    return x
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_np_oracle_layers(name):
+    c = CASES[name]
+    _, specs = parse_vgsl(c['spec'])
+    if c['lens'] is None:
+        y, _ = np_oracle.forward(specs, c['sd'], c['x'])
+        assert y.shape == c['y'].shape
+        np.testing.assert_allclose(y, c['y'], atol=LAYER_TOL, rtol=1e-4)
+    else:
+        y, olens = np_oracle.forward(specs, c['sd'], _zero_pad_x(c['x'], c['lens']), c['lens'])
+        for i, want in enumerate(c['ys']):
+            w = want.shape[3]
+            assert olens[i] == w or want.shape[3] == 0
+            np.testing.assert_allclose(y[i:i + 1, ..., :w], want, atol=LAYER_TOL, rtol=1e-4)
+        if c['olens'] is not None:
+            assert list(olens) == c['olens'].tolist()
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_torch_port_layers(name):
+    c = CASES[name]
+    _, specs = parse_vgsl(c['spec'])
+    ref = CpuRecognizer(specs, c['sd'])
+    if c['lens'] is None:
+        y, _ = ref.forward(c['x'])
+        np.testing.assert_allclose(y.numpy(), c['y'], atol=2e-6, rtol=1e-5)
+    else:
+        y, olens = ref.forward(_zero_pad_x(c['x'], c['lens']), c['lens'])
+        for i, want in enumerate(c['ys']):
+            w = want.shape[3]
+            np.testing.assert_allclose(y[i:i + 1, ..., :w].numpy(), want, atol=LAYER_TOL, rtol=1e-4)
+
+
+def _bench_model(spec):
+    import kraken_amd
+    torch.manual_seed(0)
+    return kraken_amd.TorchVGSLModel(vgsl=spec)
+
+
+@pytest.mark.parametrize('spec,fixture', [(BENCH_A, 'bench_a.npz'), (BENCH_B, 'bench_b.npz')])
+def test_oracles_on_bench_networks(spec, fixture):
+    z = load_golden(fixture)
+    m = _bench_model(spec)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    _, specs = parse_vgsl(spec)
+    ref = CpuRecognizer(specs, sd)
+    x = synth_input(4, 400)
+    keep = z['n4w400_keep'].tolist()
+    # torch port: the reference's own operators -> (almost) bit-identical
+    y, _ = ref.forward(x)
+    np.testing.assert_allclose(y[keep].squeeze(2).numpy(), z['n4w400_logits'], atol=1e-5)
+    probs = y.softmax(1).squeeze(2)
+    dec = torch_greedy(probs, [probs.shape[2]] * 4)
+    want = arr_to_tuples(z['n4w400_tuples'], z['n4w400_counts'])
+    assert [[t[:3] for t in l] for l in dec] == [[t[:3] for t in l] for l in want]
+    # numpy oracle on one line (slow python LSTM loop -> keep it small)
+    yn, _ = np_oracle.forward(specs, sd, x[:1].numpy())
+    np.testing.assert_allclose(yn[0, :, 0, :], z['n4w400_logits'][0], atol=2e-4)
+    dn = np_oracle.greedy_decode(np_oracle.softmax_c(yn[:, :, 0, :]))
+    assert [t[:3] for t in dn[0]] == [t[:3] for t in want[0]]
+    for a, b in zip(dn[0], want[0]):
+        assert abs(a[3] - b[3]) < 1e-4
+
+
+def test_oracles_ragged_equals_per_line_reference():
+    """Masked padding == the reference's per-line (batch 1) result, for BENCH-A ragged widths."""
+    z = load_golden('bench_a.npz')
+    m = _bench_model(BENCH_A)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    _, specs = parse_vgsl(BENCH_A)
+    widths = z['ragged_widths'].tolist()
+    x = synth_input(len(widths), 800, seed=4321)
+    for i, w in enumerate(widths):
+        x[i, ..., w:] = 0
+    ref = CpuRecognizer(specs, sd)
+    y, olens = ref.forward(x, widths)
+    for i in range(len(widths)):
+        want = z[f'ragged{i}_logits']
+        assert olens[i] == want.shape[1]
+        np.testing.assert_allclose(y[i, :, 0, :olens[i]].numpy(), want, atol=2e-5)
+    # and the reference's own batched path is NOT batch invariant (documented in SURVEY 8a)
+    assert z['ragged_batched_maxdiff'][1:].max() > 1e-3
+    yb, _ = ref.forward(x, widths, reference_batched=True)
+    diffs = [float(np.abs(yb[i, :, 0, :olens[i]].numpy() - z[f'ragged{i}_logits']).max()) for i in range(len(widths))]
+    np.testing.assert_allclose(diffs, z['ragged_batched_maxdiff'], atol=1e-4)
+
+
+def test_oracles_known_answer_overfit_model():
+    """tests/test_rpred.py:352-358, :453-462 of the reference, through both oracles."""
+    z = load_golden('overfit.npz')
+    spec = str(z['spec'])
+    sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
+    _, specs = parse_vgsl(spec)
+    meta = json.loads(str(z['meta']))
+    l2c = {tuple(v): k for k, v in meta['codec'].items()}
+    for pad in (1, 16):
+        line = z[f'pad{pad}_line'][None]
+        want_tuples = arr_to_tuples(z[f'pad{pad}_tuples'], z[f'pad{pad}_counts'])[0]
+        y, _ = CpuRecognizer(specs, sd).forward(line)
+        np.testing.assert_allclose(y.squeeze(2).numpy(), z[f'pad{pad}_logits'], atol=1e-5)
+        yn, _ = np_oracle.forward(specs, sd, line)
+        np.testing.assert_allclose(yn[:, :, 0, :], z[f'pad{pad}_logits'], atol=2e-4)
+        probs = np_oracle.softmax_c(yn[:, :, 0, :])
+        np.testing.assert_allclose(probs, z[f'pad{pad}_probs'], atol=1e-5)
+        dec = np_oracle.greedy_decode(probs)[0]
+        assert [t[:3] for t in dec] == [t[:3] for t in want_tuples]
+        chars = np_oracle.codec_decode(l2c, dec)
+        assert ''.join(c for c, *_ in chars) == str(z[f'pad{pad}_string_display'])
+    # display-order string of the no-bidi known answer (tests/test_rpred.py:462)
+    assert str(z['pad16_string_display']) == str(z['string_rpred_pad16_nobidi']) == 'ܕܗܣܐܕ ܪܝ .ܡܡ ܐܠܠ ܗܠ ܐܘܗ ܟܘܗܢ ܡܡ ܐܠ'
+    assert str(z['string_rpred_pad1_bidi']) == 'ܡ ܘܡ ܗ ܡܕܐ ܐ ܐܐ ܡ ܗܗܐܐܐܕ'
+
+
+def test_np_greedy_decode_semantics():
+    probs = np.array([[[0.1, 0.9, 0.9, 0.2, 0.2, 0.6],
+                       [0.8, 0.05, 0.05, 0.7, 0.5, 0.3],
+                       [0.1, 0.05, 0.05, 0.1, 0.3, 0.1]]], dtype=np.float32)   # (1, C=3, T=6)
+    # labels per step: 1,0,0,1,1,0 -> runs of label 1 at [0,0] and [3,4]
+    assert np_oracle.greedy_decode(probs) == [[(1, 0, 0, pytest.approx(0.8)), (1, 3, 4, pytest.approx(0.7))]]
+    # ties resolve to the lowest class index
+    tie = np.array([[[0.5], [0.5]]], dtype=np.float32)
+    assert np_oracle.greedy_decode(tie) == [[]]
+    with pytest.raises(ValueError):
+        np_oracle.greedy_decode(np.zeros((2, 3, 4), np.float32))
+    assert np_oracle.greedy_decode(probs, [3]) == [[(1, 0, 0, pytest.approx(0.8))]]
