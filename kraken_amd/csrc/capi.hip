@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,7 +34,7 @@ int fail(int code, const std::string& msg) {
 enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR };
 const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear"};
 
-constexpr size_t kLdsBudget = 72 * 1024;  // two workgroups per CU inside the 160 KiB LDS
+
 
 // Python-style floor division (the reference does float division + floor).
 inline int floordiv(int a, int b) {
@@ -75,7 +76,8 @@ struct ConvGeom {
     bool in_seq = false, out_seq = false, pool = false;
     int Ho = 1, Hy = 1;
     int SR = 8, TH = 1, TW = 256, IH = 1, IW = 256, RS = 256, PS = 257;
-    int cchunk = 1, nchunks = 1, Kc = 1, KS = 1, CB = 1, CBpad = 1, otab_floats = 4;
+    int cchunk = 1, nchunks = 1, Kc = 1, KSG = 1, KSG_last = 1, KSGpad = 4, KS4 = 16, vec4 = 0, CB = 1, CBpad = 1,
+        otab_floats = 32;
     float* d_w = nullptr;
     float* d_b = nullptr;
 };
@@ -110,40 +112,54 @@ void plan_conv_geom(ConvGeom& g) {
         g.PS = g.IH * g.IW;
     }
     const int kk = g.kh * g.kw;
-    // largest channel chunk whose tile (+ offset table) fits the LDS budget
-    int cmax = (int)((kLdsBudget - 64) / ((size_t)g.PS * 4 + (size_t)kk * 4));
-    cmax = std::max(1, std::min(cmax, g.Cin));
+    // largest channel chunk whose LDS tile stays within 64 KiB (= NPT * 256 staged floats per workgroup)
+    constexpr int kTileFloats = 64 * 256;
+    int cmax;
+    g.vec4 = 0;
+    if (g.in_seq && g.Cin % 4 == 0) {
+        g.vec4 = 1;
+        cmax = std::min(64, g.Cin);                       // 16 lanes x 4 features per pixel row
+    } else {
+        cmax = std::max(1, std::min(kTileFloats / g.PS, g.Cin));
+    }
     g.nchunks = (g.Cin + cmax - 1) / cmax;
-    g.cchunk = (g.Cin + g.nchunks - 1) / g.nchunks;
+    g.cchunk = g.vec4 ? cmax : (g.Cin + g.nchunks - 1) / g.nchunks;
     g.Kc = g.cchunk * kk;
-    g.KS = (g.Kc + 1) / 2;
-    g.otab_floats = (2 * g.KS + 3) / 4 * 4;
+    g.KSG = ((g.Kc + 1) / 2 + 3) / 4;
+    const int kc_last = (g.Cin - (g.nchunks - 1) * g.cchunk) * kk;
+    g.KSG_last = ((kc_last + 1) / 2 + 3) / 4;
+    g.KSGpad = g.KSG + 3;                                 // slack read by the software pipeline
+    g.KS4 = 4 * g.KSGpad;
+    g.otab_floats = 2 * g.KS4;
 }
 
-// wpack[chunk][ks][cb][lane] = W[cout = cb*32 + (lane&31)][k = 2*ks + (lane>>5)], k -> (c, dy, dx)
+// wpack[chunk][group][cb][lane][e] = W[cout = cb*32 + (lane&31)][k = 2*(4*group + e) + (lane>>5)], k -> (c, dy, dx)
 // `rowmap` (optional) maps packed output column -> source row of `w` (or -1 for a zero column).
 int upload_conv_weights(ConvGeom& g, const float* w, const float* bias, const std::vector<int>* rowmap,
                         const std::vector<float>* bias_override) {
     const int kk = g.kh * g.kw;
-    std::vector<float> pack((size_t)g.nchunks * g.KS * g.CBpad * 64, 0.f);
+    if (!g.in_seq && (size_t)g.cchunk * g.PS > 64 * 256)
+        return fail(KRK_E_UNSUPPORTED, "convolution window too large for the LDS tile");
+    std::vector<float> pack((size_t)g.nchunks * g.KSGpad * g.CBpad * 256, 0.f);
     for (int ci = 0; ci < g.nchunks; ++ci)
-        for (int ks = 0; ks < g.KS; ++ks)
+        for (int gr = 0; gr < g.KSG; ++gr)
             for (int cb = 0; cb < g.CB; ++cb)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int co = cb * 32 + (lane & 31);
-                    const int k = 2 * ks + (lane >> 5);
-                    if (co >= g.Cout || k >= g.Kc) continue;
-                    const int cl = k / kk, rem = k % kk;
-                    const int c = ci * g.cchunk + cl;
-                    if (c >= g.Cin) continue;
-                    int src = co;
-                    if (rowmap) {
-                        src = (*rowmap)[co];
-                        if (src < 0) continue;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = cb * 32 + (lane & 31);
+                        const int k = 2 * (4 * gr + e) + (lane >> 5);
+                        if (co >= g.Cout || k >= g.Kc) continue;
+                        const int cl = k / kk, rem = k % kk;
+                        const int c = ci * g.cchunk + cl;
+                        if (c >= g.Cin) continue;
+                        int src = co;
+                        if (rowmap) {
+                            src = (*rowmap)[co];
+                            if (src < 0) continue;
+                        }
+                        pack[((((size_t)ci * g.KSGpad + gr) * g.CBpad + cb) * 64 + lane) * 4 + e] =
+                            w[((size_t)src * g.Cin + c) * kk + rem];
                     }
-                    pack[(((size_t)ci * g.KS + ks) * g.CBpad + cb) * 64 + lane] =
-                        w[((size_t)src * g.Cin + c) * kk + rem];
-                }
     std::vector<float> b((size_t)g.CBpad * 32, 0.f);
     for (int co = 0; co < g.Cout; ++co) {
         if (bias_override) b[co] = (*bias_override)[co];
@@ -217,18 +233,23 @@ int shape_after(const krk_plan::LenOp& op, int W) {
 void pack_lstm_recurrent(const Step& st, const float* const* whh, int M, std::vector<float>& pack) {
     const int H = st.hidden, Hp = st.Hp, G = 4 * Hp;
     const int KPI = (M == 32) ? 2 : 4;
-    const int KS = Hp / KPI, NB = G / M;
-    pack.assign((size_t)st.ndir * KS * NB * 64, 0.f);
+    const int NB = G / M;
+    const int KG = krk_lstm_kg(M, (NB + 3) / 4);
+    const int KS = Hp / KPI, NG = (KS + KG - 1) / KG;
+    pack.assign((size_t)st.ndir * NG * NB * 64 * KG, 0.f);
     for (int d = 0; d < st.ndir; ++d)
-        for (int ks = 0; ks < KS; ++ks)
+        for (int g = 0; g < NG; ++g)
             for (int b = 0; b < NB; ++b)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int k = KPI * ks + ((M == 32) ? (lane >> 5) : (lane >> 4));
-                    const int col = b * M + (lane & (M - 1));
-                    const int u = col >> 2, gt = col & 3;
-                    if (u >= H || k >= H) continue;
-                    pack[(((size_t)d * KS + ks) * NB + b) * 64 + lane] = whh[d][((size_t)gt * H + u) * H + k];
-                }
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < KG; ++e) {
+                        const int ks = g * KG + e;
+                        const int k = KPI * ks + ((M == 32) ? (lane >> 5) : (lane >> 4));
+                        const int col = b * M + (lane & (M - 1));
+                        const int u = col >> 2, gt = col & 3;
+                        if (u >= H || k >= H) continue;
+                        pack[((((size_t)d * NG + g) * NB + b) * 64 + lane) * KG + e] =
+                            whh[d][((size_t)gt * H + u) * H + k];
+                    }
 }
 
 int upload(float** dst, const std::vector<float>& v) {
@@ -650,7 +671,8 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             a.Hy = g.Hy;
             a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
             a.act = g.act;
-            a.cchunk = g.cchunk; a.nchunks = g.nchunks; a.KS = g.KS; a.Kc = g.Kc;
+            a.cchunk = g.cchunk; a.nchunks = g.nchunks; a.Kc = g.Kc;
+            a.KSG = g.KSG; a.KSG_last = g.KSG_last; a.KSGpad = g.KSGpad; a.KS4 = g.KS4; a.vec4 = g.vec4;
             a.IH = g.IH; a.IW = g.IW; a.RS = g.RS; a.PS = g.PS; a.SR = g.SR;
             a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
             a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
@@ -704,11 +726,22 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 l.ndir = s.ndir; l.dirmode = s.dirmode;
                 l.xstride = s.ndir * G;
                 l.ostride = s.ndir * s.hidden;
+                {
+                    const char* dbg = getenv("KRK_LSTM_DBG");
+                    l.dbg = dbg ? atoi(dbg) : 0;
+                }
                 // 32-line tiles once they fill most of the 256 CUs, 16-line tiles below that
                 const int tiles32 = (N + 31) / 32 * s.ndir;
-                const int M = tiles32 >= 192 ? 32 : 16;
+                int forced_m = 0;
+                if (const char* fm = getenv("KRK_LSTM_M")) forced_m = atoi(fm);
+                const int M_auto = tiles32 >= 192 ? 32 : 16;
+                const int M = (forced_m == 16 || forced_m == 32) ? forced_m : M_auto;
                 l.wp = (M == 32) ? s.d_wrec32 : s.d_wrec16;
-                l.KS = s.Hp / ((M == 32) ? 2 : 4);
+                {
+                    const int ks = s.Hp / ((M == 32) ? 2 : 4);
+                    const int kg = krk_lstm_kg(M, (G / M + 3) / 4);
+                    l.NG = (ks + kg - 1) / kg;
+                }
                 l.NB = G / M;
                 s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
                 rc = krk_launch_lstm(l, M, stream);

@@ -39,7 +39,7 @@ __device__ __forceinline__ float krk_act(float v, int act) {
 struct ConvArgs {
     const float* x;       // IN_SEQ=0: (N,Cin,H,W) planes; IN_SEQ=1: [W][Cin] rows (N=1,H=1)
     float* y;             // see epilogues in conv_mfma.hip
-    const float* wpack;   // [nchunks][KS][CBpad][64] fragment order
+    const float* wpack;   // [nchunks][KSGpad][CBpad][64][4] fragment order, 4 K-steps per lane contiguous
     const float* bias;    // [CBpad*32]
     const int* len_in;    // [N] valid input width per line or nullptr
     const int* len_out;   // [N] valid stored-output width per line or nullptr
@@ -49,7 +49,10 @@ struct ConvArgs {
     int Ho, Wo;           // conv output extent (before pooling)
     int Hy, Wy;           // stored extent (after the fused 2x2/2 max-pool, else == Ho,Wo)
     int act;
-    int cchunk, nchunks, KS, Kc;   // channels per LDS chunk, #chunks, K-steps (of 2) and K per chunk
+    int cchunk, nchunks, Kc;       // channels per LDS chunk, #chunks, K (= cchunk*kh*kw) per chunk
+    int KSG, KSG_last, KSGpad;     // groups of 4 K-steps per chunk / in the last chunk / allocated (KSG + 3)
+    int KS4;                       // offset-table entries per lane half (= 4 * KSGpad)
+    int vec4;                      // IN_SEQ: rows are 16-byte loadable (Cin % 4 == 0, cchunk % 4 == 0)
     int IH, IW, RS, PS;   // staged tile rows/cols, row stride, plane stride (floats)
     int SR;               // 32-pixel segments per tile row: tile = (8/SR) rows x (32*SR) cols
     int tiles_h, tiles_w;
@@ -59,14 +62,18 @@ struct ConvArgs {
 // ----------------------------------------------------------------------- LSTM
 struct LstmArgs {
     const float* xp;      // [N*T][xstride] input projections (+ both biases), gate-interleaved columns
-    const float* wp;      // [ndir][KS][NB][64] recurrent weights in B-fragment order
+    const float* wp;      // [ndir][NG][NB][64][KG] recurrent weights, B-fragment order, KG K-steps per lane
     float* out;           // [N][T][ostride]
     const int* lens;      // [N] valid steps per line or nullptr
     int N, T, H, Hp;      // hidden size and hidden size padded to the column-block granule
-    int KS, NB, G;        // K-steps per time step, column blocks, G = 4*Hp gate columns per direction
+    int NG, NB, G;        // K-groups (of KG MFMA K-steps) per time step, column blocks, G = 4*Hp gate columns/direction
     int ndir, dirmode;    // 1|2 directions; 0 fwd, 1 rev, 2 bidi
     int xstride, ostride;
+    int dbg;              // probe bits (env KRK_LSTM_DBG): 1 no GEMM, 2 no gate math, 4 no output pass, 8 no x prefetch
 };
+
+// K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel
+int krk_lstm_kg(int M, int blocks_per_wave);
 
 // host-side launchers (implemented in the .hip files)
 int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);

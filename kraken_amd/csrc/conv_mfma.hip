@@ -14,18 +14,33 @@
 //               the LDS offset of each K is looked up in a table so that kernel size, stride and
 //               dilation are data, not code
 //   operands  = input pixels from the LDS tile (lanes 0-31 read 32 consecutive floats: conflict-free),
-//               weights straight from global memory in fragment order (one coalesced 256-B load per
-//               fragment; the 0.2-1.3 MB of weights stay L2-resident)
+//               weights straight from global memory in fragment order, four K-steps per lane
+//               contiguous (one dwordx4 = 1 KB per wave instruction; the weights stay L2-resident)
+//   pipeline  = K-steps are processed in groups of four; offsets, pixels and weights of group g+1
+//               (weights: g+2) are fetched while the MFMAs of group g issue
+//   staging   = all global loads of a chunk are issued before the first LDS write (no load->store
+//               serialisation); sequence inputs use 16-byte loads along the feature axis
 // Masked-padding semantics: input columns >= len_in[n] read as zero, stored columns >= len_out[n]
 // are written as zero (see include/kraken_amd.h).
 #include "common.h"
 
 namespace {
 
+
+// e / d for 0 <= e < 2^23, d > 0 via one float multiply and a fix-up (no integer division)
+__device__ __forceinline__ int fast_div(int e, int d, float inv, int& rem) {
+    int q = (int)((float)e * inv);
+    int r = e - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
+
 template <int IN_SEQ, int OUT_SEQ, int POOL, int CBW>
-__global__ void __launch_bounds__(256) conv_f32_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, 2) conv_f32_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* otab = reinterpret_cast<int*>(smem);
+    int* otab = reinterpret_cast<int*>(smem);   // [2][KSG4]: offsets of K = 2*ks + half, ks-major per half
     float* tile = smem + a.otab_floats;
 
     const int tid = threadIdx.x;
@@ -63,13 +78,17 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const ConvArgs a) {
         inb[s] = (h0 + srow[s] < a.Ho) && (w0 + scol[s] < a.Wo);
         live[s] = inb[s] && (w0 + scol[s] < wlim);
     }
+    const bool any_live = live[0] || live[1];
 
-    // K -> LDS offset table (identical for every channel chunk)
-    for (int k = tid; k < 2 * a.KS; k += 256) {
+    // K -> LDS offset table (identical for every channel chunk); KS4 = padded K-steps (+2 spare groups)
+    const int KS4 = a.KS4;
+    for (int k = tid; k < 2 * KS4; k += 256) {
+        const int hh = k / KS4, ks = k - hh * KS4;
+        const int kidx = 2 * ks + hh;
         int off = 0;
-        if (k < a.Kc) {
+        if (kidx < a.Kc) {
             const int kk = a.kh * a.kw;
-            const int c = k / kk, rem = k - c * kk;
+            const int c = kidx / kk, rem = kidx - c * kk;
             const int dy = rem / a.kw, dx = rem - dy * a.kw;
             off = c * a.PS + dy * a.dh * a.RS + dx * a.dw;
         }
@@ -88,61 +107,137 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const ConvArgs a) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) boff[s] = srow[s] * a.sh * a.RS + (scol[s] + px) * a.sw;
 
-    const bool any_live = live[0] || live[1];
+    const int* otab_h = otab + half * KS4;
 
     for (int ci = 0; ci < a.nchunks; ++ci) {
-        __syncthreads();  // previous chunk fully consumed (and otab visible on the first pass)
+        // ------------------------------------------------ stage chunk ci: loads first, then LDS writes
         if (IN_SEQ) {
-            // rows of [W][Cin]: a pixel's channel chunk is contiguous -> coalesced reads,
-            // transposed into tile[c][p] (odd plane stride: conflict-free writes)
+            // rows of [W][Cin]: 16 lanes x 16 B cover 64 consecutive features of one pixel
             const int cc = a.cchunk;
-            const int total = TW * cc;
-            for (int e = tid; e < total; e += 256) {
-                const int p = e / cc, c = e - p * cc;
-                const int gp = w0 + p, gc = ci * cc + c;
-                float v = 0.f;
-                if (gp < a.W && gc < a.Cin) v = a.x[(size_t)gp * a.Cin + gc];
-                tile[c * a.PS + p] = v;
+            const int c4 = (lane & 15) * 4;
+            const int pl = wave * 4 + (lane >> 4);          // pixel within a group of 16
+            const int gc = ci * cc + c4;
+            const bool cok = c4 < cc;
+            if (a.vec4) {
+                f32x4 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int gp = w0 + i * 16 + pl;
+                    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (cok && i * 16 < TW && gp < a.W && gc < a.Cin)     // Cin % 4 == 0: whole quad valid
+                        v[i] = *reinterpret_cast<const f32x4*>(a.x + (size_t)gp * a.Cin + gc);
+                }
+                __syncthreads();   // previous chunk fully consumed
+                if (cok) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int p = i * 16 + pl;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tile[(c4 + j) * a.PS + p] = v[i][j];
+                    }
+                }
+            } else {
+                __syncthreads();
+                const int total = TW * cc;
+                const float inv = 1.0f / (float)cc;
+                for (int e = tid; e < total; e += 256) {
+                    int c;
+                    const int p = fast_div(e, cc, inv, c);
+                    const int gp = w0 + p, g2 = ci * cc + c;
+                    float v = 0.f;
+                    if (gp < a.W && g2 < a.Cin) v = a.x[(size_t)gp * a.Cin + g2];
+                    tile[c * a.PS + p] = v;
+                }
             }
         } else {
             const int gh0 = h0 * a.sh - a.ph, gw0 = w0 * a.sw - a.pw;
             const int per_c = a.IH * a.IW;
             const int total = a.cchunk * per_c;
+            const float inv_pc = 1.0f / (float)per_c, inv_iw = 1.0f / (float)a.IW;
             const float* xn = a.x + (size_t)n * a.Cin * a.H * a.W;
-            for (int e = tid; e < total; e += 256) {
-                const int c = e / per_c, r = e - c * per_c;
-                const int ih = r / a.IW, iw = r - ih * a.IW;
-                const int gc = ci * a.cchunk + c, gh = gh0 + ih, gw = gw0 + iw;
-                float v = 0.f;
-                if (gc < a.Cin && gh >= 0 && gh < a.H && gw >= 0 && gw < len_in)
-                    v = xn[((size_t)gc * a.H + gh) * a.W + gw];
-                tile[c * a.PS + ih * a.RS + iw] = v;
+            __syncthreads();   // previous chunk fully consumed
+            // batches of SB loads in flight per thread, then their LDS writes
+            constexpr int SB = 16;
+            for (int i0 = 0; i0 * 256 < total; i0 += SB) {
+                float v[SB];
+                int dst[SB];
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int e = tid + 256 * (i0 + i);
+                    v[i] = 0.f;
+                    dst[i] = -1;
+                    if (e < total) {
+                        int r, iw;
+                        const int c = fast_div(e, per_c, inv_pc, r);
+                        const int ih = fast_div(r, a.IW, inv_iw, iw);
+                        const int gc = ci * a.cchunk + c, gh = gh0 + ih, gw = gw0 + iw;
+                        dst[i] = c * a.PS + ih * a.RS + iw;
+                        if (gc < a.Cin && gh >= 0 && gh < a.H && gw >= 0 && gw < len_in)
+                            v[i] = xn[((size_t)gc * a.H + gh) * a.W + gw];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < SB; ++i)
+                    if (dst[i] >= 0) tile[dst[i]] = v[i];
             }
         }
         __syncthreads();
         if (!any_live) continue;
 
-        const float* wp = a.wpack + ((size_t)ci * a.KS * a.CBpad + cb0) * 64 + lane;
-        const size_t wstep = (size_t)a.CBpad * 64;
-#pragma unroll 2
-        for (int ks = 0; ks < a.KS; ++ks) {
-            const int off = otab[2 * ks + half];
-            float b[2];
+        // ------------------------------------------------ MFMA loop, groups of 4 K-steps, pipelined
+        const int ngroups = (ci + 1 == a.nchunks) ? a.KSG_last : a.KSG;
+        // weights: [chunk][group][cb][lane][4]
+        const float* wp = a.wpack + (((size_t)ci * a.KSGpad) * a.CBpad + cb0) * 256 + lane * 4;
+        const size_t wstep = (size_t)a.CBpad * 256;
+
+        auto load_w = [&](int g, f32x4 (&w)[CBW]) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) b[s] = tile[off + boff[s]];
-            float w[CBW];
+            for (int cb = 0; cb < CBW; ++cb) w[cb] = *reinterpret_cast<const f32x4*>(wp + (size_t)g * wstep + cb * 256);
+        };
+        auto load_off = [&](int g) { return *reinterpret_cast<const int4*>(otab_h + 4 * g); };
+        auto load_b = [&](const int4& o, float (&b)[2][4]) {
 #pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) w[cb] = wp[(size_t)ks * wstep + cb * 64];
+            for (int s = 0; s < 2; ++s) {
+                b[s][0] = tile[o.x + boff[s]];
+                b[s][1] = tile[o.y + boff[s]];
+                b[s][2] = tile[o.z + boff[s]];
+                b[s][3] = tile[o.w + boff[s]];
+            }
+        };
+        auto mma4 = [&](const float (&b)[2][4], const f32x4 (&w)[CBW]) {
 #pragma unroll
-            for (int cb = 0; cb < CBW; ++cb)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    if (live[s]) {
-                        if (OUT_SEQ)  // D[pixel][filter]
-                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], w[cb], acc[cb][s], 0, 0, 0);
-                        else          // D[filter][pixel]
-                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cb], b[s], acc[cb][s], 0, 0, 0);
-                    }
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        if (live[s]) {
+                            if (OUT_SEQ)  // D[pixel][filter]
+                                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s][e], w[cb][e], acc[cb][s], 0, 0, 0);
+                            else          // D[filter][pixel]
+                                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cb][e], b[s][e], acc[cb][s], 0, 0, 0);
+                        }
+        };
+
+        // the offset table and the weight pack carry two zero groups of slack: no tail branches
+        f32x4 wa[CBW], wb[CBW];
+        float ba[2][4], bb[2][4];
+        load_w(0, wa);
+        load_w(1, wb);
+        int4 o_next = load_off(1);
+        {
+            const int4 o0 = load_off(0);
+            load_b(o0, ba);
+        }
+        for (int g = 0; g < ngroups; g += 2) {
+            load_b(o_next, bb);                 // pixels of group g+1
+            o_next = load_off(g + 2);
+            mma4(ba, wa);
+            load_w(g + 2, wa);
+            load_b(o_next, ba);                 // pixels of group g+2
+            o_next = load_off(g + 3);
+            if (g + 1 < ngroups) mma4(bb, wb);
+            load_w(g + 3, wb);
         }
     }
 

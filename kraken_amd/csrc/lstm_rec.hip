@@ -10,16 +10,19 @@
 // with no inter-workgroup communication.  Per step it computes the M x 4H gate
 // pre-activations  acc = xproj[t] + h_{t-1} . W_hh^T  on the f32 matrix cores:
 //   - h_{t-1} lives in LDS as hs[k][line] (A operand: 32/16 consecutive lines per lane group);
-//   - W_hh streams from L2 in B-fragment order (one coalesced 256-B load per fragment,
-//     0.64 MB per step per CU for H=200 -- the weights of both directions stay L2-resident);
-//   - xproj[t] (input projection + both biases, produced by the GEMM in conv_mfma.hip)
-//     initialises the accumulators;
+//   - W_hh streams from L2 in B-fragment order.  The stream is the critical resource
+//     (0.64 MB per step per workgroup for H=200): weights are packed so that one lane's
+//     fragments for KG consecutive K-steps are contiguous (dwordx4 loads, 1-2 KB per wave
+//     instruction) and the loop is software-pipelined over two register buffers -- the
+//     loads of K-group g+1 are in flight while the MFMAs of group g issue;
+//   - xproj[t+1] (input projection + both biases, produced by the GEMM in conv_mfma.hip)
+//     is prefetched into registers during step t and initialises the accumulators;
 //   - gate columns are interleaved (col = 4*unit + gate) by the weight packer so that the
 //     four gates of a hidden unit sit in the four lanes of a DPP quad: the cell update
 //     needs three quad broadcasts and no LDS round trip; c stays in registers for the
 //     whole sequence;
 //   - h_t goes to the other LDS buffer (one barrier per step) and is streamed to `out`
-//     with coalesced stores while the next step's MFMAs run.
+//     with coalesced stores while the next step's loads are in flight.
 // M = 32 uses v_mfma_f32_32x32x2_f32, M = 16 uses v_mfma_f32_16x16x4_f32 (twice the
 // workgroups for small batches, same FLOP rate).
 #include "common.h"
@@ -40,17 +43,179 @@ __device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int M, int MAXB>
-__global__ void __launch_bounds__(256, 1) lstm_f32_kernel(const LstmArgs a) {
-    constexpr int NACC = (M == 32) ? 16 : 4;   // accumulator registers per column block
-    constexpr int KPI = (M == 32) ? 2 : 4;     // K per MFMA
-    constexpr int LS = M + 1;                  // LDS line stride of hs (odd: conflict-free both ways)
-    constexpr int UPB = M / 4;                 // hidden units per column block
-    using accv = typename std::conditional<M == 32, f32x16, f32x4>::type;
+// KG consecutive K-steps of one column block, one lane: KG floats = KG/4 dwordx4 loads.
+template <int KG>
+struct WFrag {
+    f32x4 v[KG / 4];
+    __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+        for (int i = 0; i < KG / 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+    }
+    __device__ __forceinline__ float at(int e) const { return v[e >> 2][e & 3]; }
+};
 
+// Per-wave state that survives the whole sequence.
+template <int M>
+struct LstmGeom {
+    static constexpr int NACC = (M == 32) ? 16 : 4;   // accumulator registers per column block
+    static constexpr int KPI = (M == 32) ? 2 : 4;     // K per MFMA
+    static constexpr int LS = M + 1;                  // LDS line stride of hs (odd: conflict-free both ways)
+    static constexpr int UPB = M / 4;                 // hidden units per column block
+    using accv = typename std::conditional<M == 32, f32x16, f32x4>::type;
+};
+
+// The time loop for a wave that owns exactly NBW column blocks (wave, wave+4, ...).  NBW is a
+// compile-time constant so that the K loop is one straight-line block of loads and MFMAs: a
+// run-time block count would put a scalar branch around every MFMA and stop the scheduler from
+// overlapping the weight stream with the matrix pipe.
+template <int M, int NBW, int KG, bool XPRE>
+__device__ __forceinline__ void lstm_time_loop(const LstmArgs& a, float* hs, const int* lens_s, int hrows, int Lmax,
+                                               int wave, int lane, int dir, bool rev, int n0) {
+    using G = LstmGeom<M>;
+    constexpr int NACC = G::NACC, KPI = G::KPI, LS = G::LS, UPB = G::UPB;
+    using accv = typename G::accv;
+
+    const int cl = lane & (M - 1);            // column inside a block
+    const int gate = cl & 3, ul = cl >> 2;
+    const int khalf = (M == 32) ? (lane >> 5) : (lane >> 4);
+    const int arow = lane & (M - 1);
+
+    int irow[NACC], ilen[NACC];
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+        irow[r] = (M == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) : (4 * (lane >> 4) + r);
+        ilen[r] = lens_s[irow[r]];
+    }
+
+    accv acc[NBW];
+    accv xn[XPRE ? NBW : 1];   // next step's input projection (prefetch), if registers allow
+    float cst[NBW][NACC];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) cst[j][r] = 0.f;
+
+    // weights: [dir][group][block][lane][KG]
+    const float* wbase = a.wp + ((size_t)dir * a.NG * a.NB * 64 + lane) * KG;
+    const size_t gstride = (size_t)a.NB * 64 * KG;
+    const float gscale = (gate == 2) ? 2.f : 1.f;   // tanh(x) = 2 sig(2x) - 1 for the cell gate
+
+    auto load_x = [&](int s, auto& dst) {
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            const bool on = s < ilen[r];
+            const int t = rev ? (ilen[r] - 1 - s) : s;
+            const float* xr = a.xp + ((size_t)(n0 + irow[r]) * a.T + (on ? t : 0)) * a.xstride + (size_t)dir * a.G + cl;
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) dst[j][r] = on ? xr[(size_t)(wave + 4 * j) * M] : 0.f;
+        }
+    };
+    auto load_w = [&](int g, WFrag<KG> (&dst)[NBW]) {
+        const float* wg = wbase + (size_t)g * gstride;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) dst[j].load(wg + (size_t)(wave + 4 * j) * 64 * KG);
+    };
+    auto mma_group = [&](int g, const float* hcur, const WFrag<KG> (&w)[NBW]) {
+        float av[KG];
+#pragma unroll
+        for (int e = 0; e < KG; ++e) av[e] = hcur[(KPI * (g * KG + e) + khalf) * LS + arow];
+#pragma unroll
+        for (int e = 0; e < KG; ++e)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) acc[j] = mma(av[e], w[j].at(e), acc[j]);
+    };
+
+    WFrag<KG> wa[NBW], wb[NBW];
+    load_w(0, wa);                       // group 0 of step 0
+    if constexpr (XPRE) load_x(0, xn);
+    int cur = 0;
+    for (int s = 0; s < Lmax; ++s) {
+        if constexpr (XPRE) {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) acc[j] = xn[j];
+            if (s + 1 < Lmax && !(a.dbg & 8)) load_x(s + 1, xn);   // in flight for the whole step
+        } else {
+            load_x(s, acc);
+        }
+
+        // ---- acc += h_{t-1} . W_hh^T, weight stream double-buffered in registers
+        const float* hcur = hs + cur * hrows * LS;
+        int g = 0;
+        if (a.dbg & 1) g = a.NG;          // probe: skip the recurrent GEMM
+        for (; g + 1 < a.NG; g += 2) {
+            load_w(g + 1, wb);
+            mma_group(g, hcur, wa);
+            load_w(g + 2 < a.NG ? g + 2 : 0, wa);     // wraps to group 0 of the NEXT step
+            mma_group(g + 1, hcur, wb);
+        }
+        if (g < a.NG) {
+            mma_group(g, hcur, wa);
+            load_w(0, wa);                             // group 0 of the next step
+        }
+
+        // ---- gate non-linearities, cell update, h_t -> LDS
+        float* hnext = hs + (cur ^ 1) * hrows * LS;
+        if (!(a.dbg & 2))                 // probe: skip the gate math
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int unit = (wave + 4 * j) * UPB + ul;
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * acc[j][r]));
+                gv = (gate == 2) ? (2.f * gv - 1.f) : gv;
+                const float gi = quad_bcast<0x00>(gv);
+                const float gf = quad_bcast<0x55>(gv);
+                const float gg = quad_bcast<0xAA>(gv);
+                const float go = quad_bcast<0xFF>(gv);
+                const float c = gf * cst[j][r] + gi * gg;
+                cst[j][r] = c;
+                const float h = go * krk_tanh(c);
+                if (gate == 0) hnext[unit * LS + irow[r]] = h;
+            }
+        }
+        __syncthreads();
+        // ---- h_t -> out[n][t][dir*H + k], coalesced
+        for (int i = wave; i < M; i += 4) {
+            const int li = lens_s[i];
+            if (s < li) {
+                const int t = rev ? (li - 1 - s) : s;
+                float* o = a.out + ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H;
+                for (int k = lane; k < a.H; k += 64) o[k] = hnext[k * LS + i];
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+// A wave without column blocks (4*Hp/M < 4) still takes part in the barriers and the output pass.
+template <int M>
+__device__ __forceinline__ void lstm_idle_loop(const LstmArgs& a, const float* hs, const int* lens_s, int hrows,
+                                               int Lmax, int wave, int lane, int dir, bool rev, int n0) {
+    constexpr int LS = LstmGeom<M>::LS;
+    int cur = 0;
+    for (int s = 0; s < Lmax; ++s) {
+        const float* hnext = hs + (cur ^ 1) * hrows * LS;
+        __syncthreads();
+        for (int i = wave; i < M; i += 4) {
+            const int li = lens_s[i];
+            if (s < li) {
+                const int t = rev ? (li - 1 - s) : s;
+                float* o = a.out + ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H;
+                for (int k = lane; k < a.H; k += 64) o[k] = hnext[k * LS + i];
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+// MAXB = ceil(NB / 4): every wave owns MAXB or MAXB-1 column blocks.
+template <int M, int MAXB, int KG, bool XPRE>
+__global__ void __launch_bounds__(256, 1) lstm_f32_kernel(const LstmArgs a) {
+    using G = LstmGeom<M>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* hs = smem;                                   // [2][Hp][LS]
-    int* lens_s = reinterpret_cast<int*>(smem + 2 * a.Hp * LS);  // [M]
+    const int hrows = a.NG * KG * G::KPI;              // K rows incl. zero padding of the last group
+    float* hs = smem;                                  // [2][hrows][LS]
+    int* lens_s = reinterpret_cast<int*>(smem + 2 * hrows * G::LS);  // [M]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -65,107 +230,28 @@ __global__ void __launch_bounds__(256, 1) lstm_f32_kernel(const LstmArgs a) {
         if (n < a.N) l = a.lens ? min(max(a.lens[n], 0), a.T) : a.T;
         lens_s[tid] = l;
     }
-    for (int e = tid; e < 2 * a.Hp * LS; e += 256) hs[e] = 0.f;
+    for (int e = tid; e < 2 * hrows * G::LS; e += 256) hs[e] = 0.f;
     __syncthreads();
     int Lmax = 0;
     for (int i = 0; i < M; ++i) Lmax = max(Lmax, lens_s[i]);
 
-    const int cl = lane & (M - 1);            // column inside a block
-    const int gate = cl & 3, ul = cl >> 2;
-    const int khalf = (M == 32) ? (lane >> 5) : (lane >> 4);
-    const int arow = lane & (M - 1);
-
-    int irow[NACC], ilen[NACC];
-#pragma unroll
-    for (int r = 0; r < NACC; ++r) {
-        irow[r] = (M == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) : (4 * (lane >> 4) + r);
-        ilen[r] = lens_s[irow[r]];
-    }
     const int nb_mine = (a.NB - wave + 3) / 4;   // blocks wave, wave+4, ...
-
-    accv acc[MAXB];
-    float cst[MAXB][NACC];
-#pragma unroll
-    for (int j = 0; j < MAXB; ++j)
-#pragma unroll
-        for (int r = 0; r < NACC; ++r) cst[j][r] = 0.f;
-
-    const float* wbase = a.wp + (size_t)dir * a.KS * a.NB * 64 + lane;
-    const float gscale = (gate == 2) ? 2.f : 1.f;   // tanh(x) = 2 sig(2x) - 1 for the cell gate
-
-    int cur = 0;
-    for (int s = 0; s < Lmax; ++s) {
-        // ---- accumulators <- input projection of this step (per line: own time index)
-        size_t xoff[NACC];
-        bool on[NACC];
-#pragma unroll
-        for (int r = 0; r < NACC; ++r) {
-            on[r] = s < ilen[r];
-            const int t = rev ? (ilen[r] - 1 - s) : s;
-            xoff[r] = ((size_t)(n0 + irow[r]) * a.T + (on[r] ? t : 0)) * a.xstride + (size_t)dir * a.G + cl;
-        }
-#pragma unroll
-        for (int j = 0; j < MAXB; ++j) {
-            if (j < nb_mine) {
-                const int b = wave + 4 * j;
-#pragma unroll
-                for (int r = 0; r < NACC; ++r) acc[j][r] = on[r] ? a.xp[xoff[r] + (size_t)b * M] : 0.f;
-            }
-        }
-        // ---- acc += h_{t-1} . W_hh^T
-        const float* hcur = hs + cur * a.Hp * LS;
-#pragma unroll 2
-        for (int ks = 0; ks < a.KS; ++ks) {
-            const float av = hcur[(KPI * ks + khalf) * LS + arow];
-            const float* wk = wbase + (size_t)ks * a.NB * 64;
-#pragma unroll
-            for (int j = 0; j < MAXB; ++j) {
-                if (j < nb_mine) {
-                    const float wv = wk[(wave + 4 * j) * 64];
-                    acc[j] = mma(av, wv, acc[j]);
-                }
-            }
-        }
-        // ---- gate non-linearities, cell update, h_t -> LDS
-        float* hnext = hs + (cur ^ 1) * a.Hp * LS;
-#pragma unroll
-        for (int j = 0; j < MAXB; ++j) {
-            if (j < nb_mine) {
-                const int unit = (wave + 4 * j) * UPB + ul;
-#pragma unroll
-                for (int r = 0; r < NACC; ++r) {
-                    float g = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * acc[j][r]));
-                    g = (gate == 2) ? (2.f * g - 1.f) : g;
-                    const float gi = quad_bcast<0x00>(g);
-                    const float gf = quad_bcast<0x55>(g);
-                    const float gg = quad_bcast<0xAA>(g);
-                    const float go = quad_bcast<0xFF>(g);
-                    const float c = gf * cst[j][r] + gi * gg;
-                    cst[j][r] = c;
-                    const float h = go * krk_tanh(c);
-                    if (gate == 0) hnext[unit * LS + irow[r]] = h;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- h_t -> out[n][t][dir*H + k], coalesced; overlaps the next step's MFMAs
-        for (int i = wave; i < M; i += 4) {
-            const int li = lens_s[i];
-            if (s < li) {
-                const int t = rev ? (li - 1 - s) : s;
-                float* o = a.out + ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H;
-                for (int k = lane; k < a.H; k += 64) o[k] = hnext[k * LS + i];
-            }
-        }
-        cur ^= 1;
+    if (nb_mine == MAXB) {
+        lstm_time_loop<M, MAXB, KG, XPRE>(a, hs, lens_s, hrows, Lmax, wave, lane, dir, rev, n0);
+    } else {
+        if constexpr (MAXB > 1)
+            lstm_time_loop<M, MAXB - 1, KG, XPRE>(a, hs, lens_s, hrows, Lmax, wave, lane, dir, rev, n0);
+        else
+            lstm_idle_loop<M>(a, hs, lens_s, hrows, Lmax, wave, lane, dir, rev, n0);
     }
 }
 
-template <int M, int MAXB>
+template <int M, int MAXB, int KG, bool XPRE>
 int launch_one(const LstmArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.N + M - 1) / M), (unsigned)a.ndir);
-    const size_t lds = ((size_t)2 * a.Hp * (M + 1) + M) * sizeof(float);
-    auto kfn = lstm_f32_kernel<M, MAXB>;
+    constexpr int KPI = (M == 32) ? 2 : 4;
+    const size_t lds = ((size_t)2 * a.NG * KG * KPI * (M + 1) + M) * sizeof(float);
+    auto kfn = lstm_f32_kernel<M, MAXB, KG, XPRE>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -175,15 +261,31 @@ int launch_one(const LstmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// M in {16, 32}; a.NB = 4*Hp / M column blocks, at most 4*MAXB of them.
+// K-steps per lane-contiguous weight group for a given tile size / blocks-per-wave; the packer
+// (capi.hip) asks for the same value.  Chosen so that accumulators + cell state + prefetch
+// buffers stay inside the 512-register budget of one wave per SIMD.
+int krk_lstm_kg(int M, int per_wave) {
+    if (M == 32) return 4;
+    return per_wave <= 13 ? 8 : 4;
+}
+
+// M in {16, 32}; a.NB = 4*Hp / M column blocks; a.NG = K-groups of krk_lstm_kg() steps.
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s) {
     const int per_wave = (a.NB + 3) / 4;
+#define KRK_CASE(M_, B_, KG_, X_) case B_: return launch_one<M_, B_, KG_, X_>(a, s)
     if (M == 32) {
-        if (per_wave <= 4) return launch_one<32, 4>(a, s);
-        if (per_wave <= 8) return launch_one<32, 8>(a, s);
-        return -4;
+        switch (per_wave) {
+            KRK_CASE(32, 1, 4, true); KRK_CASE(32, 2, 4, true); KRK_CASE(32, 3, 4, true); KRK_CASE(32, 4, 4, true);
+            KRK_CASE(32, 5, 4, true); KRK_CASE(32, 6, 4, false); KRK_CASE(32, 7, 4, false); KRK_CASE(32, 8, 4, false);
+            default: return -4;
+        }
     }
-    if (per_wave <= 8) return launch_one<16, 8>(a, s);
-    if (per_wave <= 16) return launch_one<16, 16>(a, s);
-    return -4;
+    switch (per_wave) {
+        KRK_CASE(16, 1, 8, true); KRK_CASE(16, 2, 8, true); KRK_CASE(16, 3, 8, true); KRK_CASE(16, 4, 8, true);
+        KRK_CASE(16, 5, 8, true); KRK_CASE(16, 6, 8, true); KRK_CASE(16, 7, 8, true); KRK_CASE(16, 8, 8, true);
+        KRK_CASE(16, 9, 8, true); KRK_CASE(16, 10, 8, true); KRK_CASE(16, 11, 8, true); KRK_CASE(16, 12, 8, true);
+        KRK_CASE(16, 13, 8, true); KRK_CASE(16, 14, 4, true); KRK_CASE(16, 15, 4, true); KRK_CASE(16, 16, 4, true);
+        default: return -4;
+    }
+#undef KRK_CASE
 }
