@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='lines per GPU per step')
     ap.add_argument('--width', type=int, default=1200)
-    ap.add_argument('--slots', type=int, default=2, help='batches in flight per GPU (streams)')
+    ap.add_argument('--slots', type=int, default=3, help='batches in flight per GPU (streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-lines', type=int, default=32, help='lines in the CPU baseline sample')
     return ap.parse_args()
@@ -123,20 +123,34 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- per-kernel-group timing from the HIP events recorded inside the timed region
-    per_layer = {}
+    # ---- per-launch timing from the HIP events recorded inside the timed region (last batch of each
+    # slot, on the stream the kernels were launched on)
+    per_launch = {}
     for slot_times in engine.layer_times():
         for i, (name, ms, flops) in enumerate(slot_times):
-            e = per_layer.setdefault(i, {'name': name, 'ms': [], 'flops': flops})
+            e = per_launch.setdefault(i, {'name': name, 'ms': [], 'flops': flops})
             e['ms'].append(ms)
-    layers = [{'i': i, 'name': v['name'], 'ms': float(np.mean(v['ms'])), 'gflop': v['flops'] / 1e9}
-              for i, v in sorted(per_layer.items())]
-    convs = [l for l in layers if l['name'] == 'conv']
-    dom = max(convs, key=lambda l: l['ms'])
-    ach = dom['gflop'] / dom['ms']   # GFLOP/ms == TFLOP/s
-    roofline = {'bound': 'mfma', 'kernel': f'conv_f32_kernel (layer {dom["i"]})', 'achieved': round(ach, 2),
-                'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                'traffic': None}
+    launches = [{'i': i, 'name': v['name'], 'ms': float(np.mean(v['ms'])), 'gflop': v['flops'] / 1e9}
+                for i, v in sorted(per_launch.items())]
+    # kernels behind the launch groups (rocprofv3 kernel names)
+    kernel_of = {'conv': 'conv_f32_kernel', 'lstm_xproj': 'conv_f32_kernel<1,1,0,4>', 'linear': 'conv_f32_kernel<1,1,0,4>',
+                 'lstm_rec': 'lstm_f32_kernel'}
+    groups = {}
+    for l in launches:
+        g = groups.setdefault(l['name'], {'ms': 0.0, 'gflop': 0.0, 'n': 0})
+        g['ms'] += l['ms']
+        g['gflop'] += l['gflop']
+        g['n'] += 1
+    # dominant kernel = the launch group with the largest share of the step
+    dom_name = max((k for k in groups if groups[k]['gflop'] > 0), key=lambda k: groups[k]['ms'])
+    dom = groups[dom_name]
+    ach = dom['gflop'] / dom['ms']   # GFLOP/ms == TFLOP/s; algorithmic FLOPs of the launches / their duration
+    roofline = {'bound': 'mfma', 'kernel': kernel_of.get(dom_name, dom_name), 'launch_group': dom_name,
+                'launches_per_step': dom['n'], 'avg_launch_ms': round(dom['ms'] / dom['n'], 4),
+                'gflop_per_launch': round(dom['gflop'] / dom['n'], 3),
+                'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None}
+    layers = launches
 
     lines = N * args.steps * world
     value = lines / dt
@@ -150,8 +164,11 @@ def main():
                    'slots': args.slots, 'parallelism': f'dp{world}', 'whole_path_tflops': round(value * 2.778e-3 *
                                                                                                  (W / 1200.0), 2)},
         'roofline': roofline,
-        'layers': [{'name': l['name'], 'ms': round(l['ms'], 3), 'tflops': round(l['gflop'] / l['ms'], 1) if l['ms'] > 0 else 0}
-                   for l in layers],
+        'launches': [{'name': l['name'], 'ms': round(l['ms'], 3), 'tflops': round(l['gflop'] / l['ms'], 1) if l['ms'] > 0 else 0}
+                     for l in layers],
+        'groups': {k: {'ms': round(v['ms'], 3), 'tflops': round(v['gflop'] / v['ms'], 1) if v['ms'] > 0 else 0,
+                       'frac_of_f32_mfma_peak': round(v['gflop'] / v['ms'] / F32_MFMA_PEAK_TFLOPS, 4) if v['ms'] > 0 else 0}
+                   for k, v in groups.items()},
         'gathered_lines': int(sum(len(b.counts) for b in gathered)),
     }
     if rank == 0:

@@ -214,7 +214,10 @@ struct krk_plan {
     bool lens_ev_pending = false;
     DevBuf d_labels, d_confs, d_final;
     bool profiling = false;
-    std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> events;          // one per profiled launch + 1
+    std::vector<const char*> prof_names;     // kernel group of each profiled launch of the last call
+    std::vector<double> prof_flops;
+    size_t prof_n = 0;
     int last_N = 0, last_W = 0;
 };
 
@@ -565,30 +568,35 @@ int krk_plan_set_profiling(krk_plan* plan, int enable) {
     if (!plan) return fail(KRK_E_INVALID, "null plan");
     plan->profiling = enable != 0;
     if (plan->profiling && plan->events.empty()) {
-        plan->events.resize(plan->steps.size() + 1);
+        plan->events.resize(2 * plan->steps.size() + 1);
         for (auto& e : plan->events)
             if (hipEventCreate(&e) != hipSuccess) return fail(KRK_E_HIP, "hipEventCreate failed");
     }
     return KRK_OK;
 }
 
-int krk_plan_num_steps(const krk_plan* plan) { return plan ? (int)plan->steps.size() : 0; }
+int krk_plan_num_steps(const krk_plan* plan) {
+    if (!plan) return 0;
+    return plan->prof_n ? (int)plan->prof_n : (int)plan->steps.size();
+}
 
 const char* krk_plan_layer_name(const krk_plan* plan, int i) {
-    if (!plan || i < 0 || i >= (int)plan->steps.size()) return nullptr;
-    return kStepNames[plan->steps[i].kind];
+    if (!plan || i < 0) return nullptr;
+    if (plan->prof_n) return i < (int)plan->prof_n ? plan->prof_names[i] : nullptr;
+    return i < (int)plan->steps.size() ? kStepNames[plan->steps[i].kind] : nullptr;
 }
 
 double krk_plan_layer_flops(const krk_plan* plan, int i) {
-    if (!plan || i < 0 || i >= (int)plan->steps.size()) return 0.0;
-    return plan->steps[i].flops;
+    if (!plan || i < 0) return 0.0;
+    if (plan->prof_n) return i < (int)plan->prof_n ? plan->prof_flops[i] : 0.0;
+    return i < (int)plan->steps.size() ? plan->steps[i].flops : 0.0;
 }
 
 int krk_plan_layer_ms(krk_plan* plan, float* ms_host, int cap) {
     if (!plan || !ms_host) return fail(KRK_E_INVALID, "bad argument");
-    if (!plan->profiling || plan->events.empty()) return fail(KRK_E_INVALID, "profiling not enabled");
-    HIPCHK(hipEventSynchronize(plan->events.back()));
-    const int n = std::min<int>(cap, (int)plan->steps.size());
+    if (!plan->profiling || plan->events.empty() || !plan->prof_n) return fail(KRK_E_INVALID, "profiling not enabled");
+    HIPCHK(hipEventSynchronize(plan->events[plan->prof_n]));
+    const int n = std::min<int>(cap, (int)plan->prof_n);
     for (int i = 0; i < n; ++i) HIPCHK(hipEventElapsedTime(&ms_host[i], plan->events[i], plan->events[i + 1]));
     return n;
 }
@@ -647,9 +655,22 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
 
     const float* cur = x_dev;
     const size_t nsteps = p->steps.size();
+    p->prof_n = 0;
+    if (p->profiling) {
+        p->prof_names.assign(p->events.size(), nullptr);
+        p->prof_flops.assign(p->events.size(), 0.0);
+    }
+    // marks the start of a profiled launch group (HIP event on the caller's stream)
+    auto mark = [&](const char* name, double flops) -> int {
+        if (!p->profiling || p->prof_n + 1 >= p->events.size()) return 0;
+        if (hipEventRecord(p->events[p->prof_n], stream) != hipSuccess) return -1;
+        p->prof_names[p->prof_n] = name;
+        p->prof_flops[p->prof_n] = flops;
+        ++p->prof_n;
+        return 0;
+    };
     for (size_t si = 0; si < nsteps; ++si) {
         Step& s = p->steps[si];
-        if (p->profiling) HIPCHK(hipEventRecord(p->events[si], stream));
         const int Win = Ws[s.len_in], Wout = Ws[s.len_out];
         const bool is_last = (si + 1 == nsteps);
         size_t out_elems = (size_t)N * s.outC * s.outH * Wout;
@@ -684,27 +705,32 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 ConvArgs a;
                 fill_conv(s.cg, a, cur, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));
                 s.flops = 2.0 * N * (double)s.cg.Ho * a.Wo * s.cg.Cout * s.cg.Cin * s.cg.kh * s.cg.kw;
+                if (mark("conv", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
                 rc = krk_launch_conv(a, false, s.cg.out_seq, s.cg.pool, stream);
                 break;
             }
             case S_MAXPOOL:
                 s.flops = 0;
+                mark("maxpool", 0);
                 rc = krk_launch_maxpool(cur, outp, lens_at(s.len_out), N, s.C, s.H, Win, s.kh, s.kw, s.sh, s.sw, s.Ho,
                                         Wout, stream);
                 break;
             case S_GN:
                 s.flops = 0;
+                mark("groupnorm", 0);
                 rc = krk_launch_groupnorm(cur, outp, s.d_gamma, s.d_beta, lens_at(s.len_in), N, s.C, s.H, Win, s.groups,
                                           1e-5f, stream);
                 break;
             case S_TOSEQ:
                 s.flops = 0;
+                mark("to_seq", 0);
                 rc = krk_launch_to_seq(cur, outp, N, s.C, s.H, Win, stream);
                 break;
             case S_LINEAR: {
                 ConvArgs a;
                 fill_conv(s.cg, a, cur, outp, 1, N * Win, nullptr, nullptr);
                 s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
+                mark("linear", s.flops);
                 rc = krk_launch_conv(a, true, true, false, stream);
                 break;
             }
@@ -715,8 +741,10 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 if (s.aux.ensure(xp_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
                 ConvArgs a;
                 fill_conv(s.cg, a, cur, (float*)s.aux.p, 1, N * T, nullptr, nullptr);
+                mark("lstm_xproj", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin);
                 rc = krk_launch_conv(a, true, true, false, stream);
                 if (rc) break;
+                mark("lstm_rec", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.hidden);
                 if (lens_host) HIPCHK(hipMemsetAsync(outp, 0, out_elems * sizeof(float), stream));
                 LstmArgs l;
                 l.xp = (const float*)s.aux.p;
@@ -753,7 +781,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                                            hipGetErrorString(hipGetLastError()));
         cur = outp;
     }
-    if (p->profiling) HIPCHK(hipEventRecord(p->events[nsteps], stream));
+    if (p->profiling) HIPCHK(hipEventRecord(p->events[p->prof_n], stream));
     if (final_ptr) *final_ptr = cur;
     if (d_olens) *d_olens = lens_at(p->nstages - 1);
     if (T_out) *T_out = Ws[p->nstages - 1];

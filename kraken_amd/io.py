@@ -229,3 +229,15 @@ def load_model_file(path, cls=None, tasks=('recognition',)):
                                f'    Missing key(s): {missing}\n    Unexpected key(s): {unexpected}')
         return model
     raise ValueError(f'No model for tasks {tasks} found in {p}')
+
+
+def load_models(path, tasks=None):
+    """
+    ``kraken.loaders`` entry point (reference contract kraken/models/loaders.py:27-43):
+    ``fn(path, tasks=None) -> list[model]``; raises ValueError when the file is not ours to load so
+    that kraken falls through to its next loader.
+    """
+    try:
+        return [load_model_file(path, tasks=tuple(tasks) if tasks else ('recognition',))]
+    except (NotImplementedError, RuntimeError, KeyError, IndexError, struct.error) as e:
+        raise ValueError(f'{path} is not loadable by the MI355X executor: {e}') from e

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""
+Condenses rocprofv3 outputs (kernel stats + separate --pmc passes) into a small JSON summary that
+is committed under profiles/.  Usage:
+
+    python tools/summarize_pmc.py <round tag> <stats dir> <FETCH_SIZE dir> <WRITE_SIZE dir> <MFMA dir>
+
+Counter conventions (/opt/skills/guides/MI355X_MICROARCH.md, sections HBM + rocprofv3): FETCH_SIZE / WRITE_SIZE are in
+KiB per dispatch; on gfx950 FETCH_SIZE under-counts WIDE (16 B/lane) coalesced streams by 2x --
+the kernels here that stream with 16-byte loads are flagged and corrected; 4-byte-per-lane
+streams were calibrated against known byte counts (conv / LSTM writes equal the output tensor
+bytes exactly) and are taken as is.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES /
+(1024 SIMDs * kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs.
+"""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+WIDE_READ_KERNELS = ('conv_f32_kernel<1,',)   # sequence GEMMs stage with dwordx4 loads
+
+
+def short(name):
+    m = re.search(r'(\w+_kernel(?:<[^>]*>)?)', name)
+    return m.group(1).replace(' ', '') if m else name[:40]
+
+
+def pmc(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    f = [x for x in os.listdir(path) if x.endswith('counter_collection.csv')][0]
+    for r in csv.DictReader(open(os.path.join(path, f))):
+        d[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    return d
+
+
+def main():
+    tag, stats_dir, fetch_dir, write_dir, mfma_dir = sys.argv[1:6]
+    out = {'round': tag, 'kernels': {}}
+    sf = [x for x in os.listdir(stats_dir) if x.endswith('kernel_stats.csv')][0]
+    for r in csv.DictReader(open(os.path.join(stats_dir, sf))):
+        k = short(r['Name'])
+        out['kernels'][k] = {'calls': int(r['Calls']), 'avg_us': round(float(r['AverageNs']) / 1e3, 1),
+                             'total_ms': round(float(r['TotalDurationNs']) / 1e6, 3), 'pct': float(r['Percentage'])}
+    fe, wr, mf = pmc(fetch_dir), pmc(write_dir), pmc(mfma_dir)
+    for k, e in out['kernels'].items():
+        if k in fe:
+            kib = sum(fe[k]['FETCH_SIZE']) / len(fe[k]['FETCH_SIZE'])
+            corr = 2.0 if k.startswith(WIDE_READ_KERNELS) else 1.0
+            e['hbm_read_MB_per_launch'] = round(kib * 1024 * corr / 1e6, 1)
+            e['fetch_correction'] = corr
+        if k in wr:
+            kib = sum(wr[k]['WRITE_SIZE']) / len(wr[k]['WRITE_SIZE'])
+            e['hbm_write_MB_per_launch'] = round(kib * 1024 / 1e6, 1)
+        if k in mf and 'GRBM_GUI_ACTIVE' in mf[k]:
+            busy = sum(mf[k]['SQ_VALU_MFMA_BUSY_CYCLES']) / len(mf[k]['SQ_VALU_MFMA_BUSY_CYCLES'])
+            cyc = sum(mf[k]['GRBM_GUI_ACTIVE']) / len(mf[k]['GRBM_GUI_ACTIVE']) / 8.0
+            e['mfma_util_chip'] = round(busy / (1024 * cyc), 4) if cyc else None
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
