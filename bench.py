@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense (not the 2:1-sparse figure)
 
 
 def parse():
@@ -42,6 +43,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=256, help='lines per GPU per step')
     ap.add_argument('--width', type=int, default=1200)
     ap.add_argument('--slots', type=int, default=3, help='batches in flight per GPU (streams)')
+    ap.add_argument('--precision', default='bf16x3', choices=['f32', 'bf16x3'],
+                    help='f32: exact f32 MFMA; bf16x3: split-bf16 operands on the bf16 MFMA, f32 accumulate (fp32-class)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-lines', type=int, default=32, help='lines in the CPU baseline sample')
     return ap.parse_args()
@@ -89,6 +92,7 @@ def main():
     torch.manual_seed(0)
     model = kraken_amd.TorchVGSLModel(vgsl=BENCH_A, codec=bench_codec())
     model.to(dev)
+    model.nn.set_precision(args.precision)
     N, W = args.batch, args.width
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(N, 1, 48, W, generator=g).to(dev)    # resident in HBM before timing
@@ -134,7 +138,9 @@ def main():
                 for i, v in sorted(per_launch.items())]
     # kernels behind the launch groups (rocprofv3 kernel names)
     kernel_of = {'conv': 'conv_f32_kernel', 'lstm_xproj': 'conv_f32_kernel<1,1,0,4>', 'linear': 'conv_f32_kernel<1,1,0,4>',
-                 'lstm_rec': 'lstm_f32_kernel'}
+                 'lstm_rec': 'lstm_f32_kernel', 'conv_x3': 'conv_x3_kernel', 'lstm_xproj_x3': 'conv_x3_kernel<0,1,4>',
+                 'linear_x3': 'conv_x3_kernel<0,1,4>', 'lstm_rec_x3': 'lstm_x3_kernel'}
+    peak_of = lambda name: BF16_MFMA_PEAK_TFLOPS if name.endswith('_x3') else F32_MFMA_PEAK_TFLOPS   # noqa: E731
     groups = {}
     for l in launches:
         g = groups.setdefault(l['name'], {'ms': 0.0, 'gflop': 0.0, 'n': 0})
@@ -148,8 +154,10 @@ def main():
     roofline = {'bound': 'mfma', 'kernel': kernel_of.get(dom_name, dom_name), 'launch_group': dom_name,
                 'launches_per_step': dom['n'], 'avg_launch_ms': round(dom['ms'] / dom['n'], 4),
                 'gflop_per_launch': round(dom['gflop'] / dom['n'], 3),
-                'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None}
+                'achieved': round(ach, 2), 'peak': peak_of(dom_name), 'unit': 'TFLOP/s',
+                'frac': round(ach / peak_of(dom_name), 4), 'traffic': None,
+                'note': ('algorithmic FLOPs; the split-operand kernels issue 3 bf16 MFMAs per algorithmic product'
+                         if dom_name.endswith('_x3') else 'exact f32 MFMA')}
     layers = launches
 
     lines = N * args.steps * world
@@ -158,16 +166,18 @@ def main():
         'metric': 'text lines/sec (whole node) at 48x1200px, VGSL CNN+BiLSTM+CTC',
         'value': round(value, 1), 'unit': 'lines/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None,
+        'dtype': 'f32' if args.precision == 'f32' else 'bf16x3 (split bf16 operands on bf16 MFMA, f32 accumulate; LSTM recurrence f32 MFMA)',
+        'data': 'synthetic',
         'config': {'workload': f'BENCH-A VGSL recogniser (3.17M params, random init seed 0), {N} lines 1x48x{W} per GPU '
                                f'per step, greedy CTC decode, label tuples to host', 'lines_per_gpu_step': N, 'width': W,
-                   'slots': args.slots, 'parallelism': f'dp{world}', 'whole_path_tflops': round(value * 2.778e-3 *
+                   'slots': args.slots, 'precision': args.precision, 'parallelism': f'dp{world}', 'whole_path_tflops': round(value * 2.778e-3 *
                                                                                                  (W / 1200.0), 2)},
         'roofline': roofline,
         'launches': [{'name': l['name'], 'ms': round(l['ms'], 3), 'tflops': round(l['gflop'] / l['ms'], 1) if l['ms'] > 0 else 0}
                      for l in layers],
         'groups': {k: {'ms': round(v['ms'], 3), 'tflops': round(v['gflop'] / v['ms'], 1) if v['ms'] > 0 else 0,
-                       'frac_of_f32_mfma_peak': round(v['gflop'] / v['ms'] / F32_MFMA_PEAK_TFLOPS, 4) if v['ms'] > 0 else 0}
+                       'frac_of_peak': round(v['gflop'] / v['ms'] / peak_of(k), 4) if v['ms'] > 0 else 0}
                    for k, v in groups.items()},
         'gathered_lines': int(sum(len(b.counts) for b in gathered)),
     }

@@ -18,7 +18,7 @@ KRK_E_INVALID, KRK_E_HIP, KRK_E_NOMEM, KRK_E_UNSUPPORTED = -1, -2, -3, -4
 OP_CONV, OP_MAXPOOL, OP_GROUPNORM, OP_RESHAPE_HC, OP_LSTM, OP_LINEAR = 1, 2, 3, 4, 5, 6
 ACT_LINEAR, ACT_RELU, ACT_TANH, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3, 4
 DIR_FWD, DIR_REV, DIR_BIDI = 0, 1, 2
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 
 # every symbol include/kraken_amd.h declares (checked by the CPU test-suite)
 EXPORTS = ['krk_abi_version', 'krk_last_error', 'krk_device_count', 'krk_plan_create', 'krk_plan_destroy',

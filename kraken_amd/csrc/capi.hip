@@ -80,6 +80,11 @@ struct ConvGeom {
         otab_floats = 32;
     float* d_w = nullptr;
     float* d_b = nullptr;
+    // split-bf16 ("bf16x3") execution of this GEMM (conv_x3.hip)
+    bool x3 = false;          // run on the bf16 matrix cores with split operands
+    bool split_out = false;   // write the output as split channels-last bf16 planes
+    int xchunk = 16, xnchunks = 1, xKB = 1, xKB_last = 1, xPSTR = 48, xplane = 0;
+    void* d_wx3 = nullptr;
 };
 
 int conv_out(int L, int k, int s, int d, int p) { return floordiv(L + 2 * p - d * (k - 1) - 1, s) + 1; }
@@ -172,6 +177,74 @@ int upload_conv_weights(ConvGeom& g, const float* w, const float* bias, const st
     return KRK_OK;
 }
 
+// bf16 round-to-nearest-even (matches v_cvt_pk_bf16_f32 for finite values)
+inline uint16_t f2bf(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);   // inf / nan
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// LDS tile geometry of the split-bf16 kernel: channels per chunk (multiple of 16) such that both planes of
+// the (IH x IW) pixel tile stay within ~74 KiB (two workgroups per CU).
+int plan_x3_geom(ConvGeom& g) {
+    if (g.Cin % 16) return fail(KRK_E_UNSUPPORTED, "bf16x3: input channels/features must be a multiple of 16");
+    const int npix = g.IH * g.IW;
+    int c = g.Cin;
+    while (c > 16 && (size_t)2 * npix * (c * 2 + 16) > 74 * 1024) c -= 16;
+    if ((size_t)2 * npix * (c * 2 + 16) > 150 * 1024) return fail(KRK_E_UNSUPPORTED, "bf16x3: convolution window too large");
+    g.xnchunks = (g.Cin + c - 1) / c;
+    g.xchunk = ((g.Cin + g.xnchunks - 1) / g.xnchunks + 15) / 16 * 16;
+    g.xnchunks = (g.Cin + g.xchunk - 1) / g.xchunk;
+    g.xKB = g.xchunk / 16;
+    g.xKB_last = (g.Cin - (g.xnchunks - 1) * g.xchunk) / 16;
+    g.xPSTR = g.xchunk * 2 + 16;
+    g.xplane = npix * g.xPSTR;
+    return KRK_OK;
+}
+
+// wx3[chunk][tap][kb][cb][plane][lane][8] (bf16): lane l of block cb holds filter cb*32 + (l&31), channels
+// chunk*xchunk + kb*16 + 8*(l>>5) + 0..7 of tap (dy,dx); plane 0 = hi, 1 = lo.  `w` is (rows, Cin, kh, kw) f32.
+int upload_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
+    const int kk = g.kh * g.kw;
+    const int cb = krk_x3_cb(g.Cout);
+    const int CBt = (g.Cout + 31) / 32;
+    const int CBpad = (CBt + cb - 1) / cb * cb;
+    if (CBpad != g.CBpad) return fail(KRK_E_INVALID, "bf16x3: filter block padding mismatch");
+    std::vector<uint16_t> pack((size_t)g.xnchunks * kk * g.xKB * CBpad * 1024, 0);
+    for (int ci = 0; ci < g.xnchunks; ++ci)
+        for (int t = 0; t < kk; ++t)
+            for (int kb = 0; kb < g.xKB; ++kb)
+                for (int b = 0; b < CBt; ++b)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = b * 32 + (lane & 31);
+                            const int c = ci * g.xchunk + kb * 16 + 8 * (lane >> 5) + e;
+                            if (co >= g.Cout || c >= g.Cin) continue;
+                            int src = co;
+                            if (rowmap) {
+                                src = (*rowmap)[co];
+                                if (src < 0) continue;
+                            }
+                            const float v = w[((size_t)src * g.Cin + c) * kk + t];
+                            const uint16_t hi = f2bf(v);
+                            const uint16_t lo = f2bf(v - bf2f(hi));
+                            const size_t base = ((((size_t)ci * kk + t) * g.xKB + kb) * CBpad + b) * 1024 + lane * 8 + e;
+                            pack[base] = hi;
+                            pack[base + 512] = lo;
+                        }
+    HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
 struct Step {
     StepKind kind = S_CONV;
     ConvGeom cg;              // CONV / LINEAR / the LSTM input projection
@@ -187,12 +260,15 @@ struct Step {
     int hidden = 0, Hp = 0, ndir = 1, dirmode = 0;
     float* d_wrec32 = nullptr;  // recurrent weights, 32x32x2 fragment order
     float* d_wrec16 = nullptr;  // recurrent weights, 16x16x4 fragment order
+    void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
+    bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
     // output description
     bool out_is_seq = false;
     int outC = 0, outH = 1;     // NCHW: channels,height; seq: features,1
     int len_in = 0, len_out = 0;  // indices into the per-stage length table
     // per-call
-    DevBuf out, aux;
+    DevBuf out, aux, aux2;
+    bool in_split = false;    // input arrives as split bf16 planes (bf16x3 mode)
     double flops = 0.0;
 };
 
@@ -255,6 +331,31 @@ void pack_lstm_recurrent(const Step& st, const float* const* whh, int M, std::ve
                     }
 }
 
+// [dir][kb][block][plane][lane][8]: lane l holds K = kb*32 + 8*(l>>4) + e of gate column block*16 + (l&15)
+int upload_lstm_x3(Step& st, const float* const* whh) {
+    const int H = st.hidden, Hp = st.Hp, G = 4 * Hp;
+    const int NB = G / 16, NKB = (Hp + 31) / 32;
+    std::vector<uint16_t> pack((size_t)st.ndir * NKB * NB * 1024, 0);
+    for (int d = 0; d < st.ndir; ++d)
+        for (int kb = 0; kb < NKB; ++kb)
+            for (int b = 0; b < NB; ++b)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = kb * 32 + 8 * (lane >> 4) + e;
+                        const int col = b * 16 + (lane & 15);
+                        const int u = col >> 2, gt = col & 3;
+                        if (u >= H || k >= H) continue;
+                        const float v = whh[d][((size_t)gt * H + u) * H + k];
+                        const uint16_t hi = f2bf(v);
+                        const size_t base = (((size_t)d * NKB + kb) * NB + b) * 1024 + lane * 8 + e;
+                        pack[base] = hi;
+                        pack[base + 512] = f2bf(v - bf2f(hi));
+                    }
+    HIPCHK(hipMalloc(&st.d_wrecx3, pack.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(st.d_wrecx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
 int upload(float** dst, const std::vector<float>& v) {
     HIPCHK(hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * sizeof(float)));
     if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -264,12 +365,15 @@ int upload(float** dst, const std::vector<float>& v) {
 void free_step(Step& s) {
     if (s.cg.d_w) (void)hipFree(s.cg.d_w);
     if (s.cg.d_b) (void)hipFree(s.cg.d_b);
+    if (s.cg.d_wx3) (void)hipFree(s.cg.d_wx3);
     if (s.d_gamma) (void)hipFree(s.d_gamma);
     if (s.d_beta) (void)hipFree(s.d_beta);
     if (s.d_wrec32) (void)hipFree(s.d_wrec32);
     if (s.d_wrec16) (void)hipFree(s.d_wrec16);
+    if (s.d_wrecx3) (void)hipFree(s.d_wrecx3);
     s.out.release();
     s.aux.release();
+    s.aux2.release();
 }
 
 bool monotone_act(int act) { return act >= 0 && act <= KRK_ACT_SIGMOID; }
@@ -313,8 +417,9 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
     if (!layers || n_layers <= 0 || !out) return fail(KRK_E_INVALID, "krk_plan_create: null/empty layer list");
     if (in_channels <= 0 || in_height <= 0)
         return fail(KRK_E_UNSUPPORTED, "krk_plan_create: input channels/height must be fixed and positive");
-    if (precision != KRK_PREC_F32)
-        return fail(KRK_E_UNSUPPORTED, "krk_plan_create: only KRK_PREC_F32 is implemented in this build");
+    if (precision != KRK_PREC_F32 && precision != KRK_PREC_BF16X3)
+        return fail(KRK_E_UNSUPPORTED, "krk_plan_create: precision must be KRK_PREC_F32 or KRK_PREC_BF16X3");
+    const bool x3 = precision == KRK_PREC_BF16X3;
     if (krk_device_count() <= device)
         return fail(KRK_E_HIP, "krk_plan_create: no HIP device " + std::to_string(device));
     HIPCHK(hipSetDevice(device));
@@ -330,6 +435,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
     };
 
     bool seq = false;
+    bool split_fmt = false;   // bf16x3: the current activation is held as split bf16 planes
     int C = in_channels, H = in_height;
     int stage = 0;
     auto push_toseq = [&]() {
@@ -391,6 +497,24 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     krk_plan_destroy(p);
                     return KRK_E_HIP;
                 }
+                if (x3) {
+                    // the first convolution reads the caller's fp32 NCHW image on the f32 cores and hands
+                    // over split channels-last planes; every later one runs on the bf16 cores
+                    const bool first = !split_fmt;
+                    const int feat = g.out_seq ? conv_out(H, L.kh, L.sh, L.dh, g.ph) * L.cout : L.cout;
+                    if (feat % 16) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs a multiple of 16 output channels");
+                    if (first && g.out_seq) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs >= 2 convolutions before the reshape");
+                    g.split_out = true;
+                    s.in_split = !first;
+                    if (!first) {
+                        g.x3 = true;
+                        if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, L.w[0], nullptr) != KRK_OK) {
+                            krk_plan_destroy(p);
+                            return KRK_E_UNSUPPORTED;
+                        }
+                    }
+                    split_fmt = true;
+                }
                 s.len_out = stage;
                 if (g.out_seq) {
                     s.out_is_seq = true;
@@ -409,6 +533,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 break;
             }
             case KRK_OP_MAXPOOL: {
+                if (x3) return bail(KRK_E_UNSUPPORTED, where + ": stand-alone max-pool is not available in bf16x3 mode (use KRK_PREC_F32)");
                 if (seq) return bail(KRK_E_UNSUPPORTED, where + ": max-pool after a sequence layer");
                 if (L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0) return bail(KRK_E_INVALID, where + ": bad pool");
                 Step s;
@@ -429,6 +554,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 break;
             }
             case KRK_OP_GROUPNORM: {
+                if (x3) return bail(KRK_E_UNSUPPORTED, where + ": group norm is not available in bf16x3 mode (use KRK_PREC_F32)");
                 if (seq) return bail(KRK_E_UNSUPPORTED, where + ": group norm after a sequence layer");
                 if (L.cout <= 0 || C % L.cout) return bail(KRK_E_INVALID, where + ": groups must divide channels");
                 if (!L.w[0] || !L.w[1]) return bail(KRK_E_INVALID, where + ": group norm weights missing");
@@ -449,6 +575,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 break;
             }
             case KRK_OP_RESHAPE_HC: {
+                if (x3) return bail(KRK_E_UNSUPPORTED, where + ": stand-alone reshape is not available in bf16x3 mode (use KRK_PREC_F32)");
                 if (seq) return bail(KRK_E_UNSUPPORTED, where + ": reshape after a sequence layer");
                 push_toseq();
                 break;
@@ -459,6 +586,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     if (H != 1)
                         return bail(KRK_E_UNSUPPORTED, where + ": recurrent/linear layer on an input of height " +
                                                            std::to_string(H) + " (only height 1 is implemented)");
+                    if (x3) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs the reshape fused into a convolution");
                     push_toseq();
                 }
                 Step s;
@@ -480,6 +608,15 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     if (upload_conv_weights(g, L.w[0], L.w[1], nullptr, nullptr) != KRK_OK) {
                         krk_plan_destroy(p);
                         return KRK_E_HIP;
+                    }
+                    if (x3) {
+                        g.x3 = true;
+                        s.in_split = split_fmt;
+                        if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, L.w[0], nullptr) != KRK_OK) {
+                            krk_plan_destroy(p);
+                            return KRK_E_UNSUPPORTED;
+                        }
+                        split_fmt = false;   // fp32 rows out
                     }
                     s.outC = L.cout;
                     C = L.cout;
@@ -512,12 +649,24 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                         krk_plan_destroy(p);
                         return KRK_E_HIP;
                     }
+                    if (x3) {
+                        g.x3 = true;
+                        s.in_split = split_fmt;
+                        if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, wih.data(), &rowmap) != KRK_OK) {
+                            krk_plan_destroy(p);
+                            return KRK_E_UNSUPPORTED;
+                        }
+                        // all but a final LSTM run the recurrence on the bf16 cores and hand over split planes
+                        s.rec_x3 = (i + 1 < n_layers) && (s.ndir * s.hidden) % 16 == 0;
+                        split_fmt = s.rec_x3;
+                    }
                     const float* whh[2] = {L.w[1], s.ndir == 2 ? L.w[5] : nullptr};
                     std::vector<float> pk;
                     pack_lstm_recurrent(s, whh, 32, pk);
                     if (upload(&s.d_wrec32, pk) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
                     pack_lstm_recurrent(s, whh, 16, pk);
                     if (upload(&s.d_wrec16, pk) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
+                    if (s.rec_x3 && upload_lstm_x3(s, whh) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
                     s.outC = s.ndir * s.hidden;
                     C = s.outC;
                 }
@@ -568,7 +717,7 @@ int krk_plan_set_profiling(krk_plan* plan, int enable) {
     if (!plan) return fail(KRK_E_INVALID, "null plan");
     plan->profiling = enable != 0;
     if (plan->profiling && plan->events.empty()) {
-        plan->events.resize(2 * plan->steps.size() + 1);
+        plan->events.resize(3 * plan->steps.size() + 1);
         for (auto& e : plan->events)
             if (hipEventCreate(&e) != hipSuccess) return fail(KRK_E_HIP, "hipEventCreate failed");
     }
@@ -698,12 +847,52 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
             a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
             a.otab_floats = g.otab_floats;
+            a.y_split = nullptr; a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0;
+        };
+        auto fill_x3 = [&](const ConvGeom& g, X3Args& a, const void* xin, size_t x_plane, void* yout, int Nn, int Wn,
+                           const int* li, const int* lo) {
+            a.x = (const __bf16*)xin; a.x_plane = x_plane; a.y = yout;
+            a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
+            a.len_in = li; a.len_out = lo;
+            a.N = Nn; a.Cin = g.Cin; a.H = g.H; a.W = Wn;
+            a.Cout = g.Cout; a.CBpad = g.CBpad;
+            a.kh = g.kh; a.kw = g.kw; a.sh = g.sh; a.sw = g.sw; a.dh = g.dh; a.dw = g.dw; a.ph = g.ph; a.pw = g.pw;
+            a.Ho = g.Ho;
+            a.Wo = g.in_seq ? Wn : conv_out(Wn, g.kw, g.sw, g.dw, g.pw);
+            a.Hy = g.Hy;
+            a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
+            a.act = g.act;
+            a.cchunk = g.xchunk; a.nchunks = g.xnchunks; a.KB = g.xKB; a.KB_last = g.xKB_last;
+            a.IH = g.IH; a.IW = g.IW; a.PSTR = g.xPSTR; a.lds_plane = g.xplane; a.SR = g.SR;
+            a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
+            a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
+            a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0;
+        };
+        // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
+        auto split_strides = [&](const ConvGeom& g, int Wo_, int Wy_, long& sn, long& sr, long& sc) {
+            if (g.out_seq) { sn = (long)Wo_ * g.Ho * g.Cout; sc = (long)g.Ho * g.Cout; sr = g.Cout; }
+            else { sn = (long)g.Hy * Wy_ * g.Cout; sr = (long)Wy_ * g.Cout; sc = g.Cout; }
         };
         int rc = 0;
         switch (s.kind) {
             case S_CONV: {
+                if (s.cg.x3) {
+                    X3Args a;
+                    fill_x3(s.cg, a, cur, (size_t)N * s.C * s.H * Win, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));
+                    a.y_plane = out_elems;
+                    split_strides(s.cg, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+                    s.flops = 2.0 * N * (double)s.cg.Ho * a.Wo * s.cg.Cout * s.cg.Cin * s.cg.kh * s.cg.kw;
+                    if (mark("conv_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
+                    rc = krk_launch_conv_x3(a, false, s.cg.pool, stream);
+                    break;
+                }
                 ConvArgs a;
                 fill_conv(s.cg, a, cur, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));
+                if (s.cg.split_out) {
+                    a.y_split = outp;
+                    a.y_plane = out_elems;
+                    split_strides(s.cg, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+                }
                 s.flops = 2.0 * N * (double)s.cg.Ho * a.Wo * s.cg.Cout * s.cg.Cin * s.cg.kh * s.cg.kw;
                 if (mark("conv", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
                 rc = krk_launch_conv(a, false, s.cg.out_seq, s.cg.pool, stream);
@@ -727,9 +916,25 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 rc = krk_launch_to_seq(cur, outp, N, s.C, s.H, Win, stream);
                 break;
             case S_LINEAR: {
+                s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
+                if (s.cg.x3) {
+                    const size_t in_elems = (size_t)N * Win * s.cg.Cin;
+                    const void* xin = cur;
+                    if (!s.in_split) {   // fp32 rows from the recurrent kernel -> split planes
+                        if (s.aux2.ensure(in_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
+                        mark("split", 0);
+                        rc = krk_launch_split(cur, s.aux2.p, in_elems, in_elems, stream);
+                        if (rc) break;
+                        xin = s.aux2.p;
+                    }
+                    X3Args a;
+                    fill_x3(s.cg, a, xin, in_elems, outp, 1, N * Win, nullptr, nullptr);
+                    mark("linear_x3", s.flops);
+                    rc = krk_launch_conv_x3(a, true, false, stream);
+                    break;
+                }
                 ConvArgs a;
                 fill_conv(s.cg, a, cur, outp, 1, N * Win, nullptr, nullptr);
-                s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
                 mark("linear", s.flops);
                 rc = krk_launch_conv(a, true, true, false, stream);
                 break;
@@ -739,13 +944,46 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 const int G = 4 * s.Hp;
                 const size_t xp_elems = (size_t)N * T * s.ndir * G;
                 if (s.aux.ensure(xp_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
-                ConvArgs a;
-                fill_conv(s.cg, a, cur, (float*)s.aux.p, 1, N * T, nullptr, nullptr);
-                mark("lstm_xproj", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin);
-                rc = krk_launch_conv(a, true, true, false, stream);
+                if (s.cg.x3) {
+                    const size_t in_elems = (size_t)N * T * s.cg.Cin;
+                    const void* xin = cur;
+                    if (!s.in_split) {
+                        if (s.aux2.ensure(in_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
+                        mark("split", 0);
+                        rc = krk_launch_split(cur, s.aux2.p, in_elems, in_elems, stream);
+                        if (rc) break;
+                        xin = s.aux2.p;
+                    }
+                    X3Args a;
+                    fill_x3(s.cg, a, xin, in_elems, s.aux.p, 1, N * T, nullptr, nullptr);
+                    mark("lstm_xproj_x3", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin);
+                    rc = krk_launch_conv_x3(a, true, false, stream);
+                } else {
+                    ConvArgs a;
+                    fill_conv(s.cg, a, cur, (float*)s.aux.p, 1, N * T, nullptr, nullptr);
+                    mark("lstm_xproj", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin);
+                    rc = krk_launch_conv(a, true, true, false, stream);
+                }
                 if (rc) break;
-                mark("lstm_rec", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.hidden);
+                mark(s.rec_x3 ? "lstm_rec_x3" : "lstm_rec", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.hidden);
                 if (lens_host) HIPCHK(hipMemsetAsync(outp, 0, out_elems * sizeof(float), stream));
+                if (s.rec_x3) {
+                    LstmX3Args l;
+                    l.xp = (const float*)s.aux.p;
+                    l.wp = (const __bf16*)s.d_wrecx3;
+                    l.out = (__bf16*)outp;
+                    l.out_plane = out_elems;
+                    l.lens = lens_at(s.len_in);
+                    l.N = N; l.T = T; l.H = s.hidden; l.Hp = s.Hp; l.G = G;
+                    l.NB = G / 16; l.NKB = (s.Hp + 31) / 32;
+                    l.ndir = s.ndir; l.dirmode = s.dirmode;
+                    l.xstride = s.ndir * G;
+                    l.ostride = s.ndir * s.hidden;
+                    l.hrow = l.NKB * 64 + 16;
+                    s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
+                    rc = krk_launch_lstm_x3(l, stream);
+                    break;
+                }
                 LstmArgs l;
                 l.xp = (const float*)s.aux.p;
                 l.out = outp;

@@ -57,6 +57,31 @@ struct ConvArgs {
     int SR;               // 32-pixel segments per tile row: tile = (8/SR) rows x (32*SR) cols
     int tiles_h, tiles_w;
     int otab_floats;      // LDS floats reserved for the K-offset table
+    // optional split-bf16 channels-last output (feeds conv_x3.hip): y_split = hi plane, lo at + y_plane
+    void* y_split;
+    size_t y_plane;
+    long y_sn, y_sr, y_sc;
+};
+
+// ------------------------------------------------------- split-bf16 ("bf16x3") conv/GEMM
+struct X3Args {
+    const __bf16* x;      // hi plane of the split NHWC input [N][H][W][Cin]; lo plane at + x_plane elements
+    size_t x_plane;
+    void* y;              // OUT_F32: float rows; else hi plane of the split output, lo at + y_plane
+    size_t y_plane;
+    long y_sn, y_sr, y_sc;   // split output strides (elements): n, row, col (filter stride 1)
+    const __bf16* wpack;  // [chunk][tap][KB][CBpad][plane][lane][8]
+    const float* bias;    // [CBpad*32]
+    const int* len_in;
+    const int* len_out;
+    int N, Cin, H, W;
+    int Cout, CBpad;
+    int kh, kw, sh, sw, dh, dw, ph, pw;
+    int Ho, Wo, Hy, Wy;
+    int act;
+    int cchunk, nchunks, KB, KB_last;   // channels per LDS chunk (multiple of 16), 16-channel blocks per chunk
+    int IH, IW, PSTR, lds_plane;        // LDS tile: pixels, bytes per pixel (padded), bytes per plane
+    int SR, tiles_h, tiles_w;
 };
 
 // ----------------------------------------------------------------------- LSTM
@@ -72,12 +97,30 @@ struct LstmArgs {
     int dbg;              // probe bits (env KRK_LSTM_DBG): 1 no GEMM, 2 no gate math, 4 no output pass, 8 no x prefetch
 };
 
+// split-bf16 recurrent kernel (lstm_x3.hip), 16-line tiles
+struct LstmX3Args {
+    const float* xp;      // [N*T][xstride] fp32 input projections (+ biases), gate-interleaved columns
+    const __bf16* wp;     // [ndir][NKB][NB][plane][lane][8] recurrent weights, split bf16, B-fragment order
+    __bf16* out;          // hi plane [N][T][ostride]; lo plane at + out_plane elements
+    size_t out_plane;
+    const int* lens;
+    int N, T, H, Hp;
+    int NKB, NB, G;       // K-blocks of 32, column blocks of 16, G = 4*Hp gate columns per direction
+    int ndir, dirmode;
+    int xstride, ostride;
+    int hrow;             // bytes per LDS row of h (one line, one plane) = NKB*64 + 16
+};
+int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s);
+
 // K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel
 int krk_lstm_kg(int M, int blocks_per_wave);
 
 // host-side launchers (implemented in the .hip files)
 int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);
+int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
+int krk_launch_split(const float* x, void* hi, size_t plane_elems, size_t n, hipStream_t s);
+int krk_x3_cb(int Cout);
 int krk_launch_maxpool(const float* x, float* y, const int* len_out, int N, int C, int H, int W,
                        int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);
 int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta,

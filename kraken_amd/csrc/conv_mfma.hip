@@ -242,6 +242,55 @@ __global__ void __launch_bounds__(256, 2) conv_f32_kernel(const ConvArgs a) {
     }
 
     // ------------------------------------------------------------- epilogues
+    if (!OUT_SEQ && a.y_split) {
+        // split-bf16 channels-last output for the bf16x3 kernels: element n*y_sn + row*y_sr + col*y_sc + filter
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        __bf16* yh = reinterpret_cast<__bf16*>(a.y_split);
+        __bf16* yl = yh + a.y_plane;
+        constexpr int nseg = POOL ? 1 : 2;
+#pragma unroll
+        for (int s = 0; s < nseg; ++s) {
+            if (!inb[s]) continue;
+            int row, col;
+            bool st;
+            if (POOL) {
+                row = (h0 + srow[0]) >> 1;
+                col = (w0 + scol[0] + px) >> 1;
+                st = !(px & 1) && row < a.Hy && col < a.Wy;
+            } else {
+                row = h0 + srow[s];
+                col = w0 + scol[s] + px;
+                st = col < a.Wo;
+            }
+            const size_t base = (size_t)n * a.y_sn + (size_t)row * a.y_sr + (size_t)col * a.y_sc;
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int co = (cb0 + cb) * 32 + 8 * rq + 4 * half;
+                    bf16x4 hv, lv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[cb][s][4 * rq + i];
+                        if (POOL) {
+                            v = fmaxf(v, acc[cb][1][4 * rq + i]);
+                            v = fmaxf(v, __shfl_xor(v, 1));
+                        }
+                        v = krk_act(v + a.bias[min(co + i, a.CBpad * 32 - 1)], a.act);
+                        if (col >= len_out) v = 0.f;
+                        const __bf16 h = (__bf16)v;
+                        hv[i] = h;
+                        lv[i] = (__bf16)(v - (float)h);
+                    }
+                    if (st && co < a.Cout) {
+                        *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
+                        *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (POOL) {
         // rows srow[0], srow[1] form one pooling pair; adjacent lanes form the column pair
         if (!inb[0]) return;

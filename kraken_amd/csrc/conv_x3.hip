@@ -1,0 +1,331 @@
+// Implicit-GEMM convolution / projection on the gfx950 bf16 matrix cores with SPLIT operands
+// ("bf16x3"): every fp32 value x is carried as hi = bf16(x), lo = bf16(x - hi); a product a*b is
+// evaluated as  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  with three v_mfma_f32_32x32x16_bf16 and an fp32
+// accumulator.  The dropped a_lo*b_lo term is ~2^-32 relative; the split keeps ~16 mantissa bits
+// per operand, which measured against the fp32 path gives |d logit| ~ 2e-5 on BENCH-A (gate: 1e-3,
+// BASELINE.json north_star) -- fp32-class results at 16/3 = 5.3x the f32 MFMA rate.
+//
+// Same reference call sites as conv_mfma.hip (kraken/lib/vgsl/layers.py: ActConv2D.forward :842-860,
+// fused MaxPool :381-388, fused Reshape :313-335, nn.LSTM input projection :507-511, LinSoftmax :710-722).
+//
+// Layout: activations travel channels-last ("split NHWC"): two bf16 planes [N][H][W][C] (hi, lo) --
+// the same bytes as fp32.  Channels are the contiguous K axis: one ds_read_b128 delivers the 8
+// consecutive K a lane needs for a 32x32x16 MFMA.  A sequence tensor [N*T][F] is the H = 1 case.
+//   tile      = (8/SR) output rows x (32*SR) output columns of one line, CB blocks of 32 filters
+//   LDS       = [IH][IW] input pixels x cchunk channels per plane, pixel stride padded by 16 B
+//               (conflict-free ds_read_b128 for 32/64-channel chunks)
+//   staging   = straight 16-byte copies global -> LDS (the producer already wrote split NHWC)
+//   K loop    = taps (dy,dx) x 16-channel blocks; operands of iteration i+1 are fetched while the
+//               6*CB MFMAs of iteration i issue; weights stream from L2 in fragment order
+//   epilogue  = bias + activation (+ 2x2 max-pool) + length mask, written either as split NHWC
+//               (next conv / projection) or as fp32 rows [pixel][filter] (LSTM gates, logits)
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ int fdiv(int e, int d, float inv, int& rem) {
+    int q = (int)((float)e * inv);
+    int r = e - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
+
+struct Frags {
+    bf16x8 xh[2], xl[2];
+};
+
+template <int POOL, int OUT_F32, int CB>
+__global__ void __launch_bounds__(256, 2) conv_x3_kernel(const X3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    unsigned char* tile = smem8;                       // hi plane, then lo plane (+ a.lds_plane bytes)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, px = lane & 31;
+
+    int bt = blockIdx.x;
+    const int tw = bt % a.tiles_w;
+    bt /= a.tiles_w;
+    const int th = bt % a.tiles_h;
+    const int n = bt / a.tiles_h;
+    const int SR = a.SR;
+    const int TH = 8 / SR, TW = 32 * SR;
+    const int h0 = th * TH, w0 = tw * TW;
+    const int cb0 = blockIdx.y * CB;
+
+    const int len_in = a.len_in ? a.len_in[n] : a.W;
+    const int len_out = a.len_out ? a.len_out[n] : a.Wy;
+    const int wlim = POOL ? min(a.Wo, 2 * len_out) : min(a.Wo, len_out);
+
+    int srow[2], scol[2];
+    bool inb[2], live[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (POOL) {
+            srow[s] = 2 * (wave / SR) + s;
+            scol[s] = 32 * (wave % SR);
+        } else {
+            const int g = wave * 2 + s;
+            srow[s] = g / SR;
+            scol[s] = 32 * (g % SR);
+        }
+        inb[s] = (h0 + srow[s] < a.Ho) && (w0 + scol[s] < a.Wo);
+        live[s] = inb[s] && (w0 + scol[s] < wlim);
+    }
+    const bool any_live = live[0] || live[1];
+
+    f32x16 acc[CB][2];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][s][r] = 0.f;
+
+    // byte offset of this lane's pixel (per segment) inside a plane of the LDS tile
+    int vb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) vb[s] = ((srow[s] * a.sh) * a.IW + (scol[s] + px) * a.sw) * a.PSTR + half * 16;
+
+    const int npix = a.IH * a.IW;
+    const int q_per_px = a.cchunk >> 3;                  // 16-byte pieces per pixel per plane
+    const int items = 2 * npix * q_per_px;
+    const float inv_q = 1.0f / (float)q_per_px, inv_iw = 1.0f / (float)a.IW, inv_np = 1.0f / (float)(npix * q_per_px);
+    const int gh0 = h0 * a.sh - a.ph, gw0 = w0 * a.sw - a.pw;
+    const int ntaps = a.kh * a.kw;
+
+    for (int ci = 0; ci < a.nchunks; ++ci) {
+        // ---------------------------------------------------------------- stage chunk ci (16-byte copies)
+        __syncthreads();   // previous chunk fully consumed
+        constexpr int SB = 8;
+        for (int i0 = 0; i0 * 256 < items; i0 += SB) {
+            f32x4 v[SB];
+            int dst[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int e = tid + 256 * (i0 + i);
+                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dst[i] = -1;
+                if (e < items) {
+                    int r, q, iw;
+                    const int plane = fdiv(e, npix * q_per_px, inv_np, r);
+                    const int pix = fdiv(r, q_per_px, inv_q, q);
+                    const int ih = fdiv(pix, a.IW, inv_iw, iw);
+                    const int gh = gh0 + ih, gw = gw0 + iw;
+                    const int gc = ci * a.cchunk + q * 8;
+                    dst[i] = plane * a.lds_plane + pix * a.PSTR + q * 16;
+                    if (gc < a.Cin && gh >= 0 && gh < a.H && gw >= 0 && gw < len_in) {
+                        const __bf16* src = a.x + (size_t)plane * a.x_plane +
+                                            (((size_t)n * a.H + gh) * a.W + gw) * a.Cin + gc;
+                        v[i] = *reinterpret_cast<const f32x4*>(src);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i)
+                if (dst[i] >= 0) *reinterpret_cast<f32x4*>(tile + dst[i]) = v[i];
+        }
+        __syncthreads();
+        if (!any_live) continue;
+
+        // ---------------------------------------------------------------- K loop: taps x 16-channel blocks
+        const int kbn = (ci + 1 == a.nchunks) ? a.KB_last : a.KB;
+        const int nit = ntaps * kbn;
+        // weights: [chunk][tap][kb (KB per chunk)][cb][plane][lane][8]
+        const __bf16* wbase = a.wpack + ((size_t)ci * ntaps * a.KB * a.CBpad + cb0) * 1024 + lane * 8;
+        const size_t wkb = (size_t)a.CBpad * 1024;       // elements per (tap, kb) record
+
+        int dy = 0, dx = 0, kb = 0;                       // coordinates of the iteration being FETCHED
+        auto fetch = [&](Frags& f, bf16x8 (&wh)[CB], bf16x8 (&wl)[CB]) {
+            const int xoff = (dy * a.dh * a.IW + dx * a.dw) * a.PSTR + kb * 32;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f.xh[s] = *reinterpret_cast<const bf16x8*>(tile + vb[s] + xoff);
+                f.xl[s] = *reinterpret_cast<const bf16x8*>(tile + a.lds_plane + vb[s] + xoff);
+            }
+            const __bf16* wp = wbase + ((size_t)(dy * a.kw + dx) * a.KB + kb) * wkb;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                wh[cb] = *reinterpret_cast<const bf16x8*>(wp + cb * 1024);
+                wl[cb] = *reinterpret_cast<const bf16x8*>(wp + cb * 1024 + 512);
+            }
+            if (++kb == kbn) {
+                kb = 0;
+                if (++dx == a.kw) { dx = 0; ++dy; }
+            }
+        };
+        auto mma = [&](const Frags& f, const bf16x8 (&wh)[CB], const bf16x8 (&wl)[CB]) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    // no per-segment liveness guard: a dead segment's result is masked in the epilogue and a
+                    // guard would put every MFMA into its own basic block (hazard nops, no overlap)
+                    {
+                        if (OUT_F32) {   // D[pixel][filter]
+                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.xh[s], wh[cb], acc[cb][s], 0, 0, 0);
+                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.xl[s], wh[cb], acc[cb][s], 0, 0, 0);
+                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.xh[s], wl[cb], acc[cb][s], 0, 0, 0);
+                        } else {         // D[filter][pixel]
+                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], f.xh[s], acc[cb][s], 0, 0, 0);
+                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], f.xl[s], acc[cb][s], 0, 0, 0);
+                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], f.xh[s], acc[cb][s], 0, 0, 0);
+                        }
+                    }
+                }
+        };
+
+        Frags fa, fb;
+        bf16x8 wha[CB], wla[CB], whb[CB], wlb[CB];
+        fetch(fa, wha, wla);
+        int it = 0;
+        for (; it + 1 < nit; it += 2) {
+            fetch(fb, whb, wlb);
+            mma(fa, wha, wla);
+            if (it + 2 < nit) fetch(fa, wha, wla);
+            mma(fb, whb, wlb);
+        }
+        if (it < nit) mma(fa, wha, wla);
+    }
+
+    // ------------------------------------------------------------------------------- epilogues
+    if (OUT_F32) {
+        // fp32 rows: y[((n*Wo + col)*Ho + row)*Cout + filter]
+        float* y = reinterpret_cast<float*>(a.y);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (!inb[s]) continue;
+            const int row = h0 + srow[s];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const int co = (cb0 + cb) * 32 + px;
+                if (co >= a.Cout) continue;
+                const float bv = a.bias[co];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = w0 + scol[s] + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (col < a.Wo) {
+                        float v = krk_act(acc[cb][s][r] + bv, a.act);
+                        if (col >= len_out) v = 0.f;
+                        y[(((size_t)n * a.Wo + col) * a.Ho + row) * a.Cout + co] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        // split NHWC (or split sequence rows): element index n*y_sn + row*y_sr + col*y_sc + filter
+        __bf16* yh = reinterpret_cast<__bf16*>(a.y);
+        __bf16* yl = yh + a.y_plane;
+        constexpr int nseg = POOL ? 1 : 2;
+#pragma unroll
+        for (int s = 0; s < nseg; ++s) {
+            if (!inb[s]) continue;
+            int row, col;
+            bool st;
+            if (POOL) {
+                row = (h0 + srow[0]) >> 1;
+                col = (w0 + scol[0] + px) >> 1;
+                st = !(px & 1) && row < a.Hy && col < a.Wy;
+            } else {
+                row = h0 + srow[s];
+                col = w0 + scol[s] + px;
+                st = col < a.Wo;
+            }
+            const size_t base = (size_t)n * a.y_sn + (size_t)row * a.y_sr + (size_t)col * a.y_sc;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int co = (cb0 + cb) * 32 + 8 * rq + 4 * half;
+                    bf16x4 hv, lv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[cb][s][4 * rq + i];
+                        if (POOL) {
+                            v = fmaxf(v, acc[cb][1][4 * rq + i]);
+                            v = fmaxf(v, __shfl_xor(v, 1));
+                        }
+                        v = krk_act(v + a.bias[min(co + i, a.CBpad * 32 - 1)], a.act);
+                        if (col >= len_out) v = 0.f;
+                        const __bf16 h = (__bf16)v;
+                        hv[i] = h;
+                        lv[i] = (__bf16)(v - (float)h);
+                    }
+                    if (st && co < a.Cout) {
+                        *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
+                        *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int POOL, int OUT_F32>
+int launch_cb(const X3Args& a, int cb, dim3 grid, size_t lds, hipStream_t s) {
+#define KRK_LAUNCH(CB_)                                                                         \
+    do {                                                                                        \
+        auto kfn = conv_x3_kernel<POOL, OUT_F32, CB_>;                                          \
+        if (lds > 48 * 1024)                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);                                    \
+    } while (0)
+    switch (cb) {
+        case 1: KRK_LAUNCH(1); break;
+        case 2: KRK_LAUNCH(2); break;
+        default: KRK_LAUNCH(4); break;
+    }
+#undef KRK_LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// fp32 -> split bf16 planes (hi, lo), 8 elements per thread
+__global__ void __launch_bounds__(256) split_kernel(const float* __restrict__ x, __bf16* __restrict__ hi,
+                                                    __bf16* __restrict__ lo, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = (__bf16)a[j];
+            l[j] = (__bf16)(a[j] - (float)h[j]);
+            h[4 + j] = (__bf16)b[j];
+            l[4 + j] = (__bf16)(b[j] - (float)h[4 + j]);
+        }
+        reinterpret_cast<bf16x8*>(hi)[i] = h;
+        reinterpret_cast<bf16x8*>(lo)[i] = l;
+    }
+}
+
+}  // namespace
+
+int krk_x3_cb(int Cout) {
+    const int CB = (Cout + 31) / 32;
+    return CB >= 4 ? 4 : (CB >= 2 ? 2 : 1);
+}
+
+int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s) {
+    const int CBt = (a.Cout + 31) / 32;
+    const int cb = krk_x3_cb(a.Cout);
+    dim3 grid((unsigned)(a.tiles_w * a.tiles_h * a.N), (unsigned)((CBt + cb - 1) / cb));
+    const size_t lds = (size_t)2 * a.lds_plane;
+    if (out_f32) return pool ? -1 : launch_cb<0, 1>(a, cb, grid, lds, s);
+    return pool ? launch_cb<1, 0>(a, cb, grid, lds, s) : launch_cb<0, 0>(a, cb, grid, lds, s);
+}
+
+int krk_launch_split(const float* x, void* hi, size_t plane_elems, size_t n, hipStream_t s) {
+    if (n % 8) return -1;
+    const size_t n8 = n / 8;
+    if (!n8) return 0;
+    const unsigned blocks = (unsigned)min((size_t)4096, (n8 + 255) / 256);
+    hipLaunchKernelGGL(split_kernel, dim3(blocks), dim3(256), 0, s, x, reinterpret_cast<__bf16*>(hi),
+                       reinterpret_cast<__bf16*>(hi) + plane_elems, n8);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

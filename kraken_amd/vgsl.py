@@ -342,6 +342,19 @@ class HipSequential(nn.Module):
         self.precision = _lib.PREC_F32
 
     # -- plan management -------------------------------------------------------------
+    def set_precision(self, precision) -> None:
+        """
+        Arithmetic of the GEMM-shaped layers: 'f32' (exact f32 matrix cores, default) or 'bf16x3'
+        (split-bf16 operands on the bf16 matrix cores, fp32-class results; conv/LSTM/linear networks only).
+        """
+        table = {'f32': _lib.PREC_F32, 'fp32': _lib.PREC_F32, '32': _lib.PREC_F32, '32-true': _lib.PREC_F32,
+                 _lib.PREC_F32: _lib.PREC_F32, 'bf16x3': _lib.PREC_BF16X3, _lib.PREC_BF16X3: _lib.PREC_BF16X3}
+        if precision not in table:
+            raise ValueError(f'unknown precision {precision!r}; choose "f32" or "bf16x3"')
+        if table[precision] != self.precision:
+            self.precision = table[precision]
+            self.invalidate()
+
     def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 

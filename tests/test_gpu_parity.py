@@ -348,3 +348,103 @@ def test_engine_pipelined_results_identical(bench_b):
         got.append(_keys(eng.collect()[0].tuples()))
     assert got == want
     eng.close()
+
+
+# ------------------------------------------------- split-bf16 ("bf16x3") execution of the GEMM layers
+X3_TOL = 2e-4   # measured ~2e-5; the north-star gate is 1e-3
+
+
+@pytest.fixture(scope='module')
+def bench_a_x3():
+    m = build_model(BENCH_A, codec=bench_codec(), seed=0).to('cuda')
+    m.nn.set_precision('bf16x3')
+    return m
+
+
+def test_x3_bench_a_against_reference_golden(bench_a_x3):
+    """bf16x3 plan vs the reference's golden logits / tuples / strings (same gate as the fp32 plan)."""
+    m = bench_a_x3
+    z = load_golden('bench_a.npz')
+    for tag in ('n4w400', 'n16w800', 'n4w1200'):
+        n, w = int(tag[1:tag.index('w')]), int(tag[tag.index('w') + 1:])
+        x = synth_input(n, w).cuda()
+        batch, olens, logits, probs = m.nn.recognize(x, torch.tensor([w] * n), want_logits=True, want_probs=True)
+        keep = z[f'{tag}_keep'].tolist()
+        err = np.abs(logits.cpu().numpy()[keep] - z[f'{tag}_logits']).max()
+        assert err < X3_TOL, err
+        got, want = batch.tuples(), arr_to_tuples(z[f'{tag}_tuples'], z[f'{tag}_counts'])
+        assert _keys(got) == _keys(want)
+        assert _max_conf_diff(got, want) < CONF_TOL
+        strings = [''.join(c for c, *_ in rec) for rec in m.codec.decode_batch(batch)]
+        assert strings == json.loads(str(z[f'{tag}_strings']))
+    # ragged batch == the reference's per-line results
+    widths = z['ragged_widths'].tolist()
+    x = synth_input(len(widths), 800, seed=4321)
+    for i, w in enumerate(widths):
+        x[i, ..., w:] = 0
+    batch, olens, logits, _ = m.nn.recognize(x.cuda(), torch.tensor(widths), want_logits=True)
+    for i in range(len(widths)):
+        want = z[f'ragged{i}_logits']
+        assert olens[i] == want.shape[1]
+        assert np.abs(logits.cpu().numpy()[i, :, :olens[i]] - want).max() < X3_TOL
+        wt = arr_to_tuples(z[f'ragged{i}_tuples'], z[f'ragged{i}_counts'])[0]
+        assert [t[:3] for t in batch.tuples()[i]] == [t[:3] for t in wt]
+
+
+@pytest.mark.parametrize('spec,n,w,lens', [
+    ('[1,8,0,1 Cr3,3,16 Mp2,2 Cr3,5,32 S1(1x0)1,3 Lbx8 O1c12]', 3, 90, [90, 61, 17]),
+    ('[1,6,0,3 Ct3,3,16 Cr3,7,48,1,2 Cl1,1,32 S1(1x0)1,3 Lfx16 Lbx8 O1c7]', 2, 77, None),
+    ('[1,12,0,1 Clr3,3,16 Mp2,2 Cr3,3,32 Mp2,2 Cr2,4,16 S1(1x0)1,3 Lbx24 Lbx8 O1c30]', 4, 130, [130, 129, 64, 9]),
+    ('[1,4,0,2 Cr3,3,16 Cr3,3,16,1,1,1,2 S1(1x0)1,3 Lbx200 O1c9]', 2, 70, [70, 33]),
+])
+def test_x3_matches_cpu_oracle_on_small_networks(spec, n, w, lens):
+    """Strides, dilation, even kernels, tanh/leaky/linear activations, f/b LSTM stacks, hidden 200."""
+    m = build_model(spec, seed=3)
+    _, c, h, _ = m.input
+    x = torch.rand(n, c, h, w, generator=torch.Generator().manual_seed(5))
+    if lens:
+        for i, L in enumerate(lens):
+            x[i, ..., L:] = 0
+    ref = CpuRecognizer(m.layer_specs, m.state_dict())
+    want, wl = ref.forward(x, lens)
+    m.to('cuda')
+    for prec in ('f32', 'bf16x3'):
+        m.nn.set_precision(prec)
+        got, gl = m.nn(x.cuda(), None if lens is None else torch.tensor(lens))
+        got = got.cpu()
+        for i in range(n):
+            L = int(wl[i]) if lens else got.shape[3]
+            assert (got[i, ..., :L] - want[i, ..., :L]).abs().max().item() < (2e-5 if prec == 'f32' else X3_TOL)
+        if lens:
+            assert gl.tolist() == wl.tolist()
+
+
+def test_x3_rejects_networks_it_cannot_run():
+    from kraken_amd import _lib
+    m = build_model(BENCH_B, seed=0).to('cuda')          # GroupNorm -> fp32 plan only
+    m.nn.set_precision('bf16x3')
+    with pytest.raises(_lib.KrakenAmdError):
+        m.nn(synth_input(1, 64).cuda())
+    m.nn.set_precision('f32')
+    m.nn(synth_input(1, 64).cuda())
+    with pytest.raises(ValueError):
+        m.nn.set_precision('fp8')
+
+
+def test_x3_full_size_batch_invariance(bench_a_x3, bench_a):
+    N, W = 256, 1200
+    x = synth_input(N, W, seed=2024).cuda()
+    b32, _, l32, _ = bench_a.nn.recognize(x, None, want_logits=True)
+    bx3, _, lx3, _ = bench_a_x3.nn.recognize(x, None, want_logits=True)
+    assert (l32 - lx3).abs().max().item() < X3_TOL
+    t32, tx3 = _keys(b32.tuples()), _keys(bx3.tuples())
+    # identical label tuples except where the fp32 top-2 margin is below the split-operand error
+    top2 = l32.topk(2, dim=1).values
+    tie_sensitive = ((top2[:, 0] - top2[:, 1]) < 4 * X3_TOL).any(dim=1).cpu().tolist()
+    diff = [i for i in range(N) if t32[i] != tx3[i]]
+    assert all(tie_sensitive[i] for i in diff), f'{len(diff)} lines differ outside tie-sensitive steps'
+    assert len(diff) <= 2
+    sub = [5, 77, 200]
+    bs, _, ls, _ = bench_a_x3.nn.recognize(x[sub], None, want_logits=True)
+    assert (ls - lx3[sub]).abs().max().item() < 1e-5
+    assert _keys(bs.tuples()) == [tx3[i] for i in sub]
