@@ -7,7 +7,7 @@ Benchmark of the kraken line-recognition hot path on MI355X.
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path (VGSL conv stack + 3 BiLSTM + linear + softmax + CTC
-best-path decode, label tuples copied back to the host) over ONE batch of 256 synthetic
+best-path decode, label tuples copied back to the host, host codec -> strings) over ONE batch of 256 synthetic
 1x48x1200 line images per GPU (BASELINE.json configs[1]; BENCH-A spec of SURVEY.md section 8d, random-init
 weights `torch.manual_seed(0)`).  Inputs are resident in HBM before the timed region.  Ranks
 shard lines (weak scaling: 256 lines per rank per step) and the decoded label sequences are
@@ -98,14 +98,23 @@ def main():
     x = torch.rand(N, 1, 48, W, generator=g).to(dev)    # resident in HBM before timing
     engine = RecognitionEngine(model, device=local_rank, max_batch=N, max_width=W, slots=args.slots)
 
+    codec = model.codec
+    n_chars = [0]
+
+    def finish():
+        batch, olens = engine.collect()
+        strings = codec.decode_strings(batch)          # host codec: label tuples -> text, inside the timed region
+        n_chars[0] += sum(map(len, strings))
+        return batch, olens
+
     def run(steps):
         last = None
         for _ in range(steps):
             if engine.free_slots() == 0:
-                last = engine.collect()
+                last = finish()
             engine.submit(x)
         while engine.free_slots() < len(engine.slots):
-            last = engine.collect()
+            last = finish()
         return last
 
     run(args.warmup)
@@ -180,6 +189,7 @@ def main():
                        'frac_of_peak': round(v['gflop'] / v['ms'] / peak_of(k), 4) if v['ms'] > 0 else 0}
                    for k, v in groups.items()},
         'gathered_lines': int(sum(len(b.counts) for b in gathered)),
+        'decoded_chars': int(n_chars[0]),
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -146,6 +146,48 @@ class PytorchCodec(object):
         """Decodes a whole ``DecodedBatch`` (see vgsl.py); equivalent to ``decode`` per line."""
         return [self.decode(t) for t in batch.tuples()]
 
+    # ---- vectorised fast path ---------------------------------------------------------------
+    def _single_lut(self):
+        """label -> code point table, valid when every code is ONE label mapping to ONE code point."""
+        lut = getattr(self, '_lut', None)
+        if lut is None:
+            if any(len(k) != 1 or len(v) != 1 for k, v in self.l2c.items()):
+                lut = False
+            else:
+                lut = np.zeros(self.max_label + 1, dtype=np.uint32)      # 0 = not decodable
+                for (lab,), ch in self.l2c.items():
+                    lut[lab] = ord(ch)
+            self._lut = lut
+        return lut
+
+    def decode_strings(self, batch) -> list[str]:
+        """
+        Text of every line of a ``DecodedBatch`` -- ``''.join(c for c, *_ in decode(line))`` for all lines
+        without a Python loop per label: one table lookup over the compact label array, one UTF-32 decode,
+        one slice per line.  Falls back to ``decode`` for codecs with multi-label / multi-code-point entries.
+        """
+        lut = self._single_lut()
+        if lut is False:
+            return [''.join(c for c, *_ in rec) for rec in self.decode_batch(batch)]
+        counts = np.asarray(batch.counts)
+        labels = np.asarray(batch.labels)
+        n, t = labels.shape if labels.ndim == 2 else (len(counts), 0)
+        keep = np.arange(t)[None, :] < counts[:, None]
+        flat = labels[keep]
+        cps = np.where(flat < len(lut), lut[np.minimum(flat, len(lut) - 1)], 0).astype('<u4')
+        ok = cps != 0                                   # undecodable labels are skipped (non-strict mode)
+        if self.strict and not ok.all():
+            bad = flat[~ok][:5].tolist()
+            raise KrakenEncodeException(f'Non-decodable sequence {tuple(bad)}... encountered.')
+        per_line = np.add.reduceat(ok.astype(np.int64), np.r_[0, np.cumsum(counts)[:-1]]) if len(flat) else np.zeros(n, np.int64)
+        per_line = np.where(counts > 0, per_line, 0)
+        text = cps[ok].tobytes().decode('utf-32-le')
+        out, pos = [], 0
+        for k in per_line.tolist():
+            out.append(text[pos:pos + k])
+            pos += k
+        return out
+
     def merge(self, codec: 'PytorchCodec') -> tuple['PytorchCodec', set]:
         """
         Transforms this codec into one encoding the code point sequences of `codec`, reusing

@@ -218,10 +218,12 @@ int upload_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowma
     const int CBt = (g.Cout + 31) / 32;
     const int CBpad = (CBt + cb - 1) / cb * cb;
     if (CBpad != g.CBpad) return fail(KRK_E_INVALID, "bf16x3: filter block padding mismatch");
-    std::vector<uint16_t> pack((size_t)g.xnchunks * kk * g.xKB * CBpad * 1024, 0);
-    for (int ci = 0; ci < g.xnchunks; ++ci)
+    // + 8 zero records of slack: the kernel's weight cursor prefetches up to 4 records past the end
+    std::vector<uint16_t> pack(((size_t)g.xnchunks * kk * g.xKB + 8) * CBpad * 1024, 0);
+    for (int ci = 0; ci < g.xnchunks; ++ci) {
+        const int kbn = (ci + 1 == g.xnchunks) ? g.xKB_last : g.xKB;   // the last chunk is packed densely
         for (int t = 0; t < kk; ++t)
-            for (int kb = 0; kb < g.xKB; ++kb)
+            for (int kb = 0; kb < kbn; ++kb)
                 for (int b = 0; b < CBt; ++b)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
@@ -236,10 +238,12 @@ int upload_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowma
                             const float v = w[((size_t)src * g.Cin + c) * kk + t];
                             const uint16_t hi = f2bf(v);
                             const uint16_t lo = f2bf(v - bf2f(hi));
-                            const size_t base = ((((size_t)ci * kk + t) * g.xKB + kb) * CBpad + b) * 1024 + lane * 8 + e;
+                            const size_t rec = (size_t)ci * kk * g.xKB + (size_t)t * kbn + kb;
+                            const size_t base = (rec * CBpad + b) * 1024 + lane * 8 + e;
                             pack[base] = hi;
                             pack[base + 512] = lo;
                         }
+    }
     HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return KRK_OK;
@@ -867,6 +871,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
             a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
             a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0;
+            a.dbg = getenv("KRK_X3_DBG") ? atoi(getenv("KRK_X3_DBG")) : 0;
         };
         // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
         auto split_strides = [&](const ConvGeom& g, int Wo_, int Wy_, long& sn, long& sr, long& sc) {

@@ -81,7 +81,7 @@ struct X3Args {
     int act;
     int cchunk, nchunks, KB, KB_last;   // channels per LDS chunk (multiple of 16), 16-channel blocks per chunk
     int IH, IW, PSTR, lds_plane;        // LDS tile: pixels, bytes per pixel (padded), bytes per plane
-    int SR, tiles_h, tiles_w;
+    int SR, tiles_h, tiles_w;    int dbg;                            // probe bits (env KRK_X3_DBG): 1 skip K loop, 2 skip staging loads, 4 skip stores
 };
 
 // ----------------------------------------------------------------------- LSTM

@@ -21,7 +21,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 template <int CTRL>
-__device__ __forceinline__ float quad_bcast(float v) {
+__device__ __forceinline__ float quad_perm(float v) {   // DPP quad_perm: 0xB1 = lane^1, 0x4E = lane^2
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
@@ -50,11 +50,9 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
 
     f32x4 acc[NBW];
     f32x4 xn[XPRE ? NBW : 1];
-    float cst[NBW][4];
+    float cst[NBW];          // cell state of (line 4*(lane>>4) + gate, unit): one per column block
 #pragma unroll
-    for (int j = 0; j < NBW; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cst[j][r] = 0.f;
+    for (int j = 0; j < NBW; ++j) cst[j] = 0.f;
 
     // weights: [dir][kb][block][plane][lane][8] bf16
     const __bf16* wbase = a.wp + ((size_t)dir * a.NKB * a.NB * 2 * 64 + lane) * 8;
@@ -118,28 +116,40 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
         }
 
         // ---- gate non-linearities, cell update, h_t -> LDS as (hi, lo)
+        // Lane q of a quad holds gate q of one unit for the tile's lines 4*(lane>>4) + r, r = 0..3.  After the
+        // per-lane activation a 4x4 (register x lane) transpose inside the quad -- two DPP butterfly stages --
+        // gives lane q all four gates of line r = q, so every lane updates ONE cell (no 4-fold redundancy).
         unsigned char* hnext = hs + (cur ^ 1) * buf;
+        const int myrow = 4 * (lane >> 4) + gate;        // the line this lane owns after the transpose
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
             const int unit = (wave + 4 * j) * 4 + ul;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * acc[j][r]));
-                gv = (gate == 2) ? (2.f * gv - 1.f) : gv;
-                const float gi = quad_bcast<0x00>(gv);
-                const float gf = quad_bcast<0x55>(gv);
-                const float gg = quad_bcast<0xAA>(gv);
-                const float go = quad_bcast<0xFF>(gv);
-                const float c = gf * cst[j][r] + gi * gg;
-                cst[j][r] = c;
-                const float h = go * krk_tanh(c);
-                if (gate == 0) {
-                    const __bf16 hh = (__bf16)h;
-                    __bf16* dst = reinterpret_cast<__bf16*>(hnext + irow[r] * RS) + unit;
-                    dst[0] = hh;
-                    *reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(dst) + plane) = (__bf16)(h - (float)hh);
-                }
+                const float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * acc[j][r]));
+                v[r] = (gate == 2) ? (2.f * gv - 1.f) : gv;
             }
+            float b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {               // swap bit 0 of (register, lane)
+                const float p = quad_perm<0xB1>(v[r ^ 1]);
+                b[r] = (((r ^ gate) & 1) != 0) ? p : v[r];
+            }
+            float g4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {               // swap bit 1 of (register, lane)
+                const float p = quad_perm<0x4E>(b[r ^ 2]);
+                g4[r] = (((r ^ gate) & 2) != 0) ? p : b[r];
+            }
+            // g4[0..3] = sig(i), sig(f), tanh(g), sig(o) of (line myrow, unit)
+            const float c = g4[1] * cst[j] + g4[0] * g4[2];
+            cst[j] = c;
+            const float h = g4[3] * krk_tanh(c);
+            const __bf16 hh = (__bf16)h;
+            __bf16* dst = reinterpret_cast<__bf16*>(hnext + myrow * RS) + unit;
+            dst[0] = hh;
+            *reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(dst) + plane) = (__bf16)(h - (float)hh);
         }
         __syncthreads();
         // ---- h_t -> split output planes out[plane][n][t][dir*H + k], coalesced 2-byte rows

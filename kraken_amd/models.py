@@ -107,7 +107,10 @@ class TorchSeqRecognizer(object):
         return self.codec.decode_batch(batch)
 
     def predict_string(self, line: torch.Tensor, lens: Optional[torch.Tensor] = None) -> list[str]:
-        return [''.join(x[0] for x in rec) for rec in self.predict(line, lens)]
+        if self.decoder is not _ctc.greedy_decoder or not hasattr(self.codec, 'decode_strings'):
+            return [''.join(x[0] for x in rec) for rec in self.predict(line, lens)]
+        batch, _ = self._run(line, lens, False)
+        return self.codec.decode_strings(batch)
 
     def predict_labels(self, line: torch.Tensor, lens: torch.Tensor = None):
         """list (per line) of (label, start, end, max confidence) tuples."""

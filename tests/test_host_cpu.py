@@ -234,6 +234,31 @@ def test_codec_merge_and_add_labels():
     assert ext2.decode([(7, 0, 0, 0.5), (8, 1, 1, 1.0)]) == [('x', 0, 1, 0.75), ('y', 0, 1, 0.75)]
 
 
+def test_codec_vectorised_strings_equal_per_line_decode():
+    from kraken_amd.vgsl import DecodedBatch
+    rng = np.random.RandomState(0)
+    n, t = 64, 40
+    counts = rng.randint(0, t + 1, size=n).astype(np.int32)
+    counts[3] = 0
+    labels = rng.randint(1, 256, size=(n, t)).astype(np.int32)
+    labels[5, 2] = 999          # not decodable -> skipped
+    labels[6, :] = 300
+    z = np.zeros_like(labels)
+    batch = DecodedBatch(labels, z, z, np.zeros((n, t), np.float32), counts)
+    single = PytorchCodec(bench_codec())
+    want = [''.join(c for c, *_ in rec) for rec in single.decode_batch(batch)]
+    assert single.decode_strings(batch) == want
+    multi = PytorchCodec({'a': [1], 'bc': [2], 'd': [3, 4]})        # multi-label / multi-code-point: falls back
+    small = DecodedBatch(np.array([[1, 2, 3, 4], [3, 1, 0, 0]], np.int32), np.zeros((2, 4), np.int32),
+                         np.zeros((2, 4), np.int32), np.ones((2, 4), np.float32), np.array([4, 2], np.int32))
+    assert multi.decode_strings(small) == ['abcd', 'a']
+    with pytest.raises(KrakenEncodeException):
+        PytorchCodec(bench_codec(), strict=True).decode_strings(batch)
+    empty = DecodedBatch(np.zeros((2, 0), np.int32), np.zeros((2, 0), np.int32), np.zeros((2, 0), np.int32),
+                         np.zeros((2, 0), np.float32), np.zeros(2, np.int32))
+    assert single.decode_strings(empty) == ['', '']
+
+
 # ---------------------------------------------------------------------------- preprocessing
 def test_transforms_match_reference_outputs():
     from PIL import Image
