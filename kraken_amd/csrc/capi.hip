@@ -985,6 +985,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     l.xstride = s.ndir * G;
                     l.ostride = s.ndir * s.hidden;
                     l.hrow = l.NKB * 64 + 16;
+                    l.dbg = getenv("KRK_LSTM_DBG") ? atoi(getenv("KRK_LSTM_DBG")) : 0;
                     s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
                     rc = krk_launch_lstm_x3(l, stream);
                     break;

@@ -109,6 +109,7 @@ struct LstmX3Args {
     int ndir, dirmode;
     int xstride, ostride;
     int hrow;             // bytes per LDS row of h (one line, one plane) = NKB*64 + 16
+    int dbg;              // probe bits (env KRK_LSTM_DBG): 1 no weight loads, 2 no gate math, 4 no MFMA, 8 no x prefetch
 };
 int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s);
 

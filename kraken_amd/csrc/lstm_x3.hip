@@ -20,56 +20,84 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-template <int CTRL>
-__device__ __forceinline__ float quad_perm(float v) {   // DPP quad_perm: 0xB1 = lane^1, 0x4E = lane^2
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-
 struct WPair {
     bf16x8 hi, lo;
 };
 
+// h_t (hi, lo rows in LDS) -> split output planes out[plane][n][t][dir*H + k]; 16-byte pieces when H % 8 == 0
+__device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigned char* hnext, const int* lens_s, int s,
+                                              int wave, int lane, int dir, bool rev, int n0) {
+    constexpr int M = 16;
+    const int RS = a.hrow, plane = M * RS;
+    if ((a.H & 7) == 0) {
+        const int per_line = a.H >> 3;                   // 16-byte pieces per line per plane
+        const int total = 4 * per_line * 2;              // this wave: 4 lines x 2 planes
+        for (int e = lane; e < total; e += 64) {
+            const int pl = e / (4 * per_line), r = e - pl * 4 * per_line;
+            const int li = r / per_line, q = r - li * per_line;
+            const int i = wave * 4 + li;
+            const int len = lens_s[i];
+            if (s < len) {
+                const int t = rev ? (len - 1 - s) : s;
+                const size_t o = ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H + q * 8;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(hnext + pl * plane + i * RS + q * 16);
+                *reinterpret_cast<f32x4*>(a.out + pl * a.out_plane + o) = v;
+            }
+        }
+    } else {
+        for (int i = wave * 4; i < wave * 4 + 4; ++i) {
+            const int len = lens_s[i];
+            if (s < len) {
+                const int t = rev ? (len - 1 - s) : s;
+                const size_t o = ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H;
+                const __bf16* src = reinterpret_cast<const __bf16*>(hnext + i * RS);
+                for (int k = lane; k < a.H; k += 64) {
+                    a.out[o + k] = src[k];
+                    a.out[a.out_plane + o + k] = *reinterpret_cast<const __bf16*>(reinterpret_cast<const unsigned char*>(src + k) + plane);
+                }
+            }
+        }
+    }
+}
+
+// Orientation: D = W . h^T, i.e. the MFMA's A operand is the weight fragment (16 gate columns x 32 K) and B is
+// h (32 K x 16 lines).  With gate columns interleaved (col = 4*unit + gate) the D fragment of lane l holds
+// rows 4*(l>>4) + r = the FOUR GATES (r = i,f,g,o) of unit (l>>4) of the block, for line l&15: the cell update
+// is purely per-lane (no cross-lane traffic), and xproj[t] for a block is ONE 16-byte load per lane.
 template <int NBW, bool XPRE>
 __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char* hs, const int* lens_s, int Lmax,
                                              int wave, int lane, int dir, bool rev, int n0) {
     constexpr int M = 16;
-    const int cl = lane & 15;
-    const int gate = cl & 3, ul = cl >> 2;
-    const int kq = lane >> 4;                 // which 8 of the 32 K of a block this lane holds
+    const int line = lane & 15;               // the line (B/D column) this lane owns
+    const int us = lane >> 4;                 // unit inside a block (D rows 4*us..4*us+3), also the K octet of operands
     const int RS = a.hrow;                    // bytes per h row (one line, one plane)
     const int plane = M * RS;                 // bytes per plane
     const int buf = 2 * plane;                // bytes per (hi, lo) buffer
-
-    int irow[4], ilen[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        irow[r] = 4 * (lane >> 4) + r;
-        ilen[r] = lens_s[irow[r]];
-    }
+    const int mylen = lens_s[line];
 
     f32x4 acc[NBW];
-    f32x4 xn[XPRE ? NBW : 1];
-    float cst[NBW];          // cell state of (line 4*(lane>>4) + gate, unit): one per column block
+    float cst[NBW];                           // cell state of (line, unit): one per column block
 #pragma unroll
     for (int j = 0; j < NBW; ++j) cst[j] = 0.f;
 
-    // weights: [dir][kb][block][plane][lane][8] bf16
+    // weights: [dir][kb][block][plane][lane][8] bf16; lane l: gate column l&15 of the block, K octet l>>4
     const __bf16* wbase = a.wp + ((size_t)dir * a.NKB * a.NB * 2 * 64 + lane) * 8;
     const size_t kstride = (size_t)a.NB * 1024;
-    const float gscale = (gate == 2) ? 2.f : 1.f;
+    const float* xrow = a.xp + (size_t)(n0 + line) * a.T * a.xstride + (size_t)dir * a.G + us * 4;
 
     auto load_x = [&](int s, auto& dst) {
+        const bool on = s < mylen;
+        const int t = on ? (rev ? (mylen - 1 - s) : s) : 0;
+        const float* xr = xrow + (size_t)t * a.xstride;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool on = s < ilen[r];
-            const int t = rev ? (ilen[r] - 1 - s) : s;
-            const float* xr = a.xp + ((size_t)(n0 + irow[r]) * a.T + (on ? t : 0)) * a.xstride + (size_t)dir * a.G + cl;
-#pragma unroll
-            for (int j = 0; j < NBW; ++j) dst[j][r] = on ? xr[(size_t)(wave + 4 * j) * M] : 0.f;
+        for (int j = 0; j < NBW; ++j) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (on) v = *reinterpret_cast<const f32x4*>(xr + (wave + 4 * j) * M);
+            dst[j] = v;
         }
     };
     auto load_w = [&](int kb, WPair (&dst)[NBW]) {
+        if (a.dbg & 1) return;
         const __bf16* wk = wbase + (size_t)kb * kstride;
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
@@ -79,26 +107,30 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
         }
     };
     auto mma_block = [&](int kb, const unsigned char* hcur, const WPair (&w)[NBW]) {
-        const unsigned char* ap = hcur + cl * RS + (kb * 32 + kq * 8) * 2;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + plane);
+        if (a.dbg & 4) return;
+        const unsigned char* hp = hcur + line * RS + (kb * 32 + us * 8) * 2;
+        const bf16x8 hh = *reinterpret_cast<const bf16x8*>(hp);
+        const bf16x8 hl = *reinterpret_cast<const bf16x8*>(hp + plane);
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w[j].hi, acc[j], 0, 0, 0);
+        for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j].hi, hh, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w[j].hi, acc[j], 0, 0, 0);
+        for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j].hi, hl, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w[j].lo, acc[j], 0, 0, 0);
+        for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j].lo, hh, acc[j], 0, 0, 0);
     };
 
     WPair wa[NBW], wb[NBW];
-    load_w(0, wa);
-    if constexpr (XPRE) load_x(0, xn);
+    if (a.dbg & 1) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) { wa[j].hi = bf16x8{}; wa[j].lo = bf16x8{}; wb[j].hi = bf16x8{}; wb[j].lo = bf16x8{}; }
+    }
     int cur = 0;
-    for (int s = 0; s < Lmax; ++s) {
+    // one time step; `xbuf` holds xproj of this step and is refilled with the next step's after the last weight
+    // load (vmcnt retires in order: an HBM-latency load in front of weight loads would stall their MFMAs)
+    auto step = [&](int s, f32x4 (&xbuf)[XPRE ? NBW : 1]) {
         if constexpr (XPRE) {
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) acc[j] = xn[j];
-            if (s + 1 < Lmax) load_x(s + 1, xn);
+            for (int j = 0; j < NBW; ++j) acc[j] = xbuf[j];
         } else {
             load_x(s, acc);
         }
@@ -114,81 +146,47 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
             mma_block(kb, hcur, wa);
             load_w(0, wa);
         }
+        if constexpr (XPRE) {
+            if (s + 1 < Lmax && !(a.dbg & 8)) load_x(s + 1, xbuf);
+        }
 
-        // ---- gate non-linearities, cell update, h_t -> LDS as (hi, lo)
-        // Lane q of a quad holds gate q of one unit for the tile's lines 4*(lane>>4) + r, r = 0..3.  After the
-        // per-lane activation a 4x4 (register x lane) transpose inside the quad -- two DPP butterfly stages --
-        // gives lane q all four gates of line r = q, so every lane updates ONE cell (no 4-fold redundancy).
+        // ---- gate non-linearities, cell update (per lane: one (line, unit)), h_t -> LDS as (hi, lo)
         unsigned char* hnext = hs + (cur ^ 1) * buf;
-        const int myrow = 4 * (lane >> 4) + gate;        // the line this lane owns after the transpose
+        if (!(a.dbg & 2))
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
-            const int unit = (wave + 4 * j) * 4 + ul;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * acc[j][r]));
-                v[r] = (gate == 2) ? (2.f * gv - 1.f) : gv;
-            }
-            float b[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {               // swap bit 0 of (register, lane)
-                const float p = quad_perm<0xB1>(v[r ^ 1]);
-                b[r] = (((r ^ gate) & 1) != 0) ? p : v[r];
-            }
-            float g4[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {               // swap bit 1 of (register, lane)
-                const float p = quad_perm<0x4E>(b[r ^ 2]);
-                g4[r] = (((r ^ gate) & 2) != 0) ? p : b[r];
-            }
-            // g4[0..3] = sig(i), sig(f), tanh(g), sig(o) of (line myrow, unit)
-            const float c = g4[1] * cst[j] + g4[0] * g4[2];
+            const int unit = (wave + 4 * j) * 4 + us;
+            const float gi = krk_sigmoid(acc[j][0]);
+            const float gf = krk_sigmoid(acc[j][1]);
+            const float gg = krk_tanh(acc[j][2]);
+            const float go = krk_sigmoid(acc[j][3]);
+            const float c = gf * cst[j] + gi * gg;
             cst[j] = c;
-            const float h = g4[3] * krk_tanh(c);
+            const float h = go * krk_tanh(c);
             const __bf16 hh = (__bf16)h;
-            __bf16* dst = reinterpret_cast<__bf16*>(hnext + myrow * RS) + unit;
+            __bf16* dst = reinterpret_cast<__bf16*>(hnext + line * RS) + unit;
             dst[0] = hh;
             *reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(dst) + plane) = (__bf16)(h - (float)hh);
         }
         __syncthreads();
-        // ---- h_t -> split output planes out[plane][n][t][dir*H + k], coalesced 2-byte rows
-        for (int i = wave; i < M; i += 4) {
-            const int li = lens_s[i];
-            if (s < li) {
-                const int t = rev ? (li - 1 - s) : s;
-                const size_t o = ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H;
-                const __bf16* src = reinterpret_cast<const __bf16*>(hnext + i * RS);
-                for (int k = lane; k < a.H; k += 64) {
-                    a.out[o + k] = src[k];
-                    a.out[a.out_plane + o + k] = *reinterpret_cast<const __bf16*>(reinterpret_cast<const unsigned char*>(src + k) + plane);
-                }
-            }
-        }
+        lstm_x3_store(a, hnext, lens_s, s, wave, lane, dir, rev, n0);
         cur ^= 1;
-    }
+    };
+
+    f32x4 xa[XPRE ? NBW : 1];
+    load_w(0, wa);
+    if constexpr (XPRE) load_x(0, xa);
+    for (int s = 0; s < Lmax; ++s) step(s, xa);
 }
 
 __device__ __forceinline__ void lstm_x3_idle(const LstmX3Args& a, const unsigned char* hs, const int* lens_s, int Lmax,
                                              int wave, int lane, int dir, bool rev, int n0) {
     constexpr int M = 16;
-    const int RS = a.hrow, plane = M * RS, buf = 2 * plane;
+    const int buf = 2 * M * a.hrow;
     int cur = 0;
     for (int s = 0; s < Lmax; ++s) {
-        const unsigned char* hnext = hs + (cur ^ 1) * buf;
         __syncthreads();
-        for (int i = wave; i < M; i += 4) {
-            const int li = lens_s[i];
-            if (s < li) {
-                const int t = rev ? (li - 1 - s) : s;
-                const size_t o = ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H;
-                const __bf16* src = reinterpret_cast<const __bf16*>(hnext + i * RS);
-                for (int k = lane; k < a.H; k += 64) {
-                    a.out[o + k] = src[k];
-                    a.out[a.out_plane + o + k] = *reinterpret_cast<const __bf16*>(reinterpret_cast<const unsigned char*>(src + k) + plane);
-                }
-            }
-        }
+        lstm_x3_store(a, hs + (cur ^ 1) * buf, lens_s, s, wave, lane, dir, rev, n0);
         cur ^= 1;
     }
 }
