@@ -168,6 +168,20 @@ def main():
                 'note': ('algorithmic FLOPs; the split-operand kernels issue 3 bf16 MFMAs per algorithmic product'
                          if dom_name.endswith('_x3') else 'exact f32 MFMA')}
     layers = launches
+    # HBM traffic of the dominant kernel from the committed PMC summary of this same command (separate
+    # rocprofv3 --pmc passes, see tools/summarize_pmc.py); null when no summary is available
+    try:
+        tag = 'r01_bf16x3' if args.precision == 'bf16x3' else 'r01'
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_summary.json')))['kernels']
+        kname = roofline['kernel'].split('<')[0]
+        hit = [v for k, v in pmc.items() if k.startswith(kname) and 'hbm_write_MB_per_launch' in v]
+        if hit:
+            v = max(hit, key=lambda e: e.get('total_ms', 0))
+            rd = v.get('hbm_read_MB_x2', v.get('hbm_read_MB_per_launch', 0.0))
+            roofline['traffic'] = {'read_MB': rd, 'write_MB': v['hbm_write_MB_per_launch'], 'per': 'launch',
+                                   'source': f'profiles/{tag}_pmc_summary.json (FETCH_SIZE/WRITE_SIZE passes)'}
+    except Exception:
+        pass
 
     lines = N * args.steps * world
     value = lines / dt

@@ -6,10 +6,12 @@ is committed under profiles/.  Usage:
     python tools/summarize_pmc.py <round tag> <stats dir> <FETCH_SIZE dir> <WRITE_SIZE dir> <MFMA dir>
 
 Counter conventions (/opt/skills/guides/MI355X_MICROARCH.md, sections HBM + rocprofv3): FETCH_SIZE / WRITE_SIZE are in
-KiB per dispatch; on gfx950 FETCH_SIZE under-counts WIDE (16 B/lane) coalesced streams by 2x --
-the kernels here that stream with 16-byte loads are flagged and corrected; 4-byte-per-lane
-streams were calibrated against known byte counts (conv / LSTM writes equal the output tensor
-bytes exactly) and are taken as is.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES /
+KiB per dispatch and are reported RAW.  Calibration against known byte counts in these kernels:
+WRITE_SIZE is exact (LSTM output 61.4 MB -> 61.6, conv1 output 472 MB -> 472.1); FETCH_SIZE is exact for
+the 4-byte staging reads of the f32 convolutions (315 MB expected incl. halo -> 315.7) but reads HALF
+for the LSTM's xproj stream (245.8 MB + weights expected -> 129): the guide's gfx950 caveat ("exactly
+1/2 of a wide coalesced streaming read").  `hbm_read_MB_x2` gives the doubled value for the kernels
+whose dominant read stream is known to be affected.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES /
 (1024 SIMDs * kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs.
 """
 import collections
@@ -19,7 +21,7 @@ import os
 import re
 import sys
 
-WIDE_READ_KERNELS = ('conv_f32_kernel<1,',)   # sequence GEMMs stage with dwordx4 loads
+HALVED_READ_KERNELS = ('lstm_f32_kernel', 'lstm_x3_kernel')   # calibrated: xproj stream reads half
 
 
 def short(name):
@@ -47,9 +49,9 @@ def main():
     for k, e in out['kernels'].items():
         if k in fe:
             kib = sum(fe[k]['FETCH_SIZE']) / len(fe[k]['FETCH_SIZE'])
-            corr = 2.0 if k.startswith(WIDE_READ_KERNELS) else 1.0
-            e['hbm_read_MB_per_launch'] = round(kib * 1024 * corr / 1e6, 1)
-            e['fetch_correction'] = corr
+            e['hbm_read_MB_per_launch'] = round(kib * 1024 / 1e6, 1)
+            if k.startswith(HALVED_READ_KERNELS):
+                e['hbm_read_MB_x2'] = round(2 * kib * 1024 / 1e6, 1)
         if k in wr:
             kib = sum(wr[k]['WRITE_SIZE']) / len(wr[k]['WRITE_SIZE'])
             e['hbm_write_MB_per_launch'] = round(kib * 1024 / 1e6, 1)
