@@ -81,9 +81,9 @@ def unpack_decoded(flat: np.ndarray, n: int, k: int) -> tuple[DecodedBatch, np.n
     return DecodedBatch(out[0], out[1], out[2], out[3].view(np.float32), counts.copy()), olens.copy()
 
 
-def gather_decoded(batch: DecodedBatch, olens, group=None) -> list[DecodedBatch]:
-    """All ranks receive every rank's decoded lines, in rank order."""
-    if not td.is_initialized() or td.get_world_size(group) == 1:
+def gather_decoded(batch: DecodedBatch, olens, group=None, force: bool = False) -> list[DecodedBatch]:
+    """All ranks receive every rank's decoded lines, in rank order (`force`: run the collectives even alone)."""
+    if not td.is_initialized() or (td.get_world_size(group) == 1 and not force):
         return [batch]
     world = td.get_world_size(group)
     backend = td.get_backend(group)

@@ -448,3 +448,72 @@ def test_x3_full_size_batch_invariance(bench_a_x3, bench_a):
     bs, _, ls, _ = bench_a_x3.nn.recognize(x[sub], None, want_logits=True)
     assert (ls - lx3[sub]).abs().max().item() < 1e-5
     assert _keys(bs.tuples()) == [tx3[i] for i in sub]
+
+
+# ------------------------------------------------------- BASELINE.json configs 3 and 4 at full size
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+def test_config3_rank_shard_of_2048_lines(prec, bench_a, bench_a_x3):
+    """One rank's share of config 3 (2048 lines 1x48x1200): M=32 recurrent tiles in the fp32 plan."""
+    m = bench_a if prec == 'f32' else bench_a_x3
+    N, W = 2048, 1200
+    x = synth_input(64, W, seed=31).cuda().repeat(N // 64, 1, 1, 1)        # 64 distinct lines, repeated
+    batch, olens, _, _ = m.nn.recognize(x, None)
+    t = _keys(batch.tuples())
+    assert olens.tolist() == [150] * N
+    for i in range(64, N):
+        assert t[i] == t[i % 64]
+    small, _, _, _ = m.nn.recognize(x[:64], None)
+    assert _keys(small.tuples()) == t[:64]
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+def test_config4_1024_ragged_lines_width_sorted(prec, bench_a, bench_a_x3):
+    """Config 4: 1024 lines with W ~ U{400..2400}, width-sorted into buckets of 128, vs per-line results."""
+    m = bench_a if prec == 'f32' else bench_a_x3
+    rng = np.random.RandomState(40)
+    widths = np.sort(rng.randint(400, 2401, size=1024))
+    base = synth_input(8, 2400, seed=41)
+    got, got_olens = [], []
+    for lo in range(0, 1024, 128):
+        ws = widths[lo:lo + 128]
+        wmax = int(ws.max())
+        xb = torch.zeros(128, 1, 48, wmax)
+        for i, w in enumerate(ws):
+            xb[i, ..., :w] = base[(lo + i) % 8, ..., :w]
+        b, ol, _, _ = m.nn.recognize(xb.cuda(), torch.from_numpy(ws.astype(np.int64)))
+        got += b.tuples()
+        got_olens += ol.tolist()
+    assert got_olens == [int(w) // 8 for w in widths]
+    # per-line (batch 1, lens None) results of a sample, through the same plan: batch invariance at scale
+    for i in (0, 255, 600, 1023):
+        w = int(widths[i])
+        one, _, _, _ = m.nn.recognize(base[i % 8:i % 8 + 1, ..., :w].contiguous().cuda(), None)
+        assert _keys(one.tuples())[0] == [t[:3] for t in got[i]]
+    ref = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()})
+    i = 333
+    w = int(widths[i])
+    want = ref.predict_labels(base[i % 8:i % 8 + 1, ..., :w])
+    assert [t[:3] for t in got[i]] == [t[:3] for t in want[0]]
+
+
+def test_edge_shapes(bench_a, bench_a_x3):
+    """Batch 1 (the legacy rpred shape), widths that are not multiples of 8, lines narrower than the kernels."""
+    ref = CpuRecognizer(bench_a.layer_specs, {k: v.cpu() for k, v in bench_a.state_dict().items()})
+    for w in (1203, 37, 13, 9):
+        x = synth_input(1, w, seed=w)
+        want, _ = ref.forward(x)
+        for m, tol in ((bench_a, 2e-5), (bench_a_x3, X3_TOL)):
+            got, olens = m.nn(x.cuda())
+            assert olens is None and tuple(got.shape) == tuple(want.shape)
+            assert (got.cpu() - want).abs().max().item() < tol
+    # a batch mixing a very short and a long line
+    x = torch.zeros(2, 1, 48, 900)
+    x[0] = synth_input(1, 900, seed=1)[0]
+    x[1, ..., :11] = synth_input(1, 11, seed=2)[0]
+    lens = torch.tensor([900, 11])
+    want, wl = ref.forward(x, lens.tolist())
+    for m, tol in ((bench_a, 2e-5), (bench_a_x3, X3_TOL)):
+        got, gl = m.nn(x.cuda(), lens)
+        assert gl.tolist() == wl.tolist() == [112, 1]
+        for i in range(2):
+            assert (got.cpu()[i, ..., :gl[i]] - want[i, ..., :wl[i]]).abs().max().item() < tol
