@@ -249,6 +249,35 @@ int upload_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowma
     return KRK_OK;
 }
 
+// gemm_x3.hip weight order: [column group of 128][K/16][plane][k-half][column][8] (bf16); `w` is (rows, K) f32.
+int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
+    if (g.Cin % 16) return fail(KRK_E_UNSUPPORTED, "bf16x3: input features must be a multiple of 16");
+    const int ncg = (g.Cout + 127) / 128, nkb = g.Cin / 16;
+    std::vector<uint16_t> pack((size_t)ncg * nkb * 4096, 0);
+    for (int cg = 0; cg < ncg; ++cg)
+        for (int kb = 0; kb < nkb; ++kb)
+            for (int col = 0; col < 128; ++col) {
+                const int co = cg * 128 + col;
+                if (co >= g.Cout) continue;
+                int src = co;
+                if (rowmap) {
+                    src = (*rowmap)[co];
+                    if (src < 0) continue;
+                }
+                for (int h = 0; h < 2; ++h)
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = w[(size_t)src * g.Cin + kb * 16 + h * 8 + e];
+                        const uint16_t hi = f2bf(v);
+                        const size_t base = ((size_t)cg * nkb + kb) * 4096 + ((size_t)h * 128 + col) * 8 + e;
+                        pack[base] = hi;
+                        pack[base + 2048] = f2bf(v - bf2f(hi));
+                    }
+            }
+    HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
 struct Step {
     StepKind kind = S_CONV;
     ConvGeom cg;              // CONV / LINEAR / the LSTM input projection
@@ -616,7 +645,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     if (x3) {
                         g.x3 = true;
                         s.in_split = split_fmt;
-                        if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, L.w[0], nullptr) != KRK_OK) {
+                        if (upload_gemm_x3_weights(g, L.w[0], nullptr) != KRK_OK) {
                             krk_plan_destroy(p);
                             return KRK_E_UNSUPPORTED;
                         }
@@ -656,7 +685,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     if (x3) {
                         g.x3 = true;
                         s.in_split = split_fmt;
-                        if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, wih.data(), &rowmap) != KRK_OK) {
+                        if (upload_gemm_x3_weights(g, wih.data(), &rowmap) != KRK_OK) {
                             krk_plan_destroy(p);
                             return KRK_E_UNSUPPORTED;
                         }
@@ -870,8 +899,15 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             a.IH = g.IH; a.IW = g.IW; a.PSTR = g.xPSTR; a.lds_plane = g.xplane; a.SR = g.SR;
             a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
             a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
-            a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0;
+            a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0; a.y_blkM = 0; a.y_cols = 0;
             a.dbg = getenv("KRK_X3_DBG") ? atoi(getenv("KRK_X3_DBG")) : 0;
+        };
+        auto fill_gemm = [&](const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane, float* yout, int rows) {
+            a.x = (const __bf16*)xin; a.x_plane = x_plane;
+            a.w = (const __bf16*)g.d_wx3; a.bias = g.d_b; a.y = yout;
+            a.M = rows; a.K = g.Cin; a.Cout = g.Cout;
+            a.ncg = (g.Cout + 127) / 128; a.ntiles = (rows + 255) / 256;
+            a.act = g.act;
         };
         // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
         auto split_strides = [&](const ConvGeom& g, int Wo_, int Wy_, long& sn, long& sr, long& sc) {
@@ -886,6 +922,10 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     fill_x3(s.cg, a, cur, (size_t)N * s.C * s.H * Win, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));
                     a.y_plane = out_elems;
                     split_strides(s.cg, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+                    if (s.cg.out_seq) {   // sequence rows for the projection: K-blocked
+                        a.y_cols = s.cg.pool ? a.Wy : a.Wo;
+                        a.y_blkM = N * a.y_cols;
+                    }
                     s.flops = 2.0 * N * (double)s.cg.Ho * a.Wo * s.cg.Cout * s.cg.Cin * s.cg.kh * s.cg.kw;
                     if (mark("conv_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
                     rc = krk_launch_conv_x3(a, false, s.cg.pool, stream);
@@ -928,14 +968,14 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     if (!s.in_split) {   // fp32 rows from the recurrent kernel -> split planes
                         if (s.aux2.ensure(in_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
                         mark("split", 0);
-                        rc = krk_launch_split(cur, s.aux2.p, in_elems, in_elems, stream);
+                        rc = krk_launch_split_rows(cur, s.aux2.p, (int)(in_elems / s.cg.Cin), s.cg.Cin, stream);
                         if (rc) break;
                         xin = s.aux2.p;
                     }
-                    X3Args a;
-                    fill_x3(s.cg, a, xin, in_elems, outp, 1, N * Win, nullptr, nullptr);
+                    GemmX3Args a;
+                    fill_gemm(s.cg, a, xin, in_elems, (float*)outp, N * Win);
                     mark("linear_x3", s.flops);
-                    rc = krk_launch_conv_x3(a, true, false, stream);
+                    rc = krk_launch_gemm_x3(a, stream);
                     break;
                 }
                 ConvArgs a;
@@ -955,14 +995,14 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     if (!s.in_split) {
                         if (s.aux2.ensure(in_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
                         mark("split", 0);
-                        rc = krk_launch_split(cur, s.aux2.p, in_elems, in_elems, stream);
+                        rc = krk_launch_split_rows(cur, s.aux2.p, (int)(in_elems / s.cg.Cin), s.cg.Cin, stream);
                         if (rc) break;
                         xin = s.aux2.p;
                     }
-                    X3Args a;
-                    fill_x3(s.cg, a, xin, in_elems, s.aux.p, 1, N * T, nullptr, nullptr);
+                    GemmX3Args a;
+                    fill_gemm(s.cg, a, xin, in_elems, (float*)s.aux.p, N * T);
                     mark("lstm_xproj_x3", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin);
-                    rc = krk_launch_conv_x3(a, true, false, stream);
+                    rc = krk_launch_gemm_x3(a, stream);
                 } else {
                     ConvArgs a;
                     fill_conv(s.cg, a, cur, (float*)s.aux.p, 1, N * T, nullptr, nullptr);

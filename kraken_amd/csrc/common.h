@@ -81,8 +81,22 @@ struct X3Args {
     int act;
     int cchunk, nchunks, KB, KB_last;   // channels per LDS chunk (multiple of 16), 16-channel blocks per chunk
     int IH, IW, PSTR, lds_plane;        // LDS tile: pixels, bytes per pixel (padded), bytes per plane
+    int y_blkM, y_cols;          // > 0: sequence output in K-blocked order, y_blkM rows of y_cols per line (see gemm_x3.hip)
     int SR, tiles_h, tiles_w;    int dbg;                            // probe bits (env KRK_X3_DBG): 1 skip K loop, 2 skip staging loads, 4 skip stores
 };
+
+// split-bf16 row projection (gemm_x3.hip): Y[M][Cout] = X[M][K] . W^T + b
+struct GemmX3Args {
+    const __bf16* x;      // hi plane, K-blocked rows [K/8][M][8]; lo plane at + x_plane elements
+    size_t x_plane;
+    const __bf16* w;      // [ncg][K/16][plane][k-half][128 columns][8]
+    const float* bias;    // [Cout]
+    float* y;             // [M][Cout]
+    int M, K, Cout;
+    int ncg, ntiles;      // column groups of 128, row tiles of 256
+    int act;
+};
+int krk_launch_gemm_x3(const GemmX3Args& a, hipStream_t s);
 
 // ----------------------------------------------------------------------- LSTM
 struct LstmArgs {
@@ -101,7 +115,7 @@ struct LstmArgs {
 struct LstmX3Args {
     const float* xp;      // [N*T][xstride] fp32 input projections (+ biases), gate-interleaved columns
     const __bf16* wp;     // [ndir][NKB][NB][plane][lane][8] recurrent weights, split bf16, B-fragment order
-    __bf16* out;          // hi plane [N][T][ostride]; lo plane at + out_plane elements
+    __bf16* out;          // hi plane, K-blocked sequence rows [ostride/8][N*T][8]; lo plane at + out_plane elements
     size_t out_plane;
     const int* lens;
     int N, T, H, Hp;
@@ -121,6 +135,8 @@ int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hip
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);
 int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
 int krk_launch_split(const float* x, void* hi, size_t plane_elems, size_t n, hipStream_t s);
+// fp32 rows [M][K] -> K-blocked split planes [K/8][M][8] (hi, lo at + M*K elements)
+int krk_launch_split_rows(const float* x, void* hi, int M, int K, hipStream_t s);
 int krk_x3_cb(int Cout);
 int krk_launch_maxpool(const float* x, float* y, const int* len_out, int N, int C, int H, int W,
                        int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);

@@ -258,8 +258,13 @@ __global__ void __launch_bounds__(256, 2) conv_x3_kernel(const X3Args a) {
                         lv[i] = (__bf16)(v - (float)h);
                     }
                     if (st && co < a.Cout) {
-                        *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
-                        *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                        size_t o = base + co;
+                        if (a.y_blkM > 0) {   // K-blocked sequence rows: feature f = row*Cout + co -> [f/8][line*cols + col][f%8]
+                            const int f = row * a.Cout + co;
+                            o = ((size_t)(f >> 3) * a.y_blkM + (size_t)n * a.y_cols + col) * 8 + (f & 7);
+                        }
+                        *reinterpret_cast<bf16x4*>(yh + o) = hv;
+                        *reinterpret_cast<bf16x4*>(yl + o) = lv;
                     }
                 }
             }
@@ -304,7 +309,38 @@ __global__ void __launch_bounds__(256) split_kernel(const float* __restrict__ x,
     }
 }
 
+// fp32 rows [M][K] -> K-blocked split planes [K/8][M][8]: one 16-byte piece per thread, rows fastest
+__global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ x, __bf16* __restrict__ hi,
+                                                         __bf16* __restrict__ lo, int M, int K8) {
+    const size_t total = (size_t)M * K8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int pc = (int)(i / M), row = (int)(i - (size_t)pc * M);
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)row * K8 * 8 + pc * 8);
+        const f32x4 a = src[0], b = src[1];
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = (__bf16)a[j];
+            l[j] = (__bf16)(a[j] - (float)h[j]);
+            h[4 + j] = (__bf16)b[j];
+            l[4 + j] = (__bf16)(b[j] - (float)h[4 + j]);
+        }
+        reinterpret_cast<bf16x8*>(hi)[i] = h;
+        reinterpret_cast<bf16x8*>(lo)[i] = l;
+    }
+}
+
 }  // namespace
+
+int krk_launch_split_rows(const float* x, void* hi, int M, int K, hipStream_t s) {
+    if (K % 8) return -1;
+    const size_t total = (size_t)M * (K / 8);
+    if (!total) return 0;
+    const unsigned blocks = (unsigned)min((size_t)8192, (total + 255) / 256);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(blocks), dim3(256), 0, s, x, reinterpret_cast<__bf16*>(hi),
+                       reinterpret_cast<__bf16*>(hi) + (size_t)M * K, M, K / 8);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int krk_x3_cb(int Cout) {
     const int CB = (Cout + 31) / 32;

@@ -1,0 +1,141 @@
+// Row-major projection  Y[M][Cout] = X[M][K] . W^T + b  on the gfx950 bf16 matrix cores with SPLIT
+// operands ("bf16x3", see conv_x3.hip): the LSTM input projection of every time step of every line
+// (torch.nn.LSTM's W_ih x_t + b_ih + b_hh, reference kraken/lib/vgsl/layers.py:507-511) and the
+// LinSoftmax projection (layers.py:710-722).  M = lines x time steps (38 400 rows on the headline
+// batch), K = 384/400, Cout = 1600 (two directions x four gates x 200) or the alphabet size.
+//
+// Both operands travel through LDS so that every byte is fetched from L2/HBM once per workgroup
+// (four waves share one copy; per-wave weight loads saturated the 64 B/clk texture path before):
+//   tile      = 256 rows x 128 columns per workgroup, 4 waves x 2 row segments x 4 column blocks
+//   K step    = 16: 16 KB of X (256 rows x 16 x hi/lo) + 8 KB of W per step, THREE LDS buffers filled
+//               by asynchronous global -> LDS copies (global_load_lds_dwordx4) issued two steps ahead;
+//               counted vmcnt + ONE raw s_barrier per step, no staging registers, no ds_write pass
+//   X layout  = K-blocked split planes [K/8][M][8 bf16] (written that way by the producers): the 64
+//               lanes of one copy read 1 KB contiguous (row-major X costs one cache line per lane)
+//   LDS order = [plane][k-half][row][8 bf16]: a wave's ds_read_b128 covers contiguous 512-byte runs
+//   grid      = 1-D, XCD-aware: the column groups of one row tile run back-to-back on the SAME XCD,
+//               so X is read from HBM once and re-read from that XCD's L2
+//   epilogue  = + bias, fp32 rows [row][Cout] (the recurrent kernel / decoder read these)
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int TM = 256;        // rows per workgroup
+constexpr int TN = 128;        // columns per workgroup (4 blocks of 32)
+constexpr int A_Q = 4 * TM;    // 16-byte pieces of the X tile per K step
+constexpr int B_Q = 4 * TN;    // 16-byte pieces of the W tile per K step
+
+__global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];   // 3 x (X tile + W tile) = 72 KB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, px = lane & 31;
+
+    // workgroup id -> (row tile, column group): id%8 is the XCD the hardware dispatches to
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int cg = j % a.ncg;
+    const int tile = (j / a.ncg) * 8 + xcd;
+    if (tile >= a.ntiles) return;
+    const int row0 = tile * TM;
+    const int nkb = a.K >> 4;
+
+    // this lane's global sources: X pieces (plane, k-half) of row row0+tid, W pieces tid and tid+256.
+    // Rows past the end re-read the last row; their results are never stored.
+    const int myrow = min(row0 + tid, a.M - 1);
+    const __bf16* xa = a.x + (size_t)myrow * 8;          // piece q of this row: + q*M*8
+    const f32x4* wb = reinterpret_cast<const f32x4*>(a.w) + (size_t)cg * nkb * B_Q + tid;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // asynchronous global -> LDS copies (global_load_lds_dwordx4): the destination is wave-uniform
+    // base + lane*16, which is exactly the [piece][row] order of the tile
+    auto issue = [&](int kb, int buf) {
+        f32x4* dst = lds + buf * (A_Q + B_Q) + wave * 64;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_global_load_lds((const void*)(xa + p * a.x_plane + (size_t)(kb * 2 + h) * a.M * 8),
+                                                 (lds_ptr)(dst + (p * 2 + h) * TM), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(wb + (size_t)kb * B_Q), (lds_ptr)(dst + A_Q), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(wb + (size_t)kb * B_Q + 256), (lds_ptr)(dst + A_Q + 256), 16, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][s][r] = 0.f;
+
+    // three LDS buffers, copies two K steps ahead: 6 copies per wave per step, so "vmcnt(6)" = this
+    // wave's copies of step kb have landed while those of step kb+1 are still in flight
+    issue(0, 0);
+    if (nkb > 1) issue(1, 1);
+
+    const int arow = wave * 64 + px;   // first segment's row inside the tile
+    int buf = 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // everyone's copies of step kb landed; everyone finished reading step kb-1
+        bf16x8 xh[2], xl[2], wh[4], wl[4];
+        const f32x4* L = lds + buf * (A_Q + B_Q);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            xh[s] = __builtin_bit_cast(bf16x8, L[(0 + half) * TM + arow + 32 * s]);
+            xl[s] = __builtin_bit_cast(bf16x8, L[(2 + half) * TM + arow + 32 * s]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            wh[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (0 + half) * TN + cb * 32 + px]);
+            wl[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (2 + half) * TN + cb * 32 + px]);
+        }
+        if (kb + 2 < nkb) issue(kb + 2, buf == 0 ? 2 : buf - 1);   // into the buffer step kb-1 used
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[s], wh[cb], acc[cb][s], 0, 0, 0);
+                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[s], wh[cb], acc[cb][s], 0, 0, 0);
+                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[s], wl[cb], acc[cb][s], 0, 0, 0);
+            }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    // epilogue: D[row][col]: lane holds column px, rows (r&3) + 8*(r>>2) + 4*half of its segment
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int co = (cg * 4 + cb) * 32 + px;
+        if (co >= a.Cout) continue;
+        const float bv = a.bias[co];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rbase = row0 + wave * 64 + 32 * s + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < a.M) a.y[(size_t)row * a.Cout + co] = acc[cb][s][r] + bv;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int krk_launch_gemm_x3(const GemmX3Args& a, hipStream_t s) {
+    if (a.K % 16 || a.M <= 0) return a.M == 0 ? 0 : -1;
+    const int slots = (a.ntiles + 7) / 8 * 8;
+    const size_t lds = (size_t)3 * (A_Q + B_Q) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)(slots * a.ncg)), dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

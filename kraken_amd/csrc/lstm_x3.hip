@@ -39,7 +39,8 @@ __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigne
             const int len = lens_s[i];
             if (s < len) {
                 const int t = rev ? (len - 1 - s) : s;
-                const size_t o = ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H + q * 8;
+                // K-blocked sequence rows [feature/8][line*T + t][8] (what gemm_x3.hip streams)
+                const size_t o = ((size_t)(dir * per_line + q) * ((size_t)a.N * a.T) + (size_t)(n0 + i) * a.T + t) * 8;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(hnext + pl * plane + i * RS + q * 16);
                 *reinterpret_cast<f32x4*>(a.out + pl * a.out_plane + o) = v;
             }
@@ -49,11 +50,13 @@ __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigne
             const int len = lens_s[i];
             if (s < len) {
                 const int t = rev ? (len - 1 - s) : s;
-                const size_t o = ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H;
+                const size_t rowi = (size_t)(n0 + i) * a.T + t, rows = (size_t)a.N * a.T;
                 const __bf16* src = reinterpret_cast<const __bf16*>(hnext + i * RS);
                 for (int k = lane; k < a.H; k += 64) {
-                    a.out[o + k] = src[k];
-                    a.out[a.out_plane + o + k] = *reinterpret_cast<const __bf16*>(reinterpret_cast<const unsigned char*>(src + k) + plane);
+                    const int f = dir * a.H + k;
+                    const size_t o = ((size_t)(f >> 3) * rows + rowi) * 8 + (f & 7);
+                    a.out[o] = src[k];
+                    a.out[a.out_plane + o] = *reinterpret_cast<const __bf16*>(reinterpret_cast<const unsigned char*>(src + k) + plane);
                 }
             }
         }
