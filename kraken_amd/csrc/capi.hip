@@ -908,6 +908,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             a.M = rows; a.K = g.Cin; a.Cout = g.Cout;
             a.ncg = (g.Cout + 127) / 128; a.ntiles = (rows + 255) / 256;
             a.act = g.act;
+            a.dbg = getenv("KRK_X3_DBG") ? atoi(getenv("KRK_X3_DBG")) : 0;
         };
         // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
         auto split_strides = [&](const ConvGeom& g, int Wo_, int Wy_, long& sn, long& sr, long& sc) {

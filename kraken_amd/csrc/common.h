@@ -95,6 +95,7 @@ struct GemmX3Args {
     int M, K, Cout;
     int ncg, ntiles;      // column groups of 128, row tiles of 256
     int act;
+    int dbg;              // probe bits (env KRK_X3_DBG): 1 no MFMA, 2 no copies, 4 no stores, 8 no LDS reads
 };
 int krk_launch_gemm_x3(const GemmX3Args& a, hipStream_t s);
 

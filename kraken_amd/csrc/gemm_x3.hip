@@ -74,8 +74,9 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
 
     // three LDS buffers, copies two K steps ahead: 6 copies per wave per step, so "vmcnt(6)" = this
     // wave's copies of step kb have landed while those of step kb+1 are still in flight
-    issue(0, 0);
-    if (nkb > 1) issue(1, 1);
+    const bool no_mma = a.dbg & 1, no_copy = a.dbg & 2, no_lds = a.dbg & 8;
+    if (!no_copy) { issue(0, 0);
+    if (nkb > 1) issue(1, 1); }
 
     const int arow = wave * 64 + px;   // first segment's row inside the tile
     int buf = 0;
@@ -83,8 +84,9 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
         if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // everyone's copies of step kb landed; everyone finished reading step kb-1
-        bf16x8 xh[2], xl[2], wh[4], wl[4];
+        bf16x8 xh[2] = {}, xl[2] = {}, wh[4] = {}, wl[4] = {};
         const f32x4* L = lds + buf * (A_Q + B_Q);
+        if (!no_lds) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             xh[s] = __builtin_bit_cast(bf16x8, L[(0 + half) * TM + arow + 32 * s]);
@@ -95,33 +97,49 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
             wh[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (0 + half) * TN + cb * 32 + px]);
             wl[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (2 + half) * TN + cb * 32 + px]);
         }
-        if (kb + 2 < nkb) issue(kb + 2, buf == 0 ? 2 : buf - 1);   // into the buffer step kb-1 used
+        }
+        if (kb + 2 < nkb && !no_copy) issue(kb + 2, buf == 0 ? 2 : buf - 1);   // into the buffer step kb-1 used
+        if (!no_mma)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[s], wh[cb], acc[cb][s], 0, 0, 0);
-                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[s], wh[cb], acc[cb][s], 0, 0, 0);
-                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[s], wl[cb], acc[cb][s], 0, 0, 0);
+                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xh[s], acc[cb][s], 0, 0, 0);
+                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xl[s], acc[cb][s], 0, 0, 0);
+                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], xh[s], acc[cb][s], 0, 0, 0);
             }
         buf = buf == 2 ? 0 : buf + 1;
     }
 
-    // epilogue: D[row][col]: lane holds column px, rows (r&3) + 8*(r>>2) + 4*half of its segment
+    // epilogue: D[column][row] (weights are the MFMA's A operand): lane = row px of its segment, registers
+    // 4j..4j+3 = columns 8j + 4*half + 0..3 of the block -> 16-byte stores at compile-time offsets
+    const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int co = (cg * 4 + cb) * 32 + px;
-        if (co >= a.Cout) continue;
-        const float bv = a.bias[co];
+    for (int s = 0; s < 2; ++s) {
+        const int row = row0 + wave * 64 + 32 * s + px;
+        if (row >= a.M || (a.dbg & 4)) continue;
+        const int col0 = cg * TN + 4 * half;
+        float* yp = a.y + (size_t)row * a.Cout + col0;
+        const float* bp = a.bias + col0;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int rbase = row0 + wave * 64 + 32 * s + 4 * half;
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < a.M) a.y[(size_t)row * a.Cout + co] = acc[cb][s][r] + bv;
+            for (int j = 0; j < 4; ++j) {
+                const int o = cb * 32 + 8 * j;
+                if (vec) {
+                    if (col0 + o < a.Cout) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + o);
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = acc[cb][s][4 * j + i] + bv[i];
+                        *reinterpret_cast<f32x4*>(yp + o) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (col0 + o + i < a.Cout) yp[o + i] = acc[cb][s][4 * j + i] + bp[o + i];
+                }
             }
-        }
     }
 }
 
