@@ -22,6 +22,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
 import argparse
 import json
 import os
+
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # one hardware queue per engine slot (read when HIP starts)
 import sys
 import time
 
@@ -42,7 +44,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='lines per GPU per step')
     ap.add_argument('--width', type=int, default=1200)
-    ap.add_argument('--slots', type=int, default=3, help='batches in flight per GPU (streams)')
+    ap.add_argument('--slots', type=int, default=4, help='batches in flight per GPU (streams)')
     ap.add_argument('--precision', default='bf16x3', choices=['f32', 'bf16x3'],
                     help='f32: exact f32 MFMA; bf16x3: split-bf16 operands on the bf16 MFMA, f32 accumulate (fp32-class)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
