@@ -85,6 +85,7 @@ struct ConvGeom {
     bool split_out = false;   // write the output as split channels-last bf16 planes
     int xchunk = 16, xnchunks = 1, xKB = 1, xKB_last = 1, xPSTR = 48, xplane = 0;
     void* d_wx3 = nullptr;
+    bool c1x3 = false;        // one-channel first convolution on the bf16 cores (conv1_x3.hip); weights in d_wx3
 };
 
 int conv_out(int L, int k, int s, int d, int p) { return floordiv(L + 2 * p - d * (k - 1) - 1, s) + 1; }
@@ -244,6 +245,24 @@ int upload_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowma
                             pack[base + 512] = lo;
                         }
     }
+    HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
+// conv1_x3.hip weight order: [kernel row dy][plane][lane][8]; lane = filter + 32*half holds taps 8*half..+7.  `w` is (Cout, 1, kh, kw).
+int upload_conv1_x3_weights(ConvGeom& g, const float* w) {
+    std::vector<uint16_t> pack((size_t)g.kh * 2 * 64 * 8, 0);
+    for (int dy = 0; dy < g.kh; ++dy)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+                const int f = lane & 31, dx = 8 * (lane >> 5) + e;
+                if (f >= g.Cout || dx >= g.kw) continue;
+                const float v = w[((size_t)f * g.kh + dy) * g.kw + dx];
+                const uint16_t hi = f2bf(v);
+                pack[((size_t)(dy * 2 + 0) * 64 + lane) * 8 + e] = hi;
+                pack[((size_t)(dy * 2 + 1) * 64 + lane) * 8 + e] = f2bf(v - bf2f(hi));
+            }
     HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return KRK_OK;
@@ -544,6 +563,13 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                         if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, L.w[0], nullptr) != KRK_OK) {
                             krk_plan_destroy(p);
                             return KRK_E_UNSUPPORTED;
+                        }
+                    } else if (!g.out_seq && krk_conv1_x3_supported(g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw) &&
+                               !getenv("KRK_NO_CONV1_X3")) {
+                        g.c1x3 = true;
+                        if (upload_conv1_x3_weights(g, L.w[0]) != KRK_OK) {
+                            krk_plan_destroy(p);
+                            return KRK_E_HIP;
                         }
                     }
                     split_fmt = true;
@@ -930,6 +956,23 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     s.flops = 2.0 * N * (double)s.cg.Ho * a.Wo * s.cg.Cout * s.cg.Cin * s.cg.kh * s.cg.kw;
                     if (mark("conv_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
                     rc = krk_launch_conv_x3(a, false, s.cg.pool, stream);
+                    break;
+                }
+                if (s.cg.c1x3) {
+                    const ConvGeom& g = s.cg;
+                    Conv1Args a;
+                    a.x = cur; a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
+                    a.y = (__bf16*)outp; a.y_plane = out_elems;
+                    a.len_in = lens_at(s.len_in); a.len_out = lens_at(s.len_out);
+                    a.N = N; a.H = g.H; a.W = Win; a.Cout = g.Cout; a.kh = g.kh; a.kw = g.kw; a.ph = g.ph; a.pw = g.pw;
+                    a.Ho = g.Ho; a.Wo = conv_out(Win, g.kw, g.sw, g.dw, g.pw);
+                    a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
+                    a.act = g.act;
+                    a.tiles_h = (g.Ho + 7) / 8; a.tiles_w = (a.Wo + 127) / 128;
+                    split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+                    s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
+                    if (mark("conv1_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
+                    rc = krk_launch_conv1_x3(a, g.pool, stream);
                     break;
                 }
                 ConvArgs a;

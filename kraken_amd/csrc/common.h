@@ -85,6 +85,23 @@ struct X3Args {
     int SR, tiles_h, tiles_w;    int dbg;                            // probe bits (env KRK_X3_DBG): 1 skip K loop, 2 skip staging loads, 4 skip stores
 };
 
+// first convolution of a one-channel image on the bf16 cores (conv1_x3.hip)
+struct Conv1Args {
+    const float* x;       // [N][1][H][W] fp32
+    const __bf16* wpack;  // [kh][plane][64 lanes][8]: lane (filter, half) holds taps 8*half..+7 of kernel row dy
+    const float* bias;    // [32]
+    __bf16* y;            // hi plane of the split channels-last output; lo plane at + y_plane
+    size_t y_plane;
+    long y_sn, y_sr, y_sc;
+    const int* len_in;
+    const int* len_out;
+    int N, H, W, Cout, kh, kw, ph, pw;
+    int Ho, Wo, Hy, Wy;
+    int act, tiles_h, tiles_w;
+};
+bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
+int krk_launch_conv1_x3(const Conv1Args& a, bool pool, hipStream_t s);
+
 // split-bf16 row projection (gemm_x3.hip): Y[M][Cout] = X[M][K] . W^T + b
 struct GemmX3Args {
     const __bf16* x;      // hi plane, K-blocked rows [K/8][M][8]; lo plane at + x_plane elements

@@ -1,0 +1,231 @@
+// First convolution of a grayscale line (Cin = 1) on the gfx950 bf16 matrix cores with split operands
+// ("bf16x3", see conv_x3.hip).  Reference: kraken/lib/vgsl/layers.py ActConv2D.forward :842-860 applied to
+// the (N, 1, H, W) input, with the following 2x2 MaxPool (:381-388) fused.
+//
+// With one input channel the GEMM's K axis is the kernel WINDOW, not channels: one MFMA K block of 16 is
+// the 16 horizontal taps dx = 0..15 of one kernel row dy (taps >= kw carry zero weights), so a 3x13 kernel
+// is 3 K blocks instead of the 39 K = 2 steps the fp32 path (conv_mfma.hip) issues.
+//
+//   MFMA      D[filter][pixel] += W[filter][dx] . X[dx][pixel],  X[dx][pixel] = in[row + dy][col + dx]
+//   columns   the 32 MFMA columns of lane group c are pixels 4c + s (s = 0..3: four interleaved segments),
+//             so the 8 taps a lane feeds are 8 CONSECUTIVE input pixels starting at 4c + 8*half + s: three
+//             aligned ds_read_b64 give the 12-pixel window and v_alignbyte shifts produce the four segments
+//   tile      4 waves x (2 output rows x 128 columns); an input row fetched once serves both output rows
+//             (kernel rows dy and dy-1) and all four segments: 6 LDS reads per 24 MFMAs
+//   weights   kh x (hi, lo) A fragments = kh*8 VGPRs, resident for the whole kernel
+//   staging   fp32 input -> (hi, lo) bf16 rows in LDS (6 KB per tile), register-prefetched one column
+//             tile ahead; a workgroup walks all column tiles of its 8 output rows
+//   epilogue  2x2 max-pool inside a lane (segments s, s+1 and the two rows), bias + activation, length
+//             mask, split channels-last (NHWC) bf16 planes for conv_x3.hip
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int LW = 144;     // LDS row: 128 output columns + 15 taps, padded to 8-byte reads
+constexpr int TW = 128;     // output columns per tile
+constexpr int TH = 8;       // output rows per tile (2 per wave)
+
+template <int KH, bool POOL>
+__global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
+    constexpr int IH = TH + KH - 1;
+    constexpr int NST = (IH * LW + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 tile[2][2][IH][LW];   // [buffer][plane][row][column]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, c = lane & 31;
+
+    const int n = blockIdx.x / a.tiles_h;
+    const int h0 = (blockIdx.x - n * a.tiles_h) * TH;
+    const int len_in = a.len_in ? a.len_in[n] : a.W;
+    const int len_out = a.len_out ? a.len_out[n] : a.Wy;
+    const int wlim = POOL ? min(a.Wo, 2 * len_out) : min(a.Wo, len_out);
+
+    // resident weights: A fragment of kernel row dy = 32 filters x 16 taps, lane (filter, half) holds taps 8*half..+7
+    bf16x8 wh[KH], wl[KH];
+#pragma unroll
+    for (int dy = 0; dy < KH; ++dy) {
+        wh[dy] = *reinterpret_cast<const bf16x8*>(a.wpack + ((size_t)(dy * 2 + 0) * 64 + lane) * 8);
+        wl[dy] = *reinterpret_cast<const bf16x8*>(a.wpack + ((size_t)(dy * 2 + 1) * 64 + lane) * 8);
+    }
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + 8 * j + 4 * half);
+
+    // staging: element e = tid + 256*i of the IH x LW input window
+    int s_off[NST], s_iw[NST];
+    bool s_ok[NST];
+    const float* xin = a.x + (size_t)n * a.H * a.W;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = tid + 256 * i;
+        const int ih = e / LW, iw = e - ih * LW;
+        const int gh = h0 - a.ph + ih;
+        s_ok[i] = e < IH * LW && gh >= 0 && gh < a.H;
+        s_off[i] = gh * a.W + iw - a.pw;
+        s_iw[i] = iw - a.pw;
+    }
+    float st[NST];
+    auto gload = [&](int w0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int gw = w0 + s_iw[i];
+            st[i] = 0.f;
+            if (s_ok[i] && gw >= 0 && gw < len_in) st[i] = xin[s_off[i] + w0];
+        }
+    };
+    auto lstore = [&](int buf) {
+        __bf16* t = &tile[buf][0][0][0];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = tid + 256 * i;
+            if (e < IH * LW) {
+                const __bf16 h = (__bf16)st[i];
+                t[e] = h;
+                t[IH * LW + e] = (__bf16)(st[i] - (float)h);
+            }
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int tw = 0; tw < a.tiles_w; ++tw) {
+        const int w0 = tw * TW;
+        const int buf = tw & 1;
+        if (tw + 1 < a.tiles_w) gload(w0 + TW);
+
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[o][s][r] = 0.f;
+
+        if (w0 < wlim) {
+#pragma unroll
+            for (int i = 0; i < KH + 1; ++i) {
+                bf16x8 f[2][4];   // [plane][segment]
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const u32x2* src = reinterpret_cast<const u32x2*>(&tile[buf][p][2 * wave + i][4 * c + 8 * half]);
+                    const u32x2 q0 = src[0], q1 = src[1], q2 = src[2];
+                    const unsigned d0 = q0[0], d1 = q0[1], d2 = q1[0], d3 = q1[1], d4 = q2[0], d5 = q2[1];
+                    f[p][0] = __builtin_bit_cast(bf16x8, u32x4{d0, d1, d2, d3});
+                    f[p][2] = __builtin_bit_cast(bf16x8, u32x4{d1, d2, d3, d4});
+                    f[p][1] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2),
+                                                               __builtin_amdgcn_alignbyte(d3, d2, 2), __builtin_amdgcn_alignbyte(d4, d3, 2)});
+                    f[p][3] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbyte(d2, d1, 2), __builtin_amdgcn_alignbyte(d3, d2, 2),
+                                                               __builtin_amdgcn_alignbyte(d4, d3, 2), __builtin_amdgcn_alignbyte(d5, d4, 2)});
+                }
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int dy = i - o;
+                    if (dy < 0 || dy >= KH) continue;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc[o][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], f[0][s], acc[o][s], 0, 0, 0);
+                        acc[o][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], f[1][s], acc[o][s], 0, 0, 0);
+                        acc[o][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[dy], f[0][s], acc[o][s], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue: lane = pixels w0 + 4c + s of rows h0 + 2*wave + o; register 4j+i = filter 8j + 4*half + i
+        __bf16* yh = a.y;
+        __bf16* yl = a.y + a.y_plane;
+        if (POOL) {
+            const int prow = (h0 >> 1) + wave;
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const int pcol = (w0 >> 1) + 2 * c + sp;
+                const bool ok = prow < a.Hy && pcol < a.Wy;
+                const size_t base = (size_t)n * a.y_sn + (size_t)prow * a.y_sr + (size_t)pcol * a.y_sc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf16x4 hv, lv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * j + i;
+                        float v = fmaxf(fmaxf(acc[0][2 * sp][r], acc[0][2 * sp + 1][r]), fmaxf(acc[1][2 * sp][r], acc[1][2 * sp + 1][r]));
+                        v = krk_act(v + bias4[j][i], a.act);
+                        if (pcol >= len_out) v = 0.f;
+                        const __bf16 h = (__bf16)v;
+                        hv[i] = h;
+                        lv[i] = (__bf16)(v - (float)h);
+                    }
+                    const int co = 8 * j + 4 * half;
+                    if (ok && co < a.Cout) {
+                        *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
+                        *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int row = h0 + 2 * wave + o;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int col = w0 + 4 * c + s;
+                    const bool ok = row < a.Ho && col < a.Wo;
+                    const size_t base = (size_t)n * a.y_sn + (size_t)row * a.y_sr + (size_t)col * a.y_sc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16x4 hv, lv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = krk_act(acc[o][s][4 * j + i] + bias4[j][i], a.act);
+                            if (col >= len_out) v = 0.f;
+                            const __bf16 h = (__bf16)v;
+                            hv[i] = h;
+                            lv[i] = (__bf16)(v - (float)h);
+                        }
+                        const int co = 8 * j + 4 * half;
+                        if (ok && co < a.Cout) {
+                            *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
+                            *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                        }
+                    }
+                }
+            }
+        }
+
+        if (tw + 1 < a.tiles_w) lstore(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+template <int KH>
+int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
+    dim3 grid((unsigned)(a.N * a.tiles_h));
+    if (pool) hipLaunchKernelGGL((conv1_x3_kernel<KH, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv1_x3_kernel<KH, false>), grid, dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw) {
+    return Cin == 1 && Cout <= 32 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5) && kw >= 1 && kw <= 16 && sh == 1 &&
+           sw == 1 && dh == 1 && dw == 1;
+}
+
+int krk_launch_conv1_x3(const Conv1Args& a, bool pool, hipStream_t s) {
+    if (a.N <= 0) return 0;
+    switch (a.kh) {
+        case 1: return launch_kh<1>(a, pool, s);
+        case 3: return launch_kh<3>(a, pool, s);
+        case 5: return launch_kh<5>(a, pool, s);
+        default: return -1;
+    }
+}
