@@ -86,7 +86,12 @@ struct ConvGeom {
     int xchunk = 16, xnchunks = 1, xKB = 1, xKB_last = 1, xPSTR = 48, xplane = 0;
     void* d_wx3 = nullptr;
     bool c1x3 = false;        // one-channel first convolution on the bf16 cores (conv1_x3.hip); weights in d_wx3
+    bool taps = false;        // wide-kernel convolution with taps as K (conv_taps_x3.hip); reads NHCW planes
+    bool out_nhcw = false;    // conv1_x3 writes [N][H][C][pitch] planes for a following taps convolution
 };
+
+// row pitch (elements) of the "NHCW" planes between conv1_x3 and conv_taps_x3: whole 16-byte pieces
+int nhcw_pitch(int w) { return (w + 7) / 8 * 8; }
 
 int conv_out(int L, int k, int s, int d, int p) { return floordiv(L + 2 * p - d * (k - 1) - 1, s) + 1; }
 
@@ -263,6 +268,26 @@ int upload_conv1_x3_weights(ConvGeom& g, const float* w) {
                 pack[((size_t)(dy * 2 + 0) * 64 + lane) * 8 + e] = hi;
                 pack[((size_t)(dy * 2 + 1) * 64 + lane) * 8 + e] = f2bf(v - bf2f(hi));
             }
+    HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
+// conv_taps_x3.hip weight order: [channel][kernel row][plane][lane][8]; lane = filter + 32*half holds taps 8*half..+7
+int upload_conv_taps_weights(ConvGeom& g, const float* w) {
+    std::vector<uint16_t> pack((size_t)g.Cin * g.kh * 2 * 64 * 8, 0);
+    for (int ch = 0; ch < g.Cin; ++ch)
+        for (int dy = 0; dy < g.kh; ++dy)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int f = lane & 31, dx = 8 * (lane >> 5) + e;
+                    if (f >= g.Cout || dx >= g.kw) continue;
+                    const float v = w[(((size_t)f * g.Cin + ch) * g.kh + dy) * g.kw + dx];
+                    const uint16_t hi = f2bf(v);
+                    const size_t base = ((size_t)(ch * g.kh + dy) * 2) * 64 * 8 + (size_t)lane * 8 + e;
+                    pack[base] = hi;
+                    pack[base + 512] = f2bf(v - bf2f(hi));
+                }
     HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return KRK_OK;
@@ -554,11 +579,19 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     // over split channels-last planes; every later one runs on the bf16 cores
                     const bool first = !split_fmt;
                     const int feat = g.out_seq ? conv_out(H, L.kh, L.sh, L.dh, g.ph) * L.cout : L.cout;
-                    if (feat % 16) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs a multiple of 16 output channels");
+                    if (feat % 4) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs a multiple of 4 output channels");   // the consumer checks its own K granule
                     if (first && g.out_seq) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs >= 2 convolutions before the reshape");
                     g.split_out = true;
                     s.in_split = !first;
-                    if (!first) {
+                    if (!first && !g.out_seq && !p->steps.empty() && p->steps.back().kind == S_CONV && p->steps.back().cg.c1x3 &&
+                        krk_conv_taps_supported(g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw) && !getenv("KRK_NO_CONV_TAPS")) {
+                        g.taps = true;
+                        p->steps.back().cg.out_nhcw = true;
+                        if (upload_conv_taps_weights(g, L.w[0]) != KRK_OK) {
+                            krk_plan_destroy(p);
+                            return KRK_E_HIP;
+                        }
+                    } else if (!first) {
                         g.x3 = true;
                         if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, L.w[0], nullptr) != KRK_OK) {
                             krk_plan_destroy(p);
@@ -882,6 +915,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         const int Win = Ws[s.len_in], Wout = Ws[s.len_out];
         const bool is_last = (si + 1 == nsteps);
         size_t out_elems = (size_t)N * s.outC * s.outH * Wout;
+        if (s.kind == S_CONV && s.cg.out_nhcw) out_elems = (size_t)N * s.outC * s.outH * nhcw_pitch(Wout);
         float* outp;
         if (is_last && final_out) outp = final_out;
         else {
@@ -944,6 +978,26 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         int rc = 0;
         switch (s.kind) {
             case S_CONV: {
+                if (s.cg.taps) {
+                    const ConvGeom& g = s.cg;
+                    ConvTapArgs a;
+                    a.pitch = nhcw_pitch(Win);
+                    a.x = (const __bf16*)cur; a.x_plane = (size_t)N * s.C * s.H * a.pitch;
+                    a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
+                    a.y = (__bf16*)outp; a.y_plane = out_elems;
+                    a.len_out = lens_at(s.len_out);
+                    a.N = N; a.H = g.H; a.Cin = g.Cin; a.Cout = g.Cout; a.kh = g.kh; a.kw = g.kw; a.ph = g.ph; a.pw = g.pw;
+                    a.Ho = g.Ho; a.Wo = conv_out(Win, g.kw, g.sw, g.dw, g.pw);
+                    a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
+                    a.act = g.act;
+                    a.tiles_h = (g.Ho + 3) / 4; a.tiles_w = (a.Wo + 127) / 128;
+                    a.dbg = getenv("KRK_X3_DBG") ? atoi(getenv("KRK_X3_DBG")) : 0;
+                    split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+                    s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
+                    if (mark("conv_taps_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
+                    rc = krk_launch_conv_taps(a, g.pool, stream);
+                    break;
+                }
                 if (s.cg.x3) {
                     X3Args a;
                     fill_x3(s.cg, a, cur, (size_t)N * s.C * s.H * Win, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));
@@ -970,6 +1024,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     a.act = g.act;
                     a.tiles_h = (g.Ho + 7) / 8; a.tiles_w = (a.Wo + 127) / 128;
                     split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+                    a.y_pitch = g.out_nhcw ? nhcw_pitch(a.Wy) : 0;
                     s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
                     if (mark("conv1_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
                     rc = krk_launch_conv1_x3(a, g.pool, stream);

@@ -98,9 +98,28 @@ struct Conv1Args {
     int N, H, W, Cout, kh, kw, ph, pw;
     int Ho, Wo, Hy, Wy;
     int act, tiles_h, tiles_w;
+    int y_pitch;          // > 0: write "NHCW" planes [N][Hy][Cout][y_pitch] (for conv_taps_x3.hip) instead of NHWC
 };
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
 int krk_launch_conv1_x3(const Conv1Args& a, bool pool, hipStream_t s);
+
+// wide-kernel convolution with taps as the K axis (conv_taps_x3.hip)
+struct ConvTapArgs {
+    const __bf16* x;      // hi plane [N][H][Cin][pitch]; lo plane at + x_plane elements
+    size_t x_plane;
+    const __bf16* wpack;  // [Cin][kh][plane][64 lanes][8]
+    const float* bias;    // [32]
+    __bf16* y;            // split NHWC output (strides below), lo plane at + y_plane
+    size_t y_plane;
+    long y_sn, y_sr, y_sc;
+    const int* len_out;
+    int N, H, pitch, Cin, Cout, kh, kw, ph, pw;
+    int Ho, Wo, Hy, Wy;
+    int act, tiles_h, tiles_w;
+    int dbg;              // probe bits (env KRK_X3_DBG): 1 no K loop, 4 no staging loads, 16 no stores
+};
+bool krk_conv_taps_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
+int krk_launch_conv_taps(const ConvTapArgs& a, bool pool, hipStream_t s);
 
 // split-bf16 row projection (gemm_x3.hip): Y[M][Cout] = X[M][K] . W^T + b
 struct GemmX3Args {

@@ -30,7 +30,7 @@ constexpr int LW = 144;     // LDS row: 128 output columns + 15 taps, padded to 
 constexpr int TW = 128;     // output columns per tile
 constexpr int TH = 8;       // output rows per tile (2 per wave)
 
-template <int KH, bool POOL>
+template <int KH, bool POOL, bool NHCW>
 __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
     constexpr int IH = TH + KH - 1;
     constexpr int NST = (IH * LW + 255) / 256;
@@ -54,22 +54,17 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
         wh[dy] = *reinterpret_cast<const bf16x8*>(a.wpack + ((size_t)(dy * 2 + 0) * 64 + lane) * 8);
         wl[dy] = *reinterpret_cast<const bf16x8*>(a.wpack + ((size_t)(dy * 2 + 1) * 64 + lane) * 8);
     }
-    f32x4 bias4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + 8 * j + 4 * half);
-
     // staging: element e = tid + 256*i of the IH x LW input window
-    int s_off[NST], s_iw[NST];
-    bool s_ok[NST];
+    int s_off[NST], s_iw[NST];   // s_iw = column relative to w0, or a large negative number for a row outside the image
     const float* xin = a.x + (size_t)n * a.H * a.W;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const int e = tid + 256 * i;
         const int ih = e / LW, iw = e - ih * LW;
         const int gh = h0 - a.ph + ih;
-        s_ok[i] = e < IH * LW && gh >= 0 && gh < a.H;
+        const bool ok = e < IH * LW && gh >= 0 && gh < a.H;
         s_off[i] = gh * a.W + iw - a.pw;
-        s_iw[i] = iw - a.pw;
+        s_iw[i] = ok ? iw - a.pw : -(1 << 28);
     }
     float st[NST];
     auto gload = [&](int w0) {
@@ -77,7 +72,7 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
         for (int i = 0; i < NST; ++i) {
             const int gw = w0 + s_iw[i];
             st[i] = 0.f;
-            if (s_ok[i] && gw >= 0 && gw < len_in) st[i] = xin[s_off[i] + w0];
+            if (gw >= 0 && gw < len_in) st[i] = xin[s_off[i] + w0];
         }
     };
     auto lstore = [&](int buf) {
@@ -143,7 +138,48 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
         // ---- epilogue: lane = pixels w0 + 4c + s of rows h0 + 2*wave + o; register 4j+i = filter 8j + 4*half + i
         __bf16* yh = a.y;
         __bf16* yl = a.y + a.y_plane;
-        if (POOL) {
+        f32x4 bias4[4];   // (re)loaded per tile: 16 VGPRs the K loop does not have to carry
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + 8 * j + 4 * half);
+        if constexpr (NHCW) {
+            // "NHCW" planes [N][Hy][Cout][pitch]: a lane owns 2 (pooled) or 4 consecutive columns of each of its 16
+            // filters -> one 4/8-byte store per filter, 128/256 bytes contiguous across the wave.  Columns between
+            // the line's length and the pitch are written as zeros (the consumer stages whole 16-byte pieces).
+            constexpr int NO = POOL ? 1 : 2;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const int row = POOL ? (h0 >> 1) + wave : h0 + 2 * wave + o;
+                const int col0 = POOL ? (w0 >> 1) + 2 * c : w0 + 4 * c;
+                if (row >= a.Hy || col0 >= a.y_pitch) continue;
+                const int lim = min(len_out, a.Wy);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (f >= a.Cout) continue;
+                    constexpr int NV = POOL ? 2 : 4;
+                    __bf16 hv[NV], lv[NV];
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) {
+                        float v;
+                        if (POOL) v = fmaxf(fmaxf(acc[0][2 * e][r], acc[0][2 * e + 1][r]), fmaxf(acc[1][2 * e][r], acc[1][2 * e + 1][r]));
+                        else v = acc[o][e][r];
+                        v = krk_act(v + bias4[r >> 2][r & 3], a.act);
+                        if (col0 + e >= lim) v = 0.f;
+                        hv[e] = (__bf16)v;
+                        lv[e] = (__bf16)(v - (float)hv[e]);
+                    }
+                    const size_t o_ = (((size_t)n * a.Hy + row) * a.Cout + f) * a.y_pitch + col0;
+                    if (POOL) {
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<bf16x2*>(yh + o_) = bf16x2{hv[0], hv[1]};
+                        *reinterpret_cast<bf16x2*>(yl + o_) = bf16x2{lv[0], lv[1]};
+                    } else {
+                        *reinterpret_cast<bf16x4*>(yh + o_) = bf16x4{hv[0], hv[1], hv[2], hv[3]};
+                        *reinterpret_cast<bf16x4*>(yl + o_) = bf16x4{lv[0], lv[1], lv[2], lv[3]};
+                    }
+                }
+            }
+        } else if constexpr (POOL) {
             const int prow = (h0 >> 1) + wave;
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
@@ -208,8 +244,11 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
 template <int KH>
 int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
     dim3 grid((unsigned)(a.N * a.tiles_h));
-    if (pool) hipLaunchKernelGGL((conv1_x3_kernel<KH, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv1_x3_kernel<KH, false>), grid, dim3(256), 0, s, a);
+    const bool nhcw = a.y_pitch > 0;
+    if (pool && nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true>), grid, dim3(256), 0, s, a);
+    else if (pool) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, false>), grid, dim3(256), 0, s, a);
+    else if (nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv1_x3_kernel<KH, false, false>), grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -1,0 +1,254 @@
+// Wide-kernel convolution (11 <= kw <= 16, stride 1) on the gfx950 bf16 matrix cores with split operands,
+// using the horizontal TAPS of one input channel as the MFMA K block (the scheme of conv1_x3.hip extended to
+// Cin channels).  Reference: kraken/lib/vgsl/layers.py ActConv2D.forward :842-860 (+ fused MaxPool :381-388);
+// this is the 3x13 second convolution of kraken's default recognition spec.
+//
+// Why: with channels as K (conv_x3.hip) every (tap, pixel fragment) is re-read from LDS -- 39 taps x 2 KB per
+// 3 MFMAs -- and every wave streams the whole filter bank per tile; the kernel sat at 40 % MFMA busy.  With
+// taps as K one 12-pixel window read per (channel, input row) feeds 2 output rows x 2 segments x 3 terms = 12
+// MFMAs, and a 2 KB weight fragment pair (channel, kernel row) is used for 12 MFMAs too: 3x less LDS and 4x
+// less L1 traffic per MFMA, for 16/13 more MFMA work (taps 13..15 carry zero weights).
+//
+//   input     split bf16 planes in "NHCW" order [N][H][Cin][pitch] (pitch % 8 == 0, written by conv1_x3.hip)
+//   tile      4 waves = 2 row pairs x 2 column halves; a wave owns 2 output rows x 64 columns, its 32 MFMA
+//             columns are pixels 2c + s (s = 0, 1): lane c reads pixels 2c + 8*half + s + shift ..+7
+//   LDS       [plane][4 channels][kh+3 rows][152 columns], two buffers, register-staged one chunk ahead
+//   weights   [Cin][kh][plane][lane][8] A fragments straight from L2, prefetched one channel ahead
+//   epilogue  2x2 max-pool inside a lane, bias + activation, length mask, split NHWC planes (for conv_x3.hip)
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int LW = 152;   // LDS row: 8 (aligned left margin) + 128 + 15, rounded to 16-byte pieces
+constexpr int CC = 4;     // channels per LDS chunk
+constexpr int TW = 128, TH = 4;
+
+// 8 consecutive bf16 starting at element T of a window held in dwords d[]
+template <int T>
+__device__ __forceinline__ bf16x8 window8(const unsigned (&d)[6]) {
+    if constexpr (T % 2 == 0) {
+        return __builtin_bit_cast(bf16x8, u32x4{d[T / 2], d[T / 2 + 1], d[T / 2 + 2], d[T / 2 + 3]});
+    } else {
+        constexpr int b = T / 2;
+        return __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbyte(d[b + 1], d[b], 2), __builtin_amdgcn_alignbyte(d[b + 2], d[b + 1], 2),
+                                                __builtin_amdgcn_alignbyte(d[b + 3], d[b + 2], 2), __builtin_amdgcn_alignbyte(d[b + 4], d[b + 3], 2)});
+    }
+}
+
+template <int KH, int PW, bool POOL>
+__global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) {
+    constexpr int IH = TH + KH - 1;
+    constexpr int SHIFT = 8 - PW;                    // LDS column 0 is image column w0 - 8
+    constexpr int ROWS = 2 * CC * IH;                // LDS rows per chunk (both planes)
+    constexpr int PIECES = ROWS * (LW / 8);          // 16-byte pieces per chunk
+    constexpr int NST = (PIECES + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 tile[2][2][CC][IH][LW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, c = lane & 31;
+    const int rp = wave >> 1, chalf = wave & 1;
+
+    int bt = blockIdx.x;
+    const int tw = bt % a.tiles_w;
+    bt /= a.tiles_w;
+    const int th = bt % a.tiles_h;
+    const int n = bt / a.tiles_h;
+    const int h0 = th * TH, w0 = tw * TW;
+    const int len_out = a.len_out ? a.len_out[n] : a.Wy;
+    const int wlim = POOL ? min(a.Wo, 2 * len_out) : min(a.Wo, len_out);
+
+    // ---- staging bookkeeping: piece e = tid + 256*i -> (plane, channel, row, 16-byte piece)
+    long s_src[NST];
+    int s_dst[NST];
+    bool s_ok[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = tid + 256 * i;
+        const int row = e / (LW / 8), q = e - row * (LW / 8);
+        const int plane = row / (CC * IH), r2 = row - plane * (CC * IH);
+        const int ch = r2 / IH, ih = r2 - ch * IH;
+        const int gh = h0 - a.ph + ih, gw = w0 - 8 + 8 * q;
+        s_ok[i] = e < PIECES && gh >= 0 && gh < a.H && gw >= 0 && gw < a.pitch;
+        s_src[i] = (long)plane * (long)a.x_plane + (((long)n * a.H + gh) * a.Cin + ch) * a.pitch + gw;
+        s_dst[i] = e * 8;
+    }
+    f32x4 st[NST];
+    auto gload = [&](int ch0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (s_ok[i] && !(a.dbg & 4)) st[i] = *reinterpret_cast<const f32x4*>(a.x + s_src[i] + (long)ch0 * a.pitch);
+        }
+    };
+    auto lstore = [&](int buf) {
+        __bf16* t = &tile[buf][0][0][0][0];
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (tid + 256 * i < PIECES) *reinterpret_cast<f32x4*>(t + s_dst[i]) = st[i];
+    };
+
+    // ---- weights: fragments of one channel = KH kernel rows x (hi, lo), prefetched one channel ahead
+    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(a.wpack) + lane;
+    auto wload = [&](int chg, bf16x8 (&wh)[KH], bf16x8 (&wl)[KH]) {
+#pragma unroll
+        for (int dy = 0; dy < KH; ++dy) {
+            wh[dy] = wbase[((size_t)(chg * KH + dy) * 2 + 0) * 64];
+            wl[dy] = wbase[((size_t)(chg * KH + dy) * 2 + 1) * 64];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[o][s][r] = 0.f;
+
+    const bool live = (w0 + 64 * chalf) < wlim;      // this wave's columns are inside the line
+    const int nchunks = a.Cin / CC;
+
+    bf16x8 wha[KH], wla[KH], whb[KH], wlb[KH];
+    gload(0);
+    wload(0, wha, wla);
+    lstore(0);
+    __syncthreads();
+
+    // one channel: KH+1 input rows, each window feeds both output rows of the pair
+    auto channel = [&](int buf, int ch, const bf16x8 (&wh)[KH], const bf16x8 (&wl)[KH]) {
+#pragma unroll
+        for (int i = 0; i < KH + 1; ++i) {
+            unsigned dh[6], dl[6];
+            const unsigned* ph = reinterpret_cast<const unsigned*>(&tile[buf][0][ch][2 * rp + i][64 * chalf + 2 * c + 8 * half]);
+            const unsigned* pl = reinterpret_cast<const unsigned*>(&tile[buf][1][ch][2 * rp + i][64 * chalf + 2 * c + 8 * half]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                dh[k] = ph[k];
+                dl[k] = pl[k];
+            }
+            const bf16x8 fh0 = window8<SHIFT>(dh), fh1 = window8<SHIFT + 1>(dh);
+            const bf16x8 fl0 = window8<SHIFT>(dl), fl1 = window8<SHIFT + 1>(dl);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int dy = i - o;
+                if (dy < 0 || dy >= KH) continue;
+                acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fh0, acc[o][0], 0, 0, 0);
+                acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fh1, acc[o][1], 0, 0, 0);
+                acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fl0, acc[o][0], 0, 0, 0);
+                acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fl1, acc[o][1], 0, 0, 0);
+                acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[dy], fh0, acc[o][0], 0, 0, 0);
+                acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[dy], fh1, acc[o][1], 0, 0, 0);
+            }
+        }
+    };
+
+    for (int k = 0; k < nchunks; ++k) {
+        const int buf = k & 1;
+        if (k + 1 < nchunks) gload((k + 1) * CC);
+        if (live && !(a.dbg & 1)) {
+            static_assert(CC == 4, "channel loop is unrolled for 4-channel chunks");
+            const int cg = k * CC;
+            wload(cg + 1, whb, wlb);
+            channel(buf, 0, wha, wla);
+            wload(cg + 2, wha, wla);
+            channel(buf, 1, whb, wlb);
+            wload(cg + 3, whb, wlb);
+            channel(buf, 2, wha, wla);
+            wload(min(cg + 4, a.Cin - 1), wha, wla);
+            channel(buf, 3, whb, wlb);
+        }
+        if (k + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = pixels w0 + 64*chalf + 2c + s of rows h0 + 2*rp + o; register 4j+i = filter 8j + 4*half + i
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + 8 * j + 4 * half);
+    __bf16* yh = a.y;
+    __bf16* yl = a.y + a.y_plane;
+    if (POOL) {
+        const int prow = (h0 >> 1) + rp;
+        const int pcol = (w0 >> 1) + 32 * chalf + c;
+        const bool ok = prow < a.Hy && pcol < a.Wy;
+        const size_t base = (size_t)n * a.y_sn + (size_t)prow * a.y_sr + (size_t)pcol * a.y_sc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 hv, lv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * j + i;
+                float v = fmaxf(fmaxf(acc[0][0][r], acc[0][1][r]), fmaxf(acc[1][0][r], acc[1][1][r]));
+                v = krk_act(v + bias4[j][i], a.act);
+                if (pcol >= len_out) v = 0.f;
+                const __bf16 h = (__bf16)v;
+                hv[i] = h;
+                lv[i] = (__bf16)(v - (float)h);
+            }
+            const int co = 8 * j + 4 * half;
+            if (ok && co < a.Cout && !(a.dbg & 16)) {
+                *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
+                *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int row = h0 + 2 * rp + o;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int col = w0 + 64 * chalf + 2 * c + s;
+                const bool ok = row < a.Ho && col < a.Wo;
+                const size_t base = (size_t)n * a.y_sn + (size_t)row * a.y_sr + (size_t)col * a.y_sc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf16x4 hv, lv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = krk_act(acc[o][s][4 * j + i] + bias4[j][i], a.act);
+                        if (col >= len_out) v = 0.f;
+                        const __bf16 h = (__bf16)v;
+                        hv[i] = h;
+                        lv[i] = (__bf16)(v - (float)h);
+                    }
+                    const int co = 8 * j + 4 * half;
+                    if (ok && co < a.Cout && !(a.dbg & 16)) {
+                        *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
+                        *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int PW>
+int launch_pw(const ConvTapArgs& a, bool pool, hipStream_t s) {
+    dim3 grid((unsigned)(a.N * a.tiles_h * a.tiles_w));
+    if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false>), grid, dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+bool krk_conv_taps_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw) {
+    return Cin % 4 == 0 && Cin >= 4 && Cout <= 32 && Cout % 4 == 0 && kh == 3 && kw >= 11 && kw <= 16 && sh == 1 && sw == 1 &&
+           dh == 1 && dw == 1;
+}
+
+int krk_launch_conv_taps(const ConvTapArgs& a, bool pool, hipStream_t s) {
+    if (a.N <= 0) return 0;
+    switch (a.pw) {
+        case 5: return launch_pw<5>(a, pool, s);
+        case 6: return launch_pw<6>(a, pool, s);
+        case 7: return launch_pw<7>(a, pool, s);
+        default: return -1;
+    }
+}

@@ -396,6 +396,14 @@ def test_x3_bench_a_against_reference_golden(bench_a_x3):
     ('[1,6,0,3 Ct3,3,16 Cr3,7,48,1,2 Cl1,1,32 S1(1x0)1,3 Lfx16 Lbx8 O1c7]', 2, 77, None),
     ('[1,12,0,1 Clr3,3,16 Mp2,2 Cr3,3,32 Mp2,2 Cr2,4,16 S1(1x0)1,3 Lbx24 Lbx8 O1c30]', 4, 130, [130, 129, 64, 9]),
     ('[1,4,0,2 Cr3,3,16 Cr3,3,16,1,1,1,2 S1(1x0)1,3 Lbx200 O1c9]', 2, 70, [70, 33]),
+    # conv1_x3 (one-channel first conv, taps as K): kh 1/3/5, with and without the fused pool, NHWC and NHCW
+    # outputs; conv_taps_x3 (kw 11..16: pw 5/6/7, even kernels); odd class counts (scalar gemm epilogue);
+    # widths below one 128-column tile, across several, and not a multiple of anything
+    ('[1,12,0,1 Cr3,5,8 Cr3,16,16 Cr3,3,16 S1(1x0)1,3 Lbx16 O1c13]', 3, 133, [133, 70, 5]),
+    ('[1,16,0,1 Cr5,7,16 Mp2,2 Cr3,12,32 Mp2,2 Cr3,3,32 S1(1x0)1,3 Lbx8 O1c7]', 3, 301, [301, 300, 155]),
+    ('[1,8,0,1 Ct1,3,4 Cs3,15,16 Cl3,3,16 S1(1x0)1,3 Lfx16 O1c5]', 2, 96, None),
+    ('[1,10,0,1 Cr1,16,32 Mp2,2 Cr3,11,32 Cr3,13,16 S1(1x0)1,3 Lbx8 Lbx8 O1c11]', 4, 517, [517, 516, 260, 31]),
+    ('[1,9,0,1 Cr3,13,28 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,16 S1(1x0)1,3 Lbx8 O1c3]', 2, 260, [260, 131]),
 ])
 def test_x3_matches_cpu_oracle_on_small_networks(spec, n, w, lens):
     """Strides, dilation, even kernels, tanh/leaky/linear activations, f/b LSTM stacks, hidden 200."""
@@ -517,3 +525,17 @@ def test_edge_shapes(bench_a, bench_a_x3):
         assert gl.tolist() == wl.tolist() == [112, 1]
         for i in range(2):
             assert (got.cpu()[i, ..., :gl[i]] - want[i, ..., :wl[i]]).abs().max().item() < tol
+
+
+def test_x3_plan_uses_the_specialised_kernels(bench_a_x3):
+    """The headline network must run on the kernels DESIGN.md describes (no silent fall back to the generic ones)."""
+    from kraken_amd.engine import RecognitionEngine
+    eng = RecognitionEngine(bench_a_x3, device=0, max_batch=4, max_width=256, slots=1)
+    eng.set_profiling(True)
+    eng.submit(synth_input(4, 256).cuda())
+    eng.collect()
+    names = [n for n, _, _ in eng.layer_times()[0]]
+    eng.close()
+    assert names[:4] == ['conv1_x3', 'conv_taps_x3', 'conv_x3', 'conv_x3']
+    assert names.count('lstm_xproj_x3') == 3 and names.count('lstm_rec_x3') == 2 and names.count('lstm_rec') == 1
+    assert names[-1] == 'linear_x3' or 'linear_x3' in names
