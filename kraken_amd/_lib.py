@@ -10,7 +10,8 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libkraken_amd.so')
+# KRAKEN_AMD_LIB: alternative build of the same library (kernel experiments); still a HIP build, never a fallback
+LIB_PATH = os.environ.get('KRAKEN_AMD_LIB') or os.path.join(HERE, 'libkraken_amd.so')
 
 KRK_OK = 0
 KRK_E_INVALID, KRK_E_HIP, KRK_E_NOMEM, KRK_E_UNSUPPORTED = -1, -2, -3, -4

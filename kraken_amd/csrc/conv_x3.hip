@@ -40,7 +40,10 @@ struct Frags {
 };
 
 template <int POOL, int OUT_F32, int CB>
-__global__ void __launch_bounds__(256, 2) conv_x3_kernel(const X3Args a) {
+#ifndef KRK_X3_OCC
+#define KRK_X3_OCC 2
+#endif
+__global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     unsigned char* tile = smem8;                       // hi plane, then lo plane (+ a.lds_plane bytes)
 

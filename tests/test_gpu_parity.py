@@ -537,5 +537,5 @@ def test_x3_plan_uses_the_specialised_kernels(bench_a_x3):
     names = [n for n, _, _ in eng.layer_times()[0]]
     eng.close()
     assert names[:4] == ['conv1_x3', 'conv_taps_x3', 'conv_x3', 'conv_x3']
-    assert names.count('lstm_xproj_x3') == 3 and names.count('lstm_rec_x3') == 2 and names.count('lstm_rec') == 1
+    assert names.count('lstm_xproj_x3') == 3 and names.count('lstm_rec_x3') == 3
     assert names[-1] == 'linear_x3' or 'linear_x3' in names
