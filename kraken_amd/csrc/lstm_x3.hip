@@ -25,17 +25,19 @@ struct WPair {
 };
 
 // h_t (hi, lo rows in LDS) -> split output planes out[plane][n][t][dir*H + k]; 16-byte pieces when H % 8 == 0
+template <int NW>
 __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigned char* hnext, const int* lens_s, int s,
                                               int wave, int lane, int dir, bool rev, int n0) {
     constexpr int M = 16;
+    constexpr int LPW = M / NW;                          // lines each wave copies out
     const int RS = a.hrow, plane = M * RS;
     if ((a.H & 7) == 0) {
         const int per_line = a.H >> 3;                   // 16-byte pieces per line per plane
-        const int total = 4 * per_line * 2;              // this wave: 4 lines x 2 planes
+        const int total = LPW * per_line * 2;            // this wave: LPW lines x 2 planes
         for (int e = lane; e < total; e += 64) {
-            const int pl = e / (4 * per_line), r = e - pl * 4 * per_line;
+            const int pl = e / (LPW * per_line), r = e - pl * LPW * per_line;
             const int li = r / per_line, q = r - li * per_line;
-            const int i = wave * 4 + li;
+            const int i = wave * LPW + li;
             const int len = lens_s[i];
             if (s < len) {
                 const int t = rev ? (len - 1 - s) : s;
@@ -46,7 +48,7 @@ __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigne
             }
         }
     } else {
-        for (int i = wave * 4; i < wave * 4 + 4; ++i) {
+        for (int i = wave * LPW; i < wave * LPW + LPW; ++i) {
             const int len = lens_s[i];
             if (s < len) {
                 const int t = rev ? (len - 1 - s) : s;
@@ -67,7 +69,7 @@ __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigne
 // h (32 K x 16 lines).  With gate columns interleaved (col = 4*unit + gate) the D fragment of lane l holds
 // rows 4*(l>>4) + r = the FOUR GATES (r = i,f,g,o) of unit (l>>4) of the block, for line l&15: the cell update
 // is purely per-lane (no cross-lane traffic), and xproj[t] for a block is ONE 16-byte load per lane.
-template <int NBW, bool XPRE>
+template <int NW, int NBW, bool XPRE>
 __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char* hs, const int* lens_s, int Lmax,
                                              int wave, int lane, int dir, bool rev, int n0) {
     constexpr int M = 16;
@@ -95,7 +97,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (on) v = *reinterpret_cast<const f32x4*>(xr + (wave + 4 * j) * M);
+            if (on) v = *reinterpret_cast<const f32x4*>(xr + (wave + NW * j) * M);
             dst[j] = v;
         }
     };
@@ -104,7 +106,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
         const __bf16* wk = wbase + (size_t)kb * kstride;
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
-            const __bf16* p = wk + (size_t)(wave + 4 * j) * 1024;
+            const __bf16* p = wk + (size_t)(wave + NW * j) * 1024;
             dst[j].hi = *reinterpret_cast<const bf16x8*>(p);
             dst[j].lo = *reinterpret_cast<const bf16x8*>(p + 512);
         }
@@ -158,7 +160,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
         if (!(a.dbg & 2))
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
-            const int unit = (wave + 4 * j) * 4 + us;
+            const int unit = (wave + NW * j) * 4 + us;
             const float gi = krk_sigmoid(acc[j][0]);
             const float gf = krk_sigmoid(acc[j][1]);
             const float gg = krk_tanh(acc[j][2]);
@@ -172,7 +174,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
             *reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(dst) + plane) = (__bf16)(h - (float)hh);
         }
         __syncthreads();
-        lstm_x3_store(a, hnext, lens_s, s, wave, lane, dir, rev, n0);
+        lstm_x3_store<NW>(a, hnext, lens_s, s, wave, lane, dir, rev, n0);
         cur ^= 1;
     };
 
@@ -182,6 +184,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
     for (int s = 0; s < Lmax; ++s) step(s, xa);
 }
 
+template <int NW>
 __device__ __forceinline__ void lstm_x3_idle(const LstmX3Args& a, const unsigned char* hs, const int* lens_s, int Lmax,
                                              int wave, int lane, int dir, bool rev, int n0) {
     constexpr int M = 16;
@@ -189,13 +192,13 @@ __device__ __forceinline__ void lstm_x3_idle(const LstmX3Args& a, const unsigned
     int cur = 0;
     for (int s = 0; s < Lmax; ++s) {
         __syncthreads();
-        lstm_x3_store(a, hs + (cur ^ 1) * buf, lens_s, s, wave, lane, dir, rev, n0);
+        lstm_x3_store<NW>(a, hs + (cur ^ 1) * buf, lens_s, s, wave, lane, dir, rev, n0);
         cur ^= 1;
     }
 }
 
-template <int MAXB, bool XPRE>
-__global__ void __launch_bounds__(256, 1) lstm_x3_kernel(const LstmX3Args a) {
+template <int NW, int MAXB, bool XPRE>
+__global__ void __launch_bounds__(64 * NW, 1) lstm_x3_kernel(const LstmX3Args a) {
     constexpr int M = 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     unsigned char* hs = smem8;                                       // [2 buffers][2 planes][16][hrow]
@@ -214,38 +217,51 @@ __global__ void __launch_bounds__(256, 1) lstm_x3_kernel(const LstmX3Args a) {
         if (n < a.N) l = a.lens ? min(max(a.lens[n], 0), a.T) : a.T;
         lens_s[tid] = l;
     }
-    for (int e = tid; e < M * a.hrow; e += 256) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // 4*M*hrow bytes
+    for (int e = tid; e < M * a.hrow; e += 64 * NW) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // 4*M*hrow bytes
     __syncthreads();
     int Lmax = 0;
     for (int i = 0; i < M; ++i) Lmax = max(Lmax, lens_s[i]);
 
-    const int nb_mine = (a.NB - wave + 3) / 4;
+    const int nb_mine = (a.NB - wave + NW - 1) / NW;
     if (nb_mine == MAXB) {
-        lstm_x3_loop<MAXB, XPRE>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
+        lstm_x3_loop<NW, MAXB, XPRE>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
     } else {
-        if constexpr (MAXB > 1) lstm_x3_loop<MAXB - 1, XPRE>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
-        else lstm_x3_idle(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
+        if constexpr (MAXB > 1) lstm_x3_loop<NW, MAXB - 1, XPRE>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
+        else lstm_x3_idle<NW>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
     }
 }
 
-template <int MAXB, bool XPRE>
+template <int NW, int MAXB, bool XPRE>
 int launch_one(const LstmX3Args& a, hipStream_t s) {
     dim3 grid((unsigned)((a.N + 15) / 16), (unsigned)a.ndir);
     const size_t lds = (size_t)4 * 16 * a.hrow + 16 * sizeof(int);
-    auto kfn = lstm_x3_kernel<MAXB, XPRE>;
+    auto kfn = lstm_x3_kernel<NW, MAXB, XPRE>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kfn, grid, dim3(64 * NW), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 }  // namespace
 
 // a.NB = 4*Hp/16 column blocks of 16 gate columns; a.NKB = K-blocks of 32 (Hp padded to a multiple of 32).
+// Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs each) once a wave would own more than 4 blocks -- the
+// second wave hides the L2 weight stream and the serial gate math of the first; 4 otherwise.
 int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s) {
+    int nw = a.NB > 16 && a.NB <= 64 ? 8 : 4;
+    if (const char* e = getenv("KRK_LSTM_NW")) nw = atoi(e) == 8 && a.NB <= 64 ? 8 : 4;
+    if (nw == 8) {
+        const int per_wave = (a.NB + 7) / 8;
+#define KRK_CASE(B_) case B_: return launch_one<8, B_, true>(a, s)
+        switch (per_wave) {
+            KRK_CASE(1); KRK_CASE(2); KRK_CASE(3); KRK_CASE(4); KRK_CASE(5); KRK_CASE(6); KRK_CASE(7); KRK_CASE(8);
+            default: return -4;
+        }
+#undef KRK_CASE
+    }
     const int per_wave = (a.NB + 3) / 4;
-#define KRK_CASE(B_) case B_: return launch_one<B_, true>(a, s)
+#define KRK_CASE(B_) case B_: return launch_one<4, B_, true>(a, s)
     switch (per_wave) {
         KRK_CASE(1); KRK_CASE(2); KRK_CASE(3); KRK_CASE(4); KRK_CASE(5); KRK_CASE(6); KRK_CASE(7); KRK_CASE(8);
         KRK_CASE(9); KRK_CASE(10); KRK_CASE(11); KRK_CASE(12); KRK_CASE(13); KRK_CASE(14); KRK_CASE(15); KRK_CASE(16);
