@@ -40,8 +40,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense (n
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--batch', type=int, default=256, help='lines per GPU per step')
     ap.add_argument('--width', type=int, default=1200)
     ap.add_argument('--slots', type=int, default=4, help='batches in flight per GPU (streams)')
@@ -151,8 +151,9 @@ def main():
                 for i, v in sorted(per_launch.items())]
     # kernels behind the launch groups (rocprofv3 kernel names)
     kernel_of = {'conv': 'conv_f32_kernel', 'lstm_xproj': 'conv_f32_kernel<1,1,0,4>', 'linear': 'conv_f32_kernel<1,1,0,4>',
-                 'lstm_rec': 'lstm_f32_kernel', 'conv_x3': 'conv_x3_kernel', 'lstm_xproj_x3': 'conv_x3_kernel<0,1,4>',
-                 'linear_x3': 'conv_x3_kernel<0,1,4>', 'lstm_rec_x3': 'lstm_x3_kernel'}
+                 'lstm_rec': 'lstm_f32_kernel', 'conv_x3': 'conv_x3_kernel', 'conv1_x3': 'conv1_x3_kernel',
+                 'conv_taps_x3': 'conv_taps_kernel', 'lstm_xproj_x3': 'gemm_x3_kernel', 'linear_x3': 'gemm_x3_kernel',
+                 'lstm_rec_x3': 'lstm_x3_kernel'}
     peak_of = lambda name: BF16_MFMA_PEAK_TFLOPS if name.endswith('_x3') else F32_MFMA_PEAK_TFLOPS   # noqa: E731
     groups = {}
     for l in launches:
@@ -194,7 +195,7 @@ def main():
         'value': round(value, 1), 'unit': 'lines/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32' if args.precision == 'f32' else 'bf16x3 (split bf16 operands hi+lo on the bf16 MFMA, 3 MFMAs per product, f32 accumulate; first conv exact f32 MFMA)',
+        'dtype': 'f32' if args.precision == 'f32' else 'bf16x3 (every value carried as bf16 hi+lo; 3 bf16 MFMAs per product, f32 accumulate; |d logit| vs fp32 ~1.4e-5)',
         'data': 'synthetic',
         'config': {'workload': f'BENCH-A VGSL recogniser (3.17M params, random init seed 0), {N} lines 1x48x{W} per GPU '
                                f'per step, greedy CTC decode, label tuples to host', 'lines_per_gpu_step': N, 'width': W,
