@@ -15,7 +15,8 @@
 //   LDS order = [plane][k-half][row][8 bf16]: a wave's ds_read_b128 covers contiguous 512-byte runs
 //   grid      = 1-D, XCD-aware: the column groups of one row tile run back-to-back on the SAME XCD,
 //               so X is read from HBM once and re-read from that XCD's L2
-//   epilogue  = + bias, fp32 rows [row][Cout] (the recurrent kernel / decoder read these)
+//   epilogue  = + bias, transposed through the (now free) LDS buffers so that each store instruction writes
+//               two full 512-byte row runs of the fp32 rows [row][Cout] the recurrent kernel / decoder read
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -43,7 +44,6 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
     if (tile >= a.ntiles) return;
     const int row0 = tile * TM;
     const int nkb = a.K >> 4;
-
     // this lane's global sources: X pieces (plane, k-half) of row row0+tid, W pieces tid and tid+256.
     // Rows past the end re-read the last row; their results are never stored.
     const int myrow = min(row0 + tid, a.M - 1);
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
 
     // three LDS buffers, copies two K steps ahead: 6 copies per wave per step, so "vmcnt(6)" = this
     // wave's copies of step kb have landed while those of step kb+1 are still in flight
-    const bool no_mma = a.dbg & 1, no_copy = a.dbg & 2, no_lds = a.dbg & 8;
+    const bool no_mma = (a.dbg & 1), no_copy = (a.dbg & 2), no_lds = (a.dbg & 8);
     if (!no_copy) { issue(0, 0);
     if (nkb > 1) issue(1, 1); }
 
@@ -112,34 +112,45 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
     }
 
     // epilogue: D[column][row] (weights are the MFMA's A operand): lane = row px of its segment, registers
-    // 4j..4j+3 = columns 8j + 4*half + 0..3 of the block -> 16-byte stores at compile-time offsets
+    // 4j..4j+3 = columns 8j + 4*half + 0..3 of the block.  The tile is transposed through LDS (the pipeline
+    // buffers are free now) so that every global store covers two full 512-byte row runs.
+    __builtin_amdgcn_s_barrier();                      // slower waves may still be reading the last K step
+    constexpr int RSTR = TN + 4;                       // floats per LDS row: +16 B keeps the column writes conflict-free
+    float* T = reinterpret_cast<float*>(lds) + wave * (32 * RSTR);
+    const int col0 = cg * TN;
     const bool vec = (a.Cout & 3) == 0;
+    const bool nostore = (a.dbg & 4);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int row = row0 + wave * 64 + 32 * s + px;
-        if (row >= a.M || (a.dbg & 4)) continue;
-        const int col0 = cg * TN + 4 * half;
-        float* yp = a.y + (size_t)row * a.Cout + col0;
-        const float* bp = a.bias + col0;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int o = cb * 32 + 8 * j;
-                if (vec) {
-                    if (col0 + o < a.Cout) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + o);
-                        f32x4 v;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col0 + cb * 32 + 8 * j + 4 * half);
+                f32x4 v;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = acc[cb][s][4 * j + i] + bv[i];
-                        *reinterpret_cast<f32x4*>(yp + o) = v;
+                for (int i = 0; i < 4; ++i) v[i] = acc[cb][s][4 * j + i] + bv[i];
+                *reinterpret_cast<f32x4*>(T + px * RSTR + cb * 32 + 8 * j + 4 * half) = v;
+            }
+        const int rbase = row0 + wave * 64 + 32 * s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = 2 * i + half;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(T + r * RSTR + 4 * px);
+            const int row = rbase + r, col = col0 + 4 * px;
+            if (row < a.M && !nostore) {
+                float* yp = a.y + (size_t)row * a.Cout + col;
+                if (vec) {
+                    if (col < a.Cout) {
+                        *reinterpret_cast<f32x4*>(yp) = v;
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (col0 + o + i < a.Cout) yp[o + i] = acc[cb][s][4 * j + i] + bp[o + i];
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < a.Cout) yp[e] = v[e];
                 }
             }
+        }
     }
 }
 
