@@ -201,6 +201,17 @@ const char* krk_plan_layer_name(const krk_plan* plan, int i);
 double krk_plan_layer_flops(const krk_plan* plan, int i);
 int krk_plan_num_steps(const krk_plan* plan);
 
+/* Cross-batch scheduling for callers that keep several plans in flight on separate streams
+ * (kraken_amd/engine.py; no reference analogue -- the reference runs one batch at a time,
+ * kraken/lib/vgsl/rpred.py:210-229).  `krk_plan_front_event` returns a hipEvent_t (as void*, owned by
+ * the plan) that every krk_forward / krk_recognize call records once the batch's convolution block and
+ * first LSTM input projection have been enqueued; `krk_plan_wait_front(plan, ev)` makes the NEXT call on
+ * `plan` wait for `ev` before its first kernel (one shot).  Chaining batch k+1 behind batch k's front event
+ * keeps the full-chip convolution blocks of different batches from time-slicing each other while the
+ * 32-CU recurrent kernels of batch k overlap the convolutions of batch k+1. */
+void* krk_plan_front_event(krk_plan* plan);
+int krk_plan_wait_front(krk_plan* plan, void* event);
+
 #ifdef __cplusplus
 }
 #endif

@@ -366,6 +366,9 @@ struct krk_plan {
     size_t h_lens_cap = 0;
     hipEvent_t lens_ev = nullptr;
     bool lens_ev_pending = false;
+    // cross-plan gating of the convolution block (krk_plan_front_event / krk_plan_wait_front)
+    hipEvent_t front_ev = nullptr;      // recorded when this plan's convolution block has been enqueued-and-run
+    hipEvent_t front_wait = nullptr;    // not owned: another plan's front_ev the next call waits for (one shot)
     DevBuf d_labels, d_confs, d_final;
     bool profiling = false;
     std::vector<hipEvent_t> events;          // one per profiled launch + 1
@@ -486,6 +489,7 @@ void krk_plan_destroy(krk_plan* plan) {
     plan->d_final.release();
     if (plan->h_lens_pinned) (void)hipHostFree(plan->h_lens_pinned);
     if (plan->lens_ev) (void)hipEventDestroy(plan->lens_ev);
+    if (plan->front_ev) (void)hipEventDestroy(plan->front_ev);
     for (auto e : plan->events) (void)hipEventDestroy(e);
     delete plan;
 }
@@ -773,6 +777,8 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
     p->nstages = stage + 1;
     if (hipEventCreateWithFlags(&p->lens_ev, hipEventDisableTiming) != hipSuccess)
         return bail(KRK_E_HIP, "hipEventCreate failed");
+    if (hipEventCreateWithFlags(&p->front_ev, hipEventDisableTiming) != hipSuccess)
+        return bail(KRK_E_HIP, "hipEventCreate failed");
     HIPCHK(hipDeviceSynchronize());
     *out = p;
     return KRK_OK;
@@ -817,6 +823,14 @@ int krk_plan_set_profiling(krk_plan* plan, int enable) {
     return KRK_OK;
 }
 
+void* krk_plan_front_event(krk_plan* plan) { return plan ? (void*)plan->front_ev : nullptr; }
+
+int krk_plan_wait_front(krk_plan* plan, void* event) {
+    if (!plan) return fail(KRK_E_INVALID, "krk_plan_wait_front: null plan");
+    plan->front_wait = (hipEvent_t)event;
+    return KRK_OK;
+}
+
 int krk_plan_num_steps(const krk_plan* plan) {
     if (!plan) return 0;
     return plan->prof_n ? (int)plan->prof_n : (int)plan->steps.size();
@@ -857,6 +871,11 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
     HIPCHK(hipSetDevice(p->device));
     p->last_N = N;
     p->last_W = W;
+    if (p->front_wait) {   // one-shot: this batch's convolution block starts after the other plan's has finished
+        HIPCHK(hipStreamWaitEvent(stream, p->front_wait, 0));
+        p->front_wait = nullptr;
+    }
+    bool front_done = false;
 
     // ---- per-stage widths (tensor extents) and per-line valid widths
     std::vector<int> Ws(p->nstages);
@@ -1110,6 +1129,10 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     rc = krk_launch_conv(a, true, true, false, stream);
                 }
                 if (rc) break;
+                if (!front_done) {   // convolution block + first projection are enqueued: the next batch may start its own
+                    HIPCHK(hipEventRecord(p->front_ev, stream));
+                    front_done = true;
+                }
                 mark(s.rec_x3 ? "lstm_rec_x3" : "lstm_rec", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.hidden);
                 if (lens_host) HIPCHK(hipMemsetAsync(outp, 0, out_elems * sizeof(float), stream));
                 if (s.rec_x3) {
@@ -1165,6 +1188,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                                            hipGetErrorString(hipGetLastError()));
         cur = outp;
     }
+    if (!front_done) HIPCHK(hipEventRecord(p->front_ev, stream));
     if (p->profiling) HIPCHK(hipEventRecord(p->events[p->prof_n], stream));
     if (final_ptr) *final_ptr = cur;
     if (d_olens) *d_olens = lens_at(p->nstages - 1);

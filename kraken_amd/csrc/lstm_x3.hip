@@ -25,10 +25,9 @@ struct WPair {
 };
 
 // h_t (hi, lo rows in LDS) -> split output planes out[plane][n][t][dir*H + k]; 16-byte pieces when H % 8 == 0
-template <int NW>
+template <int NW, int M>
 __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigned char* hnext, const int* lens_s, int s,
                                               int wave, int lane, int dir, bool rev, int n0) {
-    constexpr int M = 16;
     constexpr int LPW = M / NW;                          // lines each wave copies out
     const int RS = a.hrow, plane = M * RS;
     if ((a.H & 7) == 0) {
@@ -69,35 +68,39 @@ __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigne
 // h (32 K x 16 lines).  With gate columns interleaved (col = 4*unit + gate) the D fragment of lane l holds
 // rows 4*(l>>4) + r = the FOUR GATES (r = i,f,g,o) of unit (l>>4) of the block, for line l&15: the cell update
 // is purely per-lane (no cross-lane traffic), and xproj[t] for a block is ONE 16-byte load per lane.
-template <int NW, int NBW, bool XPRE>
+template <int NW, int G, int NBW, bool XPRE>
 __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char* hs, const int* lens_s, int Lmax,
                                              int wave, int lane, int dir, bool rev, int n0) {
-    constexpr int M = 16;
-    const int line = lane & 15;               // the line (B/D column) this lane owns
+    constexpr int M = 16 * G;                 // lines per workgroup: G groups of 16 share every weight fragment
+    const int line = lane & 15;               // the line (B/D column) this lane owns inside each group
     const int us = lane >> 4;                 // unit inside a block (D rows 4*us..4*us+3), also the K octet of operands
     const int RS = a.hrow;                    // bytes per h row (one line, one plane)
     const int plane = M * RS;                 // bytes per plane
     const int buf = 2 * plane;                // bytes per (hi, lo) buffer
-    const int mylen = lens_s[line];
-
-    f32x4 acc[NBW];
-    float cst[NBW];                           // cell state of (line, unit): one per column block
+    int mylen[G];
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) cst[j] = 0.f;
+    for (int g = 0; g < G; ++g) mylen[g] = lens_s[16 * g + line];
+
+    f32x4 acc[G][NBW];
+    float cst[G][NBW];                        // cell state of (line, unit): one per column block
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) cst[g][j] = 0.f;
 
     // weights: [dir][kb][block][plane][lane][8] bf16; lane l: gate column l&15 of the block, K octet l>>4
     const __bf16* wbase = a.wp + ((size_t)dir * a.NKB * a.NB * 2 * 64 + lane) * 8;
     const size_t kstride = (size_t)a.NB * 1024;
-    const float* xrow = a.xp + (size_t)(n0 + line) * a.T * a.xstride + (size_t)dir * a.G + us * 4;
+    const float* xrow0 = a.xp + (size_t)(n0 + line) * a.T * a.xstride + (size_t)dir * a.G + us * 4;
 
-    auto load_x = [&](int s, auto& dst) {
-        const bool on = s < mylen;
-        const int t = on ? (rev ? (mylen - 1 - s) : s) : 0;
-        const float* xr = xrow + (size_t)t * a.xstride;
+    auto load_x = [&](int s, int g, f32x4 (&dst)[NBW]) {
+        const bool on = s < mylen[g];
+        const int t = on ? (rev ? (mylen[g] - 1 - s) : s) : 0;
+        const float* xr = xrow0 + ((size_t)16 * g * a.T + t) * a.xstride;
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (on) v = *reinterpret_cast<const f32x4*>(xr + (wave + NW * j) * M);
+            if (on) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + (wave + NW * j) * 16));   // read once: keep it out of the way of W_hh in L2
             dst[j] = v;
         }
     };
@@ -113,15 +116,18 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
     };
     auto mma_block = [&](int kb, const unsigned char* hcur, const WPair (&w)[NBW]) {
         if (a.dbg & 4) return;
-        const unsigned char* hp = hcur + line * RS + (kb * 32 + us * 8) * 2;
-        const bf16x8 hh = *reinterpret_cast<const bf16x8*>(hp);
-        const bf16x8 hl = *reinterpret_cast<const bf16x8*>(hp + plane);
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j].hi, hh, acc[j], 0, 0, 0);
+        for (int g = 0; g < G; ++g) {
+            const unsigned char* hp = hcur + (16 * g + line) * RS + (kb * 32 + us * 8) * 2;
+            const bf16x8 hh = *reinterpret_cast<const bf16x8*>(hp);
+            const bf16x8 hl = *reinterpret_cast<const bf16x8*>(hp + plane);
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j].hi, hl, acc[j], 0, 0, 0);
+            for (int j = 0; j < NBW; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j].hi, hh, acc[g][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j].lo, hh, acc[j], 0, 0, 0);
+            for (int j = 0; j < NBW; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j].hi, hl, acc[g][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j].lo, hh, acc[g][j], 0, 0, 0);
+        }
     };
 
     WPair wa[NBW], wb[NBW];
@@ -130,14 +136,17 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
         for (int j = 0; j < NBW; ++j) { wa[j].hi = bf16x8{}; wa[j].lo = bf16x8{}; wb[j].hi = bf16x8{}; wb[j].lo = bf16x8{}; }
     }
     int cur = 0;
-    // one time step; `xbuf` holds xproj of this step and is refilled with the next step's after the last weight
-    // load (vmcnt retires in order: an HBM-latency load in front of weight loads would stall their MFMAs)
-    auto step = [&](int s, f32x4 (&xbuf)[XPRE ? NBW : 1]) {
-        if constexpr (XPRE) {
+    // one time step; with XPRE `xbuf` holds xproj of this step and is refilled with the next step's after the last
+    // weight load (vmcnt retires in order: an HBM-latency load in front of weight loads would stall their MFMAs)
+    auto step = [&](int s, f32x4 (&xbuf)[XPRE ? G : 1][XPRE ? NBW : 1]) {
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) acc[j] = xbuf[j];
-        } else {
-            load_x(s, acc);
+        for (int g = 0; g < G; ++g) {
+            if constexpr (XPRE) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) acc[g][j] = xbuf[g][j];
+            } else {
+                load_x(s, g, acc[g]);
+            }
         }
         const unsigned char* hcur = hs + cur * buf;
         int kb = 0;
@@ -152,64 +161,73 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
             load_w(0, wa);
         }
         if constexpr (XPRE) {
-            if (s + 1 < Lmax && !(a.dbg & 8)) load_x(s + 1, xbuf);
+            if (s + 1 < Lmax && !(a.dbg & 8)) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) load_x(s + 1, g, xbuf[g]);
+            }
         }
 
         // ---- gate non-linearities, cell update (per lane: one (line, unit)), h_t -> LDS as (hi, lo)
         unsigned char* hnext = hs + (cur ^ 1) * buf;
         if (!(a.dbg & 2))
 #pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
         for (int j = 0; j < NBW; ++j) {
             const int unit = (wave + NW * j) * 4 + us;
-            const float gi = krk_sigmoid(acc[j][0]);
-            const float gf = krk_sigmoid(acc[j][1]);
-            const float gg = krk_tanh(acc[j][2]);
-            const float go = krk_sigmoid(acc[j][3]);
-            const float c = gf * cst[j] + gi * gg;
-            cst[j] = c;
+            const float gi = krk_sigmoid(acc[g][j][0]);
+            const float gf = krk_sigmoid(acc[g][j][1]);
+            const float gg = krk_tanh(acc[g][j][2]);
+            const float go = krk_sigmoid(acc[g][j][3]);
+            const float c = gf * cst[g][j] + gi * gg;
+            cst[g][j] = c;
             const float h = go * krk_tanh(c);
             const __bf16 hh = (__bf16)h;
-            __bf16* dst = reinterpret_cast<__bf16*>(hnext + line * RS) + unit;
+            __bf16* dst = reinterpret_cast<__bf16*>(hnext + (16 * g + line) * RS) + unit;
             dst[0] = hh;
             *reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(dst) + plane) = (__bf16)(h - (float)hh);
         }
         __syncthreads();
-        lstm_x3_store<NW>(a, hnext, lens_s, s, wave, lane, dir, rev, n0);
+        lstm_x3_store<NW, M>(a, hnext, lens_s, s, wave, lane, dir, rev, n0);
         cur ^= 1;
     };
 
-    f32x4 xa[XPRE ? NBW : 1];
+    f32x4 xa[XPRE ? G : 1][XPRE ? NBW : 1];
     load_w(0, wa);
-    if constexpr (XPRE) load_x(0, xa);
+    if constexpr (XPRE) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) load_x(0, g, xa[g]);
+    }
     for (int s = 0; s < Lmax; ++s) step(s, xa);
 }
 
-template <int NW>
+template <int NW, int M>
 __device__ __forceinline__ void lstm_x3_idle(const LstmX3Args& a, const unsigned char* hs, const int* lens_s, int Lmax,
                                              int wave, int lane, int dir, bool rev, int n0) {
-    constexpr int M = 16;
     const int buf = 2 * M * a.hrow;
     int cur = 0;
     for (int s = 0; s < Lmax; ++s) {
         __syncthreads();
-        lstm_x3_store<NW>(a, hs + (cur ^ 1) * buf, lens_s, s, wave, lane, dir, rev, n0);
+        lstm_x3_store<NW, M>(a, hs + (cur ^ 1) * buf, lens_s, s, wave, lane, dir, rev, n0);
         cur ^= 1;
     }
 }
 
-template <int NW, int MAXB, bool XPRE>
+template <int NW, int G, int MAXB, bool XPRE>
 __global__ void __launch_bounds__(64 * NW, 1) lstm_x3_kernel(const LstmX3Args a) {
-    constexpr int M = 16;
+    constexpr int M = 16 * G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
-    unsigned char* hs = smem8;                                       // [2 buffers][2 planes][16][hrow]
-    int* lens_s = reinterpret_cast<int*>(smem8 + 4 * M * a.hrow);   // [16]
+    unsigned char* hs = smem8;                                       // [2 buffers][2 planes][M][hrow]
+    int* lens_s = reinterpret_cast<int*>(smem8 + 4 * M * a.hrow);   // [M]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y;
+    // 1-D grid, direction = workgroup id % ndir: the hardware deals workgroups to XCDs round-robin by id, so with two
+    // directions even XCDs only ever hold the forward weights in their L2 and odd XCDs the reverse ones
+    const int dir = blockIdx.x % a.ndir;
     const bool rev = (a.dirmode == 1) || (a.dirmode == 2 && dir == 1);
-    const int n0 = blockIdx.x * M;
+    const int n0 = (blockIdx.x / a.ndir) * M;
 
     if (tid < M) {
         const int n = n0 + tid;
@@ -224,18 +242,19 @@ __global__ void __launch_bounds__(64 * NW, 1) lstm_x3_kernel(const LstmX3Args a)
 
     const int nb_mine = (a.NB - wave + NW - 1) / NW;
     if (nb_mine == MAXB) {
-        lstm_x3_loop<NW, MAXB, XPRE>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
+        lstm_x3_loop<NW, G, MAXB, XPRE>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
     } else {
-        if constexpr (MAXB > 1) lstm_x3_loop<NW, MAXB - 1, XPRE>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
-        else lstm_x3_idle<NW>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
+        if constexpr (MAXB > 1) lstm_x3_loop<NW, G, MAXB - 1, XPRE>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
+        else lstm_x3_idle<NW, M>(a, hs, lens_s, Lmax, wave, lane, dir, rev, n0);
     }
 }
 
-template <int NW, int MAXB, bool XPRE>
+template <int NW, int G, int MAXB, bool XPRE>
 int launch_one(const LstmX3Args& a, hipStream_t s) {
-    dim3 grid((unsigned)((a.N + 15) / 16), (unsigned)a.ndir);
-    const size_t lds = (size_t)4 * 16 * a.hrow + 16 * sizeof(int);
-    auto kfn = lstm_x3_kernel<NW, MAXB, XPRE>;
+    constexpr int M = 16 * G;
+    dim3 grid((unsigned)((a.N + M - 1) / M * a.ndir));
+    const size_t lds = (size_t)4 * M * a.hrow + M * sizeof(int);
+    auto kfn = lstm_x3_kernel<NW, G, MAXB, XPRE>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -246,14 +265,27 @@ int launch_one(const LstmX3Args& a, hipStream_t s) {
 }  // namespace
 
 // a.NB = 4*Hp/16 column blocks of 16 gate columns; a.NKB = K-blocks of 32 (Hp padded to a multiple of 32).
-// Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs each) once a wave would own more than 4 blocks -- the
-// second wave hides the L2 weight stream and the serial gate math of the first; 4 otherwise.
+// Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs) once a wave would own more than 4 blocks -- the second
+// wave hides the L2 weight stream and the serial gate math of the first; 4 otherwise.
+// Lines per workgroup: 16, or (KRK_LSTM_G=2) 32 = two groups of 16 sharing every weight fragment: the per-CU weight
+// stream is then paid once per 32 lines and the kernel holds half as many CUs (chip time per line -33 %), but a
+// launch takes 1.9 instead of 1.36 ms and the pipelined engine loses more to the longer per-batch chain.
 int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s) {
     int nw = a.NB > 16 && a.NB <= 64 ? 8 : 4;
     if (const char* e = getenv("KRK_LSTM_NW")) nw = atoi(e) == 8 && a.NB <= 64 ? 8 : 4;
+    int g = 1;   // 32-line tiles are opt-in: measured 80 k vs 91 k lines/s on the pipelined bench (longer per-batch chain)
+    if (const char* e = getenv("KRK_LSTM_G")) g = (atoi(e) == 2 && nw == 8 && a.NB <= 56) ? 2 : 1;
     if (nw == 8) {
         const int per_wave = (a.NB + 7) / 8;
-#define KRK_CASE(B_) case B_: return launch_one<8, B_, true>(a, s)
+        if (g == 2) {
+#define KRK_CASE(B_) case B_: return launch_one<8, 2, B_, false>(a, s)
+            switch (per_wave) {
+                KRK_CASE(1); KRK_CASE(2); KRK_CASE(3); KRK_CASE(4); KRK_CASE(5); KRK_CASE(6); KRK_CASE(7);
+                default: return -4;
+            }
+#undef KRK_CASE
+        }
+#define KRK_CASE(B_) case B_: return launch_one<8, 1, B_, true>(a, s)
         switch (per_wave) {
             KRK_CASE(1); KRK_CASE(2); KRK_CASE(3); KRK_CASE(4); KRK_CASE(5); KRK_CASE(6); KRK_CASE(7); KRK_CASE(8);
             default: return -4;
@@ -261,7 +293,7 @@ int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s) {
 #undef KRK_CASE
     }
     const int per_wave = (a.NB + 3) / 4;
-#define KRK_CASE(B_) case B_: return launch_one<4, B_, true>(a, s)
+#define KRK_CASE(B_) case B_: return launch_one<4, 1, B_, true>(a, s)
     switch (per_wave) {
         KRK_CASE(1); KRK_CASE(2); KRK_CASE(3); KRK_CASE(4); KRK_CASE(5); KRK_CASE(6); KRK_CASE(7); KRK_CASE(8);
         KRK_CASE(9); KRK_CASE(10); KRK_CASE(11); KRK_CASE(12); KRK_CASE(13); KRK_CASE(14); KRK_CASE(15); KRK_CASE(16);

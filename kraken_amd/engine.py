@@ -11,6 +11,7 @@ only.  With two or more slots the small LSTM recurrent kernels of one batch (a f
 overlap the convolutions of the next, which is where single-batch latency leaves CUs idle.
 """
 import ctypes as C
+import os
 from collections import deque
 from typing import Optional
 
@@ -53,6 +54,11 @@ class RecognitionEngine:
             self.slots = [_Slot(model, device, max_batch, max_t) for _ in range(slots)]
         self._next = 0
         self._inflight = deque()
+        # front event of the batch submitted last: the next batch's convolution block queues behind it, so the
+        # full-chip convolution blocks of different batches run one after another (no convoy of all slots doing
+        # convolutions together and then all doing recurrences together) -- see include/kraken_amd.h
+        self._last_front = None
+        self.chain_fronts = os.environ.get('KRK_NO_FRONT_CHAIN') is None
 
     def set_profiling(self, on: bool):
         for s in self.slots:
@@ -87,6 +93,9 @@ class RecognitionEngine:
             lens_arr = np.ascontiguousarray(np.asarray(lens, dtype=np.int32))
         cur = torch.cuda.current_stream(self.device)
         slot.stream.wait_stream(cur)   # the input may have been produced on the caller's stream
+        if self.chain_fronts and self._last_front is not None and len(self.slots) > 1:
+            _lib.check(self.lib.krk_plan_wait_front(slot.plan.handle, self._last_front))
+        self._last_front = self.lib.krk_plan_front_event(slot.plan.handle)
         with torch.cuda.stream(slot.stream):
             _lib.check(self.lib.krk_recognize(slot.plan.handle, x.data_ptr(),
                                               lens_arr.ctypes.data if lens_arr is not None else None, N, W,

@@ -539,3 +539,14 @@ def test_x3_plan_uses_the_specialised_kernels(bench_a_x3):
     assert names[:4] == ['conv1_x3', 'conv_taps_x3', 'conv_x3', 'conv_x3']
     assert names.count('lstm_xproj_x3') == 3 and names.count('lstm_rec_x3') == 3
     assert names[-1] == 'linear_x3' or 'linear_x3' in names
+
+
+def test_lstm_32_line_tiles_match_16_line_tiles(bench_a_x3, monkeypatch):
+    """KRK_LSTM_G=2 (two 16-line groups per recurrent workgroup) is an execution choice, not a numerical one."""
+    x = synth_input(40, 256).cuda()          # 40 lines: one full 32-line tile + a ragged one
+    lens = torch.tensor([256 - 3 * i for i in range(40)])
+    base = bench_a_x3.nn.recognize(x, lens)[0].tuples()
+    monkeypatch.setenv('KRK_LSTM_G', '2')
+    got = bench_a_x3.nn.recognize(x, lens)[0].tuples()
+    assert _keys(got) == _keys(base)
+    assert _max_conf_diff(got, base) < 1e-6
