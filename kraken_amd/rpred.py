@@ -214,29 +214,33 @@ class mm_rpred(object):
     def _scale(self, val, net_scale, in_scale, max_val):
         return int(round(min(max(((val * net_scale) - self.pad) * in_scale, 0), max_val - 1)))
 
+    def _scale_all(self, vals, net_scale, in_scale, max_val):
+        """Vectorised `_scale` (kraken/rpred.py:329-330): np.rint rounds half to even exactly like Python's round()."""
+        v = (np.asarray(vals, dtype=np.float64) * net_scale - self.pad) * in_scale
+        return np.rint(np.minimum(np.maximum(v, 0), max_val - 1)).astype(np.int64).tolist()
+
     def _finish(self, p: _Pending, preds, out_width: int):
         net_scale = p.tensor.shape[2] / out_width
         in_scale = p.box_size[0] / (p.tensor.shape[2] - 2 * self.pad)
         text = ''.join(x[0] for x in preds)
-        pos, conf = [], []
+        conf = [x[3] for x in preds]
+        starts, ends = [x[1] for x in preds], [x[2] for x in preds]
         if self._valid_norm:
             coords = p.line.bbox
-            horizontal = self.bounds.text_direction.startswith('horizontal')
-            for _, start, end, c in preds:
-                if horizontal:
-                    xmin = coords[0] + self._scale(start, net_scale, in_scale, p.box_size[0])
-                    xmax = coords[0] + self._scale(end, net_scale, in_scale, p.box_size[0])
-                    pos.append([[xmin, coords[1]], [xmin, coords[3]], [xmax, coords[3]], [xmax, coords[1]]])
-                else:
-                    ymin = coords[1] + self._scale(start, net_scale, in_scale, p.box_size[1])
-                    ymax = coords[1] + self._scale(end, net_scale, in_scale, p.box_size[1])
-                    pos.append([[coords[0], ymin], [coords[2], ymin], [coords[2], ymax], [coords[0], ymax]])
-                conf.append(c)
+            if self.bounds.text_direction.startswith('horizontal'):
+                lo = self._scale_all(starts, net_scale, in_scale, p.box_size[0])
+                hi = self._scale_all(ends, net_scale, in_scale, p.box_size[0])
+                x0, y0, y1 = coords[0], coords[1], coords[3]
+                pos = [[[x0 + a, y0], [x0 + a, y1], [x0 + b, y1], [x0 + b, y0]] for a, b in zip(lo, hi)]
+            else:
+                lo = self._scale_all(starts, net_scale, in_scale, p.box_size[1])
+                hi = self._scale_all(ends, net_scale, in_scale, p.box_size[1])
+                x0, x1, y0 = coords[0], coords[2], coords[1]
+                pos = [[[x0, y0 + a], [x1, y0 + a], [x1, y0 + b], [x0, y0 + b]] for a, b in zip(lo, hi)]
         else:
-            for _, start, end, c in preds:
-                pos.append([self._scale(start, net_scale, in_scale, p.box_size[0]),
-                            self._scale(end, net_scale, in_scale, p.box_size[0])])
-                conf.append(c)
+            lo = self._scale_all(starts, net_scale, in_scale, p.box_size[0])
+            hi = self._scale_all(ends, net_scale, in_scale, p.box_size[0])
+            pos = [[a, b] for a, b in zip(lo, hi)]
         rec = self._record_cls(text, pos, conf, p.line)
         if self.bidi_reordering:
             return rec.logical_order(base_dir=self.bidi_reordering if self.bidi_reordering in ('L', 'R') else None)

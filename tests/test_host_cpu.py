@@ -345,3 +345,16 @@ def test_product_never_imports_the_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), fn
             assert '/root/reference' not in src, fn
+
+
+def test_vectorised_cut_scaling_equals_the_scalar_rule():
+    """rpred._scale_all (numpy) must reproduce rpred._scale (Python round/min/max, kraken/rpred.py:329-330) bit for bit."""
+    import types
+    from kraken_amd.rpred import mm_rpred
+    rng = np.random.default_rng(0)
+    for pad in (0, 16):
+        me = types.SimpleNamespace(pad=pad)
+        for net_scale, in_scale, max_val in [(8.0, 1.0, 1200), (8.0, 0.5, 600), (1232 / 154, 2544 / 1200, 2544), (7.97, 3.25, 4000)]:
+            vals = list(range(0, 160)) + rng.integers(0, 400, 64).tolist()
+            want = [mm_rpred._scale(me, v, net_scale, in_scale, max_val) for v in vals]
+            assert mm_rpred._scale_all(me, vals, net_scale, in_scale, max_val) == want
