@@ -31,8 +31,8 @@ int fail(int code, const std::string& msg) {
             return fail(KRK_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
-enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR };
-const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear"};
+enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG };
+const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img"};
 
 
 
@@ -340,6 +340,8 @@ struct Step {
     float* d_wrec16 = nullptr;  // recurrent weights, 16x16x4 fragment order
     void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
+    int img_axis = 0;           // LSTM over image rows (1) or columns (2): sequences = N*H (N*W), steps = W (H); 0 = plain sequence
+    int yaxis = 0;              // IMG2ROWS / ROWS2IMG: 1 = columns are the sequences
     // output description
     bool out_is_seq = false;
     int outC = 0, outH = 1;     // NCHW: channels,height; seq: features,1
@@ -679,7 +681,21 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
             }
             case KRK_OP_LSTM:
             case KRK_OP_LINEAR: {
-                if (!seq) {
+                // LSTM over the rows (kw = 0) or columns (kw = 1) of an image: reference TransposedSummarizingRNN on a
+                // 4-D input (layers.py:519-547; the BLLA segmenter's Lbx/Lby pairs).  img2rows -> LSTM -> rows2img.
+                const bool img_lstm = L.op == KRK_OP_LSTM && !seq && (H != 1 || L.kw == 1);
+                if (img_lstm) {
+                    if (x3) return bail(KRK_E_UNSUPPORTED, where + ": LSTMs over image rows/columns run in the f32 plan only");
+                    Step a;
+                    a.kind = S_IMG2ROWS;
+                    a.C = C; a.H = H; a.yaxis = L.kw == 1;
+                    a.outC = C; a.outH = H;
+                    a.len_in = a.len_out = stage;
+                    p->steps.push_back(std::move(a));
+                }
+                if (L.op == KRK_OP_LSTM && seq && L.kw == 1)
+                    return bail(KRK_E_UNSUPPORTED, where + ": y-axis LSTM after the height collapse");
+                if (!seq && !img_lstm) {
                     if (H != 1)
                         return bail(KRK_E_UNSUPPORTED, where + ": recurrent/linear layer on an input of height " +
                                                            std::to_string(H) + " (only height 1 is implemented)");
@@ -689,8 +705,9 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 Step s;
                 s.C = C;
                 s.H = 1;
-                s.out_is_seq = true;
-                s.outH = 1;
+                s.out_is_seq = !img_lstm;
+                s.outH = img_lstm ? H : 1;
+                s.img_axis = img_lstm ? (L.kw == 1 ? 2 : 1) : 0;
                 s.len_in = s.len_out = stage;
                 ConvGeom& g = s.cg;
                 g.Cin = C;
@@ -768,6 +785,14 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     C = s.outC;
                 }
                 p->steps.push_back(std::move(s));
+                if (img_lstm) {
+                    Step b;
+                    b.kind = S_ROWS2IMG;
+                    b.C = C; b.H = H; b.yaxis = L.kw == 1;
+                    b.outC = C; b.outH = H;
+                    b.len_in = b.len_out = stage;
+                    p->steps.push_back(std::move(b));
+                }
                 break;
             }
             default:
@@ -1071,13 +1096,32 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             case S_GN:
                 s.flops = 0;
                 mark("groupnorm", 0);
-                rc = krk_launch_groupnorm(cur, outp, s.d_gamma, s.d_beta, lens_at(s.len_in), N, s.C, s.H, Win, s.groups,
-                                          1e-5f, stream);
+                {
+                    const int chunks = krk_groupnorm_chunks(N, s.C, s.H, Win, s.groups);
+                    float* scratch = nullptr;
+                    if (chunks > 1) {
+                        if (s.aux.ensure((size_t)2 * N * s.groups * chunks * sizeof(float)))
+                            return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
+                        scratch = (float*)s.aux.p;
+                    }
+                    rc = krk_launch_groupnorm(cur, outp, s.d_gamma, s.d_beta, lens_at(s.len_in), N, s.C, s.H, Win, s.groups,
+                                              1e-5f, scratch, stream);
+                }
                 break;
             case S_TOSEQ:
                 s.flops = 0;
                 mark("to_seq", 0);
                 rc = krk_launch_to_seq(cur, outp, N, s.C, s.H, Win, stream);
+                break;
+            case S_IMG2ROWS:
+                s.flops = 0;
+                mark("img2rows", 0);
+                rc = krk_launch_img2rows(cur, outp, N, s.C, s.H, Win, s.yaxis, stream);
+                break;
+            case S_ROWS2IMG:
+                s.flops = 0;
+                mark("rows2img", 0);
+                rc = krk_launch_rows2img(cur, outp, N, s.C, s.H, Win, s.yaxis, stream);
                 break;
             case S_LINEAR: {
                 s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
@@ -1104,7 +1148,12 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 break;
             }
             case S_LSTM: {
-                const int T = Win;
+                if (s.img_axis && lens_host)
+                    return fail(KRK_E_UNSUPPORTED, "forward: seq_lens with an LSTM over image rows/columns (the reference raises too, layers.py:528-530)");
+                // sequences and steps: plain (N, W); image rows (N*H, W); image columns (N*W, H)
+                const int Nimg = N, Himg = s.outH;
+                const int T = s.img_axis == 2 ? Himg : Win;
+                const int N = s.img_axis == 1 ? Nimg * Himg : (s.img_axis == 2 ? Nimg * Win : Nimg);
                 const int G = 4 * s.Hp;
                 const size_t xp_elems = (size_t)N * T * s.ndir * G;
                 if (s.aux.ensure(xp_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");

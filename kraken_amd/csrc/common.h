@@ -177,9 +177,14 @@ int krk_launch_split_rows(const float* x, void* hi, int M, int K, hipStream_t s)
 int krk_x3_cb(int Cout);
 int krk_launch_maxpool(const float* x, float* y, const int* len_out, int N, int C, int H, int W,
                        int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);
-int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta,
-                         const int* lens, int N, int C, int H, int W, int G, float eps, hipStream_t s);
+// `scratch`: 2 * N*G * krk_groupnorm_chunks(...) floats (or nullptr: always one workgroup per (line, group))
+int krk_groupnorm_chunks(int N, int C, int H, int W, int G);
+int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const int* lens,
+                         int N, int C, int H, int W, int G, float eps, float* scratch, hipStream_t s);
 int krk_launch_to_seq(const float* x, float* y, int N, int C, int H, int W, hipStream_t s);
+// (N,C,H,W) <-> sequence rows [(n,h)][w][C] (yaxis = 0) or [(n,w)][h][C] (yaxis = 1) for LSTMs over image rows/columns
+int krk_launch_img2rows(const float* x, float* y, int N, int C, int H, int W, int yaxis, hipStream_t s);
+int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, int yaxis, hipStream_t s);
 int krk_launch_rowmax(const float* scores, long sn, long sc, long st, int N, int C, int T,
                       int softmax, float temp, float* probs, int* labels, float* confs,
                       hipStream_t s);

@@ -82,6 +82,58 @@ __global__ void __launch_bounds__(256) groupnorm_kernel(const float* __restrict_
     }
 }
 
+// Large images (the BLLA segmenter normalises 64..256 channels of a 900 x 675 map): one workgroup per (line, group)
+// would leave all but 32 CUs idle, so the same three passes are split over `chunks` workgroups per (line, group) with
+// the partial sums combined in a fixed order (no atomics: results do not depend on scheduling).
+//   pass 0: partial sums            -> part[ng][chunk]
+//   pass 1: mean, partial centred squares -> part[NG*chunks + ng*chunks + chunk]
+//   pass 2: mean, variance, apply
+__global__ void __launch_bounds__(256) groupnorm_split_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const int* __restrict__ lens, float* __restrict__ part,
+                                                              int C, int H, int W, int G, float eps, int chunks, int pass) {
+    __shared__ float red[4];
+    const int ng = blockIdx.y, n = ng / G, g = ng - n * G, ch = blockIdx.x;
+    const int NG = gridDim.y;
+    const int Cg = C / G;
+    int L = lens ? lens[n] : W;
+    L = min(max(L, 1), W);
+    const size_t base = ((size_t)n * C + (size_t)g * Cg) * H * W;
+    const int rows = Cg * H, tot = rows * W;
+    const float cnt = (float)rows * (float)L;
+    const int per = (tot + chunks - 1) / chunks;
+    const int e0 = ch * per, e1 = min(tot, e0 + per);
+    float mean = 0.f, rstd = 0.f;
+    if (pass >= 1) {
+        float sm = 0.f;
+        for (int i = 0; i < chunks; ++i) sm += part[(size_t)ng * chunks + i];
+        mean = sm / cnt;
+    }
+    if (pass == 2) {
+        float sq = 0.f;
+        for (int i = 0; i < chunks; ++i) sq += part[(size_t)(NG + ng) * chunks + i];
+        rstd = 1.0f / sqrtf(sq / cnt + eps);
+    }
+    if (pass < 2) {
+        float acc = 0.f;
+        for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+            const int w = e % W;
+            if (w < L) {
+                const float d = x[base + e] - mean;      // pass 0: mean == 0 -> plain sum
+                acc += pass == 0 ? d : d * d;
+            }
+        }
+        const float tot_acc = block_sum(acc, red);
+        if (threadIdx.x == 0) part[(size_t)(pass * NG + ng) * chunks + ch] = tot_acc;
+    } else {
+        for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+            const int r = e / W, w = e - r * W;
+            const int c = g * Cg + r / H;
+            y[base + e] = w < L ? (x[base + e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------- NCHW -> [N][W][H*C] rows
 // reference: Reshape.forward kraken/lib/vgsl/layers.py:313-335 for S1(1x0)1,3 (feature
 // index h*C + c) followed by the NCHW->NWC permute of TransposedSummarizingRNN (:519) /
@@ -106,6 +158,55 @@ __global__ void __launch_bounds__(256) to_seq_kernel(const float* __restrict__ x
     for (int i = ty; i < 32; i += 8) {
         const int w = w0 + i, f = f0 + tx;
         if (w < W && f < F) y[((size_t)n * W + w) * F + f] = t[tx][i];
+    }
+}
+
+// ----------------------------------------------------- image <-> sequence rows (2-D LSTM layers)
+// reference: TransposedSummarizingRNN.forward on an (N, C, H, W) image (kraken/lib/vgsl/layers.py:519-547): every
+// image row (Lxx) or column (Lxy, `transpose`) is one sequence: NCHW -> [(n,h)][w][c]  or  [(n,w)][h][c], and the
+// LSTM output rows go back to (N, O, H, W).  32x32 LDS tiles: reads coalesced along the source's fast axis.
+// yaxis = 0: pixel index p = h*W + w;  yaxis = 1: p = w*H + h.
+__global__ void __launch_bounds__(256) img2rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int C, int H, int W, int yaxis) {
+    __shared__ float t[32][33];
+    const int n = blockIdx.z, HW = H * W;
+    const int c0 = blockIdx.y * 32, q0 = blockIdx.x * 32;     // q = h*W + w (source order)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, q = q0 + tx;
+        t[i][tx] = (c < C && q < HW) ? x[((size_t)n * C + c) * HW + q] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int q = q0 + i, c = c0 + tx;
+        if (q < HW && c < C) {
+            const int h = q / W, w = q - h * W;
+            const size_t pix = yaxis ? (size_t)w * H + h : (size_t)q;
+            y[((size_t)n * HW + pix) * C + c] = t[tx][i];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) rows2img_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int C, int H, int W, int yaxis) {
+    __shared__ float t[32][33];
+    const int n = blockIdx.z, HW = H * W;
+    const int c0 = blockIdx.y * 32, q0 = blockIdx.x * 32;     // q = destination pixel h*W + w
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int q = q0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (q < HW && c < C) {
+            const int h = q / W, w = q - h * W;
+            const size_t pix = yaxis ? (size_t)w * H + h : (size_t)q;
+            v = x[((size_t)n * HW + pix) * C + c];
+        }
+        t[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, q = q0 + tx;
+        if (c < C && q < HW) y[((size_t)n * C + c) * HW + q] = t[tx][i];
     }
 }
 
@@ -266,8 +367,23 @@ int krk_launch_maxpool(const float* x, float* y, const int* len_out, int N, int 
     return last_ok();
 }
 
+int krk_groupnorm_chunks(int N, int C, int H, int W, int G) {
+    const long per_group = (long)(C / G) * H * W;
+    if (per_group < (1L << 17) || (long)N * G >= 512) return 1;     // text lines: one workgroup per (line, group)
+    long chunks = (per_group + (1L << 15) - 1) >> 15;                // ~32k elements per workgroup
+    const long cap = (2048 + (long)N * G - 1) / ((long)N * G);      // ~2k workgroups per pass are plenty
+    return (int)(chunks < cap ? chunks : (cap < 1 ? 1 : cap));
+}
+
 int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const int* lens,
-                         int N, int C, int H, int W, int G, float eps, hipStream_t s) {
+                         int N, int C, int H, int W, int G, float eps, float* scratch, hipStream_t s) {
+    const int chunks = scratch ? krk_groupnorm_chunks(N, C, H, W, G) : 1;
+    if (chunks > 1) {
+        for (int pass = 0; pass < 3; ++pass)
+            hipLaunchKernelGGL(groupnorm_split_kernel, dim3(chunks, N * G), dim3(256), 0, s, x, y, gamma, beta, lens, scratch,
+                               C, H, W, G, eps, chunks, pass);
+        return last_ok();
+    }
     hipLaunchKernelGGL(groupnorm_kernel, dim3(N, G), dim3(256), 0, s, x, y, gamma, beta, lens, C, H, W, G, eps);
     return last_ok();
 }
@@ -275,6 +391,18 @@ int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const flo
 int krk_launch_to_seq(const float* x, float* y, int N, int C, int H, int W, hipStream_t s) {
     dim3 grid((W + 31) / 32, (C * H + 31) / 32, N);
     hipLaunchKernelGGL(to_seq_kernel, grid, dim3(256), 0, s, x, y, C, H, W);
+    return last_ok();
+}
+
+int krk_launch_img2rows(const float* x, float* y, int N, int C, int H, int W, int yaxis, hipStream_t s) {
+    dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(img2rows_kernel, grid, dim3(256), 0, s, x, y, C, H, W, yaxis);
+    return last_ok();
+}
+
+int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, int yaxis, hipStream_t s) {
+    dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(rows2img_kernel, grid, dim3(256), 0, s, x, y, C, H, W, yaxis);
     return last_ok();
 }
 

@@ -116,6 +116,8 @@ def parse_vgsl(spec: str):
         idx += 1
         g = mm.groupdict()
         tag = g['cell'] if kind == 'rnn' else _TYPE_TAG[kind]
+        if kind == 'output' and g['dim'] == '2':
+            tag = g['type']   # heatmap heads are named after their type letter: 'l_8' (reference model.py:811)
         name = g.get('name') or f'{tag}_{idx}'
         n, c, h, w = shape
         p: dict[str, Any] = {}
@@ -156,11 +158,12 @@ def parse_vgsl(spec: str):
             # the reference derives this shape from a dummy tensor with variable dims set to 1
             oshape = (n or 1, c * h, 1, w or 1)
         elif kind == 'rnn':
-            if g['axis'] == 'y' or g['sum'] or g['legacy']:
-                raise NotImplementedError(f'RNN variant "{block}" (y-axis / summarising / legacy) is not supported '
+            if g['sum'] or g['legacy'] or g['cell'] != 'L':
+                raise NotImplementedError(f'RNN variant "{block}" (summarising / legacy / GRU) is not supported '
                                           'by the HIP executor')
             hidden = int(g['out'])
-            p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'])
+            # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523)
+            p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'])
             oshape = (n, hidden * (2 if g['dir'] == 'b' else 1), h, w)
         else:  # output
             dim, typ, out = int(g['dim']), g['type'], int(g['out'])
@@ -266,6 +269,7 @@ class _Plan:
                 d.op = _lib.OP_LSTM
                 d.cout = p['hidden']
                 d.direction = _DIRS[p['direction']]
+                d.kw = 1 if p.get('axis', 'x') == 'y' else 0   # include/kraken_amd.h: time axis of an LSTM layer
                 sfx = [''] + (['_reverse'] if p['direction'] == 'b' else [])
                 for s in sfx:
                     arrays += [_f32(getattr(mod.layer, f'weight_ih_l0{s}')), _f32(getattr(mod.layer, f'weight_hh_l0{s}')),
@@ -426,13 +430,19 @@ class HipSequential(nn.Module):
         return out, olens
 
     def _specs_out_is_seq(self) -> bool:
-        for spec in reversed(self._specs):
+        """True when the network ends in the time-major sequence layout (after the height collapse)."""
+        seq = False
+        for spec in self._specs:
             if spec.kind == 'dropout':
                 continue
-            if spec.kind in ('rnn', 'linear', 'reshape'):
-                return True
-            return False
-        return False
+            if spec.kind in ('reshape', 'linear'):
+                seq = True
+            elif spec.kind == 'rnn':
+                # an LSTM over the rows/columns of an image (height > 1 or y axis) returns an image again
+                seq = seq or (spec.in_shape[2] == 1 and spec.params.get('axis', 'x') == 'x')
+            else:
+                seq = False
+        return seq
 
     @torch.no_grad()
     def recognize(self, x: torch.Tensor, seq_lens=None, temperature: float = 1.0, want_logits: bool = False,

@@ -153,6 +153,21 @@ def lstm(x, weights, hidden, direction='b', lens=None):
     return np.ascontiguousarray(out.transpose(0, 2, 1))[:, :, None, :]
 
 
+def lstm_image(x, weights, hidden, direction='b', axis='x'):
+    """
+    TransposedSummarizingRNN.forward on a 4-D image (kraken/lib/vgsl/layers.py:519-547): with axis 'x' every image
+    row (n, h) is one sequence over W (NCHW -> HNWC -> (H*N, W, C)); with axis 'y' (`transpose`, :521-523) every
+    column (n, w) is one sequence over H.  No seq_lens (the reference raises for height > 1, :528-530).
+    x (N,C,H,W) -> (N, D*hidden, H, W).
+    """
+    N, C, H, W = x.shape
+    if axis == 'y':
+        return lstm_image(x.transpose(0, 1, 3, 2), weights, hidden, direction, 'x').transpose(0, 1, 3, 2)
+    rows = x.transpose(0, 2, 1, 3).reshape(N * H, C, 1, W)            # one height-1 "line" per image row
+    o = lstm(rows, weights, hidden, direction, None)                   # (N*H, D*hidden, 1, W)
+    return np.ascontiguousarray(o[:, :, 0, :].reshape(N, H, -1, W).transpose(0, 2, 1, 3))
+
+
 def linear(x, w, b):
     """LinSoftmax.forward, kraken/lib/vgsl/layers.py:710-722: Linear over the channel axis; logits, no softmax."""
     N, C, H, W = x.shape
@@ -201,7 +216,11 @@ def forward(specs, sd, x, lens=None):
             ws = []
             for sfx in [''] + (['_reverse'] if p['direction'] == 'b' else []):
                 ws.append(tuple(sd[f'nn.{nm}.layer.{w}_l0{sfx}'] for w in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')))
-            x = lstm(x, ws, p['hidden'], p['direction'], cur)
+            if x.shape[2] != 1 or p.get('axis', 'x') == 'y':
+                assert cur is None, 'seq_lens with an LSTM over image rows/columns (the reference raises)'
+                x = lstm_image(x, ws, p['hidden'], p['direction'], p.get('axis', 'x'))
+            else:
+                x = lstm(x, ws, p['hidden'], p['direction'], cur)
         elif k == 'linear':
             x = linear(x, sd[f'nn.{nm}.lin.weight'], sd[f'nn.{nm}.lin.bias'])
         else:

@@ -87,6 +87,11 @@ class CpuRecognizer:
                 x = x.permute(0, 2, 1, 3).reshape(n, h * c, 1, w)
             elif s.kind == 'rnn':       # layers.py:513-547
                 n, c, h, w = x.shape
+                if s.params.get('axis', 'x') == 'y':     # `transpose`: HNWC -> WNHC, columns are the sequences (:521-523)
+                    seq = x.permute(2, 0, 3, 1).transpose(0, 2).reshape(w * n, h, c)
+                    o, _ = self.rnn[nm](seq)
+                    x = o.reshape(w, n, h, -1).transpose(0, 2).permute(1, 3, 0, 2)
+                    continue
                 seq = x.permute(2, 0, 3, 1).reshape(h * n, w, c)
                 if cur is not None:
                     packed = pack_padded_sequence(seq, cur.cpu().clamp(min=1), batch_first=True, enforce_sorted=False)

@@ -17,6 +17,7 @@ Nothing here runs on the GPU box; the fixtures travel instead.  What is pinned:
                    greedy_decoder tuples for equal-width batches, and per-line (batch = 1) results for
                    the ragged widths {401, 613, 800} -- the parity target for masked padding.
   layers.npz       single-layer networks through the reference's layer wrappers: odd/even kernels,
+  image_lstm.npz   LSTMs over image rows / columns (Lxx, Lxy on 4-D inputs) and a scaled-down BLLA segmenter.
                    strides, dilation (incl. the Cr4,2,*,4,2 form of tests/test_vgsl.py:71), max-pool
                    floor cases, masked GroupNorm, the S1(1x0)1,3 reshape, f/r/b LSTMs with ragged lens.
   codec.npz        PytorchCodec.decode / encode known answers incl. multi-label codes.
@@ -121,9 +122,21 @@ def bench_fixture(spec, path, seed=0, cases=None):
     print('wrote', path, {k: (v.shape if hasattr(v, 'shape') else '') for k, v in out.items() if 'logits' in k})
 
 
+IMAGE_LSTM_CASES = {
+    # LSTMs over image rows (x) and columns (y) -- TransposedSummarizingRNN on 4-D inputs -- and a scaled-down
+    # BLLA segmenter (reference default spec kraken/configs/vgsl.py:122 + the O2l heatmap head, model.py:806-811)
+    'lstm_x_img':  ('[1,5,0,3 Lbx6]', 2, 9, None),
+    'lstm_y_img':  ('[1,5,0,3 Lby6]', 2, 9, None),
+    'lstm_fy_img': ('[1,7,0,4 Lfy5]', 1, 6, None),
+    'lstm_xy_h1':  ('[1,1,0,6 Lby4]', 2, 5, None),
+    'blla_small':  ('[1,48,0,3 Cr7,7,16,2,2 Gn8 Cr3,3,32,2,2 Gn8 Cr3,3,32 Gn8 Lbx8 Lby8 Cr1,1,8 Gn8 Lby8 Lbx8 O2l3]', 1, 70, None),
+    'blla_batch2': ('[1,20,0,3 Cr7,7,8,2,2 Gn4 Lbx4 Lby4 Cr1,1,8 Gn4 Lby4 Lbx4 O2l2]', 2, 33, None),
+}
+
+
 @torch.inference_mode()
-def layer_fixture(path):
-    cases = {
+def layer_fixture(path, cases=None):
+    cases = cases or {
         'conv_odd':      ('[1,9,0,3 Cr3,5,7]', 2, 37, None),
         'conv_even_str': ('[1,12,0,1 Cr4,2,5,4,2]', 2, 41, None),
         'conv_stride2':  ('[1,30,0,1 Cr3,3,8,2,2]', 2, 45, [45, 31]),
@@ -315,7 +328,7 @@ def transforms_fixture(path):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'bench_a', 'bench_b', 'layers', 'codec', 'transforms']
+    which = sys.argv[1:] or ['overfit', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'codec', 'transforms']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'bench_a' in which:
@@ -325,6 +338,8 @@ if __name__ == '__main__':
                       cases=(('n4w400', 4, 400, [0, 3]), ('n16w800', 16, 800, [7])))
     if 'layers' in which:
         layer_fixture(os.path.join(HERE, 'layers.npz'))
+    if 'image_lstm' in which:
+        layer_fixture(os.path.join(HERE, 'image_lstm.npz'), IMAGE_LSTM_CASES)
     if 'codec' in which:
         codec_fixture(os.path.join(HERE, 'codec.npz'))
     if 'transforms' in which:

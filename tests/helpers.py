@@ -27,8 +27,8 @@ def arr_to_tuples(flat, counts):
     return out
 
 
-def layer_cases():
-    z = load_golden('layers.npz')
+def layer_cases(fname='layers.npz'):
+    z = load_golden(fname)
     cases = json.loads(str(z['cases']))
     out = {}
     for name, meta in cases.items():

@@ -24,6 +24,7 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3
 CONF_TOL = 1e-4
 CASES = layer_cases()
+CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, scaled-down BLLA segmenter
 
 
 def _keys(tuples):
@@ -550,3 +551,35 @@ def test_lstm_32_line_tiles_match_16_line_tiles(bench_a_x3, monkeypatch):
     got = bench_a_x3.nn.recognize(x, lens)[0].tuples()
     assert _keys(got) == _keys(base)
     assert _max_conf_diff(got, base) < 1e-6
+
+
+@pytest.mark.parametrize('lens', [None, [400, 333]])
+def test_groupnorm_large_image_split_path(lens):
+    """Maps with >= 128k elements per (line, group) take the multi-workgroup GroupNorm (BLLA-sized inputs)."""
+    m = build_model('[1,96,0,8 Gn2 Cr3,3,4]', seed=11)
+    x = torch.randn(2, 8, 96, 400, generator=torch.Generator().manual_seed(3))
+    if lens:
+        for i, L in enumerate(lens):
+            x[i, ..., L:] = 0
+    want, _ = CpuRecognizer(m.layer_specs, m.state_dict()).forward(x, lens)
+    m.to('cuda')
+    got, _ = m.nn(x.cuda(), None if lens is None else torch.tensor(lens))
+    for i in range(2):
+        L = lens[i] if lens else 400
+        assert (got.cpu()[i, ..., :L] - want[i, ..., :L]).abs().max().item() < 2e-5
+
+
+def test_blla_segmenter_forward_matches_oracle():
+    """BASELINE.json config 5 at reduced size: the reference's default BLLA spec (+ 4-class heatmap head) on a
+    (1, 3, 360, 270) page; the full 1800 x 1350 page is timed and checked by tools/blla_forward.py."""
+    spec = ('[1,360,0,3 Cr7,7,64,2,2 Gn32 Cr3,3,128,2,2 Gn32 Cr3,3,128 Gn32 Cr3,3,256 Gn32 Cr3,3,256 Gn32 '
+            'Lbx32 Lby32 Cr1,1,32 Gn32 Lby32 Lbx32 O2l4]')
+    m = build_model(spec, seed=2)
+    x = torch.rand(1, 3, 360, 270, generator=torch.Generator().manual_seed(4))
+    want, _ = CpuRecognizer(m.layer_specs, m.state_dict()).forward(x)
+    m.to('cuda')
+    got, olens = m.nn(x.cuda())
+    assert olens is None and tuple(got.shape) == tuple(want.shape) == (1, 4, 90, 68)
+    assert (got.cpu() - want).abs().max().item() < LOGIT_TOL
+    with pytest.raises(Exception):          # seq_lens + 2-D LSTMs: the reference raises too (layers.py:528-530)
+        m.nn(x.cuda(), torch.tensor([270]))

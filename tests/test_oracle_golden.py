@@ -16,6 +16,7 @@ from tests.specs import BENCH_A, BENCH_B
 
 LAYER_TOL = 2e-5
 CASES = layer_cases()
+CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, scaled-down BLLA segmenter
 
 
 def _zero_pad_x(x, lens):
