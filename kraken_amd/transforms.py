@@ -119,6 +119,16 @@ class ImageInputTransforms:
         return int(p), int(p)
 
     def __call__(self, im: Image.Image) -> torch.Tensor:
+        im = self.pil_stage(im)
+        arr = np.array(im, dtype=np.uint8)
+        t = torch.from_numpy(arr)
+        t = t[None] if t.dim() == 2 else t.permute(2, 0, 1)
+        t = t.to(torch.float32) / 255.0
+        t = t.max() - t
+        return t.permute(*self._perm).to(self._dtype)
+
+    def pil_stage(self, im: Image.Image) -> Image.Image:
+        """The transforms in front of PILToTensor (mode, dewarp / resize, padding): what the segmenter keeps as `scal_im`."""
         im = im.convert(self._mode)
         sh, sw = self._scale
         if (sh, sw) != (0, 0):
@@ -138,11 +148,10 @@ class ImageInputTransforms:
                     ow = int(w * oh / h)
                 im = im.resize((ow, oh), Image.Resampling.LANCZOS)
         if self._pad:
-            px, py = self._horizontal_pad()
-            im = ImageOps.expand(im, border=(px, py), fill=255 if self._mode == 'L' else (255, 255, 255))
-        arr = np.array(im, dtype=np.uint8)
-        t = torch.from_numpy(arr)
-        t = t[None] if t.dim() == 2 else t.permute(2, 0, 1)
-        t = t.to(torch.float32) / 255.0
-        t = t.max() - t
-        return t.permute(*self._perm).to(self._dtype)
+            p = self._pad
+            if isinstance(p, (tuple, list)) and len(p) == 4:
+                border = tuple(int(v) for v in p)            # torchvision v2.Pad order: left, top, right, bottom
+            else:
+                border = self._horizontal_pad()
+            im = ImageOps.expand(im, border=border, fill=255 if self._mode == 'L' else (255, 255, 255))
+        return im

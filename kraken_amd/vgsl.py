@@ -368,15 +368,33 @@ class HipSequential(nn.Module):
         self._plan = None
         self._plan_key = None
 
-    def plan(self, device_index: int) -> _Plan:
-        key = (device_index, self.precision, self._weights_version())
+    def plan(self, device_index: int, height: Optional[int] = None) -> _Plan:
+        # legacy [1,1,0,48]-style inputs keep the line height in the channel axis: C=48, H=1
+        _, c, h, _ = self._input
+        if height is not None and height != h:
+            self._specs_for_height(height)   # raises if the weights do not fit that height
+            h = height
+        key = (device_index, self.precision, self._weights_version(), h)
         if self._plan is None or self._plan_key != key:
             self.invalidate()
-            # legacy [1,1,0,48]-style inputs keep the line height in the channel axis: C=48, H=1
-            _, c, h, _ = self._input
             self._plan = _Plan(self._specs, self, c, h, device_index, self.precision)
             self._plan_key = key
         return self._plan
+
+    def _specs_for_height(self, height: int):
+        """
+        Shape inference for an input whose height differs from the spec's (a padded page in the segmenter,
+        spred.py:253-259: torch modules do not care).  Allowed when every weight-bearing layer keeps its input
+        channel count; a height-collapsing reshape does not, and the reference would fail in the next layer too.
+        """
+        n, c, _, w = self._input
+        text = f'[{n},{height},{w},{c} ' + ' '.join(s.text for s in self._specs) + ']'
+        _, specs = parse_vgsl(text)
+        for a, b in zip(self._specs, specs):
+            if a.kind in ('conv', 'groupnorm', 'rnn', 'linear') and a.in_shape[1] != b.in_shape[1]:
+                raise ValueError(f'input height {height} does not fit layer {a.name} of a network built for height '
+                                 f'{self._input[2]} ({b.in_shape[1]} input features instead of {a.in_shape[1]})')
+        return specs
 
     def _apply(self, fn, *args, **kwargs):
         r = super()._apply(fn, *args, **kwargs)
@@ -397,6 +415,8 @@ class HipSequential(nn.Module):
     def _prep(self, x: torch.Tensor, seq_lens):
         if x.dim() != 4:
             raise ValueError(f'expected a (N, C, H, W) tensor, got shape {tuple(x.shape)}')
+        if x.shape[1] != self._input[1]:
+            raise ValueError(f'expected {self._input[1]} input channels, got {x.shape[1]}')
         dev = self._device_index(x)
         xd = x.detach().to(device=f'cuda:{dev}', dtype=torch.float32).contiguous()
         lens = None
@@ -413,7 +433,7 @@ class HipSequential(nn.Module):
         logits tensor (a permuted view of the time-major buffer the kernels write) on the GPU.
         """
         dev, xd, lens = self._prep(x, seq_lens)
-        plan = self.plan(dev)
+        plan = self.plan(dev, xd.shape[2])
         N, _, _, W = xd.shape
         c, h, w = plan.out_shape(W)
         seq_out = self._specs_out_is_seq()
@@ -453,7 +473,7 @@ class HipSequential(nn.Module):
         (N, C, T) permuted views on the GPU.
         """
         dev, xd, lens = self._prep(x, seq_lens)
-        plan = self.plan(dev)
+        plan = self.plan(dev, xd.shape[2])
         N, _, _, W = xd.shape
         c, h, T = plan.out_shape(W)
         with torch.cuda.device(dev):

@@ -583,3 +583,48 @@ def test_blla_segmenter_forward_matches_oracle():
     assert (got.cpu() - want).abs().max().item() < LOGIT_TOL
     with pytest.raises(Exception):          # seq_lens + 2-D LSTMs: the reference raises too (layers.py:528-530)
         m.nn(x.cuda(), torch.tensor([270]))
+
+
+def test_blla_compute_segmentation_map_mirror():
+    """kraken_amd.blla.compute_segmentation_map == the reference recipe (spred.py:237-287) evaluated with the CPU oracle."""
+    from PIL import Image
+    import torch.nn.functional as F
+    from kraken_amd.blla import compute_segmentation_map
+    from kraken_amd.transforms import ImageInputTransforms
+    spec = '[1,64,0,3 Cr7,7,16,2,2 Gn8 Cr3,3,32,2,2 Gn8 Lbx8 Lby8 Cr1,1,8 Gn8 Lby8 Lbx8 O2l3]'
+    m = build_model(spec, seed=5)
+    m.model_type = 'segmentation'
+    m.user_metadata['class_mapping'] = {'baselines': {'default': 2}, 'regions': {}, 'aux': {'_start_separator': 0, '_end_separator': 1}}
+    rng = np.random.default_rng(0)
+    im = Image.fromarray(rng.integers(0, 256, (150, 200, 3), dtype=np.uint8), 'RGB')
+    for pad in (0, (4, 2)):
+        res = compute_segmentation_map(m, im, input_padding=pad)
+        p4 = (pad,) * 4 if isinstance(pad, int) else (pad[0], pad[0], pad[1], pad[1])
+        ts = ImageInputTransforms(1, 64, 0, 3, p4, valid_norm=False)
+        want, _ = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()}).forward(ts(im).unsqueeze(0))
+        scal = np.array(ts.pil_stage(im).convert('L'))
+        o = torch.sigmoid(F.interpolate(want, size=scal.shape))
+        pp = [p if p else None for p in p4]
+        pp[1] = -pp[1] if pp[1] else None
+        pp[3] = -pp[3] if pp[3] else None
+        o = o[:, :, pp[2]:pp[3], pp[0]:pp[1]].squeeze().numpy()
+        assert res['heatmap'].shape == o.shape and res['scal_im'].shape == scal[pp[2]:pp[3], pp[0]:pp[1]].shape
+        assert np.abs(res['heatmap'] - o).max() < 1e-4
+        np.testing.assert_allclose(res['scale'], np.divide(im.size, o.shape[:0:-1]))
+        assert res['cls_map'] == m.user_metadata['class_mapping']
+
+
+def test_input_height_and_channels_are_checked(bench_a):
+    """A recogniser built for height 48 must refuse other heights (its reshape would feed the LSTM a different
+    feature count); height-agnostic networks (convolutions, 2-D LSTMs) get a plan per height."""
+    with pytest.raises(ValueError):
+        bench_a.nn(torch.rand(1, 1, 40, 64).cuda())
+    with pytest.raises(ValueError):
+        bench_a.nn(torch.rand(1, 3, 48, 64).cuda())
+    m = build_model('[1,16,0,1 Cr3,3,8 Mp2,2 Cr3,3,4]', seed=1)
+    for h in (16, 22):
+        x = torch.rand(2, 1, h, 31, generator=torch.Generator().manual_seed(h))
+        want, _ = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()}).forward(x)
+        m.to('cuda')
+        got, _ = m.nn(x.cuda())
+        assert tuple(got.shape) == tuple(want.shape) and (got.cpu() - want).abs().max().item() < 2e-5
