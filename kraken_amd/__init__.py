@@ -8,6 +8,7 @@ The package mirrors the reference's module layout for the path only:
     kraken_amd.ctc_decoder  greedy_decoder                    (kraken.lib.ctc_decoder)
     kraken_amd.codec        PytorchCodec                      (kraken.lib.codec)
     kraken_amd.rpred        rpred, mm_rpred                   (kraken.rpred)
+    kraken_amd.blla         compute_segmentation_map          (kraken.lib.vgsl.spred, forward only)
     kraken_amd.dist         line sharding + gather over RCCL  (new; no reference analogue)
 
 All arithmetic of the forward pass and the CTC decode lives in ``csrc/*.hip`` behind the
