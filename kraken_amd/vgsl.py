@@ -83,7 +83,7 @@ def parse_vgsl(spec: str):
     Parses a sequential VGSL spec into the input 4-tuple (batch, channels, height, width)
     and a list of LayerSpec.  Grammar: SURVEY.md Appendix A (reference model.py:579-817).
     Raises ValueError for malformed specs and NotImplementedError for valid VGSL the
-    HIP executor does not cover (parallel blocks, transposed conv, y-axis/summarising/legacy
+    HIP executor does not cover (parallel blocks, transposed conv, summarising/legacy
     RNNs, addition, wav2vec masking).
     """
     spec = spec.strip()
