@@ -204,9 +204,10 @@ int plan_x3_geom(ConvGeom& g) {
     if (g.Cin % 16) return fail(KRK_E_UNSUPPORTED, "bf16x3: input channels/features must be a multiple of 16");
     const int npix = g.IH * g.IW;
     int c = g.Cin;
-    const size_t budget = getenv("KRK_X3_LDS_KB") ? (size_t)atoi(getenv("KRK_X3_LDS_KB")) * 1024 : 74 * 1024;
+    // 2 workgroups per CU: 160 KB / 2 minus the 24 KB weight ring of conv_x3.hip
+    const size_t budget = getenv("KRK_X3_LDS_KB") ? (size_t)atoi(getenv("KRK_X3_LDS_KB")) * 1024 : 52 * 1024;
     while (c > 16 && (size_t)2 * npix * (c * 2 + 16) > budget) c -= 16;
-    if ((size_t)2 * npix * (c * 2 + 16) > 150 * 1024) return fail(KRK_E_UNSUPPORTED, "bf16x3: convolution window too large");
+    if ((size_t)2 * npix * (c * 2 + 16) > 130 * 1024) return fail(KRK_E_UNSUPPORTED, "bf16x3: convolution window too large");
     g.xnchunks = (g.Cin + c - 1) / c;
     g.xchunk = ((g.Cin + g.xnchunks - 1) / g.xnchunks + 15) / 16 * 16;
     g.xnchunks = (g.Cin + g.xchunk - 1) / g.xchunk;

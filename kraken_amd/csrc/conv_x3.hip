@@ -15,8 +15,8 @@
 //   LDS       = [IH][IW] input pixels x cchunk channels per plane, pixel stride padded by 16 B
 //               (conflict-free ds_read_b128 for 32/64-channel chunks)
 //   staging   = straight 16-byte copies global -> LDS (the producer already wrote split NHWC)
-//   K loop    = taps (dy,dx) x 16-channel blocks; operands of iteration i+1 are fetched while the
-//               6*CB MFMAs of iteration i issue; weights stream from L2 in fragment order
+//   K loop    = taps (dy,dx) x 16-channel blocks; weights ring through LDS in 8 KB stages (asynchronous
+//               global -> LDS copies two stages ahead, one barrier per 24 MFMAs), shared by the four waves
 //   epilogue  = bias + activation (+ 2x2 max-pool) + length mask, written either as split NHWC
 //               (next conv / projection) or as fp32 rows [pixel][filter] (LSTM gates, logits)
 #include "common.h"
@@ -46,6 +46,7 @@ template <int POOL, int OUT_F32, int CB>
 __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     unsigned char* tile = smem8;                       // hi plane, then lo plane (+ a.lds_plane bytes)
+    unsigned char* wring = smem8 + 2 * a.lds_plane;    // weight ring: 3 stages x 8 KB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                     const int gh = gh0 + ih, gw = gw0 + iw;
                     const int gc = ci * a.cchunk + q * 8;
                     dst[i] = plane * a.lds_plane + pix * a.PSTR + q * 16;
-                    if (gc < a.Cin && gh >= 0 && gh < a.H && gw >= 0 && gw < len_in) {
+                    if (gc < a.Cin && gh >= 0 && gh < a.H && gw >= 0 && gw < len_in && !(a.dbg & 2)) {
                         const __bf16* src = a.x + (size_t)plane * a.x_plane +
                                             (((size_t)n * a.H + gh) * a.W + gw) * a.Cin + gc;
                         v[i] = *reinterpret_cast<const f32x4*>(src);
@@ -135,66 +136,78 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                 if (dst[i] >= 0) *reinterpret_cast<f32x4*>(tile + dst[i]) = v[i];
         }
         __syncthreads();
-        if (!any_live) continue;
 
         // ---------------------------------------------------------------- K loop: taps x 16-channel blocks
+        // Weights travel through LDS: per-wave fragment loads from L2 need ~85 B/clk/CU at full MFMA rate against a
+        // 64 B/clk L1 path, and all four waves want the same bytes.  A stage = IT iterations x CB blocks x (hi, lo) =
+        // 8 KB = 24 MFMAs per wave; three stages ring through LDS, filled by global_load_lds_dwordx4 two stages ahead
+        // (2 copies per wave and stage), counted vmcnt + one raw s_barrier per stage -- the gemm_x3.hip pipeline.
         const int kbn = (ci + 1 == a.nchunks) ? a.KB_last : a.KB;
-        const int nit = ntaps * kbn;
-        // weights: [chunk][tap][kb (KB per chunk)][cb][plane][lane][8]
-        const __bf16* wbase = a.wpack + ((size_t)ci * ntaps * a.KB * a.CBpad + cb0) * 1024 + lane * 8;
-        const size_t wkb = (size_t)a.CBpad * 1024;       // elements per (tap, kb) record
-
-        int dy = 0, dx = 0, kb = 0;                       // coordinates of the iteration being FETCHED
-        auto fetch = [&](Frags& f, bf16x8 (&wh)[CB], bf16x8 (&wl)[CB]) {
-            const int xoff = (dy * a.dh * a.IW + dx * a.dw) * a.PSTR + kb * 32;
+        const int nit = ntaps * kbn;                      // iteration it = tap * kbn + kb: record it of this chunk
+        constexpr int IT = 4 / CB;
+        const int nst = (nit + IT - 1) / IT;
+        const size_t wkb = (size_t)a.CBpad * 1024;        // elements per (tap, kb) record
+        const __bf16* wrec0 = a.wpack + ((size_t)ci * ntaps * a.KB * a.CBpad + cb0) * 1024 + lane * 8;
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        auto issue = [&](int st, int slot) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f.xh[s] = *reinterpret_cast<const bf16x8*>(tile + vb[s] + xoff);
-                f.xl[s] = *reinterpret_cast<const bf16x8*>(tile + a.lds_plane + vb[s] + xoff);
-            }
-            const __bf16* wp = wbase + ((size_t)(dy * a.kw + dx) * a.KB + kb) * wkb;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                wh[cb] = *reinterpret_cast<const bf16x8*>(wp + cb * 1024);
-                wl[cb] = *reinterpret_cast<const bf16x8*>(wp + cb * 1024 + 512);
-            }
-            if (++kb == kbn) {
-                kb = 0;
-                if (++dx == a.kw) { dx = 0; ++dy; }
+            for (int k = 0; k < 2; ++k) {
+                const int p = wave * 2 + k;               // 1 KB piece of the stage: (iteration, block, plane)
+                const int it_in = p / (2 * CB), rem = p - it_in * (2 * CB);
+                const __bf16* src = wrec0 + (size_t)(st * IT + it_in) * wkb + rem * 512;
+                __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)(wring + slot * 8192 + p * 1024), 16, 0, 0);
             }
         };
-        auto mma = [&](const Frags& f, const bf16x8 (&wh)[CB], const bf16x8 (&wl)[CB]) {
+
+        int dy = 0, dx = 0, kb = 0;                       // coordinates of the iteration being computed
+        issue(0, 0);
+        if (nst > 1) issue(1, 1);
+        int slot = 0;
+        for (int st = 0; st < nst; ++st) {
+            if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // stage st landed for everyone; stage st-1 fully read
+            if (st + 2 < nst && !(a.dbg & 8)) issue(st + 2, slot >= 1 ? slot - 1 : 2);
+            if (any_live && !(a.dbg & 1)) {
+                const int nk = min(IT, nit - st * IT);
+                const unsigned char* wst = wring + slot * 8192 + lane * 16;
+                for (int k = 0; k < nk; ++k) {
+                    const int xoff = (dy * a.dh * a.IW + dx * a.dw) * a.PSTR + kb * 32;
+                    bf16x8 xh[2], xl[2], wh[CB], wl[CB];
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    // no per-segment liveness guard: a dead segment's result is masked in the epilogue and a
-                    // guard would put every MFMA into its own basic block (hazard nops, no overlap)
-                    {
-                        if (OUT_F32) {   // D[pixel][filter]
-                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.xh[s], wh[cb], acc[cb][s], 0, 0, 0);
-                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.xl[s], wh[cb], acc[cb][s], 0, 0, 0);
-                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.xh[s], wl[cb], acc[cb][s], 0, 0, 0);
-                        } else {         // D[filter][pixel]
-                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], f.xh[s], acc[cb][s], 0, 0, 0);
-                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], f.xl[s], acc[cb][s], 0, 0, 0);
-                            acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], f.xh[s], acc[cb][s], 0, 0, 0);
-                        }
+                    for (int sg = 0; sg < 2; ++sg) {
+                        xh[sg] = *reinterpret_cast<const bf16x8*>(tile + vb[sg] + xoff);
+                        xl[sg] = *reinterpret_cast<const bf16x8*>(tile + a.lds_plane + vb[sg] + xoff);
                     }
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        wh[cb] = *reinterpret_cast<const bf16x8*>(wst + (k * CB + cb) * 2048);
+                        wl[cb] = *reinterpret_cast<const bf16x8*>(wst + (k * CB + cb) * 2048 + 1024);
+                    }
+                    if (++kb == kbn) {
+                        kb = 0;
+                        if (++dx == a.kw) { dx = 0; ++dy; }
+                    }
+                    // no per-segment liveness guard: a dead segment's result is masked in the epilogue and a guard
+                    // would put every MFMA into its own basic block (hazard nops, no overlap)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int sg = 0; sg < 2; ++sg) {
+                            if (OUT_F32) {   // D[pixel][filter]
+                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[sg], wh[cb], acc[cb][sg], 0, 0, 0);
+                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[sg], wh[cb], acc[cb][sg], 0, 0, 0);
+                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[sg], wl[cb], acc[cb][sg], 0, 0, 0);
+                            } else {         // D[filter][pixel]
+                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xh[sg], acc[cb][sg], 0, 0, 0);
+                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xl[sg], acc[cb][sg], 0, 0, 0);
+                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], xh[sg], acc[cb][sg], 0, 0, 0);
+                            }
+                        }
                 }
-        };
-
-        Frags fa, fb;
-        bf16x8 wha[CB], wla[CB], whb[CB], wlb[CB];
-        fetch(fa, wha, wla);
-        int it = 0;
-        for (; it + 1 < nit; it += 2) {
-            fetch(fb, whb, wlb);
-            mma(fa, wha, wla);
-            if (it + 2 < nit) fetch(fa, wha, wla);
-            mma(fb, whb, wlb);
+            }
+            slot = slot == 2 ? 0 : slot + 1;
         }
-        if (it < nit) mma(fa, wha, wla);
     }
 
     // ------------------------------------------------------------------------------- epilogues
@@ -260,7 +273,7 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                         hv[i] = h;
                         lv[i] = (__bf16)(v - (float)h);
                     }
-                    if (st && co < a.Cout) {
+                    if (st && co < a.Cout && !(a.dbg & 4)) {
                         size_t o = base + co;
                         if (a.y_blkM > 0) {   // K-blocked sequence rows: feature f = row*Cout + co -> [f/8][line*cols + col][f%8]
                             const int f = row * a.Cout + co;
@@ -354,7 +367,7 @@ int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s) 
     const int CBt = (a.Cout + 31) / 32;
     const int cb = krk_x3_cb(a.Cout);
     dim3 grid((unsigned)(a.tiles_w * a.tiles_h * a.N), (unsigned)((CBt + cb - 1) / cb));
-    const size_t lds = (size_t)2 * a.lds_plane;
+    const size_t lds = (size_t)2 * a.lds_plane + 3 * 8192;   // input tile (hi, lo) + weight ring
     if (out_f32) return pool ? -1 : launch_cb<0, 1>(a, cb, grid, lds, s);
     return pool ? launch_cb<1, 0>(a, cb, grid, lds, s) : launch_cb<0, 0>(a, cb, grid, lds, s);
 }
