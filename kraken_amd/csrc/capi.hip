@@ -1071,6 +1071,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     a.tiles_h = (g.Ho + 7) / 8; a.tiles_w = (a.Wo + 127) / 128;
                     split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
                     a.y_pitch = g.out_nhcw ? nhcw_pitch(a.Wy) : 0;
+                    a.dbg = getenv("KRK_X3_DBG") ? atoi(getenv("KRK_X3_DBG")) : 0;
                     s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
                     if (mark("conv1_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
                     rc = krk_launch_conv1_x3(a, g.pool, stream);

@@ -98,6 +98,7 @@ struct Conv1Args {
     int N, H, W, Cout, kh, kw, ph, pw;
     int Ho, Wo, Hy, Wy;
     int act, tiles_h, tiles_w;
+    int dbg;              // probe bits (env KRK_X3_DBG): 1 no K loop, 2 no staging loads, 4 no stores
     int y_pitch;          // > 0: write "NHCW" planes [N][Hy][Cout][y_pitch] (for conv_taps_x3.hip) instead of NHWC
 };
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
         for (int i = 0; i < NST; ++i) {
             const int gw = w0 + s_iw[i];
             st[i] = 0.f;
-            if (gw >= 0 && gw < len_in) st[i] = xin[s_off[i] + w0];
+            if (gw >= 0 && gw < len_in && !(a.dbg & 2)) st[i] = xin[s_off[i] + w0];
         }
     };
     auto lstore = [&](int buf) {
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[o][s][r] = 0.f;
 
-        if (w0 < wlim) {
+        if (w0 < wlim && !(a.dbg & 1)) {
 #pragma unroll
             for (int i = 0; i < KH + 1; ++i) {
                 bf16x8 f[2][4];   // [plane][segment]
@@ -146,39 +146,47 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
             // filters -> one 4/8-byte store per filter, 128/256 bytes contiguous across the wave.  Columns between
             // the line's length and the pitch are written as zeros (the consumer stages whole 16-byte pieces).
             constexpr int NO = POOL ? 1 : 2;
+            constexpr int NV = POOL ? 2 : 4;
+            // the activation is chosen once per tile, not per element: ReLU (every kraken recogniser) is one v_max
+            auto store_tile = [&](auto actf) {
 #pragma unroll
-            for (int o = 0; o < NO; ++o) {
-                const int row = POOL ? (h0 >> 1) + wave : h0 + 2 * wave + o;
-                const int col0 = POOL ? (w0 >> 1) + 2 * c : w0 + 4 * c;
-                if (row >= a.Hy || col0 >= a.y_pitch) continue;
-                const int lim = min(len_out, a.Wy);
+                for (int o = 0; o < NO; ++o) {
+                    const int row = POOL ? (h0 >> 1) + wave : h0 + 2 * wave + o;
+                    const int col0 = POOL ? (w0 >> 1) + 2 * c : w0 + 4 * c;
+                    if (row >= a.Hy || col0 >= a.y_pitch || (a.dbg & 4)) continue;
+                    const int lim = min(len_out, a.Wy);
+                    // 64-bit base once, 32-bit filter offsets: filter f of this row starts f * pitch elements further
+                    __bf16* rowh = yh + ((size_t)n * a.Hy + row) * a.Cout * a.y_pitch + col0;
+                    __bf16* rowl = rowh + a.y_plane;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (f >= a.Cout) continue;
-                    constexpr int NV = POOL ? 2 : 4;
-                    __bf16 hv[NV], lv[NV];
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (f >= a.Cout) continue;
+                        __bf16 hv[NV], lv[NV];
 #pragma unroll
-                    for (int e = 0; e < NV; ++e) {
-                        float v;
-                        if (POOL) v = fmaxf(fmaxf(acc[0][2 * e][r], acc[0][2 * e + 1][r]), fmaxf(acc[1][2 * e][r], acc[1][2 * e + 1][r]));
-                        else v = acc[o][e][r];
-                        v = krk_act(v + bias4[r >> 2][r & 3], a.act);
-                        if (col0 + e >= lim) v = 0.f;
-                        hv[e] = (__bf16)v;
-                        lv[e] = (__bf16)(v - (float)hv[e]);
-                    }
-                    const size_t o_ = (((size_t)n * a.Hy + row) * a.Cout + f) * a.y_pitch + col0;
-                    if (POOL) {
-                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                        *reinterpret_cast<bf16x2*>(yh + o_) = bf16x2{hv[0], hv[1]};
-                        *reinterpret_cast<bf16x2*>(yl + o_) = bf16x2{lv[0], lv[1]};
-                    } else {
-                        *reinterpret_cast<bf16x4*>(yh + o_) = bf16x4{hv[0], hv[1], hv[2], hv[3]};
-                        *reinterpret_cast<bf16x4*>(yl + o_) = bf16x4{lv[0], lv[1], lv[2], lv[3]};
+                        for (int e = 0; e < NV; ++e) {
+                            float v;
+                            if (POOL) v = fmaxf(fmaxf(acc[0][2 * e][r], acc[0][2 * e + 1][r]), fmaxf(acc[1][2 * e][r], acc[1][2 * e + 1][r]));
+                            else v = acc[o][e][r];
+                            v = actf(v + bias4[r >> 2][r & 3]);
+                            if (col0 + e >= lim) v = 0.f;
+                            hv[e] = (__bf16)v;
+                            lv[e] = (__bf16)(v - (float)hv[e]);
+                        }
+                        const int off = f * a.y_pitch;
+                        if (POOL) {
+                            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                            *reinterpret_cast<bf16x2*>(rowh + off) = bf16x2{hv[0], hv[1]};
+                            *reinterpret_cast<bf16x2*>(rowl + off) = bf16x2{lv[0], lv[1]};
+                        } else {
+                            *reinterpret_cast<bf16x4*>(rowh + off) = bf16x4{hv[0], hv[1], hv[2], hv[3]};
+                            *reinterpret_cast<bf16x4*>(rowl + off) = bf16x4{lv[0], lv[1], lv[2], lv[3]};
+                        }
                     }
                 }
-            }
+            };
+            if (a.act == ACT_RELU) store_tile([](float v) { return fmaxf(v, 0.f); });
+            else store_tile([&](float v) { return krk_act(v, a.act); });
         } else if constexpr (POOL) {
             const int prow = (h0 >> 1) + wave;
 #pragma unroll

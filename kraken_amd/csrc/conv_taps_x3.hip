@@ -173,6 +173,8 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
     for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + 8 * j + 4 * half);
     __bf16* yh = a.y;
     __bf16* yl = a.y + a.y_plane;
+    // the activation is chosen once per tile, not per element: ReLU is a single v_max
+    auto store_tile = [&](auto actf) {
     if (POOL) {
         const int prow = (h0 >> 1) + rp;
         const int pcol = (w0 >> 1) + 32 * chalf + c;
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * j + i;
                 float v = fmaxf(fmaxf(acc[0][0][r], acc[0][1][r]), fmaxf(acc[1][0][r], acc[1][1][r]));
-                v = krk_act(v + bias4[j][i], a.act);
+                v = actf(v + bias4[j][i]);
                 if (pcol >= len_out) v = 0.f;
                 const __bf16 h = (__bf16)v;
                 hv[i] = h;
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
                     bf16x4 hv, lv;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = krk_act(acc[o][s][4 * j + i] + bias4[j][i], a.act);
+                        float v = actf(acc[o][s][4 * j + i] + bias4[j][i]);
                         if (col >= len_out) v = 0.f;
                         const __bf16 h = (__bf16)v;
                         hv[i] = h;
@@ -226,6 +228,9 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
             }
         }
     }
+    };
+    if (a.act == ACT_RELU) store_tile([](float v) { return fmaxf(v, 0.f); });
+    else store_tile([&](float v) { return krk_act(v, a.act); });
 }
 
 template <int PW>

@@ -235,6 +235,8 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
             }
         }
     } else {
+        // the activation is chosen once per tile, not per element: ReLU is a single v_max
+        auto store_tile = [&](auto actf) {
         // split NHWC (or split sequence rows): element index n*y_sn + row*y_sr + col*y_sc + filter
         __bf16* yh = reinterpret_cast<__bf16*>(a.y);
         __bf16* yl = yh + a.y_plane;
@@ -260,6 +262,7 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                 for (int rq = 0; rq < 4; ++rq) {
                     const int co = (cb0 + cb) * 32 + 8 * rq + 4 * half;
                     bf16x4 hv, lv;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + min(co, a.CBpad * 32 - 4));   // co % 4 == 0, padded buffer
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = acc[cb][s][4 * rq + i];
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                             v = fmaxf(v, acc[cb][1][4 * rq + i]);
                             v = fmaxf(v, __shfl_xor(v, 1));
                         }
-                        v = krk_act(v + a.bias[min(co + i, a.CBpad * 32 - 1)], a.act);
+                        v = actf(v + bv[i]);
                         if (col >= len_out) v = 0.f;
                         const __bf16 h = (__bf16)v;
                         hv[i] = h;
@@ -285,6 +288,9 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                 }
             }
         }
+        };
+        if (a.act == ACT_RELU) store_tile([](float v) { return fmaxf(v, 0.f); });
+        else store_tile([&](float v) { return krk_act(v, a.act); });
     }
 }
 
