@@ -57,7 +57,7 @@ class RecognitionEngine:
         # front event of the batch submitted last: the next batch's convolution block queues behind it, so the
         # full-chip convolution blocks of different batches run one after another (no convoy of all slots doing
         # convolutions together and then all doing recurrences together) -- see include/kraken_amd.h
-        self._last_front = None
+        self._fronts = []
         self.chain_fronts = os.environ.get('KRK_NO_FRONT_CHAIN') is None
 
     def set_profiling(self, on: bool):
@@ -93,9 +93,11 @@ class RecognitionEngine:
             lens_arr = np.ascontiguousarray(np.asarray(lens, dtype=np.int32))
         cur = torch.cuda.current_stream(self.device)
         slot.stream.wait_stream(cur)   # the input may have been produced on the caller's stream
-        if self.chain_fronts and self._last_front is not None and len(self.slots) > 1:
-            _lib.check(self.lib.krk_plan_wait_front(slot.plan.handle, self._last_front))
-        self._last_front = self.lib.krk_plan_front_event(slot.plan.handle)
+        lag = int(os.environ.get('KRK_FRONT_LAG', '1'))
+        if self.chain_fronts and len(self._fronts) >= lag and len(self.slots) > 1:
+            _lib.check(self.lib.krk_plan_wait_front(slot.plan.handle, self._fronts[-lag]))
+        self._fronts.append(self.lib.krk_plan_front_event(slot.plan.handle))
+        del self._fronts[:-4]
         with torch.cuda.stream(slot.stream):
             _lib.check(self.lib.krk_recognize(slot.plan.handle, x.data_ptr(),
                                               lens_arr.ctypes.data if lens_arr is not None else None, N, W,
