@@ -573,6 +573,11 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     p->lenops.push_back({1, 2, 2, 1, 0});
                     ++stage;
                     ++i;
+                    // bf16x3: conv_x3.hip can pool AND write the collapsed sequence rows in one epilogue
+                    if (x3 && split_fmt && i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
+                        g.out_seq = true;
+                        ++i;
+                    }
                 } else if (i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
                     g.out_seq = true;
                     ++i;
@@ -586,7 +591,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     // the first convolution reads the caller's fp32 NCHW image on the f32 cores and hands
                     // over split channels-last planes; every later one runs on the bf16 cores
                     const bool first = !split_fmt;
-                    const int feat = g.out_seq ? conv_out(H, L.kh, L.sh, L.dh, g.ph) * L.cout : L.cout;
+                    const int feat = g.out_seq ? g.Hy * L.cout : L.cout;
                     if (feat % 4) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs a multiple of 4 output channels");   // the consumer checks its own K granule
                     if (first && g.out_seq) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs >= 2 convolutions before the reshape");
                     g.split_out = true;
@@ -618,7 +623,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 s.len_out = stage;
                 if (g.out_seq) {
                     s.out_is_seq = true;
-                    s.outC = g.Ho * g.Cout;
+                    s.outC = g.Hy * g.Cout;   // Hy == Ho unless a pool is fused in front of the reshape
                     s.outH = 1;
                     seq = true;
                     C = s.outC;

@@ -1,0 +1,62 @@
+"""Randomised differential test: bf16x3 plan vs f32 plan vs the CPU oracle over random batch sizes, widths and ragged
+lengths, on specs that exercise every bf16x3 kernel (conv1_x3 / conv_taps_x3 / conv_x3 / gemm_x3 / lstm_x3).
+Usage: python tools/fuzz_plans.py [seconds]"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+import kraken_amd  # noqa: E402
+from oracle.torch_port import CpuRecognizer  # noqa: E402
+from tests.specs import BENCH_A  # noqa: E402
+
+SPECS = [
+    BENCH_A,
+    '[1,48,0,1 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,64 Mp2,2 Cr3,9,64 S1(1x0)1,3 Lbx104 Lbx24 O1c97]',
+    '[1,32,0,1 Cr3,11,16 Cr3,15,32 Mp2,2 Cr5,5,32 Mp2,2 S1(1x0)1,3 Lfx48 Lbx16 O1c33]',
+    '[1,24,0,1 Cr5,16,8 Mp2,2 Cr3,12,32 Cr3,14,16 Mp2,2 S1(1x0)1,3 Lbx200 O1c12]',
+    '[1,16,0,3 Ct3,3,16 Cr3,7,48,1,2 Cl1,1,32 S1(1x0)1,3 Lbx8 O1c7]',
+]
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(time.time()) if '--time-seed' in sys.argv else 0)
+t0, n_cases, worst = time.time(), 0, 0.0
+models = []
+for i, spec in enumerate(SPECS):
+    torch.manual_seed(i)
+    m = kraken_amd.TorchVGSLModel(vgsl=spec)
+    ref = CpuRecognizer(m.layer_specs, {k: v.clone() for k, v in m.state_dict().items()})
+    m.to('cuda')
+    models.append((spec, m, ref))
+while time.time() - t0 < budget:
+    spec, m, ref = models[rng.integers(len(models))]
+    _, c, h, _ = m.input
+    n = int(rng.integers(1, 12))
+    w = int(rng.choice([rng.integers(40, 130), rng.integers(130, 700), 128, 256, 257, 511]))
+    ragged = rng.random() < 0.6
+    lens = sorted((int(v) for v in rng.integers(max(24, w // 3), w + 1, n)), reverse=True) if ragged else None
+    if lens:
+        lens[0] = w
+    x = torch.rand(n, c, h, w, generator=torch.Generator().manual_seed(int(rng.integers(1 << 30))))
+    if lens:
+        for i, L in enumerate(lens):
+            x[i, ..., L:] = 0
+    out = {}
+    for prec in ('f32', 'bf16x3'):
+        m.nn.set_precision(prec)
+        y, ol = m.nn(x.cuda(), None if lens is None else torch.tensor(lens))
+        out[prec] = (y.cpu(), None if ol is None else ol.tolist())
+    check_cpu = n_cases % 4 == 0
+    want = ref.forward(x, lens) if check_cpu else None
+    for i in range(n):
+        L = out['f32'][1][i] if lens else out['f32'][0].shape[3]
+        d = (out['f32'][0][i, ..., :L] - out['bf16x3'][0][i, ..., :L]).abs().max().item()
+        worst = max(worst, d)
+        assert d < 2e-4, (spec, n, w, lens, i, d)
+        if check_cpu:
+            dc = (out['f32'][0][i, ..., :L] - want[0][i, ..., :L]).abs().max().item()
+            assert dc < 5e-5, ('f32 vs cpu', spec, n, w, lens, i, dc)
+    assert out['f32'][1] == out['bf16x3'][1]
+    n_cases += 1
+print(f'{n_cases} random cases, worst |f32 - bf16x3| = {worst:.2e}: OK')
