@@ -405,6 +405,9 @@ def test_x3_bench_a_against_reference_golden(bench_a_x3):
     ('[1,8,0,1 Ct1,3,4 Cs3,15,16 Cl3,3,16 S1(1x0)1,3 Lfx16 O1c5]', 2, 96, None),
     ('[1,10,0,1 Cr1,16,32 Mp2,2 Cr3,11,32 Cr3,13,16 S1(1x0)1,3 Lbx8 Lbx8 O1c11]', 4, 517, [517, 516, 260, 31]),
     ('[1,9,0,1 Cr3,13,28 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,16 S1(1x0)1,3 Lbx8 O1c3]', 2, 260, [260, 131]),
+    # kraken's default recognition spec at its native height of 120 px (kraken/configs/vgsl.py:102) + output layer
+    ('[1,120,0,1 Cr3,13,32 Do0.1,2 Mp2,2 Cr3,13,32 Do0.1,2 Mp2,2 Cr3,9,64 Do0.1,2 Mp2,2 Cr3,9,64 Do0.1,2 S1(1x0)1,3 '
+     'Lbx200 Do0.1,2 Lbx200 Do0.1,2 Lbx200 Do O1c133]', 4, 700, [700, 655, 301, 64]),
     # pool AND height collapse fused into one conv_x3 epilogue (Mp directly in front of S1)
     ('[1,32,0,1 Cr3,11,16 Cr3,15,32 Mp2,2 Cr5,5,32 Mp2,2 S1(1x0)1,3 Lfx48 Lbx16 O1c33]', 3, 203, [203, 150, 77]),
 ])
