@@ -36,6 +36,13 @@ const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "l
 
 
 
+// Probe / experiment switches (documented in DESIGN.md section 5.1 and in the kernels): read once per call site.
+// The test-suite flips a few of them between calls (monkeypatch), so they are looked up per call, not cached.
+static int env_int(const char* name, int dflt = 0) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 // Python-style floor division (the reference does float division + floor).
 inline int floordiv(int a, int b) {
     int q = a / b, r = a % b;
@@ -205,7 +212,7 @@ int plan_x3_geom(ConvGeom& g) {
     const int npix = g.IH * g.IW;
     int c = g.Cin;
     // 2 workgroups per CU: 160 KB / 2 minus the 24 KB weight ring of conv_x3.hip
-    const size_t budget = getenv("KRK_X3_LDS_KB") ? (size_t)atoi(getenv("KRK_X3_LDS_KB")) * 1024 : 52 * 1024;
+    const size_t budget = (size_t)env_int("KRK_X3_LDS_KB", 52) * 1024;
     while (c > 16 && (size_t)2 * npix * (c * 2 + 16) > budget) c -= 16;
     if ((size_t)2 * npix * (c * 2 + 16) > 130 * 1024) return fail(KRK_E_UNSUPPORTED, "bf16x3: convolution window too large");
     g.xnchunks = (g.Cin + c - 1) / c;
@@ -1011,7 +1018,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
             a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
             a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0; a.y_blkM = 0; a.y_cols = 0;
-            a.dbg = getenv("KRK_X3_DBG") ? atoi(getenv("KRK_X3_DBG")) : 0;
+            a.dbg = env_int("KRK_X3_DBG");
         };
         auto fill_gemm = [&](const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane, float* yout, int rows) {
             a.x = (const __bf16*)xin; a.x_plane = x_plane;
@@ -1019,7 +1026,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             a.M = rows; a.K = g.Cin; a.Cout = g.Cout;
             a.ncg = (g.Cout + 127) / 128; a.ntiles = (rows + 255) / 256;
             a.act = g.act;
-            a.dbg = getenv("KRK_X3_DBG") ? atoi(getenv("KRK_X3_DBG")) : 0;
+            a.dbg = env_int("KRK_X3_DBG");
         };
         // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
         auto split_strides = [&](const ConvGeom& g, int Wo_, int Wy_, long& sn, long& sr, long& sc) {
@@ -1042,7 +1049,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
                     a.act = g.act;
                     a.tiles_h = (g.Ho + 3) / 4; a.tiles_w = (a.Wo + 127) / 128;
-                    a.dbg = getenv("KRK_X3_DBG") ? atoi(getenv("KRK_X3_DBG")) : 0;
+                    a.dbg = env_int("KRK_X3_DBG");
                     split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
                     s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
                     if (mark("conv_taps_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
@@ -1076,7 +1083,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     a.tiles_h = (g.Ho + 7) / 8; a.tiles_w = (a.Wo + 127) / 128;
                     split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
                     a.y_pitch = g.out_nhcw ? nhcw_pitch(a.Wy) : 0;
-                    a.dbg = getenv("KRK_X3_DBG") ? atoi(getenv("KRK_X3_DBG")) : 0;
+                    a.dbg = env_int("KRK_X3_DBG");
                     s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
                     if (mark("conv1_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
                     rc = krk_launch_conv1_x3(a, g.pool, stream);
@@ -1204,7 +1211,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     l.xstride = s.ndir * G;
                     l.ostride = s.ndir * s.hidden;
                     l.hrow = l.NKB * 64 + 16;
-                    l.dbg = getenv("KRK_LSTM_DBG") ? atoi(getenv("KRK_LSTM_DBG")) : 0;
+                    l.dbg = env_int("KRK_LSTM_DBG");
                     s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
                     rc = krk_launch_lstm_x3(l, stream);
                     break;

@@ -35,10 +35,6 @@ __device__ __forceinline__ int fdiv(int e, int d, float inv, int& rem) {
     return q;
 }
 
-struct Frags {
-    bf16x8 xh[2], xl[2];
-};
-
 template <int POOL, int OUT_F32, int CB>
 #ifndef KRK_X3_OCC
 #define KRK_X3_OCC 2
