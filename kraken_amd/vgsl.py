@@ -534,6 +534,46 @@ class TorchVGSLModel(nn.Module):
         self.init_weights()
         self.eval()
 
+    # -- kraken.models plugin contract (reference kraken/models/base.py:27-120, model.py:491-546) ---
+    def prepare_for_inference(self, config=None):
+        """
+        Configures the model for inference: ``config`` is kraken's RecognitionInferenceConfig /
+        SegmentationInferenceConfig (or any object with the fields read below: ``batch_size``, ``temperature``,
+        ``padding``, ``bidi_reordering``, ``device``, ``input_padding``).  Called before every ``predict``
+        by kraken's task layer (tasks/recognition.py:87); the HIP plan is (re)built lazily on first use.
+        """
+        kind = type(config).__name__
+        if ('Recognition' in kind and 'recognition' not in self.model_type) or \
+           ('Segmentation' in kind and 'segmentation' not in self.model_type):
+            raise ValueError(f'{self} is a {self.model_type} model. Got incompatible {kind}.')
+        self.eval()
+        self._inf_config = config
+        dev = getattr(config, 'device', None) or 'cuda'
+        if str(dev).startswith('cpu') or str(dev) == 'auto':
+            dev = 'cuda'                      # this implementation has no CPU path
+        self.to(dev)
+        return self
+
+    def predict(self, *args, **kwargs):
+        """
+        Recognition models: ``predict(im, segmentation)`` -> generator of ocr_records (batched underneath,
+        kraken_amd.rpred); segmentation models: ``predict(im)`` -> the heatmap dictionary of
+        ``_compute_segmentation_map`` (vectorisation into a Segmentation stays in kraken).
+        """
+        cfg = getattr(self, '_inf_config', None)
+        if 'segmentation' in self.model_type and 'recognition' not in self.model_type:
+            from .blla import compute_segmentation_map
+            return compute_segmentation_map(self, args[0] if args else kwargs['im'],
+                                            input_padding=getattr(cfg, 'input_padding', 0))
+        from .models import TorchSeqRecognizer
+        from .rpred import rpred
+        im = args[0] if args else kwargs['im']
+        segmentation = args[1] if len(args) > 1 else kwargs['segmentation']
+        rec = TorchSeqRecognizer(self, temperature=getattr(cfg, 'temperature', 1.0), device=str(next(self.parameters()).device))
+        return rpred(rec, im, segmentation, pad=getattr(cfg, 'padding', 16),
+                     bidi_reordering=getattr(cfg, 'bidi_reordering', True),
+                     batch_size=max(int(getattr(cfg, 'batch_size', 1) or 1), 1))
+
     # -- initialisation (reference model.py:450-479) ------------------------------------
     def init_weights(self) -> None:
         """LSTM orthogonal (+ forget-gate bias 1), conv U(-0.1, 0.1), linear Xavier-uniform with zero

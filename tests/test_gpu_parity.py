@@ -186,6 +186,34 @@ def test_rpred_mirror_reproduces_reference_record():
     assert sorted(rec.prediction) == sorted(str(z['string_rpred_pad1_bidi']))
 
 
+def test_model_plugin_contract_predict():
+    """kraken.models plugin seam: prepare_for_inference(config) + predict(im, segmentation) yield the
+    records of the reference's known-answer test through the model object itself."""
+    import types
+    import warnings
+    from PIL import Image
+    from kraken_amd.containers import BBoxLine, Segmentation
+    z = load_golden('overfit.npz')
+    meta = json.loads(str(z['meta']))
+    sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
+    m = build_model(str(z['spec']), sd, codec=meta['codec'])
+    m.seg_type, m.one_channel_mode, m.model_type = 'bbox', '1', ['recognition']
+    cfg = types.SimpleNamespace(batch_size=4, temperature=1.0, padding=16, bidi_reordering=False, device='cuda:0')
+    assert m.prepare_for_inference(cfg) is m
+    page = Image.fromarray(z['page'], 'L')
+    seg = Segmentation(type='bbox', imagename='000236.png', text_direction='horizontal-lr', script_detection=False,
+                       lines=[BBoxLine(id='a', bbox=z['bbox'].tolist()), BBoxLine(id='b', bbox=z['bbox'].tolist())])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        recs = list(m.predict(page, seg))
+    assert [r.prediction for r in recs] == [str(z['string_rpred_pad16_nobidi'])] * 2
+
+    class SegmentationInferenceConfig:      # a recogniser must refuse a segmentation config (model.py:495-496)
+        pass
+    with pytest.raises(ValueError):
+        m.prepare_for_inference(SegmentationInferenceConfig())
+
+
 # --------------------------------------------------------------- (2) oracle on seeded inputs
 def test_decoder_operator_matches_oracle():
     """The B4 plug point: greedy_decoder(outputs, seq_lens) on probabilities, logits, ndarray, (C,T)."""
