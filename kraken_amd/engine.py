@@ -70,7 +70,8 @@ class RecognitionEngine:
         for s in self.slots:
             n = self.lib.krk_plan_num_steps(s.plan.handle)
             ms = (C.c_float * n)()
-            _lib.check(min(self.lib.krk_plan_layer_ms(s.plan.handle, ms, n), 0))
+            if min(self.lib.krk_plan_layer_ms(s.plan.handle, ms, n), 0) != 0:
+                continue                      # this slot has not run a batch since profiling was switched on
             out.append([(self.lib.krk_plan_layer_name(s.plan.handle, i).decode(), float(ms[i]),
                          float(self.lib.krk_plan_layer_flops(s.plan.handle, i))) for i in range(n)])
         return out
