@@ -348,6 +348,7 @@ struct Step {
     float* d_wrec16 = nullptr;  // recurrent weights, 16x16x4 fragment order
     void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
+    bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
     int img_axis = 0;           // LSTM over image rows (1) or columns (2): sequences = N*H (N*W), steps = W (H); 0 = plain sequence
     int yaxis = 0;              // IMG2ROWS / ROWS2IMG: 1 = columns are the sequences
     // output description
@@ -645,7 +646,8 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 break;
             }
             case KRK_OP_MAXPOOL: {
-                if (x3) return bail(KRK_E_UNSUPPORTED, where + ": stand-alone max-pool is not available in bf16x3 mode (use KRK_PREC_F32)");
+                if (x3 && (!split_fmt || C % 8))
+                    return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 max-pool needs a convolution in front and a multiple of 8 channels");
                 if (seq) return bail(KRK_E_UNSUPPORTED, where + ": max-pool after a sequence layer");
                 if (L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0) return bail(KRK_E_INVALID, where + ": bad pool");
                 Step s;
@@ -653,6 +655,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 s.C = C;
                 s.H = H;
                 s.kh = L.kh; s.kw = L.kw; s.sh = L.sh; s.sw = L.sw;
+                s.on_split = x3;
                 s.Ho = floordiv(H - (L.kh - 1) - 1, L.sh) + 1;
                 if (s.Ho <= 0) return bail(KRK_E_INVALID, where + ": pool output height <= 0");
                 s.len_in = stage;
@@ -666,7 +669,8 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 break;
             }
             case KRK_OP_GROUPNORM: {
-                if (x3) return bail(KRK_E_UNSUPPORTED, where + ": group norm is not available in bf16x3 mode (use KRK_PREC_F32)");
+                if (x3 && (!split_fmt || !krk_gn_x3_supported(C, L.cout)))
+                    return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 group norm needs a convolution in front and a power-of-two channel count");
                 if (seq) return bail(KRK_E_UNSUPPORTED, where + ": group norm after a sequence layer");
                 if (L.cout <= 0 || C % L.cout) return bail(KRK_E_INVALID, where + ": groups must divide channels");
                 if (!L.w[0] || !L.w[1]) return bail(KRK_E_INVALID, where + ": group norm weights missing");
@@ -675,6 +679,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 s.C = C;
                 s.H = H;
                 s.groups = L.cout;
+                s.on_split = x3;
                 std::vector<float> ga(L.w[0], L.w[0] + C), be(L.w[1], L.w[1] + C);
                 if (upload(&s.d_gamma, ga) != KRK_OK || upload(&s.d_beta, be) != KRK_OK) {
                     krk_plan_destroy(p);
@@ -687,9 +692,11 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 break;
             }
             case KRK_OP_RESHAPE_HC: {
-                if (x3) return bail(KRK_E_UNSUPPORTED, where + ": stand-alone reshape is not available in bf16x3 mode (use KRK_PREC_F32)");
+                if (x3 && (!split_fmt || C % 8))
+                    return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 reshape needs a convolution in front and a multiple of 8 channels");
                 if (seq) return bail(KRK_E_UNSUPPORTED, where + ": reshape after a sequence layer");
                 push_toseq();
+                p->steps.back().on_split = x3;   // writes the K-blocked split sequence rows gemm_x3.hip reads
                 break;
             }
             case KRK_OP_LSTM:
@@ -1103,12 +1110,26 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             }
             case S_MAXPOOL:
                 s.flops = 0;
+                if (s.on_split) {
+                    mark("maxpool_x3", 0);
+                    rc = krk_launch_maxpool_x3(cur, (size_t)N * s.C * s.H * Win, outp, out_elems, lens_at(s.len_out), N, s.C, s.H, Win,
+                                               s.kh, s.kw, s.sh, s.sw, s.Ho, Wout, stream);
+                    break;
+                }
                 mark("maxpool", 0);
                 rc = krk_launch_maxpool(cur, outp, lens_at(s.len_out), N, s.C, s.H, Win, s.kh, s.kw, s.sh, s.sw, s.Ho,
                                         Wout, stream);
                 break;
             case S_GN:
                 s.flops = 0;
+                if (s.on_split) {
+                    const int chunks = krk_gn_x3_chunks(N, s.H, Win);
+                    if (s.aux.ensure((size_t)2 * N * chunks * s.C * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
+                    mark("groupnorm_x3", 0);
+                    rc = krk_launch_gn_x3(cur, outp, out_elems, s.d_gamma, s.d_beta, lens_at(s.len_in), (float*)s.aux.p, N, s.C, s.H, Win,
+                                          s.groups, 1e-5f, stream);
+                    break;
+                }
                 mark("groupnorm", 0);
                 {
                     const int chunks = krk_groupnorm_chunks(N, s.C, s.H, Win, s.groups);
@@ -1124,6 +1145,11 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 break;
             case S_TOSEQ:
                 s.flops = 0;
+                if (s.on_split) {
+                    mark("to_seq_x3", 0);
+                    rc = krk_launch_toseq_x3(cur, outp, out_elems, N, s.C, s.H, Win, stream);
+                    break;
+                }
                 mark("to_seq", 0);
                 rc = krk_launch_to_seq(cur, outp, N, s.C, s.H, Win, stream);
                 break;

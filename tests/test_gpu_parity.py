@@ -463,14 +463,46 @@ def test_x3_matches_cpu_oracle_on_small_networks(spec, n, w, lens):
 
 def test_x3_rejects_networks_it_cannot_run():
     from kraken_amd import _lib
-    m = build_model(BENCH_B, seed=0).to('cuda')          # GroupNorm -> fp32 plan only
+    # GroupNorm on split planes wants a power-of-two channel count; the fp32 plan takes anything
+    m = build_model('[1,8,0,1 Cr3,3,24 Gn4 S1(1x0)1,3 Lbx8 O1c5]', seed=0).to('cuda')
     m.nn.set_precision('bf16x3')
     with pytest.raises(_lib.KrakenAmdError):
-        m.nn(synth_input(1, 64).cuda())
+        m.nn(synth_input(1, 64, h=8).cuda())
     m.nn.set_precision('f32')
-    m.nn(synth_input(1, 64).cuda())
+    m.nn(synth_input(1, 64, h=8).cuda())
     with pytest.raises(ValueError):
         m.nn.set_precision('fp8')
+
+
+def test_x3_bench_b_groupnorm_network_against_reference_golden():
+    """BENCH-B (GroupNorm + stand-alone pools + stand-alone height collapse) on the bf16 matrix cores end to end:
+    groupnorm_x3 / maxpool_x3 / to_seq_x3 (norm_x3.hip) between conv1_x3, conv_x3, gemm_x3 and lstm_x3."""
+    from kraken_amd.engine import RecognitionEngine
+    m = build_model(BENCH_B, codec=bench_codec(), seed=0).to('cuda')
+    m.nn.set_precision('bf16x3')
+    z = load_golden('bench_b.npz')
+    for tag in ('n4w400', 'n16w800'):
+        n, w = int(tag[1:tag.index('w')]), int(tag[tag.index('w') + 1:])
+        batch, olens, logits, _ = m.nn.recognize(synth_input(n, w).cuda(), torch.tensor([w] * n), want_logits=True)
+        keep = z[f'{tag}_keep'].tolist()
+        assert np.abs(logits.cpu().numpy()[keep] - z[f'{tag}_logits']).max() < X3_TOL
+        assert _keys(batch.tuples()) == _keys(arr_to_tuples(z[f'{tag}_tuples'], z[f'{tag}_counts']))
+    widths = z['ragged_widths'].tolist()          # masked GroupNorm statistics: ragged batch == per-line reference
+    x = synth_input(len(widths), 800, seed=4321)
+    for i, w in enumerate(widths):
+        x[i, ..., w:] = 0
+    batch, olens, logits, _ = m.nn.recognize(x.cuda(), torch.tensor(widths), want_logits=True)
+    for i in range(len(widths)):
+        want = z[f'ragged{i}_logits']
+        assert olens[i] == want.shape[1]
+        assert np.abs(logits.cpu().numpy()[i, :, :olens[i]] - want).max() < X3_TOL
+    eng = RecognitionEngine(m, device=0, max_batch=4, max_width=256, slots=1)
+    eng.set_profiling(True)
+    eng.submit(synth_input(4, 256).cuda())
+    eng.collect()
+    names = [n_ for n_, _, _ in eng.layer_times()[0]]
+    eng.close()
+    assert names[:7] == ['conv1_x3', 'groupnorm_x3', 'maxpool_x3', 'conv_x3', 'groupnorm_x3', 'maxpool_x3', 'to_seq_x3']
 
 
 def test_x3_full_size_batch_invariance(bench_a_x3, bench_a):
