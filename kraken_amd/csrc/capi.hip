@@ -95,6 +95,7 @@ struct ConvGeom {
     bool c1x3 = false;        // one-channel first convolution on the bf16 cores (conv1_x3.hip); weights in d_wx3
     bool taps = false;        // wide-kernel convolution with taps as K (conv_taps_x3.hip); reads NHCW planes
     bool out_nhcw = false;    // conv1_x3 writes [N][H][C][pitch] planes for a following taps convolution
+    bool out_f32 = false;     // bf16x3 convolution writes plain fp32 NHWC: its consumer is a GroupNorm (norm_x3.hip)
 };
 
 // row pitch (elements) of the "NHCW" planes between conv1_x3 and conv_taps_x3: whole 16-byte pieces
@@ -349,6 +350,7 @@ struct Step {
     void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
     bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
+    bool in_f32 = false;        // GN on split planes whose producer handed over fp32 NHWC (ConvGeom::out_f32)
     int img_axis = 0;           // LSTM over image rows (1) or columns (2): sequences = N*H (N*W), steps = W (H); 0 = plain sequence
     int yaxis = 0;              // IMG2ROWS / ROWS2IMG: 1 = columns are the sequences
     // output description
@@ -680,6 +682,12 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 s.H = H;
                 s.groups = L.cout;
                 s.on_split = x3;
+                if (x3 && !p->steps.empty() && p->steps.back().kind == S_CONV && !p->steps.back().cg.out_seq &&
+                    (p->steps.back().cg.x3 || p->steps.back().cg.c1x3 || p->steps.back().cg.taps)) {
+                    // the convolution in front hands over exact fp32 values instead of (hi, lo): see gn_x3_kernel
+                    p->steps.back().cg.out_f32 = true;
+                    s.in_f32 = true;
+                }
                 std::vector<float> ga(L.w[0], L.w[0] + C), be(L.w[1], L.w[1] + C);
                 if (upload(&s.d_gamma, ga) != KRK_OK || upload(&s.d_beta, be) != KRK_OK) {
                     krk_plan_destroy(p);
@@ -1024,7 +1032,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             a.IH = g.IH; a.IW = g.IW; a.PSTR = g.xPSTR; a.lds_plane = g.xplane; a.SR = g.SR;
             a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
             a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
-            a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0; a.y_blkM = 0; a.y_cols = 0;
+            a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0; a.y_blkM = 0; a.y_cols = 0; a.y_f32 = g.out_f32;
             a.dbg = env_int("KRK_X3_DBG");
         };
         auto fill_gemm = [&](const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane, float* yout, int rows) {
@@ -1056,6 +1064,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
                     a.act = g.act;
                     a.tiles_h = (g.Ho + 3) / 4; a.tiles_w = (a.Wo + 127) / 128;
+                    a.y_f32 = g.out_f32;
                     a.dbg = env_int("KRK_X3_DBG");
                     split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
                     s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
@@ -1090,6 +1099,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     a.tiles_h = (g.Ho + 7) / 8; a.tiles_w = (a.Wo + 127) / 128;
                     split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
                     a.y_pitch = g.out_nhcw ? nhcw_pitch(a.Wy) : 0;
+                    a.y_f32 = g.out_f32;
                     a.dbg = env_int("KRK_X3_DBG");
                     s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
                     if (mark("conv1_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
@@ -1126,8 +1136,8 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     const int chunks = krk_gn_x3_chunks(N, s.H, Win);
                     if (s.aux.ensure((size_t)2 * N * chunks * s.C * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
                     mark("groupnorm_x3", 0);
-                    rc = krk_launch_gn_x3(cur, outp, out_elems, s.d_gamma, s.d_beta, lens_at(s.len_in), (float*)s.aux.p, N, s.C, s.H, Win,
-                                          s.groups, 1e-5f, stream);
+                    rc = krk_launch_gn_x3(cur, s.in_f32, outp, out_elems, s.d_gamma, s.d_beta, lens_at(s.len_in), (float*)s.aux.p, N, s.C,
+                                          s.H, Win, s.groups, 1e-5f, stream);
                     break;
                 }
                 mark("groupnorm", 0);

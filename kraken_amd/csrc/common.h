@@ -81,6 +81,7 @@ struct X3Args {
     int act;
     int cchunk, nchunks, KB, KB_last;   // channels per LDS chunk (multiple of 16), 16-channel blocks per chunk
     int IH, IW, PSTR, lds_plane;        // LDS tile: pixels, bytes per pixel (padded), bytes per plane
+    int y_f32;                   // 1: write fp32 NHWC (same element index as the hi plane) for a GroupNorm consumer
     int y_blkM, y_cols;          // > 0: sequence output in K-blocked order, y_blkM rows of y_cols per line (see gemm_x3.hip)
     int SR, tiles_h, tiles_w;    int dbg;                            // probe bits (env KRK_X3_DBG): 1 skip K loop, 2 skip staging loads, 4 skip stores
 };
@@ -99,6 +100,7 @@ struct Conv1Args {
     int Ho, Wo, Hy, Wy;
     int act, tiles_h, tiles_w;
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no K loop, 2 no staging loads, 4 no stores
+    int y_f32;            // 1: write fp32 NHWC instead of split planes (GroupNorm consumer)
     int y_pitch;          // > 0: write "NHCW" planes [N][Hy][Cout][y_pitch] (for conv_taps_x3.hip) instead of NHWC
 };
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
@@ -117,6 +119,7 @@ struct ConvTapArgs {
     int N, H, pitch, Cin, Cout, kh, kw, ph, pw;
     int Ho, Wo, Hy, Wy;
     int act, tiles_h, tiles_w;
+    int y_f32;            // 1: write fp32 NHWC instead of split planes (GroupNorm consumer)
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no K loop, 4 no staging loads, 16 no stores
 };
 bool krk_conv_taps_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
@@ -186,8 +189,8 @@ int krk_launch_to_seq(const float* x, float* y, int N, int C, int H, int W, hipS
 // split-bf16 NHWC planes (norm_x3.hip): GroupNorm (needs 2*N*chunks*C floats of scratch), MaxPool, height collapse
 bool krk_gn_x3_supported(int C, int G);
 int krk_gn_x3_chunks(int N, int H, int W);
-int krk_launch_gn_x3(const void* x, void* y, size_t plane, const float* gamma, const float* beta, const int* lens, float* part,
-                     int N, int C, int H, int W, int G, float eps, hipStream_t s);
+int krk_launch_gn_x3(const void* x, int x_f32, void* y, size_t plane, const float* gamma, const float* beta, const int* lens,
+                     float* part, int N, int C, int H, int W, int G, float eps, hipStream_t s);
 int krk_launch_maxpool_x3(const void* x, size_t xplane, void* y, size_t yplane, const int* len_out, int N, int C, int H, int W,
                           int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);
 int krk_launch_toseq_x3(const void* x, void* y, size_t plane, int N, int C, int H, int W, hipStream_t s);

@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bf16x4 hv, lv;
+                    f32x4 fv;   // the same four values unsplit, for a GroupNorm consumer (y_f32)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * j + i;
@@ -191,12 +192,17 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
                 if (pcol >= len_out) v = 0.f;
                 const __bf16 h = (__bf16)v;
                 hv[i] = h;
+                        fv[i] = v;
                 lv[i] = (__bf16)(v - (float)h);
             }
             const int co = 8 * j + 4 * half;
             if (ok && co < a.Cout && !(a.dbg & 16)) {
-                *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
-                *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                if (a.y_f32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + base + co) = fv;
+                } else {
+                    *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
+                    *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                }
             }
         }
     } else {
@@ -211,18 +217,24 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     bf16x4 hv, lv;
+                    f32x4 fv;   // the same four values unsplit, for a GroupNorm consumer (y_f32)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = actf(acc[o][s][4 * j + i] + bias4[j][i]);
                         if (col >= len_out) v = 0.f;
                         const __bf16 h = (__bf16)v;
                         hv[i] = h;
+                        fv[i] = v;
                         lv[i] = (__bf16)(v - (float)h);
                     }
                     const int co = 8 * j + 4 * half;
                     if (ok && co < a.Cout && !(a.dbg & 16)) {
-                        *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
-                        *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                        if (a.y_f32) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + base + co) = fv;
+                        } else {
+                            *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
+                            *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                        }
                     }
                 }
             }

@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                 for (int rq = 0; rq < 4; ++rq) {
                     const int co = (cb0 + cb) * 32 + 8 * rq + 4 * half;
                     bf16x4 hv, lv;
+                    f32x4 fv;   // the same four values unsplit, for a GroupNorm consumer (y_f32)
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + min(co, a.CBpad * 32 - 4));   // co % 4 == 0, padded buffer
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -270,6 +271,7 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                         if (col >= len_out) v = 0.f;
                         const __bf16 h = (__bf16)v;
                         hv[i] = h;
+                        fv[i] = v;
                         lv[i] = (__bf16)(v - (float)h);
                     }
                     if (st && co < a.Cout && !(a.dbg & 4)) {
@@ -278,8 +280,12 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                             const int f = row * a.Cout + co;
                             o = ((size_t)(f >> 3) * a.y_blkM + (size_t)n * a.y_cols + col) * 8 + (f & 7);
                         }
-                        *reinterpret_cast<bf16x4*>(yh + o) = hv;
-                        *reinterpret_cast<bf16x4*>(yl + o) = lv;
+                        if (a.y_f32) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + o) = fv;
+                        } else {
+                            *reinterpret_cast<bf16x4*>(yh + o) = hv;
+                            *reinterpret_cast<bf16x4*>(yl + o) = lv;
+                        }
                     }
                 }
             }

@@ -22,11 +22,25 @@ __device__ __forceinline__ void unpack8(const bf16x8& h, const bf16x8& l, float 
 }
 
 // part layout: [pass 0|1][n][chunk][C]
-__global__ void __launch_bounds__(256) gn_x3_kernel(const __bf16* __restrict__ x, size_t plane, __bf16* __restrict__ y,
+template <bool XF32>
+__global__ void __launch_bounds__(256) gn_x3_kernel(const void* __restrict__ xv, size_t plane, __bf16* __restrict__ y,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const int* __restrict__ lens, float* __restrict__ part,
                                                     int N, int C, int H, int W, int G, float eps, int chunks, int pass) {
     extern __shared__ float sm[];          // [256][8] reduction scratch, then mean[C], rstd[C]
+    // XF32: the producing convolution wrote plain fp32 NHWC for this layer (same element order as the hi plane): dividing
+    // by the group's standard deviation would amplify the 2^-17 representation error of split planes by |x| / sigma
+    const __bf16* x = reinterpret_cast<const __bf16*>(xv);
+    const float* xf = reinterpret_cast<const float*>(xv);
+    auto load8 = [&](size_t o, float (&v)[8]) {
+        if (XF32) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xf + o), b = *reinterpret_cast<const f32x4*>(xf + o + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+        } else {
+            unpack8(*reinterpret_cast<const bf16x8*>(x + o), *reinterpret_cast<const bf16x8*>(x + plane + o), v);
+        }
+    };
     float* red = sm;
     float* mean_c = sm + 256 * 8;
     float* rstd_c = mean_c + C;
@@ -70,7 +84,7 @@ __global__ void __launch_bounds__(256) gn_x3_kernel(const __bf16* __restrict__ x
             if (w >= L) continue;
             const size_t o = base + (size_t)e * C + q * 8;
             float v[8];
-            unpack8(*reinterpret_cast<const bf16x8*>(x + o), *reinterpret_cast<const bf16x8*>(x + plane + o), v);
+            load8(o, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float d = pass ? v[i] - mean_c[q * 8 + i] : v[i];
@@ -94,7 +108,7 @@ __global__ void __launch_bounds__(256) gn_x3_kernel(const __bf16* __restrict__ x
             bf16x8 hv, lv;
             if (w < L) {
                 float v[8];
-                unpack8(*reinterpret_cast<const bf16x8*>(x + o), *reinterpret_cast<const bf16x8*>(x + plane + o), v);
+                load8(o, v);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int c = q * 8 + i;
@@ -175,14 +189,19 @@ int krk_gn_x3_chunks(int N, int H, int W) {
 }
 
 // `part`: 2 * N * chunks * C floats of scratch
-int krk_launch_gn_x3(const void* x, void* y, size_t plane, const float* gamma, const float* beta, const int* lens, float* part,
-                     int N, int C, int H, int W, int G, float eps, hipStream_t s) {
+int krk_launch_gn_x3(const void* x, int x_f32, void* y, size_t plane, const float* gamma, const float* beta, const int* lens,
+                     float* part, int N, int C, int H, int W, int G, float eps, hipStream_t s) {
     if (!krk_gn_x3_supported(C, G)) return -4;
     const int chunks = krk_gn_x3_chunks(N, H, W);
     const size_t lds = (size_t)(256 * 8 + 2 * C) * sizeof(float);
-    for (int pass = 0; pass < 3; ++pass)
-        hipLaunchKernelGGL(gn_x3_kernel, dim3(chunks, N), dim3(256), lds, s, (const __bf16*)x, plane, (__bf16*)y, gamma, beta, lens,
-                           part, N, C, H, W, G, eps, chunks, pass);
+    for (int pass = 0; pass < 3; ++pass) {
+        if (x_f32)
+            hipLaunchKernelGGL(gn_x3_kernel<true>, dim3(chunks, N), dim3(256), lds, s, x, plane, (__bf16*)y, gamma, beta, lens, part, N, C,
+                               H, W, G, eps, chunks, pass);
+        else
+            hipLaunchKernelGGL(gn_x3_kernel<false>, dim3(chunks, N), dim3(256), lds, s, x, plane, (__bf16*)y, gamma, beta, lens, part, N,
+                               C, H, W, G, eps, chunks, pass);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -18,10 +18,13 @@ SPECS = [
     '[1,32,0,1 Cr3,11,16 Cr3,15,32 Mp2,2 Cr5,5,32 Mp2,2 S1(1x0)1,3 Lfx48 Lbx16 O1c33]',
     '[1,24,0,1 Cr5,16,8 Mp2,2 Cr3,12,32 Cr3,14,16 Mp2,2 S1(1x0)1,3 Lbx200 O1c12]',
     '[1,16,0,3 Ct3,3,16 Cr3,7,48,1,2 Cl1,1,32 S1(1x0)1,3 Lbx8 O1c7]',
+    '[1,32,0,1 Cr3,3,16 Gn4 Mp2,2 Cr3,5,32 Gn8 Mp2,2 S1(1x0)1,3 Lbx16 O1c9]',
+    '[1,24,0,1 Cr3,3,16 Mp3,2,2,3 Cr3,3,16 Gn2 S1(1x0)1,3 Lfx16 O1c5]',
 ]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()) if '--time-seed' in sys.argv else 0)
 t0, n_cases, worst = time.time(), 0, 0.0
+worst_by = {}
 models = []
 for i, spec in enumerate(SPECS):
     torch.manual_seed(i)
@@ -53,10 +56,17 @@ while time.time() - t0 < budget:
         L = out['f32'][1][i] if lens else out['f32'][0].shape[3]
         d = (out['f32'][0][i, ..., :L] - out['bf16x3'][0][i, ..., :L]).abs().max().item()
         worst = max(worst, d)
-        assert d < 2e-4, (spec, n, w, lens, i, d)
+        worst_by[spec[:40]] = max(worst_by.get(spec[:40], 0.0), d)
+        # GroupNorm divides by the group's standard deviation: it amplifies whatever error its input carries by |x| / sigma.
+        # On these RANDOM-weight GroupNorm networks even the f32 plan differs from the CPU by up to 9e-5 (3e-6 without
+        # GroupNorm); the split-bf16 operands are 2^7 coarser: median 3e-5, rare lines up to 1.2e-3 (the same line alone
+        # gives the same number: it is conditioning, not batching).  BENCH-B stays below 2e-4 (tests/test_gpu_parity.py).
+        assert d < (2e-3 if 'Gn' in spec else 2e-4), (spec, n, w, lens, i, d)
         if check_cpu:
             dc = (out['f32'][0][i, ..., :L] - want[0][i, ..., :L]).abs().max().item()
-            assert dc < 5e-5, ('f32 vs cpu', spec, n, w, lens, i, dc)
+            assert dc < (2e-4 if 'Gn' in spec else 5e-5), ('f32 vs cpu', spec, n, w, lens, i, dc)
     assert out['f32'][1] == out['bf16x3'][1]
     n_cases += 1
 print(f'{n_cases} random cases, worst |f32 - bf16x3| = {worst:.2e}: OK')
+for k, v in worst_by.items():
+    print(f'   {k:40s} {v:.2e}')
