@@ -59,8 +59,9 @@ _GRAMMAR = [
     ('rnn', re.compile(r'^(?P<cell>L|G)(?P<dir>f|r|b)(?P<axis>x|y)(?P<sum>s)?(?P<legacy>c|o)?' + _RE_NAME +
                        r'(?P<out>\d+)$')),
     ('output', re.compile(r'^O' + _RE_NAME + r'(?P<dim>[012])(?P<type>l|s|c)(?P<aug>a)?(?P<out>\d+)$')),
+    ('identity', re.compile(r'^I' + _RE_NAME + r'$')),
 ]
-_TYPE_TAG = {'conv': 'C', 'maxpool': 'Mp', 'groupnorm': 'Gn', 'dropout': 'Do', 'reshape': 'S', 'output': 'O'}
+_TYPE_TAG = {'conv': 'C', 'maxpool': 'Mp', 'groupnorm': 'Gn', 'dropout': 'Do', 'reshape': 'S', 'output': 'O', 'identity': 'I'}
 
 
 def _floor_out(size: int, k: int, s: int, d: int = 1, p: int = 0) -> int:
@@ -109,7 +110,7 @@ def parse_vgsl(spec: str):
                 hit = (kind, mm)
                 break
         if hit is None:
-            if re.match(r'^(A|I|W)', block):
+            if re.match(r'^(A|W)', block):
                 raise NotImplementedError(f'VGSL block "{block}" is not supported by the HIP executor')
             raise ValueError(f'{block} invalid layer definition')
         kind, mm = hit
@@ -143,6 +144,8 @@ def parse_vgsl(spec: str):
         elif kind == 'dropout':
             p = dict(p=float(g['p']) if g['p'] else 0.5, dim=int(g['dim']) if g['dim'] else 1)
             oshape = shape
+        elif kind == 'identity':     # layers.Identity (model.py:637-650): elided like dropout
+            kind, p, oshape = 'dropout', dict(identity=True), shape
         elif kind == 'reshape':
             src, a, b, high, low = int(g['dim']), int(g['a']), int(g['b']), int(g['high']), int(g['low'])
             if src != high and src != low:

@@ -358,3 +358,12 @@ def test_vectorised_cut_scaling_equals_the_scalar_rule():
             vals = list(range(0, 160)) + rng.integers(0, 400, 64).tolist()
             want = [mm_rpred._scale(me, v, net_scale, in_scale, max_val) for v in vals]
             assert mm_rpred._scale_all(me, vals, net_scale, in_scale, max_val) == want
+
+
+def test_identity_op_is_parsed_and_named_like_the_reference():
+    """`I{name}` (layers.Identity, model.py:637-650) takes a slot in the global layer numbering and is elided from the plan."""
+    from kraken_amd.vgsl import parse_vgsl
+    _, specs = parse_vgsl('[1,48,0,1 Cr3,3,8 I Mp2,2 I{foo} S1(1x0)1,3 Lbx8 O1c5]')
+    # names produced by the unmodified reference for this spec (probed with tests/golden/_refshim.py)
+    assert [s.name for s in specs] == ['C_0', 'I_1', 'Mp_2', 'foo', 'S_4', 'L_5', 'O_6']
+    assert [s.kind for s in specs][1] == 'dropout' and specs[1].params.get('identity')
