@@ -98,9 +98,12 @@ typedef struct krk_plan krk_plan;
  *            w[4d+0]=weight_ih (4H,In)  w[4d+1]=weight_hh (4H,H)  w[4d+2]=bias_ih (4H)  w[4d+3]=bias_hh (4H)
  *            gate row order i,f,g,o (torch.nn.LSTM)
  *            kw = 0: time runs along W (Lxx); kw = 1: along H (Lxy, the reference's `transpose`, layers.py:521-523).
+ *            kh = 1 (with kw = 1 only): summarising LSTM (Lxys): only the last step of every column is kept, the output
+ *            has height 1 (layers.py:537-539).
  *            After the height collapse (height 1, kw = 0) the layer is a plain sequence layer; on an image
  *            (height > 1, or kw = 1) every row / column is one sequence and the output is an image again
- *            (TransposedSummarizingRNN.forward on a 4-D input, layers.py:519-547) -- f32 plan only, no seq_lens.
+ *            (TransposedSummarizingRNN.forward on a 4-D input, layers.py:519-547) -- f32 plan only; seq_lens only with
+ *            kw = 1 (columns run their full height, padding columns are zeroed afterwards), like the reference.
  *  LINEAR    cout=out features; w[0]=lin.weight (cout,In), w[1]=lin.bias (cout)
  */
 typedef struct krk_layer {

@@ -355,6 +355,7 @@ struct Step {
     bool in_f32 = false;        // GN on split planes whose producer handed over fp32 NHWC (ConvGeom::out_f32)
     int img_axis = 0;           // LSTM over image rows (1) or columns (2): sequences = N*H (N*W), steps = W (H); 0 = plain sequence
     int yaxis = 0;              // IMG2ROWS / ROWS2IMG: 1 = columns are the sequences
+    int last_only = 0;          // ROWS2IMG: keep the last step of every column (summarising LSTM): output height 1; LSTM step: time steps of the rows
     // output description
     bool out_is_seq = false;
     int outC = 0, outH = 1;     // NCHW: channels,height; seq: features,1
@@ -714,6 +715,10 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 // LSTM over the rows (kw = 0) or columns (kw = 1) of an image: reference TransposedSummarizingRNN on a
                 // 4-D input (layers.py:519-547; the BLLA segmenter's Lbx/Lby pairs).  img2rows -> LSTM -> rows2img.
                 const bool img_lstm = L.op == KRK_OP_LSTM && !seq && (H != 1 || L.kw == 1);
+                const bool summarize = L.op == KRK_OP_LSTM && L.kh == 1;
+                if (summarize && !(img_lstm && L.kw == 1))
+                    return bail(KRK_E_UNSUPPORTED, where + ": only column (y-axis) LSTMs can summarise");
+                const int Himg = H;   // image height in front of the layer
                 if (img_lstm) {
                     if (x3) return bail(KRK_E_UNSUPPORTED, where + ": LSTMs over image rows/columns run in the f32 plan only");
                     Step a;
@@ -818,10 +823,12 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 if (img_lstm) {
                     Step b;
                     b.kind = S_ROWS2IMG;
-                    b.C = C; b.H = H; b.yaxis = L.kw == 1;
-                    b.outC = C; b.outH = H;
+                    b.C = C; b.H = Himg; b.yaxis = L.kw == 1;
+                    b.last_only = summarize;
+                    b.outC = C; b.outH = summarize ? 1 : Himg;
                     b.len_in = b.len_out = stage;
                     p->steps.push_back(std::move(b));
+                    if (summarize) H = 1;
                 }
                 break;
             }
@@ -1173,7 +1180,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             case S_ROWS2IMG:
                 s.flops = 0;
                 mark("rows2img", 0);
-                rc = krk_launch_rows2img(cur, outp, N, s.C, s.H, Win, s.yaxis, stream);
+                rc = krk_launch_rows2img(cur, outp, N, s.C, s.H, Win, s.yaxis, s.yaxis ? lens_at(s.len_in) : nullptr, s.last_only, stream);
                 break;
             case S_LINEAR: {
                 s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
@@ -1200,8 +1207,8 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 break;
             }
             case S_LSTM: {
-                if (s.img_axis && lens_host)
-                    return fail(KRK_E_UNSUPPORTED, "forward: seq_lens with an LSTM over image rows/columns (the reference raises too, layers.py:528-530)");
+                if (s.img_axis == 1 && lens_host)
+                    return fail(KRK_E_UNSUPPORTED, "forward: seq_lens with an LSTM over image rows (the reference raises too, layers.py:528-530)");
                 // sequences and steps: plain (N, W); image rows (N*H, W); image columns (N*W, H)
                 const int Nimg = N, Himg = s.outH;
                 const int T = s.img_axis == 2 ? Himg : Win;
@@ -1257,7 +1264,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 LstmArgs l;
                 l.xp = (const float*)s.aux.p;
                 l.out = outp;
-                l.lens = lens_at(s.len_in);
+                l.lens = s.img_axis ? nullptr : lens_at(s.len_in);   // image columns/rows always run their full length
                 l.N = N; l.T = T; l.H = s.hidden; l.Hp = s.Hp; l.G = G;
                 l.ndir = s.ndir; l.dirmode = s.dirmode;
                 l.xstride = s.ndir * G;

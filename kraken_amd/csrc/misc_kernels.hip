@@ -3,6 +3,7 @@
 // collapse.  All are plain coalesced streaming kernels with wave-shuffle reductions;
 // none of them is reshaped into a GEMM.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -187,8 +188,22 @@ __global__ void __launch_bounds__(256) img2rows_kernel(const float* __restrict__
     }
 }
 
+// `lens` (columns-as-sequences only): output columns >= lens[n] are written as zeros (masked-padding rule).
+// `last`: the rows hold T = H steps per column but only the last one is kept (summarising LSTM, layers.py:537-539):
+//         the destination image has height 1.
 __global__ void __launch_bounds__(256) rows2img_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                       int C, int H, int W, int yaxis) {
+                                                       int C, int H, int W, int yaxis, const int* __restrict__ lens, int last) {
+    if (last) {   // (N*W, H, C) rows -> (N, C, 1, W): one thread per (n, c, w), reads strided by H*C (small tensors)
+        const int n = blockIdx.z;
+        const size_t total = (size_t)C * W;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const int c = (int)(i / W), w = (int)(i - (size_t)c * W);
+            float v = x[(((size_t)n * W + w) * H + (H - 1)) * C + c];
+            if (lens && w >= lens[n]) v = 0.f;
+            y[((size_t)n * C + c) * W + w] = v;
+        }
+        return;
+    }
     __shared__ float t[32][33];
     const int n = blockIdx.z, HW = H * W;
     const int c0 = blockIdx.y * 32, q0 = blockIdx.x * 32;     // q = destination pixel h*W + w
@@ -206,7 +221,11 @@ __global__ void __launch_bounds__(256) rows2img_kernel(const float* __restrict__
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, q = q0 + tx;
-        if (c < C && q < HW) y[((size_t)n * C + c) * HW + q] = t[tx][i];
+        if (c < C && q < HW) {
+            float v = t[tx][i];
+            if (lens && (q % W) >= lens[n]) v = 0.f;
+            y[((size_t)n * C + c) * HW + q] = v;
+        }
     }
 }
 
@@ -400,9 +419,11 @@ int krk_launch_img2rows(const float* x, float* y, int N, int C, int H, int W, in
     return last_ok();
 }
 
-int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, int yaxis, hipStream_t s) {
+int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, int yaxis, const int* lens, int last,
+                        hipStream_t s) {
     dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
-    hipLaunchKernelGGL(rows2img_kernel, grid, dim3(256), 0, s, x, y, C, H, W, yaxis);
+    if (last) grid = dim3((unsigned)std::min<size_t>(1024, ((size_t)C * W + 255) / 256), 1, N);
+    hipLaunchKernelGGL(rows2img_kernel, grid, dim3(256), 0, s, x, y, C, H, W, yaxis, lens, last);
     return last_ok();
 }
 

@@ -161,13 +161,14 @@ def parse_vgsl(spec: str):
             # the reference derives this shape from a dummy tensor with variable dims set to 1
             oshape = (n or 1, c * h, 1, w or 1)
         elif kind == 'rnn':
-            if g['sum'] or g['legacy'] or g['cell'] != 'L':
-                raise NotImplementedError(f'RNN variant "{block}" (summarising / legacy / GRU) is not supported '
+            if g['legacy'] or g['cell'] != 'L' or (g['sum'] and g['axis'] != 'y'):
+                raise NotImplementedError(f'RNN variant "{block}" (x-axis summarising / legacy / GRU) is not supported '
                                           'by the HIP executor')
             hidden = int(g['out'])
-            # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523)
-            p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'])
-            oshape = (n, hidden * (2 if g['dir'] == 'b' else 1), h, w)
+            # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523);
+            # 's' keeps only the last step of every column (:537-539): (N, C, H, W) -> (N, O, 1, W)
+            p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'], summarize=bool(g['sum']))
+            oshape = (n, hidden * (2 if g['dir'] == 'b' else 1), 1 if g['sum'] else h, w)
         else:  # output
             dim, typ, out = int(g['dim']), g['type'], int(g['out'])
             if dim == 0:
@@ -273,6 +274,7 @@ class _Plan:
                 d.cout = p['hidden']
                 d.direction = _DIRS[p['direction']]
                 d.kw = 1 if p.get('axis', 'x') == 'y' else 0   # include/kraken_amd.h: time axis of an LSTM layer
+                d.kh = 1 if p.get('summarize') else 0          # include/kraken_amd.h: keep only the last step (Lxys)
                 sfx = [''] + (['_reverse'] if p['direction'] == 'b' else [])
                 for s in sfx:
                     arrays += [_f32(getattr(mod.layer, f'weight_ih_l0{s}')), _f32(getattr(mod.layer, f'weight_hh_l0{s}')),

@@ -217,8 +217,12 @@ def forward(specs, sd, x, lens=None):
             for sfx in [''] + (['_reverse'] if p['direction'] == 'b' else []):
                 ws.append(tuple(sd[f'nn.{nm}.layer.{w}_l0{sfx}'] for w in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')))
             if x.shape[2] != 1 or p.get('axis', 'x') == 'y':
-                assert cur is None, 'seq_lens with an LSTM over image rows/columns (the reference raises)'
+                # rows as sequences + seq_lens: the reference raises (layers.py:528-530); columns as sequences: seq_lens pass
+                # through untouched (every column runs its full height) and the width mask below zeroes the padding columns
+                assert cur is None or p.get('axis', 'x') == 'y', 'seq_lens with an LSTM over image rows (the reference raises)'
                 x = lstm_image(x, ws, p['hidden'], p['direction'], p.get('axis', 'x'))
+                if p.get('summarize'):
+                    x = x[:, :, -1:, :]                     # o[:, :, -1, :].unsqueeze(2), layers.py:537-539
             else:
                 x = lstm(x, ws, p['hidden'], p['direction'], cur)
         elif k == 'linear':

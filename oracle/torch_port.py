@@ -90,7 +90,12 @@ class CpuRecognizer:
                 if s.params.get('axis', 'x') == 'y':     # `transpose`: HNWC -> WNHC, columns are the sequences (:521-523)
                     seq = x.permute(2, 0, 3, 1).transpose(0, 2).reshape(w * n, h, c)
                     o, _ = self.rnn[nm](seq)
-                    x = o.reshape(w, n, h, -1).transpose(0, 2).permute(1, 3, 0, 2)
+                    o = o.reshape(w, n, h, -1)
+                    if s.params.get('summarize'):           # keep the last step of every column (:537-539)
+                        o = o[:, :, -1, :].unsqueeze(2)
+                    x = o.transpose(0, 2).permute(1, 3, 0, 2)
+                    if masked:
+                        x = _mask(x, cur)
                     continue
                 seq = x.permute(2, 0, 3, 1).reshape(h * n, w, c)
                 if cur is not None:

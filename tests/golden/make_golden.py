@@ -129,6 +129,10 @@ IMAGE_LSTM_CASES = {
     'lstm_y_img':  ('[1,5,0,3 Lby6]', 2, 9, None),
     'lstm_fy_img': ('[1,7,0,4 Lfy5]', 1, 6, None),
     'lstm_xy_h1':  ('[1,1,0,6 Lby4]', 2, 5, None),
+    'lstm_fys':    ('[1,6,0,3 Lfys5]', 2, 8, None),
+    'lstm_bys':    ('[1,5,0,2 Lbys4]', 2, 7, None),
+    'tess_style':  ('[1,0,0,1 Cr3,3,8 Mp3,3 Lfys16 Lbx8 O1c5]', 3, 47, [47, 30, 12]),
+    'lby_ragged':  ('[1,10,0,1 Cr3,3,8 Lby4 Cr3,3,8]', 2, 21, [21, 13]),
     'blla_small':  ('[1,48,0,3 Cr7,7,16,2,2 Gn8 Cr3,3,32,2,2 Gn8 Cr3,3,32 Gn8 Lbx8 Lby8 Cr1,1,8 Gn8 Lby8 Lbx8 O2l3]', 1, 70, None),
     'blla_batch2': ('[1,20,0,3 Cr7,7,8,2,2 Gn4 Lbx4 Lby4 Cr1,1,8 Gn4 Lby4 Lbx4 O2l2]', 2, 33, None),
 }
@@ -170,7 +174,7 @@ def layer_fixture(path, cases=None):
             if 'Gn' in k or k.endswith('bias'):
                 v.copy_(torch.randn(v.shape) * 0.5 + (1.0 if k.endswith('layer.weight') else 0.0))
         _, c, h, _ = net.input
-        x = torch.randn(n, c, h, w)
+        x = torch.randn(n, c, h or 24, w)      # variable-height specs ([1,0,0,1 ...]) get 24 rows
         for k, v in net.state_dict().items():
             out[f'{name}/sd/{k}'] = v.numpy()
         out[f'{name}/x'] = x.numpy()

@@ -61,7 +61,7 @@ def test_custom_layer_names():
     ('[1,48,0,1 Cr3,3,32 S2(3x0)1,3]', ValueError),
     ('[1,48,0,1 CTr3,3,32]', NotImplementedError),
     ('[1,48,0,1 (Cr3,3,32 Cr3,3,32)]', NotImplementedError),
-    ('[1,48,0,1 Cr3,3,32 Lbys20]', NotImplementedError),
+    ('[1,48,0,1 Cr3,3,32 Lbxs20]', NotImplementedError),      # x-axis summarising (y-axis summarising is native)
     ('[1,48,0,1 Cr3,3,32 A1,2]', NotImplementedError),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxo20]', NotImplementedError),
 ])
