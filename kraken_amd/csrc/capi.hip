@@ -31,8 +31,8 @@ int fail(int code, const std::string& msg) {
             return fail(KRK_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
-enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG };
-const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img"};
+enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG, S_UNSPLIT };
+const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img", "unsplit"};
 
 
 
@@ -517,7 +517,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
         return fail(KRK_E_UNSUPPORTED, "krk_plan_create: input channels/height must be fixed and positive");
     if (precision != KRK_PREC_F32 && precision != KRK_PREC_BF16X3)
         return fail(KRK_E_UNSUPPORTED, "krk_plan_create: precision must be KRK_PREC_F32 or KRK_PREC_BF16X3");
-    const bool x3 = precision == KRK_PREC_BF16X3;
+    bool x3 = precision == KRK_PREC_BF16X3;   // cleared by leave_x3() when the rest of the network needs f32-only layers
     if (krk_device_count() <= device)
         return fail(KRK_E_HIP, "krk_plan_create: no HIP device " + std::to_string(device));
     HIPCHK(hipSetDevice(device));
@@ -551,6 +551,22 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
         H = 1;
     };
 
+    // bf16x3 plans cover what the split-operand kernels implement; a layer that only exists in the f32 plan (an LSTM over
+    // image rows/columns, GroupNorm on a channel count that is not a power of two, ...) does not reject the network:
+    // the activations are converted once (split NHWC -> fp32 NCHW) and the rest of the plan runs on the f32 kernels.
+    auto leave_x3 = [&]() {
+        if (split_fmt && !seq) {
+            Step u;
+            u.kind = S_UNSPLIT;
+            u.C = C; u.H = H;
+            u.outC = C; u.outH = H;
+            u.len_in = u.len_out = stage;
+            p->steps.push_back(std::move(u));
+        }
+        x3 = false;
+        split_fmt = false;
+    };
+
     for (int i = 0; i < n_layers; ++i) {
         const krk_layer& L = layers[i];
         const std::string where = "layer " + std::to_string(i);
@@ -561,6 +577,12 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 if (L.cout <= 0 || L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0 || L.dh <= 0 || L.dw <= 0)
                     return bail(KRK_E_INVALID, where + ": bad conv geometry");
                 if (L.act < 0 || L.act > KRK_ACT_SIGMOID) return bail(KRK_E_UNSUPPORTED, where + ": activation");
+                if (x3 && split_fmt && C % 16) {   // conv_x3 wants 16-channel K blocks; the tap kernel takes multiples of 4 after conv1_x3
+                    const bool taps_ok = !p->steps.empty() && p->steps.back().kind == S_CONV && p->steps.back().cg.c1x3 &&
+                                         krk_conv_taps_supported(C, L.cout, L.kh, L.kw, L.sh, L.sw, L.dh, L.dw) &&
+                                         !(i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC);
+                    if (!taps_ok) leave_x3();
+                }
                 Step s;
                 s.kind = S_CONV;
                 s.C = C;
@@ -651,8 +673,8 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 break;
             }
             case KRK_OP_MAXPOOL: {
-                if (x3 && (!split_fmt || C % 8))
-                    return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 max-pool needs a convolution in front and a multiple of 8 channels");
+                if (x3 && split_fmt && !seq && C % 8) leave_x3();
+                if (x3 && !split_fmt) x3 = false;          // nothing split yet (pool in front of the first convolution): f32 plan
                 if (seq) return bail(KRK_E_UNSUPPORTED, where + ": max-pool after a sequence layer");
                 if (L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0) return bail(KRK_E_INVALID, where + ": bad pool");
                 Step s;
@@ -674,8 +696,8 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 break;
             }
             case KRK_OP_GROUPNORM: {
-                if (x3 && (!split_fmt || !krk_gn_x3_supported(C, L.cout)))
-                    return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 group norm needs a convolution in front and a power-of-two channel count");
+                if (x3 && split_fmt && !seq && !krk_gn_x3_supported(C, L.cout)) leave_x3();
+                if (x3 && !split_fmt) x3 = false;
                 if (seq) return bail(KRK_E_UNSUPPORTED, where + ": group norm after a sequence layer");
                 if (L.cout <= 0 || C % L.cout) return bail(KRK_E_INVALID, where + ": groups must divide channels");
                 if (!L.w[0] || !L.w[1]) return bail(KRK_E_INVALID, where + ": group norm weights missing");
@@ -703,8 +725,8 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                 break;
             }
             case KRK_OP_RESHAPE_HC: {
-                if (x3 && (!split_fmt || C % 8))
-                    return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 reshape needs a convolution in front and a multiple of 8 channels");
+                if (x3 && split_fmt && !seq && C % 8) leave_x3();
+                if (x3 && !split_fmt) x3 = false;
                 if (seq) return bail(KRK_E_UNSUPPORTED, where + ": reshape after a sequence layer");
                 push_toseq();
                 p->steps.back().on_split = x3;   // writes the K-blocked split sequence rows gemm_x3.hip reads
@@ -720,7 +742,7 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     return bail(KRK_E_UNSUPPORTED, where + ": only column (y-axis) LSTMs can summarise");
                 const int Himg = H;   // image height in front of the layer
                 if (img_lstm) {
-                    if (x3) return bail(KRK_E_UNSUPPORTED, where + ": LSTMs over image rows/columns run in the f32 plan only");
+                    if (x3) leave_x3();   // LSTMs over image rows/columns exist in the f32 plan only
                     Step a;
                     a.kind = S_IMG2ROWS;
                     a.C = C; a.H = H; a.yaxis = L.kw == 1;
@@ -1143,7 +1165,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 s.flops = 0;
                 if (s.on_split) {
                     const int chunks = krk_gn_x3_chunks(N, s.H, Win);
-                    if (s.aux.ensure((size_t)2 * N * chunks * s.C * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
+                    if (s.aux.ensure((size_t)2 * N * (chunks + 1) * s.C * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
                     mark("groupnorm_x3", 0);
                     rc = krk_launch_gn_x3(cur, s.in_f32, outp, out_elems, s.d_gamma, s.d_beta, lens_at(s.len_in), (float*)s.aux.p, N, s.C,
                                           s.H, Win, s.groups, 1e-5f, stream);
@@ -1171,6 +1193,11 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 }
                 mark("to_seq", 0);
                 rc = krk_launch_to_seq(cur, outp, N, s.C, s.H, Win, stream);
+                break;
+            case S_UNSPLIT:
+                s.flops = 0;
+                mark("unsplit", 0);
+                rc = krk_launch_unsplit(cur, out_elems, outp, N, s.C, s.H, Win, stream);
                 break;
             case S_IMG2ROWS:
                 s.flops = 0;

@@ -194,6 +194,8 @@ int krk_launch_gn_x3(const void* x, int x_f32, void* y, size_t plane, const floa
 int krk_launch_maxpool_x3(const void* x, size_t xplane, void* y, size_t yplane, const int* len_out, int N, int C, int H, int W,
                           int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);
 int krk_launch_toseq_x3(const void* x, void* y, size_t plane, int N, int C, int H, int W, hipStream_t s);
+// split NHWC planes (hi, lo at + plane elements) -> fp32 (N,C,H,W): where a bf16x3 plan continues with f32-only layers
+int krk_launch_unsplit(const void* x, size_t plane, float* y, int N, int C, int H, int W, hipStream_t s);
 // (N,C,H,W) <-> sequence rows [(n,h)][w][C] (yaxis = 0) or [(n,w)][h][C] (yaxis = 1) for LSTMs over image rows/columns
 int krk_launch_img2rows(const float* x, float* y, int N, int C, int H, int W, int yaxis, hipStream_t s);
 int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, int yaxis, const int* lens, int last, hipStream_t s);

@@ -229,6 +229,31 @@ __global__ void __launch_bounds__(256) rows2img_kernel(const float* __restrict__
     }
 }
 
+// ----------------------------------------------------- split NHWC planes -> fp32 NCHW
+// Hand-over from the bf16x3 part of a plan to layers that only exist in the f32 plan (LSTMs over image rows/columns):
+// x = hi + lo per element, [n][hw][c] -> [n][c][hw] through 32x32 LDS tiles.
+__global__ void __launch_bounds__(256) unsplit_kernel(const __bf16* __restrict__ x, size_t plane, float* __restrict__ y,
+                                                      int C, int HW) {
+    __shared__ float t[32][33];
+    const int n = blockIdx.z;
+    const int c0 = blockIdx.y * 32, q0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int q = q0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (q < HW && c < C) {
+            const size_t o = ((size_t)n * HW + q) * C + c;
+            v = (float)x[o] + (float)x[plane + o];
+        }
+        t[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, q = q0 + tx;
+        if (c < C && q < HW) y[((size_t)n * C + c) * HW + q] = t[tx][i];
+    }
+}
+
 // ----------------------------------------------------- softmax / argmax per step
 // reference: `(logits / T).softmax(1)` (kraken/lib/vgsl/rpred.py:226, lib/models.py:115) and
 // `seq[..., :L].max(dim=0)` (kraken/lib/ctc_decoder.py:65): per (line, timestep) the maximum
@@ -424,6 +449,12 @@ int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, in
     dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
     if (last) grid = dim3((unsigned)std::min<size_t>(1024, ((size_t)C * W + 255) / 256), 1, N);
     hipLaunchKernelGGL(rows2img_kernel, grid, dim3(256), 0, s, x, y, C, H, W, yaxis, lens, last);
+    return last_ok();
+}
+
+int krk_launch_unsplit(const void* x, size_t plane, float* y, int N, int C, int H, int W, hipStream_t s) {
+    dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(unsplit_kernel, grid, dim3(256), 0, s, (const __bf16*)x, plane, y, C, H * W);
     return last_ok();
 }
 

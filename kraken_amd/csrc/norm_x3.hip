@@ -56,25 +56,12 @@ __global__ void __launch_bounds__(256) gn_x3_kernel(const void* __restrict__ xv,
     const int e0 = ch * per, e1 = min(npx, e0 + per);
     const size_t base = (size_t)n * npx * C;
 
-    if (pass >= 1) {       // per-channel mean (of its group) from the pass-0 partials
-        for (int c = tid; c < C; c += 256) {
-            const int g0 = (c / Cg) * Cg;
-            float s = 0.f;
-            for (int k = 0; k < chunks; ++k)
-                for (int j = 0; j < Cg; ++j) s += part[((size_t)n * chunks + k) * C + g0 + j];
-            mean_c[c] = s / cnt;
-        }
-    }
-    if (pass == 2) {
-        float* part1 = part + (size_t)N * chunks * C;
-        for (int c = tid; c < C; c += 256) {
-            const int g0 = (c / Cg) * Cg;
-            float s = 0.f;
-            for (int k = 0; k < chunks; ++k)
-                for (int j = 0; j < Cg; ++j) s += part1[((size_t)n * chunks + k) * C + g0 + j];
-            rstd_c[c] = 1.0f / sqrtf(s / cnt + eps);
-        }
-    }
+    // group statistics of every channel, reduced once per pass by gn_x3_stats_kernel: stats[0|1][n][C]
+    const float* stats = part + (size_t)2 * N * chunks * C;
+    if (pass >= 1)
+        for (int c = tid; c < C; c += 256) mean_c[c] = stats[(size_t)n * C + c];
+    if (pass == 2)
+        for (int c = tid; c < C; c += 256) rstd_c[c] = stats[(size_t)(N + n) * C + c];
     __syncthreads();
 
     if (pass < 2) {
@@ -124,6 +111,30 @@ __global__ void __launch_bounds__(256) gn_x3_kernel(const void* __restrict__ xv,
             *reinterpret_cast<bf16x8*>(y + plane + o) = lv;
         }
     }
+}
+
+// Combines the per-chunk partial sums of one pass in a fixed order: one workgroup per (line, group), then every channel of
+// the group gets the group's mean (which = 0) or 1/sqrt(var + eps) (which = 1) in stats[which][n][c].
+__global__ void __launch_bounds__(256) gn_x3_stats_kernel(float* __restrict__ part, const int* __restrict__ lens, int N, int C, int H,
+                                                          int W, int G, float eps, int chunks, int which) {
+    __shared__ float red[256];
+    const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int Cg = C / G;
+    int L = lens ? lens[n] : W;
+    L = min(max(L, 1), W);
+    const float cnt = (float)Cg * (float)H * (float)L;
+    const float* src = part + (size_t)which * N * chunks * C;
+    float s = 0.f;
+    for (int e = tid; e < chunks * Cg; e += 256) s += src[((size_t)n * chunks + e / Cg) * C + g * Cg + e % Cg];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    float* stats = part + (size_t)2 * N * chunks * C;
+    const float v = which ? 1.0f / sqrtf(red[0] / cnt + eps) : red[0] / cnt;
+    for (int j = tid; j < Cg; j += 256) stats[(size_t)(which * N + n) * C + g * Cg + j] = v;
 }
 
 // NHWC split planes, window kh x kw, stride sh x sw, no padding (floor); columns >= len_out[n] are written as zeros
@@ -181,20 +192,23 @@ __global__ void __launch_bounds__(256) toseq_x3_kernel(const __bf16* __restrict_
 bool krk_gn_x3_supported(int C, int G) { return C >= 8 && C <= 2048 && (C & (C - 1)) == 0 && G > 0 && C % G == 0; }
 
 int krk_gn_x3_chunks(int N, int H, int W) {
+    // memory-latency bound passes: aim at ~4 workgroups per CU (about 4096 in total), at least 512 pixels each
     const long px = (long)H * W;
-    long chunks = (px + 4095) / 4096;                       // >= 4k pixels per workgroup
+    long chunks = (px + 511) / 512;
     const long cap = (4096 + N - 1) / N;
     if (chunks > cap) chunks = cap;
-    return (int)(chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks));
+    return (int)(chunks < 1 ? 1 : (chunks > 1024 ? 1024 : chunks));
 }
 
-// `part`: 2 * N * chunks * C floats of scratch
+// `part`: 2 * N * chunks * C floats of partial sums + 2 * N * C floats of group statistics
 int krk_launch_gn_x3(const void* x, int x_f32, void* y, size_t plane, const float* gamma, const float* beta, const int* lens,
                      float* part, int N, int C, int H, int W, int G, float eps, hipStream_t s) {
     if (!krk_gn_x3_supported(C, G)) return -4;
     const int chunks = krk_gn_x3_chunks(N, H, W);
     const size_t lds = (size_t)(256 * 8 + 2 * C) * sizeof(float);
     for (int pass = 0; pass < 3; ++pass) {
+        if (pass > 0)
+            hipLaunchKernelGGL(gn_x3_stats_kernel, dim3(G, N), dim3(256), 0, s, part, lens, N, C, H, W, G, eps, chunks, pass - 1);
         if (x_f32)
             hipLaunchKernelGGL(gn_x3_kernel<true>, dim3(chunks, N), dim3(256), lds, s, x, plane, (__bf16*)y, gamma, beta, lens, part, N, C,
                                H, W, G, eps, chunks, pass);

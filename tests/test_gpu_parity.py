@@ -461,15 +461,25 @@ def test_x3_matches_cpu_oracle_on_small_networks(spec, n, w, lens):
             assert gl.tolist() == wl.tolist()
 
 
-def test_x3_rejects_networks_it_cannot_run():
-    from kraken_amd import _lib
-    # GroupNorm on split planes wants a power-of-two channel count; the fp32 plan takes anything
-    m = build_model('[1,8,0,1 Cr3,3,24 Gn4 S1(1x0)1,3 Lbx8 O1c5]', seed=0).to('cuda')
+def test_x3_plan_continues_on_f32_kernels_where_it_has_to():
+    """A bf16x3 plan does not reject layers that only exist in the f32 plan: it converts the activations once (split NHWC
+    -> fp32 NCHW, `unsplit`) and runs the rest on the f32 kernels.  Here: GroupNorm on 24 channels (not a power of two)."""
+    from kraken_amd.engine import RecognitionEngine
+    spec = '[1,8,0,1 Cr3,3,24 Gn4 S1(1x0)1,3 Lbx8 O1c5]'
+    m = build_model(spec, seed=0)
+    x = synth_input(3, 64, h=8)
+    want, _ = CpuRecognizer(m.layer_specs, m.state_dict()).forward(x)
+    m.to('cuda')
     m.nn.set_precision('bf16x3')
-    with pytest.raises(_lib.KrakenAmdError):
-        m.nn(synth_input(1, 64, h=8).cuda())
-    m.nn.set_precision('f32')
-    m.nn(synth_input(1, 64, h=8).cuda())
+    got, _ = m.nn(x.cuda())
+    assert (got.cpu() - want).abs().max().item() < X3_TOL
+    eng = RecognitionEngine(m, device=0, max_batch=3, max_width=64, slots=1)
+    eng.set_profiling(True)
+    eng.submit(x.cuda())
+    eng.collect()
+    names = [n_ for n_, _, _ in eng.layer_times()[0]]
+    eng.close()
+    assert names[:3] == ['conv1_x3', 'unsplit', 'groupnorm']
     with pytest.raises(ValueError):
         m.nn.set_precision('fp8')
 

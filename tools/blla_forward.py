@@ -12,12 +12,15 @@ from oracle.torch_port import CpuRecognizer  # noqa: E402
 
 BLLA = ('[1,1800,0,3 Cr7,7,64,2,2 Gn32 Cr3,3,128,2,2 Gn32 Cr3,3,128 Gn32 Cr3,3,256 Gn32 Cr3,3,256 Gn32 '
         'Lbx32 Lby32 Cr1,1,32 Gn32 Lby32 Lbx32 O2l8]')
-H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1800, 1350)
+_pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+H, W = (int(_pos[0]), int(_pos[1])) if len(_pos) > 1 else (1800, 1350)
 spec = BLLA.replace('[1,1800,0,3', f'[1,{H},0,3')
 torch.manual_seed(0)
 m = kraken_amd.TorchVGSLModel(vgsl=spec)
 x = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(1))
 m.to('cuda')
+if '--x3' in sys.argv:
+    m.nn.set_precision('bf16x3')   # convolutions + GroupNorm on the bf16 cores, 2-D LSTMs and the tail on the f32 kernels
 xd = x.cuda()
 y, _ = m.nn(xd)
 torch.cuda.synchronize()
