@@ -350,6 +350,7 @@ struct Step {
     float* d_wrec32 = nullptr;  // recurrent weights, 32x32x2 fragment order
     float* d_wrec16 = nullptr;  // recurrent weights, 16x16x4 fragment order
     void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
+    float* d_wrecsm = nullptr;  // recurrent weights for lstm_small.hip (Hp <= 32): register-resident A fragments
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
     bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
     bool in_f32 = false;        // GN on split planes whose producer handed over fp32 NHWC (ConvGeom::out_f32)
@@ -428,6 +429,21 @@ void pack_lstm_recurrent(const Step& st, const float* const* whh, int M, std::ve
                     }
 }
 
+// lstm_small.hip: [dir][b][ks][lane] = W[gate column 16*b + (lane&15)][k = 4*ks + (lane>>4)], Hp/4 blocks and K steps
+void pack_lstm_small(const Step& st, const float* const* whh, std::vector<float>& pack) {
+    const int H = st.hidden, NB = st.Hp / 4;
+    pack.assign((size_t)st.ndir * NB * NB * 64, 0.f);
+    for (int d = 0; d < st.ndir; ++d)
+        for (int b = 0; b < NB; ++b)
+            for (int ks = 0; ks < NB; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int col = 16 * b + (lane & 15), k = 4 * ks + (lane >> 4);
+                    const int u = col >> 2, gt = col & 3;
+                    if (u >= H || k >= H) continue;
+                    pack[(((size_t)d * NB + b) * NB + ks) * 64 + lane] = whh[d][((size_t)gt * H + u) * H + k];
+                }
+}
+
 // [dir][kb][block][plane][lane][8]: lane l holds K = kb*32 + 8*(l>>4) + e of gate column block*16 + (l&15)
 int upload_lstm_x3(Step& st, const float* const* whh) {
     const int H = st.hidden, Hp = st.Hp, G = 4 * Hp;
@@ -463,6 +479,7 @@ void free_step(Step& s) {
     if (s.cg.d_w) (void)hipFree(s.cg.d_w);
     if (s.cg.d_b) (void)hipFree(s.cg.d_b);
     if (s.cg.d_wx3) (void)hipFree(s.cg.d_wx3);
+    if (s.d_wrecsm) (void)hipFree(s.d_wrecsm);
     if (s.d_gamma) (void)hipFree(s.d_gamma);
     if (s.d_beta) (void)hipFree(s.d_beta);
     if (s.d_wrec32) (void)hipFree(s.d_wrec32);
@@ -838,6 +855,10 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
                     pack_lstm_recurrent(s, whh, 16, pk);
                     if (upload(&s.d_wrec16, pk) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
                     if (s.rec_x3 && upload_lstm_x3(s, whh) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
+                    if (!s.rec_x3 && krk_lstm_small_supported(s.Hp) && !getenv("KRK_NO_LSTM_SMALL")) {
+                        pack_lstm_small(s, whh, pk);
+                        if (upload(&s.d_wrecsm, pk) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
+                    }
                     s.outC = s.ndir * s.hidden;
                     C = s.outC;
                 }
@@ -1299,6 +1320,13 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 {
                     const char* dbg = getenv("KRK_LSTM_DBG");
                     l.dbg = dbg ? atoi(dbg) : 0;
+                }
+                if (s.d_wrecsm) {   // hidden size <= 32: one wave per 16 sequences, weights / h / c in registers
+                    l.wp = s.d_wrecsm;
+                    l.NG = l.NB = 0;
+                    s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
+                    rc = krk_launch_lstm_small(l, stream);
+                    break;
                 }
                 // 32-line tiles once they fill most of the 256 CUs, 16-line tiles below that
                 const int tiles32 = (N + 31) / 32 * s.ndir;

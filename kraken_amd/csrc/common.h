@@ -152,6 +152,10 @@ struct LstmArgs {
     int dbg;              // probe bits (env KRK_LSTM_DBG): 1 no GEMM, 2 no gate math, 4 no output pass, 8 no x prefetch
 };
 
+// small hidden sizes (Hp <= 32, lstm_small.hip): wp = [ndir][Hp/4 blocks][Hp/4 K steps][64 lanes]
+bool krk_lstm_small_supported(int Hp);
+int krk_launch_lstm_small(const LstmArgs& a, hipStream_t s);
+
 // split-bf16 recurrent kernel (lstm_x3.hip), 16-line tiles
 struct LstmX3Args {
     const float* xp;      // [N*T][xstride] fp32 input projections (+ biases), gate-interleaved columns
