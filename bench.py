@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--precision', default='bf16x3', choices=['f32', 'bf16x3'],
                     help='f32: exact f32 MFMA; bf16x3: split-bf16 operands on the bf16 MFMA, f32 accumulate (fp32-class)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-input', action='store_true',
+                    help='hand every batch over as a pinned HOST tensor (PCIe-inclusive rate; DESIGN.md quotes it, `value` never does)')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the gather even with one rank (smoke test)')
     ap.add_argument('--cpu-lines', type=int, default=32, help='lines in the CPU baseline sample')
     return ap.parse_args()
@@ -101,6 +103,8 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(N, 1, 48, W, generator=g).to(dev)    # resident in HBM before timing
     engine = RecognitionEngine(model, device=local_rank, max_batch=N, max_width=W, slots=args.slots)
+    if args.host_input:
+        x = x.cpu().pin_memory()
 
     codec = model.codec
     n_chars = [0]
@@ -196,7 +200,7 @@ def main():
         'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None,
         'dtype': 'f32' if args.precision == 'f32' else 'bf16x3 (every value carried as bf16 hi+lo; 3 bf16 MFMAs per product, f32 accumulate; |d logit| vs fp32 ~1.4e-5)',
-        'data': 'synthetic',
+        'data': 'synthetic' + (' (pinned host input per step: PCIe-inclusive)' if args.host_input else ''),
         'config': {'workload': f'BENCH-A VGSL recogniser (3.17M params, random init seed 0), {N} lines 1x48x{W} per GPU '
                                f'per step, greedy CTC decode, label tuples to host', 'lines_per_gpu_step': N, 'width': W,
                    'slots': args.slots, 'precision': args.precision, 'parallelism': f'dp{world}', 'whole_path_tflops': round(value * 2.778e-3 *

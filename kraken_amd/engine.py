@@ -36,6 +36,7 @@ class _Slot:
         self.busy = False
         self.n = self.t = 0
         self.keep = None
+        self.stage = None     # device copy of a host input batch
 
 
 class RecognitionEngine:
@@ -77,11 +78,21 @@ class RecognitionEngine:
         return out
 
     def submit(self, x: torch.Tensor, lens: Optional[np.ndarray] = None) -> int:
-        """x: (N, C, H, W) float32 CUDA tensor resident on this device.  Returns a ticket."""
+        """
+        x: (N, C, H, W) float32 tensor, resident on this device -- or a (preferably pinned) HOST tensor, which is copied
+        to a per-slot staging buffer on the slot's own stream so that the PCIe transfer of batch k+1 overlaps the kernels of
+        batch k.  Returns a ticket.
+        """
         slot_id = self._next
         slot = self.slots[slot_id]
         if slot.busy:
             raise RuntimeError('all slots busy: collect() a ticket before submitting more')
+        if not x.is_cuda:
+            if slot.stage is None or slot.stage.shape != x.shape:
+                slot.stage = torch.empty(x.shape, dtype=torch.float32, device=f'cuda:{self.device}')
+            with torch.cuda.stream(slot.stream):
+                slot.stage.copy_(x, non_blocking=True)
+            x = slot.stage
         N, _, _, W = x.shape
         _, _, T = slot.plan.out_shape(W)
         if N > slot.max_n or T > slot.max_t:
