@@ -15,7 +15,6 @@ from os import PathLike
 from os.path import abspath, expanduser, expandvars
 from typing import Optional, Union
 
-import numpy as np
 import torch
 
 from . import ctc_decoder as _ctc

@@ -22,7 +22,6 @@ import ctypes as C
 import json
 import math
 import re
-from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Any, Optional, Sequence
 

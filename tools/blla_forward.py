@@ -37,7 +37,6 @@ want, _ = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().it
 print(f'CPU oracle {time.time() - t:.1f} s on {torch.get_num_threads()} threads; max|d logit| = {(y.cpu() - want).abs().max().item():.3e} '
       f'(|logit| max {want.abs().max().item():.2f})', flush=True)
 if '--layers' in sys.argv:
-    from kraken_amd.engine import RecognitionEngine  # noqa: E402  (per-launch HIP-event times)
     import ctypes as C
     from kraken_amd import _lib
     plan = m.nn.plan(xd.device.index or 0)

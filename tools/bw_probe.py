@@ -1,4 +1,4 @@
-import torch, time
+import torch
 n = 245_760_000 // 4
 x = torch.empty(n, device='cuda'); y = torch.empty(n, device='cuda')
 def t(f, k=20):

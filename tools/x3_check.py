@@ -1,4 +1,4 @@
-import sys, time, torch, numpy as np
+import sys, torch
 sys.path.insert(0, '.')
 import kraken_amd
 from oracle.torch_port import CpuRecognizer
