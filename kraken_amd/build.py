@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 BUILD = os.path.join(CSRC, '_build')
 LIB = os.path.join(HERE, 'libkraken_amd.so')
-SOURCES = ['conv_mfma.hip', 'conv_x3.hip', 'conv1_x3.hip', 'conv_taps_x3.hip', 'gemm_x3.hip', 'norm_x3.hip', 'lstm_rec.hip', 'lstm_small.hip', 'lstm_x3.hip', 'misc_kernels.hip', 'capi.hip']
+SOURCES = ['conv_mfma.hip', 'conv_x3.hip', 'conv1_x3.hip', 'conv_taps_x3.hip', 'gemm_x3.hip', 'norm_x3.hip', 'lstm_rec.hip', 'lstm_small.hip', 'lstm_x3.hip', 'lstm_x3v2.hip', 'misc_kernels.hip', 'capi.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'kraken_amd.h')]
 ARCH = 'gfx950'
@@ -37,17 +37,26 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compiles every HIP source for gfx950 and links the C-ABI library. Returns its path."""
-    os.makedirs(BUILD, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+    """
+    Compiles every HIP source for gfx950 and links the C-ABI library. Returns its path.
+
+    ``ablate=True`` builds ``libkraken_amd_ablate.so`` instead: the same kernels with their phase-skipping probe
+    branches (``KRK_DBGBIT``, common.h) compiled in -- a measuring tool (tools/lstm_probe.py), selected with
+    ``KRAKEN_AMD_LIB``; the release library has no probe code in its hot loops.
+    """
+    bdir = BUILD + ('_ablate' if ablate else '')
+    lib_path = LIB.replace('.so', '_ablate.so') if ablate else LIB
+    flags = FLAGS + (['-DKRK_ABLATE'] if ablate else [])
+    os.makedirs(bdir, exist_ok=True)
     hipcc = _hipcc()
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(BUILD, src.replace('.hip', '.o'))
+        obj = os.path.join(bdir, src.replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(obj, [sp] + HEADERS + [os.path.abspath(__file__)]):
-            jobs.append([hipcc, *FLAGS, '-c', sp, '-o', obj])
+            jobs.append([hipcc, *flags, '-c', sp, '-o', obj])
 
     def run(cmd):
         if verbose:
@@ -59,10 +68,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', LIB])
-    return LIB
+    if jobs or force or _stale(lib_path, objs):
+        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', lib_path])
+    return lib_path
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, ablate='--ablate' in sys.argv))

@@ -179,8 +179,10 @@ class PytorchCodec(object):
         if self.strict and not ok.all():
             bad = flat[~ok][:5].tolist()
             raise KrakenEncodeException(f'Non-decodable sequence {tuple(bad)}... encountered.')
-        per_line = np.add.reduceat(ok.astype(np.int64), np.r_[0, np.cumsum(counts)[:-1]]) if len(flat) else np.zeros(n, np.int64)
-        per_line = np.where(counts > 0, per_line, 0)
+        # decodable labels per line from a prefix sum (reduceat cannot take empty / trailing segments)
+        csum = np.r_[0, np.cumsum(ok, dtype=np.int64)]
+        ends = np.cumsum(np.minimum(np.maximum(counts, 0), t), dtype=np.int64)
+        per_line = csum[ends] - csum[np.r_[0, ends[:-1]]] if n else np.zeros(0, np.int64)
         text = cps[ok].tobytes().decode('utf-32-le')
         out, pos = [], 0
         for k in per_line.tolist():

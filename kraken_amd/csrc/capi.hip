@@ -350,6 +350,7 @@ struct Step {
     float* d_wrec32 = nullptr;  // recurrent weights, 32x32x2 fragment order
     float* d_wrec16 = nullptr;  // recurrent weights, 16x16x4 fragment order
     void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
+    void* d_wrecx3v2 = nullptr; // the same fragments in [dir][block][kb] order (lstm_x3v2.hip streams a block's K blocks back to back)
     float* d_wrecsm = nullptr;  // recurrent weights for lstm_small.hip (Hp <= 32): register-resident A fragments
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
     bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
@@ -466,6 +467,15 @@ int upload_lstm_x3(Step& st, const float* const* whh) {
                     }
     HIPCHK(hipMalloc(&st.d_wrecx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(st.d_wrecx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // [dir][block][kb][plane][lane][8] for lstm_x3v2.hip
+    std::vector<uint16_t> p2(pack.size(), 0);
+    for (int d = 0; d < st.ndir; ++d)
+        for (int kb = 0; kb < NKB; ++kb)
+            for (int b = 0; b < NB; ++b)
+                std::memcpy(&p2[(((size_t)d * NB + b) * NKB + kb) * 1024], &pack[(((size_t)d * NKB + kb) * NB + b) * 1024],
+                            1024 * sizeof(uint16_t));
+    HIPCHK(hipMalloc(&st.d_wrecx3v2, p2.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(st.d_wrecx3v2, p2.data(), p2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return KRK_OK;
 }
 
@@ -485,6 +495,7 @@ void free_step(Step& s) {
     if (s.d_wrec32) (void)hipFree(s.d_wrec32);
     if (s.d_wrec16) (void)hipFree(s.d_wrec16);
     if (s.d_wrecx3) (void)hipFree(s.d_wrecx3);
+    if (s.d_wrecx3v2) (void)hipFree(s.d_wrecx3v2);
     s.out.release();
     s.aux.release();
     s.aux2.release();
@@ -1306,7 +1317,18 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     l.hrow = l.NKB * 64 + 16;
                     l.dbg = env_int("KRK_LSTM_DBG");
                     s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
-                    rc = krk_launch_lstm_x3(l, stream);
+                    rc = -4;
+                    if (env_int("KRK_LSTM_V", 1) == 2) {
+                        // lines per workgroup: 32 (half the CUs of 16-line tiles at nearly the same step time) once
+                        // that still leaves >= 8 workgroups; KRK_LSTM_NT / KRK_LSTM_NW override (probing)
+                        int nt = (N + 31) / 32 * s.ndir >= 8 ? 2 : 1;
+                        nt = env_int("KRK_LSTM_NT", nt);
+                        const int nw = env_int("KRK_LSTM_NW", 8);
+                        LstmX3Args l2 = l;
+                        l2.wp = (const __bf16*)s.d_wrecx3v2;
+                        rc = krk_launch_lstm_x3v2(l2, nt, nw, stream);
+                    }
+                    if (rc == -4) rc = krk_launch_lstm_x3(l, stream);
                     break;
                 }
                 LstmArgs l;

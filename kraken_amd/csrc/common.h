@@ -5,6 +5,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Ablation probes (skip the K loop / the loads / the stores of a kernel to price its phases) exist only in the
+// -DKRK_ABLATE build (python -m kraken_amd.build --ablate -> libkraken_amd_ablate.so, selected with KRAKEN_AMD_LIB);
+// the release kernels carry no probe branches in their hot loops.
+#ifdef KRK_ABLATE
+#define KRK_DBGBIT(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define KRK_DBGBIT(a, bit) (false)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -171,6 +180,8 @@ struct LstmX3Args {
     int dbg;              // probe bits (env KRK_LSTM_DBG): 1 no weight loads, 2 no gate math, 4 no MFMA, 8 no x prefetch
 };
 int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s);
+// second generation (lstm_x3v2.hip): nt tiles of 16 lines per workgroup, nw waves; a.wp in [dir][block][kb] order
+int krk_launch_lstm_x3v2(const LstmX3Args& a, int nt, int nw, hipStream_t s);
 
 // K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel
 int krk_lstm_kg(int M, int blocks_per_wave);

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
         for (int i = 0; i < NST; ++i) {
             const int gw = w0 + s_iw[i];
             st[i] = 0.f;
-            if (gw >= 0 && gw < len_in && !(a.dbg & 2)) st[i] = xin[s_off[i] + w0];
+            if (gw >= 0 && gw < len_in && !KRK_DBGBIT(a, 2)) st[i] = xin[s_off[i] + w0];
         }
     };
     auto lstore = [&](int buf) {
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[o][s][r] = 0.f;
 
-        if (w0 < wlim && !(a.dbg & 1)) {
+        if (w0 < wlim && !KRK_DBGBIT(a, 1)) {
 #pragma unroll
             for (int i = 0; i < KH + 1; ++i) {
                 bf16x8 f[2][4];   // [plane][segment]
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
                 for (int o = 0; o < NO; ++o) {
                     const int row = POOL ? (h0 >> 1) + wave : h0 + 2 * wave + o;
                     const int col0 = POOL ? (w0 >> 1) + 2 * c : w0 + 4 * c;
-                    if (row >= a.Hy || col0 >= a.y_pitch || (a.dbg & 4)) continue;
+                    if (row >= a.Hy || col0 >= a.y_pitch || KRK_DBGBIT(a, 4)) continue;
                     const int lim = min(len_out, a.Wy);
                     // 64-bit base once, 32-bit filter offsets: filter f of this row starts f * pitch elements further
                     __bf16* rowh = yh + ((size_t)n * a.Hy + row) * a.Cout * a.y_pitch + col0;

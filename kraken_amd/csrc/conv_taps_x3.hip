@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (s_ok[i] && !(a.dbg & 4)) st[i] = *reinterpret_cast<const f32x4*>(a.x + s_src[i] + (long)ch0 * a.pitch);
+            if (s_ok[i] && !KRK_DBGBIT(a, 4)) st[i] = *reinterpret_cast<const f32x4*>(a.x + s_src[i] + (long)ch0 * a.pitch);
         }
     };
     auto lstore = [&](int buf) {
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
     for (int k = 0; k < nchunks; ++k) {
         const int buf = k & 1;
         if (k + 1 < nchunks) gload((k + 1) * CC);
-        if (live && !(a.dbg & 1)) {
+        if (live && !KRK_DBGBIT(a, 1)) {
             static_assert(CC == 4, "channel loop is unrolled for 4-channel chunks");
             const int cg = k * CC;
             wload(cg + 1, whb, wlb);
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
                 lv[i] = (__bf16)(v - (float)h);
             }
             const int co = 8 * j + 4 * half;
-            if (ok && co < a.Cout && !(a.dbg & 16)) {
+            if (ok && co < a.Cout && !KRK_DBGBIT(a, 16)) {
                 if (a.y_f32) {
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + base + co) = fv;
                 } else {
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
                         lv[i] = (__bf16)(v - (float)h);
                     }
                     const int co = 8 * j + 4 * half;
-                    if (ok && co < a.Cout && !(a.dbg & 16)) {
+                    if (ok && co < a.Cout && !KRK_DBGBIT(a, 16)) {
                         if (a.y_f32) {
                             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + base + co) = fv;
                         } else {

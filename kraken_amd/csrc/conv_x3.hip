@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                     const int gh = gh0 + ih, gw = gw0 + iw;
                     const int gc = ci * a.cchunk + q * 8;
                     dst[i] = plane * a.lds_plane + pix * a.PSTR + q * 16;
-                    if (gc < a.Cin && gh >= 0 && gh < a.H && gw >= 0 && gw < len_in && !(a.dbg & 2)) {
+                    if (gc < a.Cin && gh >= 0 && gh < a.H && gw >= 0 && gw < len_in && !KRK_DBGBIT(a, 2)) {
                         const __bf16* src = a.x + (size_t)plane * a.x_plane +
                                             (((size_t)n * a.H + gh) * a.W + gw) * a.Cin + gc;
                         v[i] = *reinterpret_cast<const f32x4*>(src);
@@ -163,8 +163,8 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
             if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                 // stage st landed for everyone; stage st-1 fully read
-            if (st + 2 < nst && !(a.dbg & 8)) issue(st + 2, slot >= 1 ? slot - 1 : 2);
-            if (any_live && !(a.dbg & 1)) {
+            if (st + 2 < nst && !KRK_DBGBIT(a, 8)) issue(st + 2, slot >= 1 ? slot - 1 : 2);
+            if (any_live && !KRK_DBGBIT(a, 1)) {
                 const int nk = min(IT, nit - st * IT);
                 const unsigned char* wst = wring + slot * 8192 + lane * 16;
                 for (int k = 0; k < nk; ++k) {
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                         fv[i] = v;
                         lv[i] = (__bf16)(v - (float)h);
                     }
-                    if (st && co < a.Cout && !(a.dbg & 4)) {
+                    if (st && co < a.Cout && !KRK_DBGBIT(a, 4)) {
                         size_t o = base + co;
                         if (a.y_blkM > 0) {   // K-blocked sequence rows: feature f = row*Cout + co -> [f/8][line*cols + col][f%8]
                             const int f = row * a.Cout + co;

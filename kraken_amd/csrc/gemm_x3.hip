@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
 
     // three LDS buffers, copies two K steps ahead: 6 copies per wave per step, so "vmcnt(6)" = this
     // wave's copies of step kb have landed while those of step kb+1 are still in flight
-    const bool no_mma = (a.dbg & 1), no_copy = (a.dbg & 2), no_lds = (a.dbg & 8);
+    const bool no_mma = KRK_DBGBIT(a, 1), no_copy = KRK_DBGBIT(a, 2), no_lds = KRK_DBGBIT(a, 8);
     if (!no_copy) { issue(0, 0);
     if (nkb > 1) issue(1, 1); }
 
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
     float* T = reinterpret_cast<float*>(lds) + wave * (32 * RSTR);
     const int col0 = cg * TN;
     const bool vec = (a.Cout & 3) == 0;
-    const bool nostore = (a.dbg & 4);
+    const bool nostore = KRK_DBGBIT(a, 4);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll

@@ -133,7 +133,7 @@ __device__ __forceinline__ void lstm_time_loop(const LstmArgs& a, float* hs, con
         if constexpr (XPRE) {
 #pragma unroll
             for (int j = 0; j < NBW; ++j) acc[j] = xn[j];
-            if (s + 1 < Lmax && !(a.dbg & 8)) load_x(s + 1, xn);   // in flight for the whole step
+            if (s + 1 < Lmax && !KRK_DBGBIT(a, 8)) load_x(s + 1, xn);   // in flight for the whole step
         } else {
             load_x(s, acc);
         }
@@ -141,7 +141,7 @@ __device__ __forceinline__ void lstm_time_loop(const LstmArgs& a, float* hs, con
         // ---- acc += h_{t-1} . W_hh^T, weight stream double-buffered in registers
         const float* hcur = hs + cur * hrows * LS;
         int g = 0;
-        if (a.dbg & 1) g = a.NG;          // probe: skip the recurrent GEMM
+        if KRK_DBGBIT(a, 1) g = a.NG;          // probe: skip the recurrent GEMM
         for (; g + 1 < a.NG; g += 2) {
             load_w(g + 1, wb);
             mma_group(g, hcur, wa);
@@ -155,7 +155,7 @@ __device__ __forceinline__ void lstm_time_loop(const LstmArgs& a, float* hs, con
 
         // ---- gate non-linearities, cell update, h_t -> LDS
         float* hnext = hs + (cur ^ 1) * hrows * LS;
-        if (!(a.dbg & 2))                 // probe: skip the gate math
+        if (!KRK_DBGBIT(a, 2))                 // probe: skip the gate math
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
             const int unit = (wave + 4 * j) * UPB + ul;

@@ -105,7 +105,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
         }
     };
     auto load_w = [&](int kb, WPair (&dst)[NBW]) {
-        if (a.dbg & 1) return;
+        if KRK_DBGBIT(a, 1) return;
         const __bf16* wk = wbase + (size_t)kb * kstride;
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
@@ -115,7 +115,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
         }
     };
     auto mma_block = [&](int kb, const unsigned char* hcur, const WPair (&w)[NBW]) {
-        if (a.dbg & 4) return;
+        if KRK_DBGBIT(a, 4) return;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const unsigned char* hp = hcur + (16 * g + line) * RS + (kb * 32 + us * 8) * 2;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
     };
 
     WPair wa[NBW], wb[NBW];
-    if (a.dbg & 1) {
+    if KRK_DBGBIT(a, 1) {
 #pragma unroll
         for (int j = 0; j < NBW; ++j) { wa[j].hi = bf16x8{}; wa[j].lo = bf16x8{}; wb[j].hi = bf16x8{}; wb[j].lo = bf16x8{}; }
     }
@@ -161,7 +161,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
             load_w(0, wa);
         }
         if constexpr (XPRE) {
-            if (s + 1 < Lmax && !(a.dbg & 8)) {
+            if (s + 1 < Lmax && !KRK_DBGBIT(a, 8)) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) load_x(s + 1, g, xbuf[g]);
             }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
 
         // ---- gate non-linearities, cell update (per lane: one (line, unit)), h_t -> LDS as (hi, lo)
         unsigned char* hnext = hs + (cur ^ 1) * buf;
-        if (!(a.dbg & 2))
+        if (!KRK_DBGBIT(a, 2))
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll

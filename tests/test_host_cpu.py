@@ -257,6 +257,14 @@ def test_codec_vectorised_strings_equal_per_line_decode():
     empty = DecodedBatch(np.zeros((2, 0), np.int32), np.zeros((2, 0), np.int32), np.zeros((2, 0), np.int32),
                          np.zeros((2, 0), np.float32), np.zeros(2, np.int32))
     assert single.decode_strings(empty) == ['', '']
+    # trailing / interleaved lines that decode to nothing (reduceat raised IndexError on counts [3, 0])
+    for cnts in ([3, 0], [0, 2, 0], [0, 0, 4], [2, 0, 0, 1]):
+        lab = np.zeros((len(cnts), 4), np.int32)
+        for i, k in enumerate(cnts):
+            lab[i, :k] = np.arange(1, k + 1) + i
+        zz = np.zeros_like(lab)
+        b = DecodedBatch(lab, zz, zz, np.zeros(lab.shape, np.float32), np.array(cnts, np.int32))
+        assert single.decode_strings(b) == [''.join(c for c, *_ in rec) for rec in single.decode_batch(b)]
 
 
 # ---------------------------------------------------------------------------- preprocessing

@@ -1,0 +1,94 @@
+"""Probe of the recurrent kernels (dev tool, GPU): per-launch time of every variant + agreement with the first-generation kernel.
+
+    python tools/lstm_v2_probe.py            # table of variants x batch sizes
+    python tools/lstm_v2_probe.py --ablate   # phase prices from the -DKRK_ABLATE build (python -m kraken_amd.build --ablate)
+"""
+import json
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, '.')
+from tests.specs import BENCH_A as SPEC  # noqa: E402
+
+
+def child(N, T, dump):
+    import ctypes as C
+    import numpy as np
+    import torch
+    import kraken_amd
+    from kraken_amd import _lib
+    torch.manual_seed(0)
+    m = kraken_amd.TorchVGSLModel(vgsl=SPEC)
+    m.nn.set_precision('bf16x3')
+    m.to('cuda')
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(N, 1, 48, T * 8, generator=g).cuda()
+    lens = None
+    if os.environ.get('PROBE_RAGGED'):
+        lens = torch.tensor([8 * max(1, T - (7 * i) % (T // 2)) for i in range(N)])
+    plan = m.nn.plan(0)
+    lib = _lib.load()
+    lib.krk_plan_set_profiling(plan.handle, 1)
+    best = {}
+    for _ in range(6):
+        y, _ = m.nn(x, lens)
+        torch.cuda.synchronize()
+        n = lib.krk_plan_num_steps(plan.handle)
+        ms = (C.c_float * n)()
+        lib.krk_plan_layer_ms(plan.handle, ms, n)
+        for i in range(n):
+            k = lib.krk_plan_layer_name(plan.handle, i).decode() + f'@{i}'
+            best[k] = min(best.get(k, 1e9), ms[i])
+    if dump:
+        np.save(dump, y.float().cpu().numpy())
+    out = {}
+    for k, v in best.items():
+        out.setdefault(k.split('@')[0], []).append(round(v, 4))
+    print(json.dumps(out))
+
+
+def run(env, N, T, dump=None):
+    e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+    out = subprocess.run([sys.executable, __file__, 'child', str(N), str(T), dump or ''], env=e, capture_output=True, text=True)
+    try:
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return {'error': (out.stderr or out.stdout)[-400:]}
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'child':
+        child(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] or None)
+        sys.exit(0)
+    import numpy as np
+    os.makedirs('gpurun_out', exist_ok=True)
+    variants = [('v1', dict(KRK_LSTM_V=1)), ('v2 nt1 nw8', dict(KRK_LSTM_V=2, KRK_LSTM_NT=1, KRK_LSTM_NW=8)),
+                ('v2 nt2 nw8', dict(KRK_LSTM_V=2, KRK_LSTM_NT=2, KRK_LSTM_NW=8)),
+                ('v2 nt2 nw4', dict(KRK_LSTM_V=2, KRK_LSTM_NT=2, KRK_LSTM_NW=4)),
+                ('v2 nt4 nw4', dict(KRK_LSTM_V=2, KRK_LSTM_NT=4, KRK_LSTM_NW=4))]
+    if '--ablate' in sys.argv:
+        lib = os.path.abspath('kraken_amd/libkraken_amd_ablate.so')
+        for name, env in variants[1:3]:
+            for dbg in (0, 1, 2, 4, 8, 16, 9, 25, 31):
+                r = run(dict(env, KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
+                print('ablate', name, 'dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
+        sys.exit(0)
+    for N, T in ((256, 150), (64, 150), (1024, 150)):
+        ref = None
+        for name, env in variants:
+            for ragged in (0, 1):
+                dump = f'/tmp/probe_{name.replace(" ", "_")}_{N}_{ragged}.npy'
+                e = dict(env)
+                if ragged:
+                    e['PROBE_RAGGED'] = 1
+                r = run(e, N, T, dump)
+                d = None
+                if os.path.exists(dump):
+                    y = np.load(dump)
+                    if name == 'v1':
+                        ref = ref or {}
+                        ref[ragged] = y
+                    elif ref and ragged in ref:
+                        d = float(np.abs(y - ref[ragged]).max())
+                print(f'N={N} T={T} ragged={ragged} {name:12s} rec={r.get("lstm_rec_x3", r)} xproj={r.get("lstm_xproj_x3")} maxdiff_vs_v1={d}', flush=True)
