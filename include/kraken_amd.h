@@ -208,6 +208,16 @@ const char* krk_plan_layer_name(const krk_plan* plan, int i);
 double krk_plan_layer_flops(const krk_plan* plan, int i);
 int krk_plan_num_steps(const krk_plan* plan);
 
+/*
+ * Device-side status of the plan.  The recurrent cluster kernel (lstm_ws.hip) exchanges h_t between workgroups
+ * inside a launch; every wait in it is bounded, and a wait that gives up raises a status word in mapped host memory
+ * instead of hanging the device.  Call after the work of a batch has completed (stream/event synchronised):
+ * KRK_OK, or KRK_E_HIP (and the word is cleared) if any batch run on this plan since the last call is invalid.
+ * A krk_plan is single-stream and not thread-safe: do not use one plan from two streams or threads concurrently
+ * (its workspaces are plan-owned); different plans are independent.
+ */
+int krk_plan_status(krk_plan* plan);
+
 /* Cross-batch scheduling for callers that keep several plans in flight on separate streams
  * (kraken_amd/engine.py; no reference analogue -- the reference runs one batch at a time,
  * kraken/lib/vgsl/rpred.py:210-229).  `krk_plan_front_event` returns a hipEvent_t (as void*, owned by

@@ -350,7 +350,12 @@ struct Step {
     float* d_wrec32 = nullptr;  // recurrent weights, 32x32x2 fragment order
     float* d_wrec16 = nullptr;  // recurrent weights, 16x16x4 fragment order
     void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
-    void* d_wrecx3v2 = nullptr; // the same fragments in [dir][block][kb] order (lstm_x3v2.hip streams a block's K blocks back to back)
+    // weight-stationary cluster kernel (lstm_ws.hip): per-wave resident fragments, exchange granules, ticket counter
+    void* d_wrecws = nullptr;
+    DevBuf ws_gran;
+    unsigned* ws_ctrl = nullptr;
+    unsigned ws_tickets = 0, ws_epoch = 0;
+    int ws_bpc = 0;
     float* d_wrecsm = nullptr;  // recurrent weights for lstm_small.hip (Hp <= 32): register-resident A fragments
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
     bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
@@ -388,6 +393,9 @@ struct krk_plan {
     hipEvent_t front_ev = nullptr;      // recorded when this plan's convolution block has been enqueued-and-run
     hipEvent_t front_wait = nullptr;    // not owned: another plan's front_ev the next call waits for (one shot)
     DevBuf d_labels, d_confs, d_final;
+    // device-side failure word (mapped host memory): set by a kernel that gave up waiting (lstm_ws.hip exchange timeout)
+    unsigned* err_host = nullptr;
+    unsigned* err_dev = nullptr;
     bool profiling = false;
     std::vector<hipEvent_t> events;          // one per profiled launch + 1
     std::vector<const char*> prof_names;     // kernel group of each profiled launch of the last call
@@ -467,15 +475,27 @@ int upload_lstm_x3(Step& st, const float* const* whh) {
                     }
     HIPCHK(hipMalloc(&st.d_wrecx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(st.d_wrecx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    // [dir][block][kb][plane][lane][8] for lstm_x3v2.hip
-    std::vector<uint16_t> p2(pack.size(), 0);
-    for (int d = 0; d < st.ndir; ++d)
-        for (int kb = 0; kb < NKB; ++kb)
-            for (int b = 0; b < NB; ++b)
-                std::memcpy(&p2[(((size_t)d * NB + b) * NKB + kb) * 1024], &pack[(((size_t)d * NKB + kb) * NB + b) * 1024],
-                            1024 * sizeof(uint16_t));
-    HIPCHK(hipMalloc(&st.d_wrecx3v2, p2.size() * sizeof(uint16_t)));
-    HIPCHK(hipMemcpy(st.d_wrecx3v2, p2.data(), p2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    if (krk_lstm_ws_supported(H, Hp)) {
+        // lstm_ws.hip: [dir][slice 4][wave 8][i][kb][plane][lane][8]; slice r owns blocks [r*BPC, (r+1)*BPC), wave w of it the
+        // blocks r*BPC + w + 8i; fragments of blocks that do not exist stay zero (they compute h = 0 and publish nothing)
+        const int BPC = (NB + 3) / 4, BPW = (BPC + 7) / 8;
+        std::vector<uint16_t> pw((size_t)st.ndir * 32 * BPW * NKB * 1024, 0);
+        for (int d = 0; d < st.ndir; ++d)
+            for (int r = 0; r < 4; ++r)
+                for (int w = 0; w < 8; ++w)
+                    for (int i = 0; i < BPW; ++i) {
+                        const int bl = w + 8 * i, b = r * BPC + bl;
+                        if (bl >= BPC || b >= NB) continue;
+                        for (int kb = 0; kb < NKB; ++kb)
+                            std::memcpy(&pw[(((((size_t)d * 4 + r) * 8 + w) * BPW + i) * NKB + kb) * 1024],
+                                        &pack[(((size_t)d * NKB + kb) * NB + b) * 1024], 1024 * sizeof(uint16_t));
+                    }
+        HIPCHK(hipMalloc(&st.d_wrecws, pw.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(st.d_wrecws, pw.data(), pw.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&st.ws_ctrl, 64));
+        HIPCHK(hipMemset(st.ws_ctrl, 0, 64));
+        st.ws_bpc = BPC;
+    }
     return KRK_OK;
 }
 
@@ -495,7 +515,9 @@ void free_step(Step& s) {
     if (s.d_wrec32) (void)hipFree(s.d_wrec32);
     if (s.d_wrec16) (void)hipFree(s.d_wrec16);
     if (s.d_wrecx3) (void)hipFree(s.d_wrecx3);
-    if (s.d_wrecx3v2) (void)hipFree(s.d_wrecx3v2);
+    if (s.d_wrecws) (void)hipFree(s.d_wrecws);
+    if (s.ws_ctrl) (void)hipFree(s.ws_ctrl);
+    s.ws_gran.release();
     s.out.release();
     s.aux.release();
     s.aux2.release();
@@ -532,6 +554,7 @@ void krk_plan_destroy(krk_plan* plan) {
     plan->d_confs.release();
     plan->d_final.release();
     if (plan->h_lens_pinned) (void)hipHostFree(plan->h_lens_pinned);
+    if (plan->err_host) (void)hipHostFree(plan->err_host);
     if (plan->lens_ev) (void)hipEventDestroy(plan->lens_ev);
     if (plan->front_ev) (void)hipEventDestroy(plan->front_ev);
     for (auto e : plan->events) (void)hipEventDestroy(e);
@@ -895,6 +918,10 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
         return bail(KRK_E_HIP, "hipEventCreate failed");
     if (hipEventCreateWithFlags(&p->front_ev, hipEventDisableTiming) != hipSuccess)
         return bail(KRK_E_HIP, "hipEventCreate failed");
+    if (hipHostMalloc((void**)&p->err_host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&p->err_dev, p->err_host, 0) != hipSuccess)
+        return bail(KRK_E_HIP, "hipHostMalloc (status word) failed");
+    *p->err_host = 0;
     HIPCHK(hipDeviceSynchronize());
     *out = p;
     return KRK_OK;
@@ -935,6 +962,16 @@ int krk_plan_set_profiling(krk_plan* plan, int enable) {
         plan->events.resize(3 * plan->steps.size() + 1);
         for (auto& e : plan->events)
             if (hipEventCreate(&e) != hipSuccess) return fail(KRK_E_HIP, "hipEventCreate failed");
+    }
+    return KRK_OK;
+}
+
+int krk_plan_status(krk_plan* plan) {
+    if (!plan) return fail(KRK_E_INVALID, "krk_plan_status: null plan");
+    if (plan->err_host && *(volatile unsigned*)plan->err_host != 0) {
+        *(volatile unsigned*)plan->err_host = 0;
+        return fail(KRK_E_HIP, "a recurrent cluster kernel timed out waiting for its peers (lstm_ws exchange); the results of "
+                               "the batches in flight on this plan are invalid");
     }
     return KRK_OK;
 }
@@ -1104,6 +1141,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             a.M = rows; a.K = g.Cin; a.Cout = g.Cout;
             a.ncg = (g.Cout + 127) / 128; a.ntiles = (rows + 255) / 256;
             a.act = g.act;
+            a.tileT = 0;
             a.dbg = env_int("KRK_X3_DBG");
         };
         // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
@@ -1273,7 +1311,8 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                 const int T = s.img_axis == 2 ? Himg : Win;
                 const int N = s.img_axis == 1 ? Nimg * Himg : (s.img_axis == 2 ? Nimg * Win : Nimg);
                 const int G = 4 * s.Hp;
-                const size_t xp_elems = (size_t)N * T * s.ndir * G;
+                // tile-time-major projections (bf16x3 recurrence) address whole 16-line tiles: pad the row count
+                const size_t xp_elems = (size_t)(s.rec_x3 ? (N + 15) / 16 * 16 : N) * T * s.ndir * G;
                 if (s.aux.ensure(xp_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
                 if (s.cg.x3) {
                     const size_t in_elems = (size_t)N * T * s.cg.Cin;
@@ -1287,6 +1326,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     }
                     GemmX3Args a;
                     fill_gemm(s.cg, a, xin, in_elems, (float*)s.aux.p, N * T);
+                    a.tileT = s.rec_x3 ? T : 0;
                     mark("lstm_xproj_x3", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin);
                     rc = krk_launch_gemm_x3(a, stream);
                 } else {
@@ -1315,18 +1355,32 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     l.xstride = s.ndir * G;
                     l.ostride = s.ndir * s.hidden;
                     l.hrow = l.NKB * 64 + 16;
+                    l.xtiled = 1;
                     l.dbg = env_int("KRK_LSTM_DBG");
                     s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
                     rc = -4;
-                    if (env_int("KRK_LSTM_V", 1) == 2) {
-                        // lines per workgroup: 32 (half the CUs of 16-line tiles at nearly the same step time) once
-                        // that still leaves >= 8 workgroups; KRK_LSTM_NT / KRK_LSTM_NW override (probing)
-                        int nt = (N + 31) / 32 * s.ndir >= 8 ? 2 : 1;
-                        nt = env_int("KRK_LSTM_NT", nt);
-                        const int nw = env_int("KRK_LSTM_NW", 8);
-                        LstmX3Args l2 = l;
-                        l2.wp = (const __bf16*)s.d_wrecx3v2;
-                        rc = krk_launch_lstm_x3v2(l2, nt, nw, stream);
+                    // weight-stationary cluster kernel unless the shape is outside its range (then: the streaming kernel);
+                    // KRK_LSTM_V=1 forces the streaming kernel (A/B probing, tools/lstm_probe.py)
+                    if (s.d_wrecws && env_int("KRK_LSTM_V", 3) == 3) {
+                        const size_t gbytes = krk_lstm_ws_gran_bytes(N, s.ndir, s.ws_bpc);
+                        if (gbytes > s.ws_gran.cap) {
+                            if (s.ws_gran.ensure(gbytes)) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
+                            HIPCHK(hipMemsetAsync(s.ws_gran.p, 0, s.ws_gran.cap, stream));    // tags of a fresh buffer must not match
+                        }
+                        LstmWsArgs w;
+                        w.xp = l.xp; w.wp = (const __bf16*)s.d_wrecws; w.out = l.out; w.out_plane = l.out_plane; w.lens = l.lens;
+                        w.N = l.N; w.T = l.T; w.H = l.H; w.Hp = l.Hp; w.NKB = l.NKB; w.NB = l.NB; w.G = l.G;
+                        w.ndir = l.ndir; w.dirmode = l.dirmode; w.xstride = l.xstride; w.ostride = l.ostride; w.hrow = l.hrow;
+                        w.BPC = s.ws_bpc;
+                        w.gran = (unsigned long long*)s.ws_gran.p;
+                        w.ctrl = s.ws_ctrl;
+                        w.ticket_base = s.ws_tickets;
+                        s.ws_epoch = s.ws_epoch % 65535u + 1u;
+                        w.epoch = s.ws_epoch;
+                        w.err = p->err_dev;
+                        w.dbg = l.dbg;
+                        rc = krk_launch_lstm_ws(w, stream);
+                        if (rc == 0) s.ws_tickets += (unsigned)((N + 31) / 32 * s.ndir * 4);
                     }
                     if (rc == -4) rc = krk_launch_lstm_x3(l, stream);
                     break;

@@ -143,6 +143,7 @@ struct GemmX3Args {
     float* y;             // [M][Cout]
     int M, K, Cout;
     int ncg, ntiles;      // column groups of 128, row tiles of 256
+    int tileT;            // > 0: rows are (line, step) with tileT steps per line; store row n*T+t at ((n/16)*T + t)*16 + n%16
     int act;
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no MFMA, 2 no copies, 4 no stores, 8 no LDS reads
 };
@@ -177,11 +178,34 @@ struct LstmX3Args {
     int ndir, dirmode;
     int xstride, ostride;
     int hrow;             // bytes per LDS row of h (one line, one plane) = NKB*64 + 16
+    int xtiled;           // 1: xp rows are tile-time-major (see gemm_x3.hip): row of (line n, step t) = ((n/16)*T + t)*16 + n%16
     int dbg;              // probe bits (env KRK_LSTM_DBG): 1 no weight loads, 2 no gate math, 4 no MFMA, 8 no x prefetch
 };
 int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s);
-// second generation (lstm_x3v2.hip): nt tiles of 16 lines per workgroup, nw waves; a.wp in [dir][block][kb] order
-int krk_launch_lstm_x3v2(const LstmX3Args& a, int nt, int nw, hipStream_t s);
+
+// weight-stationary cluster kernel (lstm_ws.hip): four workgroups hold W_hh in registers and exchange h_t through L2
+struct LstmWsArgs {
+    const float* xp;      // fp32 input projections (+ biases), gate-interleaved columns, rows TILE-TIME-MAJOR: (line n, step t) at ((n/16)*T + t)*16 + n%16
+    const __bf16* wp;     // [ndir][slice 4][wave 8][BPW][NKB][plane][lane][8]: per-wave resident fragments, zero where a block does not exist
+    __bf16* out;          // hi plane, K-blocked sequence rows [ostride/8][N*T][8]; lo plane at + out_plane elements
+    size_t out_plane;
+    const int* lens;
+    int N, T, H, Hp;
+    int NKB, NB, G;       // K-blocks of 32, gate-column blocks of 16, G = 4*Hp gate columns per direction
+    int ndir, dirmode;
+    int xstride, ostride;
+    int hrow;             // bytes per LDS row of h (one line, one plane) = NKB*64 + 16
+    int BPC;              // gate-column blocks per cluster slice = ceil(NB/4)
+    unsigned long long* gran;   // exchange granules [cluster][group 2][parity 2][slice 4][BPC*4 units][16 lines], zeroed at allocation
+    unsigned* ctrl;       // [0]: monotonic ticket counter (cluster membership is claimed at run time)
+    unsigned ticket_base; // counter value before this launch (the host adds the grid size after every launch)
+    unsigned epoch;       // launch number folded into the granule tags (never 0)
+    unsigned* err;        // mapped host word: set to 1 if an exchange wait timed out
+    int dbg;              // probe bits (-DKRK_ABLATE build, env KRK_LSTM_DBG): 1 no exchange reads, 2 no gate math / publish, 4 no MFMA, 8 no xproj loads, 16 no output pass, 32 no step barrier
+};
+bool krk_lstm_ws_supported(int H, int Hp);
+size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC);
+int krk_launch_lstm_ws(const LstmWsArgs& a, hipStream_t s);
 
 // K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel
 int krk_lstm_kg(int M, int blocks_per_wave);

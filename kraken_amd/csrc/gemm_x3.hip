@@ -15,6 +15,11 @@
 //   LDS order = [plane][k-half][row][8 bf16]: a wave's ds_read_b128 covers contiguous 512-byte runs
 //   grid      = 1-D, XCD-aware: the column groups of one row tile run back-to-back on the SAME XCD,
 //               so X is read from HBM once and re-read from that XCD's L2
+//   row order = optionally "tile-time-major" (a.tileT = T): input row n*T + t is stored as output row
+//               ((n/16)*T + t)*16 + n%16, so the 16 lines a recurrent workgroup advances together find the
+//               projections of one time step in ONE contiguous 16-row run, and consecutive steps back to back:
+//               the recurrent kernels' per-step xproj reads walk memory linearly instead of touching 16 rows that
+//               lie T rows (~1 MB) apart -- measured 1.2 us per step of exposed xproj latency (page walks) before
 //   epilogue  = + bias, transposed through the (now free) LDS buffers so that each store instruction writes
 //               two full 512-byte row runs of the fp32 rows [row][Cout] the recurrent kernel / decoder read
 #include "common.h"
@@ -133,13 +138,24 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
                 *reinterpret_cast<f32x4*>(T + px * RSTR + cb * 32 + 8 * j + 4 * half) = v;
             }
         const int rbase = row0 + wave * 64 + 32 * s;
+        int ln = 0, tt = 0;                                // (line, step) of row rbase + half (tile-time-major output only)
+        if (a.tileT > 0) {
+            ln = (rbase + half) / a.tileT;
+            tt = (rbase + half) - ln * a.tileT;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = 2 * i + half;
             const f32x4 v = *reinterpret_cast<const f32x4*>(T + r * RSTR + 4 * px);
             const int row = rbase + r, col = col0 + 4 * px;
+            size_t orow = (size_t)row;
+            if (a.tileT > 0) {
+                orow = ((size_t)(ln >> 4) * a.tileT + tt) * 16 + (ln & 15);
+                tt += 2;
+                while (tt >= a.tileT) { tt -= a.tileT; ++ln; }
+            }
             if (row < a.M && !nostore) {
-                float* yp = a.y + (size_t)row * a.Cout + col;
+                float* yp = a.y + orow * a.Cout + col;
                 if (vec) {
                     if (col < a.Cout) {
                         *reinterpret_cast<f32x4*>(yp) = v;

@@ -1,0 +1,351 @@
+// Weight-stationary recurrent kernel of the (bi)directional LSTM: split-bf16 operands on the bf16 matrix cores, W_hh held
+// in REGISTERS by a cluster of four workgroups (one per CU) that exchange h_t through L2 every step.
+// Reference semantics: nn.LSTM inside TransposedSummarizingRNN.forward (kraken/lib/vgsl/layers.py:513-547): packed by
+// length, gates i,f,g,o, h/c start at zero, outputs past a line's length stay zero.
+//
+// Why: the streaming kernels (lstm_x3.hip) pull the whole W_hh (hi+lo = the bytes of fp32: 0.7 MB for H = 200) through one
+// CU's L1 every time step -- 5.2 us at the 135 GB/s a CU gets from L2 -- and the HBM-latency xproj loads share that
+// in-order L1 queue, so the two serialise (measured: 9.1 us per step, matrix pipe 20 % busy).  Here
+//   * a cluster = 4 workgroups x 8 waves (two per SIMD, <= 256 registers: no AGPR copies in front of the MFMAs).  Workgroup
+//     `slice` owns a quarter of the gate-column blocks (all four gates of its units, so the cell update stays per lane), a
+//     wave owns up to BPW of them and keeps their fragments for all K blocks in registers for the whole launch: no weight
+//     traffic after the prologue;
+//   * a cluster advances TWO independent groups of 16 lines in alternation ("slots"): while the h_t of one group travels
+//     (publish -> L2 -> the three peers), the matrix pipe works on the other group;
+//   * exchange = data-tagged 8-byte granules {tag = launch epoch | step+1, (hi, lo) bf16 of one (unit, line)} written with
+//     one sc1 (write-through, agent-scope) store and polled with sc1 loads: the data is the flag, no fence, no separate
+//     counter, placement independent (MI355X guide, Guideline 16 form R2).  Two parity buffers per group suffice: a slice
+//     can only publish step s+2 after it consumed every peer's step s+1, which they publish after consuming step s;
+//   * cluster membership is claimed at run time (ticket = atomicAdd): any four workgroups that have STARTED form a
+//     cluster, so a partially resident grid cannot deadlock whatever the dispatch order; every spin is bounded and a
+//     timeout raises the plan's error word (mapped host memory) instead of hanging the device;
+//   * the gather loads of the NEXT slot's group are issued at the start of a slot and checked optimistically in the middle
+//     of its MFMA stream (branch-free: the granules go to LDS whatever their tag; a lane that saw a stale tag only raises a
+//     flag), so the common case costs no wait at all; a flagged gather is polled at the start of the next slot;
+//   * xproj (HBM) is fetched one full step ahead, after the exchange loads in program order (vmcnt retires in order);
+//   * h_t leaves as K-blocked split planes for the next projection (gemm_x3.hip): after the gather every slice holds the
+//     whole h_t in LDS and writes a quarter of the lines, 16 bytes per lane, masked by the buffer bounds check.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr unsigned kOOBws = 0x80000000u;   // voffset beyond every descriptor used here (all < 2 GiB): load = 0, store dropped
+constexpr int kAuxSC1 = 16;                // buffer op cache policy: sc1 = agent-scope write-through store / L1-bypassing load
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+__device__ __forceinline__ bf16x8 ws_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// NKB K blocks of 32, BPW gate-column blocks per wave
+template <int NKB, int BPW>
+__global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
+    constexpr int NGI = 3 * BPW;            // granules a lane gathers per (group, step): 3 peers x BPC*64 / 512, BPC <= 8*BPW
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    const int RS = a.hrow;                  // bytes per h row (one line, one plane)
+    const int plane = 16 * RS;
+    const int hbuf = 2 * plane;             // one (hi, lo) buffer of one group
+    unsigned char* hs = smem8;              // [group 2][parity 2][plane 2][16 lines][RS]
+    int* lens_s = reinterpret_cast<int*>(smem8 + 4 * hbuf);         // [32]
+    unsigned* misc = reinterpret_cast<unsigned*>(lens_s + 32);      // [0] ticket, [4..7] dump row for masked LDS writes
+    const unsigned dump_off = (unsigned)(4 * hbuf + 32 * 4 + 16);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) misc[0] = atomicAdd(a.ctrl, 1u) - a.ticket_base;
+    for (int e = tid; e < hbuf; e += 512) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // 4*hbuf bytes
+    __syncthreads();
+    const unsigned ticket = __builtin_amdgcn_readfirstlane(misc[0]);
+    const int cluster = (int)(ticket >> 2), slice = (int)(ticket & 3);
+    const int dir = cluster % a.ndir;
+    const int n0 = (cluster / a.ndir) * 32;
+    const bool rev = (a.dirmode == 1) || (a.dirmode == 2 && dir == 1);
+    if (tid < 32) {
+        const int n = n0 + tid;
+        int l = 0;
+        if (n < a.N) l = a.lens ? min(max(a.lens[n], 0), a.T) : a.T;
+        lens_s[tid] = l;
+    }
+    __syncthreads();
+    int Lmax = 0;
+    for (int i = 0; i < 32; ++i) Lmax = max(Lmax, lens_s[i]);
+
+    const int line = lane & 15, us = lane >> 4;
+    const int BPC = a.BPC;
+    int mylen[2];
+    mylen[0] = lens_s[line];
+    mylen[1] = lens_s[16 + line];
+
+    // ---- weights: resident for the whole launch.  [dir][slice][wave 8][i][kb][plane][lane][8]
+    u32x4 whi[BPW][NKB], wlo[BPW][NKB];
+    {
+        const __bf16* wb = a.wp + ((((size_t)dir * 4 + slice) * 8 + wave) * BPW * NKB) * 1024 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < BPW; ++i)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                whi[i][kb] = *reinterpret_cast<const u32x4*>(wb + (size_t)(i * NKB + kb) * 1024);
+                wlo[i][kb] = *reinterpret_cast<const u32x4*>(wb + (size_t)(i * NKB + kb) * 1024 + 512);
+            }
+    }
+    // which of this wave's blocks exist (wave-uniform): local block wave + 8i < BPC, global block < NB
+    bool bval[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) bval[i] = (wave + 8 * i < BPC) && (slice * BPC + wave + 8 * i < a.NB);
+
+    // ---- xproj
+    const int nrows = min(a.N - n0, 32);
+    const unsigned xrow_bytes = (unsigned)a.xstride * 4u;
+    // rows are tile-time-major: this cluster's two 16-line groups are the tiles n0/16 and n0/16 + 1, each T*16 rows
+    const __amdgpu_buffer_rsrc_t xrs = ws_rsrc(a.xp + (size_t)n0 * a.T * a.xstride + (size_t)dir * a.G,
+                                               (unsigned)((size_t)(nrows > 16 ? 32 : 16) * a.T * xrow_bytes - (size_t)dir * a.G * 4));
+    unsigned xso[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) xso[i] = (unsigned)(slice * BPC + wave + 8 * i) * 64u;
+    auto xvoff = [&](int g, int s) -> unsigned {
+        const bool on = s < mylen[g];
+        const int t = rev ? (mylen[g] - 1 - s) : s;
+        return on ? (((unsigned)g * (unsigned)a.T + (unsigned)t) * 16u + (unsigned)line) * xrow_bytes + (unsigned)us * 16u : kOOBws;
+    };
+    f32x4 xr[2][BPW];
+    auto load_x = [&](int g, int s) {
+        const unsigned vo = xvoff(g, s);
+#pragma unroll
+        for (int i = 0; i < BPW; ++i)
+            xr[g][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, bval[i] ? vo : kOOBws, xso[i], 2));
+    };
+
+    // ---- exchange: granules [group][parity][slice][BPC*4 units][16 lines] of this cluster
+    const unsigned slice_gran = (unsigned)BPC * 64u;              // granules one slice publishes per (group, step)
+    const unsigned gp_bytes = 4u * slice_gran * 8u;               // bytes per (group, parity)
+    const __amdgpu_buffer_rsrc_t grs = ws_rsrc(reinterpret_cast<const unsigned char*>(a.gran) + (size_t)cluster * 4 * gp_bytes, 4u * gp_bytes);
+    const unsigned tagbase = (a.epoch & 0xFFFFu) << 16;
+    // what this lane publishes for block i: unit_local = (wave + 8i)*4 + us, its own line
+    unsigned pub_vo[BPW], own_lds[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int ul = (wave + 8 * i) * 4 + us;
+        const int unit = slice * BPC * 4 + ul;
+        const bool ok = bval[i];
+        pub_vo[i] = ok ? ((unsigned)slice * slice_gran + (unsigned)ul * 16u + (unsigned)line) * 8u : kOOBws;
+        own_lds[i] = (ok && unit < NKB * 32) ? (unsigned)(line * RS + unit * 2) : dump_off;
+    }
+    // what this lane gathers: item e = tid + 512 k over [peer 3][BPC*4 units][16 lines]
+    unsigned g_vo[NGI], g_lds[NGI];
+    bool g_ok[NGI];
+#pragma unroll
+    for (int k = 0; k < NGI; ++k) {
+        const unsigned e = (unsigned)tid + 512u * k;
+        const unsigned p = e / slice_gran, rem = e - p * slice_gran;
+        const int sl = (slice + 1 + (int)p) & 3;
+        const int ul = (int)(rem >> 4), ln = (int)(rem & 15);
+        const int unit = sl * BPC * 4 + ul;
+        const bool ok = p < 3 && (sl * BPC + (ul >> 2)) < a.NB;      // blocks beyond NB are never published
+        g_ok[k] = ok;
+        g_vo[k] = ok ? ((unsigned)sl * slice_gran + rem) * 8u : kOOBws;
+        g_lds[k] = (ok && unit < NKB * 32) ? (unsigned)(ln * RS + unit * 2) : dump_off;
+    }
+    u32x2 gd[NGI];
+    bool dead = false;
+    auto gather_issue = [&](int g, int par) {
+        const unsigned so = (unsigned)(g * 2 + par) * gp_bytes;
+#pragma unroll
+        for (int k = 0; k < NGI; ++k) gd[k] = __builtin_amdgcn_raw_buffer_load_b64(grs, g_vo[k], so, kAuxSC1);
+    };
+    auto gather_drop = [&](unsigned char* hb) {       // granule payloads -> LDS rows (masked items go to the dump word)
+#pragma unroll
+        for (int k = 0; k < NGI; ++k) {
+            unsigned char* dst = (g_lds[k] == dump_off) ? smem8 + dump_off : hb + g_lds[k];
+            const unsigned v = gd[k][0];
+            *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(v & 0xFFFFu);
+            *reinterpret_cast<unsigned short*>(dst + ((g_lds[k] == dump_off) ? 2 : plane)) = (unsigned short)(v >> 16);
+        }
+    };
+    // branch-free: true if some granule of h(g, step) did not carry its tag yet; the payloads go to LDS either way
+    auto gather_try = [&](int step, unsigned char* hb) -> bool {
+        const unsigned want = tagbase | ((unsigned)(step + 1) & 0xFFFFu);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NGI; ++k) ok = ok && (!g_ok[k] || gd[k][1] == want);
+        gather_drop(hb);
+        return !ok;
+    };
+    // slow path: polls until every granule of h(g, step) carries its tag, then drops it into LDS buffer hb
+    auto gather_poll = [&](int g, int par, int step, unsigned char* hb) {
+        const unsigned want = tagbase | ((unsigned)(step + 1) & 0xFFFFu);
+        const unsigned so = (unsigned)(g * 2 + par) * gp_bytes;
+        unsigned spins = 0;
+        gather_issue(g, par);
+        while (!dead) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NGI; ++k) ok = ok && (!g_ok[k] || gd[k][1] == want);
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NGI; ++k)
+                if (g_ok[k] && gd[k][1] != want) gd[k] = __builtin_amdgcn_raw_buffer_load_b64(grs, g_vo[k], so, kAuxSC1);
+            if (++spins > (1u << 21)) {          // ~ a second: give up, flag the plan, never wait again
+                dead = true;
+                if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        gather_drop(hb);
+    };
+
+    // ---- output pass: this slice writes lines [4*slice, 4*slice+4) of a group, one 16-byte piece per lane
+    const int per_line = a.H >> 3;
+    const size_t rows_total = (size_t)a.N * a.T;
+    const __amdgpu_buffer_rsrc_t ors = ws_rsrc(a.out, (unsigned)((size_t)a.out_plane * 4));
+    unsigned sp_lds, sp_g0[2];
+    int sp_len[2];
+    {
+        const int e = tid;
+        const int pl = e / (4 * per_line), r = e - pl * 4 * per_line;
+        const int li = r / per_line, q = r - li * per_line;
+        const int ln = slice * 4 + li;
+        const bool ok = e < 8 * per_line;
+        sp_lds = ok ? (unsigned)(pl * plane + ln * RS + q * 16) : 0u;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            sp_g0[g] = (unsigned)((((size_t)(dir * per_line + q)) * rows_total + (size_t)(n0 + 16 * g + ln) * a.T) * 16 + (size_t)pl * a.out_plane * 2);
+            sp_len[g] = ok ? lens_s[16 * g + ln] : 0;
+        }
+    }
+    auto store_pass = [&](int g, int step, const unsigned char* hb) {
+        const bool on = step < sp_len[g];
+        const int t = rev ? (sp_len[g] - 1 - step) : step;
+        const unsigned vo = on ? sp_g0[g] + (unsigned)t * 16u : kOOBws;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(hb + sp_lds);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ors, vo, 0, 0);
+    };
+
+    float cst[2][BPW];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) cst[g][i] = 0.f;
+
+    // one slot = one time step of one group.  `pend`: this wave's gather of h(g, s-1) met a stale tag (rare);
+    // `nxt`: 0 = no gather to start, else issue the gather of h(1-g, .) with parity nxt_par for the next slot
+    bool pend[2] = {false, false};
+    auto slot = [&](int g, int s, bool nxt, int nxt_par, int nxt_step) {
+        const int par = s & 1;
+        unsigned char* hb = hs + (g * 2 + par) * hbuf;            // h(g, s-1): own rows written by our gates, the rest gathered
+        unsigned char* hn = hs + (g * 2 + (par ^ 1)) * hbuf;      // h(g, s)
+        if (__any(pend[g]) && !KRK_DBGBIT(a, 1)) gather_poll(g, par, s - 1, hb);
+        pend[g] = false;
+        if (!KRK_DBGBIT(a, 32)) __syncthreads();
+        bf16x8 hh[NKB], hl[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const unsigned char* hp = hb + line * RS + (kb * 32 + us * 8) * 2;
+            hh[kb] = *reinterpret_cast<const bf16x8*>(hp);
+            hl[kb] = *reinterpret_cast<const bf16x8*>(hp + plane);
+        }
+        if (s > 0 && !KRK_DBGBIT(a, 16)) store_pass(g, s - 1, hb);
+        const unsigned want = tagbase | ((unsigned)(s + 1) & 0xFFFFu);
+        const unsigned pso = (unsigned)(g * 2 + (par ^ 1)) * gp_bytes;
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            f32x4 acc0 = xr[g][i], acc1 = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (KRK_DBGBIT(a, 4)) break;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(whi[i][kb]), hh[kb], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(whi[i][kb]), hl[kb], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(wlo[i][kb]), hh[kb], acc2, 0, 0, 0);
+            }
+            // the peers finished publishing the other group about when this slot began and a granule needs ~0.5 us to become
+            // visible: ask for them a block's worth of MFMAs into the slot, look at them at its end
+            if (i == 0 && nxt && !KRK_DBGBIT(a, 1)) gather_issue(1 - g, nxt_par);
+            if (KRK_DBGBIT(a, 2)) continue;
+            const f32x4 z = acc0 + (acc1 + acc2);
+            const float gi = krk_sigmoid(z[0]);
+            const float gf = krk_sigmoid(z[1]);
+            const float gg = krk_tanh(z[2]);
+            const float go = krk_sigmoid(z[3]);
+            const float c = gf * cst[g][i] + gi * gg;
+            cst[g][i] = c;
+            const float h = go * krk_tanh(c);
+            const __bf16 hb16 = (__bf16)h;
+            const __bf16 lb16 = (__bf16)(h - (float)hb16);
+            const unsigned short hbits = __builtin_bit_cast(unsigned short, hb16), lbits = __builtin_bit_cast(unsigned short, lb16);
+            unsigned char* dst = (own_lds[i] == dump_off) ? smem8 + dump_off : hn + own_lds[i];
+            *reinterpret_cast<unsigned short*>(dst) = hbits;
+            *reinterpret_cast<unsigned short*>(dst + ((own_lds[i] == dump_off) ? 2 : plane)) = lbits;
+            u32x2 gran;
+            gran[0] = (unsigned)hbits | ((unsigned)lbits << 16);
+            gran[1] = want;
+            __builtin_amdgcn_raw_buffer_store_b64(gran, grs, pub_vo[i], pso, kAuxSC1);
+        }
+        if (nxt && !KRK_DBGBIT(a, 1)) pend[1 - g] = gather_try(nxt_step, hs + ((1 - g) * 2 + nxt_par) * hbuf);   // optimistic finish of the next slot's gather
+    };
+
+    // ---- prologue
+    load_x(0, 0);
+    load_x(1, 0);
+    for (int s = 0; s < Lmax; ++s) {
+        slot(0, s, s > 0, s & 1, s - 1);              // next: slot(1, s) needs h(1, s-1), parity s&1
+        if (!KRK_DBGBIT(a, 8)) load_x(0, s + 1);
+        slot(1, s, true, (s + 1) & 1, s);             // next: slot(0, s+1) (or the epilogue) needs h(0, s), parity (s+1)&1
+        if (!KRK_DBGBIT(a, 8)) load_x(1, s + 1);
+    }
+    if (Lmax > 0) {
+        const int par = Lmax & 1;
+        unsigned char* hb0 = hs + (0 * 2 + par) * hbuf;
+        if (__any(pend[0])) gather_poll(0, par, Lmax - 1, hb0);
+        __syncthreads();
+        store_pass(0, Lmax - 1, hb0);
+        unsigned char* hb1 = hs + (1 * 2 + par) * hbuf;
+        if (!KRK_DBGBIT(a, 1)) gather_poll(1, par, Lmax - 1, hb1);
+        __syncthreads();
+        store_pass(1, Lmax - 1, hb1);
+    }
+}
+
+template <int NKB, int BPW>
+int launch_ws(const LstmWsArgs& a, hipStream_t s) {
+    const int nclusters = (a.N + 31) / 32 * a.ndir;
+    const size_t lds = (size_t)8 * 16 * a.hrow + 32 * sizeof(int) + 32;
+    auto kfn = lstm_ws_kernel<NKB, BPW>;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nclusters * 4), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+bool krk_lstm_ws_supported(int H, int Hp) {
+    const int NKB = (Hp + 31) / 32, NB = Hp / 4;
+    return (H % 8) == 0 && NKB >= 1 && NKB <= 7 && NB <= 64 && (NB + 3) / 4 <= 16;
+}
+
+size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC) {
+    return (size_t)((N + 31) / 32 * ndir) * 4 /* (group, parity) */ * 4 /* slices */ * (size_t)BPC * 64 * 8;
+}
+
+int krk_launch_lstm_ws(const LstmWsArgs& a, hipStream_t s) {
+    if (!krk_lstm_ws_supported(a.H, a.Hp)) return -4;
+    if ((size_t)a.out_plane * 4 >= 0x80000000ull) return -4;                 // 32-bit buffer offsets
+    if ((size_t)32 * a.T * a.xstride * 4 >= 0x80000000ull) return -4;
+    if (a.T >= 0xFFFF) return -4;                                             // 16-bit step tags
+    const int bpw = (a.BPC + 7) / 8;
+#define KRK_WS(NKB_, BPW_) if (a.NKB == NKB_ && bpw == BPW_) return launch_ws<NKB_, BPW_>(a, s)
+    // NB = Hp/4 in (8(NKB-1), 8 NKB]; BPC = ceil(NB/4) in {2 NKB - 1, 2 NKB}; BPW = ceil(BPC/8)
+    KRK_WS(1, 1); KRK_WS(2, 1); KRK_WS(3, 1); KRK_WS(4, 1); KRK_WS(5, 2); KRK_WS(6, 2); KRK_WS(7, 2);
+#undef KRK_WS
+    return -4;
+}

@@ -91,12 +91,14 @@ __device__ __forceinline__ void lstm_x3_loop(const LstmX3Args& a, unsigned char*
     // weights: [dir][kb][block][plane][lane][8] bf16; lane l: gate column l&15 of the block, K octet l>>4
     const __bf16* wbase = a.wp + ((size_t)dir * a.NKB * a.NB * 2 * 64 + lane) * 8;
     const size_t kstride = (size_t)a.NB * 1024;
-    const float* xrow0 = a.xp + (size_t)(n0 + line) * a.T * a.xstride + (size_t)dir * a.G + us * 4;
+    // plain rows: (line n, step t) at n*T + t; tile-time-major rows (gemm_x3.hip): ((n/16)*T + t)*16 + n%16
+    const float* xrow0 = a.xp + (a.xtiled ? ((size_t)n0 * a.T + line) : (size_t)(n0 + line) * a.T) * a.xstride + (size_t)dir * a.G + us * 4;
+    const size_t xg_step = a.xtiled ? 16 : 1, xg_tile = (size_t)16 * a.T;   // rows per time step / per 16-line group
 
     auto load_x = [&](int s, int g, f32x4 (&dst)[NBW]) {
         const bool on = s < mylen[g];
         const int t = on ? (rev ? (mylen[g] - 1 - s) : s) : 0;
-        const float* xr = xrow0 + ((size_t)16 * g * a.T + t) * a.xstride;
+        const float* xr = xrow0 + ((size_t)g * xg_tile + (size_t)t * xg_step) * a.xstride;
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -129,6 +129,7 @@ class RecognitionEngine:
         self._inflight.remove(ticket)
         slot = self.slots[ticket]
         slot.event.synchronize()
+        _lib.check(self.lib.krk_plan_status(slot.plan.handle))     # a kernel that gave up waiting raises here, never hangs
         nt = slot.max_n * slot.max_t
         h = slot.host_buf.numpy()
         n, t = slot.n, slot.max_t

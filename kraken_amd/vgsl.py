@@ -500,6 +500,7 @@ class HipSequential(nn.Module):
                                                olens.ctypes.data, C.byref(dec)))
             packed = torch.stack([labels, starts, ends, confs.view(torch.int32)]).cpu().numpy()
             cnt = counts.cpu().numpy()
+            _lib.check(plan._lib.krk_plan_status(plan.handle))
         batch = DecodedBatch(packed[0], packed[1], packed[2], packed[3].view(np.float32), cnt)
         return (batch, olens,
                 logits.permute(0, 2, 1) if want_logits else None,

@@ -1,4 +1,5 @@
-"""Probe of the recurrent kernels (dev tool, GPU): per-launch time of every variant + agreement with the first-generation kernel.
+"""Probe of the recurrent kernels (dev tool, GPU): per-launch time of the streaming (v1) and the weight-stationary cluster (ws)
+kernel on BENCH-A + agreement of their network outputs.
 
     python tools/lstm_v2_probe.py            # table of variants x batch sizes
     python tools/lstm_v2_probe.py --ablate   # phase prices from the -DKRK_ABLATE build (python -m kraken_amd.build --ablate)
@@ -63,18 +64,15 @@ if __name__ == '__main__':
         sys.exit(0)
     import numpy as np
     os.makedirs('gpurun_out', exist_ok=True)
-    variants = [('v1', dict(KRK_LSTM_V=1)), ('v2 nt1 nw8', dict(KRK_LSTM_V=2, KRK_LSTM_NT=1, KRK_LSTM_NW=8)),
-                ('v2 nt2 nw8', dict(KRK_LSTM_V=2, KRK_LSTM_NT=2, KRK_LSTM_NW=8)),
-                ('v2 nt2 nw4', dict(KRK_LSTM_V=2, KRK_LSTM_NT=2, KRK_LSTM_NW=4)),
-                ('v2 nt4 nw4', dict(KRK_LSTM_V=2, KRK_LSTM_NT=4, KRK_LSTM_NW=4))]
+    variants = [('v1', dict(KRK_LSTM_V=1)), ('ws', dict(KRK_LSTM_V=3))]
     if '--ablate' in sys.argv:
         lib = os.path.abspath('kraken_amd/libkraken_amd_ablate.so')
-        for name, env in variants[1:3]:
-            for dbg in (0, 1, 2, 4, 8, 16, 9, 25, 31):
+        for name, env in variants[1:]:
+            for dbg in (0, 1, 4, 8, 16, 3, 7, 15):
                 r = run(dict(env, KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
                 print('ablate', name, 'dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
         sys.exit(0)
-    for N, T in ((256, 150), (64, 150), (1024, 150)):
+    for N, T in ((256, 150), (64, 150), (1024, 150), (40, 60), (7, 33)):
         ref = None
         for name, env in variants:
             for ragged in (0, 1):
