@@ -6,18 +6,24 @@ Benchmark of the kraken line-recognition hot path on MI355X.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (VGSL conv stack + 3 BiLSTM + linear + softmax + CTC
-best-path decode, label tuples copied back to the host, host codec -> strings) over ONE batch of 256 synthetic
-1x48x1200 line images per GPU (BASELINE.json configs[1]; BENCH-A spec of SURVEY.md section 8d, random-init
-weights `torch.manual_seed(0)`).  Inputs are resident in HBM before the timed region.  Ranks
-shard lines (weak scaling: 256 lines per rank per step) and the decoded label sequences are
-gathered on all ranks over RCCL after the last step of the timed region.
+Default mode (the driver's contract).  One "step" = one pass of the hot path (VGSL conv stack + 3 BiLSTM + linear +
+softmax + CTC best-path decode, label tuples copied back to the host, host codec -> strings) over ONE batch of 256
+synthetic 1x48x1200 line images per GPU (BASELINE.json configs[1]; BENCH-A spec of SURVEY.md section 8d, random-init
+weights `torch.manual_seed(0)`).  Inputs are resident in HBM before the timed region (four distinct batches, rotated:
+236 MB, so a step never re-reads an input the previous step left in the last-level cache).  Ranks shard lines (weak
+scaling: 256 lines per rank per step); the decoded label sequences of EVERY step are gathered on all ranks over RCCL in
+one exchange at the end of the timed region (BASELINE config 3: "gather of decoded strings").
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     : dominant kernel (the f32-MFMA implicit-GEMM convolution) -- algorithmic FLOPs of one
-                 launch / its mean duration from HIP events on its own stream, vs the f32 MFMA peak
-  cpu_baseline : the reference's PyTorch-CPU path (oracle/torch_port.py, kind "port") timed on this
-                 box's host cores on a bounded sample (rank 0, N=1 only)
+  roofline     : the launch group with the largest share of the step -- algorithmic FLOPs of its launches / their mean
+                 duration from HIP events on the stream they ran on, vs the dense MFMA peak of its operand type
+  cpu_baseline : the reference's PyTorch-CPU path (oracle/torch_port.py, kind "port") timed on this box's host cores on
+                 a bounded sample (rank 0, N=1 only): best of a thread sweep, plus the legacy one-line-per-call shape
+
+Other modes (secondary measurements, same JSON shape, `config.workload` says which):
+  --mode api      lines/s through the REFERENCE API (kraken_amd.rpred.rpred generator: crop -> transform -> network ->
+                  records) on one synthetic page of --api-lines bbox lines, next to the resident-input engine number
+  --mode config4  BASELINE config 4: 1024 lines, widths U{400..2400}, width-bucketed batches through the same pipeline
 """
 import argparse
 import json
@@ -35,6 +41,8 @@ import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense (not the 2:1-sparse figure)
+METRIC = 'text lines/sec (whole node) at 48x1200px, VGSL CNN+BiLSTM+CTC'
+DTYPE_X3 = 'bf16x3 (every value carried as bf16 hi+lo; 3 bf16 MFMAs per product, f32 accumulate; |d logit| vs fp32 ~1.4e-5)'
 
 
 def parse():
@@ -42,6 +50,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--mode', default='engine', choices=['engine', 'api', 'config4'])
     ap.add_argument('--batch', type=int, default=256, help='lines per GPU per step')
     ap.add_argument('--width', type=int, default=1200)
     ap.add_argument('--slots', type=int, default=4, help='batches in flight per GPU (streams)')
@@ -52,100 +61,59 @@ def parse():
                     help='hand every batch over as a pinned HOST tensor (PCIe-inclusive rate; DESIGN.md quotes it, `value` never does)')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the gather even with one rank (smoke test)')
     ap.add_argument('--cpu-lines', type=int, default=32, help='lines in the CPU baseline sample')
+    ap.add_argument('--api-lines', type=int, default=2048, help='--mode api: bbox lines on the synthetic page')
+    ap.add_argument('--api-workers', type=int, default=16, help='--mode api: host threads preparing lines')
     return ap.parse_args()
 
 
-def cpu_baseline(model, width, n_lines, reps=2):
-    """kraken's CPU path (torch CPU operators + Python greedy decode + codec), bounded sample."""
+def cpu_baseline(model, width, n_lines):
+    """
+    kraken's CPU path (torch CPU operators + Python greedy decode + codec) on a bounded sample: the batched shape at the
+    best intra-op thread count of a sweep, and the legacy rpred shape (one line per call).
+    """
     from oracle.torch_port import CpuRecognizer
     ref = CpuRecognizer(model.layer_specs, {k: v.cpu() for k, v in model.state_dict().items()})
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(n_lines, 1, 48, width, generator=g)
     lens = [width] * n_lines
-    ref.predict_labels(x[:2], lens[:2])   # warm-up
-    best = None
-    for _ in range(reps):
+
+    def run(xs, ls):
+        tuples = ref.predict_labels(xs, ls)
+        return [''.join(c for c, *_ in model.codec.decode(t)) for t in tuples]
+
+    ncpu = os.cpu_count() or 1
+    saved = torch.get_num_threads()
+    sweep = {}
+    for t in sorted({min(t, ncpu) for t in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(t)
+        run(x[:2], lens[:2])                      # warm-up
         t0 = time.perf_counter()
-        tuples = ref.predict_labels(x, lens)
-        _ = [''.join(c for c, *_ in model.codec.decode(t)) for t in tuples]
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return {'value': round(n_lines / best, 2), 'unit': 'lines/s', 'cores': torch.get_num_threads(),
-            'host_cpus': os.cpu_count(), 'kind': 'port',
-            'sample': f'{n_lines} lines 1x48x{width}, fp32, best of {reps}: torch-CPU forward + softmax + '
-                      f'groupby greedy decode + codec (oracle/torch_port.py = kraken lib/models.py:138-149)'}
-
-
-def main():
-    args = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    import kraken_amd
-    from kraken_amd import _lib, dist as kdist
-    from kraken_amd.engine import RecognitionEngine
-    from tests.specs import BENCH_A, bench_codec
-
-    _lib.require_gpu()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f'cuda:{local_rank}')
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        kdist.init(backend='nccl')
-
-    torch.manual_seed(0)
-    model = kraken_amd.TorchVGSLModel(vgsl=BENCH_A, codec=bench_codec())
-    model.to(dev)
-    model.nn.set_precision(args.precision)
-    N, W = args.batch, args.width
-    g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.rand(N, 1, 48, W, generator=g).to(dev)    # resident in HBM before timing
-    engine = RecognitionEngine(model, device=local_rank, max_batch=N, max_width=W, slots=args.slots)
-    if args.host_input:
-        x = x.cpu().pin_memory()
-
-    codec = model.codec
-    n_chars = [0]
-
-    def finish():
-        batch, olens = engine.collect()
-        strings = codec.decode_strings(batch)          # host codec: label tuples -> text, inside the timed region
-        n_chars[0] += sum(map(len, strings))
-        return batch, olens
-
-    def run(steps):
-        last = None
-        for _ in range(steps):
-            if engine.free_slots() == 0:
-                last = finish()
-            engine.submit(x)
-        while engine.free_slots() < len(engine.slots):
-            last = finish()
-        return last
-
-    run(args.warmup)
-    engine.set_profiling(True)
-
-    def barrier():
-        if use_dist:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
+        run(x, lens)
+        sweep[t] = n_lines / (time.perf_counter() - t0)
+    best_t = max(sweep, key=sweep.get)
+    torch.set_num_threads(best_t)
     t0 = time.perf_counter()
-    batch, olens = run(args.steps)
-    gathered = kdist.gather_decoded(batch, olens, force=args.force_dist) if use_dist else [batch]
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    k = min(8, n_lines)
+    for i in range(k):                            # legacy shape: rpred calls the network with ONE line (kraken/rpred.py:226)
+        run(x[i:i + 1], None)
+    legacy = k / (time.perf_counter() - t0)
+    torch.set_num_threads(saved)
+    return {'value': round(sweep[best_t], 2), 'unit': 'lines/s', 'cores': best_t, 'host_cpus': ncpu, 'kind': 'port',
+            'thread_sweep': {str(t): round(v, 2) for t, v in sweep.items()},
+            'legacy_one_line_per_call': round(legacy, 2),
+            'sample': f'{n_lines} lines 1x48x{width} in one batch, fp32, best of the thread sweep: torch-CPU forward + softmax + '
+                      f'groupby greedy decode + codec (oracle/torch_port.py = kraken lib/models.py:138-149); legacy = {k} lines, one per call'}
 
-    # ---- per-launch timing from the HIP events recorded inside the timed region (last batch of each
-    # slot, on the stream the kernels were launched on)
+
+# kernels behind the launch groups (rocprofv3 kernel names)
+KERNEL_OF = {'conv': 'conv_f32_kernel', 'lstm_xproj': 'conv_f32_kernel<1,1,0,4>', 'linear': 'conv_f32_kernel<1,1,0,4>',
+             'lstm_rec': 'lstm_f32_kernel', 'conv_x3': 'conv_x3_kernel', 'conv1_x3': 'conv1_x3_kernel',
+             'conv_taps_x3': 'conv_taps_kernel', 'lstm_xproj_x3': 'gemm_x3_kernel', 'linear_x3': 'gemm_x3_kernel',
+             'lstm_rec_x3': 'lstm_ws_kernel'}
+
+
+def roofline_of(engine, precision):
+    """Per-launch timing from the HIP events recorded inside the timed region (last batch of each slot, on its own stream)."""
     per_launch = {}
     for slot_times in engine.layer_times():
         for i, (name, ms, flops) in enumerate(slot_times):
@@ -153,11 +121,6 @@ def main():
             e['ms'].append(ms)
     launches = [{'i': i, 'name': v['name'], 'ms': float(np.mean(v['ms'])), 'gflop': v['flops'] / 1e9}
                 for i, v in sorted(per_launch.items())]
-    # kernels behind the launch groups (rocprofv3 kernel names)
-    kernel_of = {'conv': 'conv_f32_kernel', 'lstm_xproj': 'conv_f32_kernel<1,1,0,4>', 'linear': 'conv_f32_kernel<1,1,0,4>',
-                 'lstm_rec': 'lstm_f32_kernel', 'conv_x3': 'conv_x3_kernel', 'conv1_x3': 'conv1_x3_kernel',
-                 'conv_taps_x3': 'conv_taps_kernel', 'lstm_xproj_x3': 'gemm_x3_kernel', 'linear_x3': 'gemm_x3_kernel',
-                 'lstm_rec_x3': 'lstm_x3_kernel'}
     peak_of = lambda name: BF16_MFMA_PEAK_TFLOPS if name.endswith('_x3') else F32_MFMA_PEAK_TFLOPS   # noqa: E731
     groups = {}
     for l in launches:
@@ -169,18 +132,18 @@ def main():
     dom_name = max((k for k in groups if groups[k]['gflop'] > 0), key=lambda k: groups[k]['ms'])
     dom = groups[dom_name]
     ach = dom['gflop'] / dom['ms']   # GFLOP/ms == TFLOP/s; algorithmic FLOPs of the launches / their duration
-    roofline = {'bound': 'mfma', 'kernel': kernel_of.get(dom_name, dom_name), 'launch_group': dom_name,
+    roofline = {'bound': 'mfma', 'kernel': KERNEL_OF.get(dom_name, dom_name), 'launch_group': dom_name,
                 'launches_per_step': dom['n'], 'avg_launch_ms': round(dom['ms'] / dom['n'], 4),
                 'gflop_per_launch': round(dom['gflop'] / dom['n'], 3),
                 'achieved': round(ach, 2), 'peak': peak_of(dom_name), 'unit': 'TFLOP/s',
                 'frac': round(ach / peak_of(dom_name), 4), 'traffic': None,
-                'note': ('algorithmic FLOPs; the split-operand kernels issue 3 bf16 MFMAs per algorithmic product'
+                'note': ('algorithmic FLOPs of the launch group / its HIP-event time with the other batches in flight; the '
+                         'split-operand kernels issue 3 bf16 MFMAs per algorithmic product'
                          if dom_name.endswith('_x3') else 'exact f32 MFMA')}
-    layers = launches
     # HBM traffic of the dominant kernel from the committed PMC summary of this same command (separate
     # rocprofv3 --pmc passes, see tools/summarize_pmc.py); null when no summary is available
     try:
-        tag = 'r01_bf16x3' if args.precision == 'bf16x3' else 'r01'
+        tag = 'r02_bf16x3' if precision == 'bf16x3' else 'r01'
         pmc = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_summary.json')))['kernels']
         kname = roofline['kernel'].split('<')[0]
         hit = [v for k, v in pmc.items() if k.startswith(kname) and 'hbm_write_MB_per_launch' in v]
@@ -191,32 +154,221 @@ def main():
                                    'source': f'profiles/{tag}_pmc_summary.json (FETCH_SIZE/WRITE_SIZE passes)'}
     except Exception:
         pass
+    return roofline, launches, {k: {'ms': round(v['ms'], 3), 'tflops': round(v['gflop'] / v['ms'], 1) if v['ms'] > 0 else 0,
+                                    'frac_of_peak': round(v['gflop'] / v['ms'] / peak_of(k), 4) if v['ms'] > 0 else 0}
+                                for k, v in groups.items()}
 
+
+def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
+    from kraken_amd.engine import RecognitionEngine
+    dev = torch.device(f'cuda:{local_rank}')
+    N, W = args.batch, args.width
+    g = torch.Generator().manual_seed(1234 + rank)
+    xs = [torch.rand(N, 1, 48, W, generator=g).to(dev) for _ in range(4)]   # resident in HBM before timing; rotated
+    engine = RecognitionEngine(model, device=local_rank, max_batch=N, max_width=W, slots=args.slots)
+    if args.host_input:
+        xs = [x.cpu().pin_memory() for x in xs]
+    codec = model.codec
+    n_chars = [0]
+    done = []
+
+    def finish():
+        batch, olens = engine.collect()
+        strings = codec.decode_strings(batch)          # host codec: label tuples -> text, inside the timed region
+        n_chars[0] += sum(map(len, strings))
+        done.append((batch, olens))
+
+    def run(steps):
+        for i in range(steps):
+            if engine.free_slots() == 0:
+                finish()
+            engine.submit(xs[i % len(xs)])
+        while engine.free_slots() < len(engine.slots):
+            finish()
+
+    def barrier():
+        if use_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    engine.set_profiling(True)
+    done.clear()
+    n_chars[0] = 0
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    batch, olens = kdist.concat_decoded(done)          # every line this rank decoded in the timed region
+    gathered = kdist.gather_decoded(batch, olens, force=args.force_dist) if use_dist else [batch]
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    roofline, launches, groups = roofline_of(engine, args.precision)
     lines = N * args.steps * world
     value = lines / dt
-    out = {
-        'metric': 'text lines/sec (whole node) at 48x1200px, VGSL CNN+BiLSTM+CTC',
-        'value': round(value, 1), 'unit': 'lines/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None,
-        'dtype': 'f32' if args.precision == 'f32' else 'bf16x3 (every value carried as bf16 hi+lo; 3 bf16 MFMAs per product, f32 accumulate; |d logit| vs fp32 ~1.4e-5)',
+    gathered_lines = int(sum(len(b.counts) for b in gathered))
+    assert gathered_lines == lines, (gathered_lines, lines)
+    return {
+        'metric': METRIC, 'value': round(value, 1), 'unit': 'lines/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else DTYPE_X3,
         'data': 'synthetic' + (' (pinned host input per step: PCIe-inclusive)' if args.host_input else ''),
         'config': {'workload': f'BENCH-A VGSL recogniser (3.17M params, random init seed 0), {N} lines 1x48x{W} per GPU '
-                               f'per step, greedy CTC decode, label tuples to host', 'lines_per_gpu_step': N, 'width': W,
-                   'slots': args.slots, 'precision': args.precision, 'parallelism': f'dp{world}', 'whole_path_tflops': round(value * 2.778e-3 *
-                                                                                                 (W / 1200.0), 2)},
+                               f'per step, greedy CTC decode, label tuples to host, host codec to strings',
+                   'lines_per_gpu_step': N, 'width': W, 'slots': args.slots, 'precision': args.precision,
+                   'parallelism': f'dp{world}', 'whole_path_tflops': round(value * 2.778e-3 * (W / 1200.0), 2)},
         'roofline': roofline,
         'launches': [{'name': l['name'], 'ms': round(l['ms'], 3), 'tflops': round(l['gflop'] / l['ms'], 1) if l['ms'] > 0 else 0}
-                     for l in layers],
-        'groups': {k: {'ms': round(v['ms'], 3), 'tflops': round(v['gflop'] / v['ms'], 1) if v['ms'] > 0 else 0,
-                       'frac_of_peak': round(v['gflop'] / v['ms'] / peak_of(k), 4) if v['ms'] > 0 else 0}
-                   for k, v in groups.items()},
-        'gathered_lines': int(sum(len(b.counts) for b in gathered)),
-        'decoded_chars': int(n_chars[0]),
+                     for l in launches],
+        'groups': groups, 'gathered_lines': gathered_lines, 'decoded_chars': int(n_chars[0]),
     }
+
+
+def _page_of_lines(n, w, h, mode, seed=7):
+    """One synthetic page: n text-line boxes of w x h stacked vertically (random ink, so no line is flat)."""
+    from PIL import Image
+    from kraken_amd.containers import BBoxLine, Segmentation
+    rng = np.random.default_rng(seed)
+    shape = (n * h, w) if mode == 'L' else (n * h, w, 3)
+    page = Image.fromarray(rng.integers(0, 256, shape, dtype=np.uint8), mode)
+    seg = Segmentation(type='bbox', imagename='synthetic', text_direction='horizontal-lr', script_detection=False,
+                       lines=[BBoxLine(id=f'l{i}', bbox=[0, i * h, w, (i + 1) * h]) for i in range(n)])
+    return page, seg
+
+
+def mode_api(args, rank, local_rank):
+    """Lines/s through the legacy generator API, for the dewarp (1-channel bbox) and the device-preparation (RGB) case."""
+    import warnings
+    import kraken_amd
+    from kraken_amd import rpred as R
+    from kraken_amd.engine import RecognitionEngine
+    from kraken_amd.models import TorchSeqRecognizer
+    from kraken_amd.specs import BENCH_A, BENCH_A_RGB, bench_codec
+    out = {}
+    n, W = args.api_lines, args.width
+    for name, spec, mode in (('bbox_L_dewarp_on_host', BENCH_A, 'L'), ('bbox_RGB_prepared_on_device', BENCH_A_RGB, 'RGB')):
+        torch.manual_seed(0)
+        m = kraken_amd.TorchVGSLModel(vgsl=spec, codec=bench_codec())
+        m.seg_type, m.model_type = 'bbox', ['recognition']
+        m.to(f'cuda:{local_rank}')
+        try:
+            m.nn.set_precision(args.precision)
+            m.nn.plan(local_rank)
+        except Exception:
+            m.nn.set_precision('f32')               # 3 input channels: the split-bf16 first convolution takes 1 channel
+        net = TorchSeqRecognizer(m, device=f'cuda:{local_rank}')
+        # line crops W-32 wide and 48 high: the network input is 48 x W after the 16 px padding
+        page, seg = _page_of_lines(n, W - 32, 48, mode)
+        res = {}
+        for label, dev_prep in (('api', True),) + ((('api_host_preparation', False),) if mode == 'RGB' else ()):
+            R.DEVICE_PREP = dev_prep
+            best = 0.0
+            for rep in range(2):
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    t0 = time.perf_counter()
+                    recs = list(R.rpred(net, page, seg, bidi_reordering=False, num_line_workers=args.api_workers))
+                    dt = time.perf_counter() - t0
+                assert len(recs) == n and all(r.prediction for r in recs)
+                best = max(best, n / dt)
+            res[label + '_lines_per_s'] = round(best, 1)
+        R.DEVICE_PREP = True
+        # the same model with inputs resident in HBM (what the default mode measures)
+        eng = RecognitionEngine(m, device=local_rank, max_batch=256, max_width=W, slots=args.slots)
+        x = torch.rand(256, m.input[1], 48, W, device=f'cuda:{local_rank}')
+        for _ in range(3):
+            eng.submit(x)
+            eng.collect()
+        steps = max(n // 256, 4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if eng.free_slots() == 0:
+                m.codec.decode_strings(eng.collect()[0])
+            eng.submit(x)
+        while eng.free_slots() < len(eng.slots):
+            m.codec.decode_strings(eng.collect()[0])
+        torch.cuda.synchronize()
+        res['engine_resident_input_lines_per_s'] = round(256 * steps / (time.perf_counter() - t0), 1)
+        res['plan'] = 'bf16x3' if m.nn.precision == 2 else 'f32'
+        res['api_over_engine'] = round(res['api_lines_per_s'] / res['engine_resident_input_lines_per_s'], 3)
+        eng.close()
+        out[name] = res
+    head = out['bbox_RGB_prepared_on_device']
+    return {'metric': 'text lines/sec through the reference API (kraken_amd.rpred.rpred generator: crop, transform, network, records)',
+            'value': head['api_lines_per_s'], 'unit': 'lines/s', 'n_gpus': 1, 'steps': 1, 'warmup': 0,
+            'ms_per_step': round(1e3 * n / head['api_lines_per_s'], 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': head['plan'], 'data': 'synthetic',
+            'config': {'workload': f'one synthetic page of {n} bbox lines {W - 32}x48 through rpred() -> ocr_records; value = the RGB '
+                                   f'(device-prepared) case, `cases` holds both', 'host_threads': args.api_workers},
+            'cases': out}
+
+
+def mode_config4(args, model, local_rank):
+    """BASELINE config 4: 1024 lines, widths U{400..2400} (seeded), width-bucketed through the LinePipeline."""
+    from kraken_amd import rpred as R
+    from kraken_amd.models import TorchSeqRecognizer
+    rng = np.random.RandomState(40)
+    widths = rng.randint(400, 2401, size=1024)
+    g = torch.Generator().manual_seed(41)
+    base = torch.rand(8, 1, 48, 2400, generator=g)
+    lines = [base[i % 8, :, :, :int(w)].contiguous() for i, w in enumerate(widths)]
+    net = TorchSeqRecognizer(model, device=f'cuda:{local_rank}')
+    best = None
+    for rep in range(3):
+        pipe = R.LinePipeline(net, batch_size=args.batch)
+        t0 = time.perf_counter()
+        pipe.submit(list(enumerate(lines)))
+        got = {}
+        while pipe.pending():
+            got.update(pipe.drain(block=True))
+        got.update(pipe.drain())
+        dt = time.perf_counter() - t0
+        assert len(got) == 1024 and all(got[i].out_width == int(widths[i]) // 8 for i in range(1024))
+        best = dt if best is None else min(best, dt)
+    px = float(np.sum(widths))
+    return {'metric': 'text lines/sec, BASELINE config 4 (1024 lines, W ~ U{400..2400}, length bucketing + packed LSTM)',
+            'value': round(1024 / best, 1), 'unit': 'lines/s', 'n_gpus': 1, 'steps': 1, 'warmup': 2,
+            'ms_per_step': round(1e3 * best, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'f32' else DTYPE_X3, 'data': 'synthetic (host tensors: PCIe-inclusive)',
+            'config': {'workload': f'1024 lines 1x48xW, W ~ U{{400..2400}} seed 40, width-sorted into batches of {args.batch}, '
+                                   f'pinned staging + {R.ENGINE_SLOTS} batches in flight', 'mean_width': round(px / 1024, 1),
+                       'equivalent_1200px_lines_per_s': round(px / 1200.0 / best, 1)}}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    import kraken_amd
+    from kraken_amd import _lib, dist as kdist
+    from kraken_amd.specs import BENCH_A, bench_codec
+
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        kdist.init(backend='nccl')
+
+    torch.manual_seed(0)
+    model = kraken_amd.TorchVGSLModel(vgsl=BENCH_A, codec=bench_codec())
+    model.to(torch.device(f'cuda:{local_rank}'))
+    model.nn.set_precision(args.precision)
+    if args.mode == 'api':
+        out = mode_api(args, rank, local_rank)
+    elif args.mode == 'config4':
+        out = mode_config4(args, model, local_rank)
+    else:
+        out = mode_engine(args, model, rank, world, local_rank, use_dist, kdist)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(model, W, args.cpu_lines)
+        if world == 1 and not args.no_cpu_baseline and args.mode == 'engine':
+            out['cpu_baseline'] = cpu_baseline(model, args.width, args.cpu_lines)
         print(json.dumps(out), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()

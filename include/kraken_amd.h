@@ -191,6 +191,22 @@ int krk_recognize(krk_plan* plan, const float* x_dev, const int* lens_host,
                   float* logits_dev, float* probs_dev, int* olens_host,
                   const krk_decode_out* out);
 
+/*
+ * Line preprocessing on the device for rectangular crops of a fixed-height model: replaces, bit for bit, the host chain
+ * the reference runs per line before the network -- im.crop(bbox) (kraken/lib/segmentation.py:1630-1643), the fixed-height
+ * LANCZOS resize + white padding + ToDtype(scale) + `max - x` of ImageInputTransforms (kraken/lib/dataset/utils.py:93-152,
+ * kraken/lib/functional_im_transforms.py:58-82; resampling arithmetic = Pillow's ImagingResample, 8 bits per channel).
+ *   page_dev   uint8 page [page_h][page_w][channels] (channels 1 = 'L', 3 = 'RGB'), uploaded once per page
+ *   boxes_dev  int32 [n][5]: x0, y0, x1, y1 of the crop (may extend past the page: zeros, like Image.crop) and the
+ *              resized width out_w = int(w * out_h / h)
+ *   x_dev      float (n, channels, out_h, batch_w): line k occupies columns [0, out_w_k + 2*pad), zeros to its right
+ *   flags_dev  int32 [n]: 1 if the line holds any non-white pixel (the reference's flat-line rule, kraken/rpred.py:221)
+ * max_in_h = tallest crop of the batch.  pad must be > 0 (the inversion `max - x` then has max = 1); KRK_E_UNSUPPORTED
+ * for geometry outside the kernel's range (crop taller than 768 rows, > 96 filter taps, out_h > 64).
+ */
+int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int channels, const int* boxes_dev, int n,
+                   int max_in_h, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream);
+
 /* Bytes of device workspace currently held by the plan (diagnostics). */
 long krk_plan_workspace_bytes(const krk_plan* plan);
 

@@ -9,7 +9,7 @@ reordering included.
 
 On a box without kraken (the GPU test box) a minimal stand-in with the same constructor and
 read accessors is provided so the hot path can still hand back records; it supports
-bounding-box lines in display order only (no UAX#9 reordering, no polygon cuts).
+records of left-to-right text in both orders (no UAX#9 reordering of right-to-left text, no polygon cuts).
 """
 from dataclasses import dataclass, field
 from typing import Any, Optional
@@ -103,8 +103,21 @@ except Exception:
             return self
 
         def logical_order(self, base_dir=None):
-            raise NotImplementedError('BiDi reordering needs kraken.containers (kraken.lib.bidi); install kraken '
-                                      'or call rpred with bidi_reordering=False')
+            """
+            Display -> logical order.  Text without right-to-left or digit-ordering characters reads the same in both
+            orders under a left-to-right base direction, so it is returned as is; anything else needs the UAX#9
+            implementation of kraken (kraken.lib.bidi), which is outside this repository's scope.
+            """
+            import unicodedata
+            if not self._display_order:
+                return self
+            rtl = {'R', 'AL', 'AN', 'RLE', 'RLO', 'RLI'}
+            if base_dir in (None, 'L') and not any(unicodedata.bidirectional(c) in rtl for c in self._prediction):
+                rec = type(self)(self._prediction, self._cuts, self._confidences, self.line, base_dir=base_dir,
+                                 display_order=False, logits=self.logits, image=self.image)
+                return rec
+            raise NotImplementedError('BiDi reordering of right-to-left text needs kraken.containers (kraken.lib.bidi); '
+                                      'install kraken or call rpred with bidi_reordering=False')
 
     class BBoxOCRRecord(ocr_record):
         type = 'bbox'

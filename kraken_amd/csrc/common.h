@@ -210,6 +210,10 @@ int krk_launch_lstm_ws(const LstmWsArgs& a, hipStream_t s);
 // K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel
 int krk_lstm_kg(int M, int blocks_per_wave);
 
+// line preprocessing on the device (prep_lines.hip): boxes_dev = [n][5] int32 (x0, y0, x1, y1, out_w)
+int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, int ch, const int* boxes_dev, int n, int max_in_h,
+                          const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
+
 // host-side launchers (implemented in the .hip files)
 int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);

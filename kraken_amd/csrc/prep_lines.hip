@@ -1,0 +1,169 @@
+// Line preprocessing on the device for the rectangular-crop / fixed-height case: page (uint8, uploaded once) ->
+// padded, inverted float line batch, written straight into the staging tensor the recognition plan reads.
+// Replaces, bit for bit, the host chain the reference runs per line before the network
+//   extract_polygons bbox branch: im.crop(bbox)                      kraken/lib/segmentation.py:1630-1643
+//   ImageInputTransforms: fixed-height LANCZOS resize, v2.Pad(fill=255),
+//                         PILToTensor, ToDtype(scale=True), max - x    kraken/lib/dataset/utils.py:93-152,
+//                                                                     kraken/lib/functional_im_transforms.py:58-82
+// whose arithmetic lives in Pillow (un-vendored; `_fixed_resize` -> Image.resize(LANCZOS) -> ImagingResample, 8 bits per
+// channel).  Pillow's published algorithm, restated here:
+//   * separable two-pass resampling, horizontal first (only the source rows the vertical pass will read), each pass
+//     storing clipped uint8;
+//   * per output index xx: scale = in/out, filterscale = max(scale, 1), support = 3 * filterscale,
+//     center = (xx + 0.5) * scale, window [int(center - support + 0.5), int(center + support + 0.5)) clipped to the
+//     image, weights lanczos((x - center + 0.5) / filterscale) = sinc(t) sinc(t/3) normalised to sum 1 in double, then
+//     rounded to 22-bit fixed point (int)(w * 2^22 +- 0.5);
+//   * pixel = clip8((2^21 + sum pixel_i * k_i) >> 22).
+// The weights are recomputed here in fp64 by every thread that needs them (a window is <= 2*ceil(3*scale)+1 taps): a
+// 256-line batch would otherwise ship 30 MB of coefficient tables over PCIe for 14 MB of pixels.
+// The float stage: ToDtype(scale=True) is uint8 / 255 in fp32 (a 256-entry table made on the host by the same division),
+// `max - x` with max = 1.0 because the white padding is part of the tensor (pad > 0 is required; pad == 0 stays on the host).
+// One workgroup = 64 output columns of one line.  Kernel is integer/byte work: HBM-bound on the page read.
+#include "common.h"
+
+namespace {
+
+constexpr int PREC_BITS = 32 - 8 - 2;
+constexpr int COLS = 64;          // output columns per workgroup
+constexpr int MAX_K = 96;         // taps per output sample (scale up to ~15)
+constexpr int MAX_ROWS = 768;     // source rows of a line
+
+__device__ __forceinline__ double sinc_f(double x) {
+    if (x == 0.0) return 1.0;
+    x = x * 3.14159265358979323846;
+    return sin(x) / x;
+}
+__device__ __forceinline__ double lanczos_f(double x) {
+    if (-3.0 <= x && x < 3.0) return sinc_f(x) * sinc_f(x / 3);
+    return 0.0;
+}
+
+// window + fixed-point weights of output sample xx (Pillow precompute_coeffs + normalize_coeffs_8bpc); returns xmax
+__device__ int resample_weights(int in_size, int out_size, int xx, int* xmin_out, int* k /* [MAX_K] */) {
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 3.0 * filterscale;
+    const double center = (xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    if (xmax > MAX_K) xmax = MAX_K;          // the launcher rejects such scales; keeps the loops bounded
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) ww += lanczos_f((x + xmin - center + 0.5) * ss);
+    for (int x = 0; x < xmax; ++x) {
+        double w = lanczos_f((x + xmin - center + 0.5) * ss);
+        if (ww != 0.0) w /= ww;
+        k[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << PREC_BITS)) : (int)(0.5 + w * (double)(1 << PREC_BITS));
+    }
+    *xmin_out = xmin;
+    return xmax;
+}
+
+__device__ __forceinline__ unsigned clip8(int v) {
+    v >>= PREC_BITS;
+    return v < 0 ? 0u : (v > 255 ? 255u : (unsigned)v);
+}
+
+__global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __restrict__ page, int page_h, int page_w, int ch,
+                                                         const int* __restrict__ boxes /* [n][5]: x0 y0 x1 y1 out_w */,
+                                                         const float* __restrict__ lut, int out_h, int pad, int batch_w,
+                                                         float* __restrict__ out, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y;
+    const int* b = boxes + 5 * n;
+    const int x0 = b[0], y0 = b[1], in_w = b[2] - b[0], in_h = b[3] - b[1], ow = b[4];
+    const int col0 = blockIdx.x * COLS;             // first column of this tile in the PADDED line [0, ow + 2*pad)
+    const int line_w = ow + 2 * pad;
+    const int tid = threadIdx.x;
+    float* orow = out + (size_t)n * ch * out_h * batch_w;
+    if (col0 >= line_w || in_w <= 0 || in_h <= 0 || ow <= 0) {
+        // batch padding right of the line (or an empty line): zeros
+        for (int e = tid; e < ch * out_h * COLS; e += 256) {
+            const int c = e / (out_h * COLS), r = (e / COLS) % out_h, x = col0 + e % COLS;
+            if (x < batch_w) orow[((size_t)c * out_h + r) * batch_w + x] = 0.f;
+        }
+        return;
+    }
+    // vertical pass geometry: source rows [yfirst, ylast) feed it (Pillow: ybox_first / ybox_last)
+    int* kv = reinterpret_cast<int*>(smem);                          // [out_h][MAX_K]
+    int* kvb = kv + out_h * MAX_K;                                   // [out_h][2]
+    int* kh = kvb + out_h * 2;                                       // [COLS][MAX_K]
+    int* khb = kh + COLS * MAX_K;                                    // [COLS][2]
+    unsigned char* tmp = reinterpret_cast<unsigned char*>(khb + COLS * 2);   // [ch][rows][COLS]
+    if (tid < out_h) {
+        int xmin;
+        const int xmax = resample_weights(in_h, out_h, tid, &xmin, kv + tid * MAX_K);
+        kvb[2 * tid] = xmin;
+        kvb[2 * tid + 1] = xmax;
+    }
+    if (tid >= 64 && tid < 64 + COLS) {
+        const int j = tid - 64, xx = col0 + j - pad;
+        int xmin = 0, xmax = 0;
+        if (xx >= 0 && xx < ow) xmax = resample_weights(in_w, ow, xx, &xmin, kh + j * MAX_K);
+        khb[2 * j] = xmin;
+        khb[2 * j + 1] = xmax;
+    }
+    __syncthreads();
+    const int yfirst = kvb[0];
+    const int ylast = kvb[2 * (out_h - 1)] + kvb[2 * (out_h - 1) + 1];
+    const int rows = ylast - yfirst;
+    // horizontal pass: tmp[c][r][j] for the source rows the vertical pass reads
+    for (int e = tid; e < ch * rows * COLS; e += 256) {
+        const int j = e % COLS, r = (e / COLS) % rows, c = e / (COLS * rows);
+        const int xmin = khb[2 * j], xmax = khb[2 * j + 1];
+        unsigned v = 255;
+        if (xmax > 0) {
+            const int gy = y0 + yfirst + r;
+            int ss0 = 1 << (PREC_BITS - 1);
+            const int* k = kh + j * MAX_K;
+            for (int x = 0; x < xmax; ++x) {
+                const int gx = x0 + xmin + x;
+                // Image.crop pads what lies outside the page with 0
+                const int px = (gy >= 0 && gy < page_h && gx >= 0 && gx < page_w) ? page[((size_t)gy * page_w + gx) * ch + c] : 0;
+                ss0 += px * k[x];
+            }
+            v = clip8(ss0);
+        }
+        tmp[(c * rows + r) * COLS + j] = (unsigned char)v;
+    }
+    __syncthreads();
+    // vertical pass + white padding + float + invert
+    bool ink = false;
+    for (int e = tid; e < ch * out_h * COLS; e += 256) {
+        const int j = e % COLS, yy = (e / COLS) % out_h, c = e / (COLS * out_h);
+        const int x = col0 + j;
+        if (x >= batch_w) continue;
+        float val = 0.f;                               // padding columns: 255 -> 1 - 1 = 0; right of the line: batch padding
+        const int xx = x - pad;
+        if (xx >= 0 && xx < ow) {
+            const int ymin = kvb[2 * yy] - yfirst, ymax = kvb[2 * yy + 1];
+            int ss0 = 1 << (PREC_BITS - 1);
+            const int* k = kv + yy * MAX_K;
+            for (int y = 0; y < ymax; ++y) ss0 += (int)tmp[(c * rows + ymin + y) * COLS + j] * k[y];
+            const unsigned v = clip8(ss0);
+            val = 1.0f - lut[v];
+            ink = ink || v != 255u;
+        }
+        orow[((size_t)c * out_h + yy) * batch_w + x] = val;
+    }
+    if (__any(ink) && (tid & 63) == 0) atomicOr(flags + n, 1);
+}
+
+}  // namespace
+
+// LDS: (out_h + COLS) * (MAX_K + 2) ints + ch * rows * COLS bytes
+int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, int ch, const int* boxes_dev, int n, int max_in_h,
+                          const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (out_h < 1 || out_h > 64 || pad < 1 || (ch != 1 && ch != 3) || max_in_h > MAX_ROWS) return -4;
+    const size_t lds = (size_t)(out_h + COLS) * (MAX_K + 2) * sizeof(int) + (size_t)ch * (max_in_h + 2) * COLS;
+    if (lds > 160 * 1024) return -4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_lines_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), s);
+    dim3 grid((unsigned)((batch_w + COLS - 1) / COLS), (unsigned)n);
+    hipLaunchKernelGGL(prep_lines_kernel, grid, dim3(256), lds, s, page, page_h, page_w, ch, boxes_dev, lut, out_h, pad, batch_w, out, flags);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

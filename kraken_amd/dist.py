@@ -23,7 +23,7 @@ import torch.distributed as td
 
 from .vgsl import DecodedBatch
 
-__all__ = ['init', 'shard_bounds', 'shard_indices', 'gather_decoded', 'pack_decoded', 'unpack_decoded']
+__all__ = ['init', 'shard_bounds', 'shard_indices', 'gather_decoded', 'pack_decoded', 'unpack_decoded', 'concat_decoded']
 
 
 def init(backend: Optional[str] = None):
@@ -79,6 +79,15 @@ def unpack_decoded(flat: np.ndarray, n: int, k: int) -> tuple[DecodedBatch, np.n
     for a in range(4):
         out[a][keep] = body[a]
     return DecodedBatch(out[0], out[1], out[2], out[3].view(np.float32), counts.copy()), olens.copy()
+
+
+def concat_decoded(batches) -> tuple[DecodedBatch, np.ndarray]:
+    """[(DecodedBatch, olens), ...] of one rank -> a single (DecodedBatch, olens): one exchange for all its batches."""
+    t = max([b.labels.shape[1] for b, _ in batches] + [1])
+    pad = lambda a: np.pad(a, ((0, 0), (0, t - a.shape[1])))   # noqa: E731
+    fields = [np.concatenate([pad(getattr(b, f)) for b, _ in batches]) for f in ('labels', 'starts', 'ends', 'confs')]
+    return (DecodedBatch(*fields, np.concatenate([np.asarray(b.counts) for b, _ in batches])),
+            np.concatenate([np.asarray(o) for _, o in batches]))
 
 
 def gather_decoded(batch: DecodedBatch, olens, group=None, force: bool = False) -> list[DecodedBatch]:

@@ -7,8 +7,17 @@ A ``RecognitionEngine`` owns ``slots`` independent execution slots; each slot ha
 device result buffers and pinned host mirrors.  ``submit`` enqueues forward + softmax + CTC
 best-path decode (one ``krk_recognize`` call) and the device->host copy of the COMPACT label
 tuples on the slot's stream and returns immediately; ``collect`` waits for that slot's event
-only.  With two or more slots the small LSTM recurrent kernels of one batch (a few dozen CUs)
-overlap the convolutions of the next, which is where single-batch latency leaves CUs idle.
+only.  With two or more slots the recurrent kernels of one batch (a quarter of the CUs) overlap
+the convolutions of the next, and the host prepares / decodes other batches meanwhile.
+
+Two ways to hand a batch over:
+
+* ``submit(x, lens)`` -- ``x`` resident on the device (bench.py) or any host tensor;
+* ``stage(n, w)`` -> pinned host array ``(n, C, H, w)`` of the next free slot, to be filled in place
+  (line k at ``[k, :, :, :w_k]``, zero elsewhere), then ``submit_staged(lens)``: what ``rpred`` /
+  ``TorchVGSLModel.predict`` use, so that padding a batch is its only host copy.
+
+Buffers grow on demand (batch size, width); nothing is sized by a guess that a page can exceed.
 """
 import ctypes as C
 import os
@@ -23,20 +32,53 @@ from .vgsl import DecodedBatch, TorchVGSLModel, _Plan
 
 
 class _Slot:
-    def __init__(self, model: TorchVGSLModel, dev: int, max_n: int, max_t: int):
+    def __init__(self, model: TorchVGSLModel, dev: int):
         self.plan = _Plan(model.nn._specs, model.nn, model.input[1], model.input[2], dev, model.nn.precision)
+        self.dev = dev
         self.stream = torch.cuda.Stream(device=dev)
         self.event = torch.cuda.Event()
-        d = torch.device(f'cuda:{dev}')
-        # one int32 block [labels | starts | ends | conf bits | counts] so the D2H is a single copy
-        self.max_n, self.max_t = max_n, max_t
-        self.dev_buf = torch.empty(4 * max_n * max_t + max_n, dtype=torch.int32, device=d)
-        self.host_buf = torch.empty(4 * max_n * max_t + max_n, dtype=torch.int32).pin_memory()
-        self.olens = np.empty(max_n, dtype=np.int32)
+        self.cap_n = self.cap_t = 0
+        self.dev_buf = self.host_buf = None
+        self.olens = np.empty(0, dtype=np.int32)
         self.busy = False
         self.n = self.t = 0
         self.keep = None
-        self.stage = None     # device copy of a host input batch
+        self.stage_host = None     # pinned (flat) host staging of an input batch
+        self.stage_dev = None      # its device copy
+        self.staged = None         # (n, c, h, w) of the batch being staged
+        self.probs = None          # (n, t, classes) softmax of the last batch, when asked for
+        self.want_probs = False
+        self.boxes_host = self.boxes_dev = None     # device-side line preprocessing (krk_prep_lines): crop boxes ...
+        self.flags_dev = self.flags_host = None     # ... and the per-line "holds ink" flags it returns
+        self.has_flags = False
+
+    def ensure_results(self, n: int, t: int):
+        """One int32 block [labels | starts | ends | conf bits | counts] so the D2H is a single copy."""
+        if n <= self.cap_n and t <= self.cap_t:
+            return
+        self.cap_n, self.cap_t = max(n, self.cap_n), max(t, self.cap_t)
+        d = torch.device(f'cuda:{self.dev}')
+        size = 4 * self.cap_n * self.cap_t + self.cap_n
+        self.dev_buf = torch.empty(size, dtype=torch.int32, device=d)
+        self.host_buf = torch.empty(size, dtype=torch.int32).pin_memory()
+        self.olens = np.empty(self.cap_n, dtype=np.int32)
+
+    def ensure_stage(self, elems: int, host: bool = True):
+        if self.stage_dev is None or self.stage_dev.numel() < elems:
+            elems = int(elems * 1.25)
+            self.stage_dev = torch.empty(elems, dtype=torch.float32, device=f'cuda:{self.dev}')
+            self.stage_host = None
+        if host and self.stage_host is None:
+            self.stage_host = torch.empty(self.stage_dev.numel(), dtype=torch.float32).pin_memory()
+
+    def ensure_boxes(self, n: int):
+        if self.boxes_host is None or self.boxes_host.shape[0] < n:
+            cap = max(n, 64) * 2
+            d = f'cuda:{self.dev}'
+            self.boxes_host = torch.empty((cap, 5), dtype=torch.int32).pin_memory()
+            self.boxes_dev = torch.empty((cap, 5), dtype=torch.int32, device=d)
+            self.flags_dev = torch.empty(cap, dtype=torch.int32, device=d)
+            self.flags_host = torch.empty(cap, dtype=torch.int32).pin_memory()
 
 
 class RecognitionEngine:
@@ -47,12 +89,12 @@ class RecognitionEngine:
         self.model = model
         self.device = device
         self.temperature = float(temperature)
+        self.in_channels, self.in_height = model.input[1], model.input[2]
         with torch.cuda.device(device):
-            probe = _Plan(model.nn._specs, model.nn, model.input[1], model.input[2], device, model.nn.precision)
-            self.classes, _, max_t = probe.out_shape(max_width)
-            probe.close()
-            self.max_batch, self.max_t = max_batch, max_t
-            self.slots = [_Slot(model, device, max_batch, max_t) for _ in range(slots)]
+            self.slots = [_Slot(model, device) for _ in range(slots)]
+            self.classes, _, max_t = self.slots[0].plan.out_shape(max_width)
+            for s in self.slots:
+                s.ensure_results(max_batch, max_t)
         self._next = 0
         self._inflight = deque()
         # front event of the batch submitted last: the next batch's convolution block queues behind it, so the
@@ -60,7 +102,9 @@ class RecognitionEngine:
         # convolutions together and then all doing recurrences together) -- see include/kraken_amd.h
         self._fronts = []
         self.chain_fronts = os.environ.get('KRK_NO_FRONT_CHAIN') is None
+        self.front_lag = int(os.environ.get('KRK_FRONT_LAG', '1'))
 
+    # ------------------------------------------------------------------ diagnostics
     def set_profiling(self, on: bool):
         for s in self.slots:
             _lib.check(self.lib.krk_plan_set_profiling(s.plan.handle, 1 if on else 0))
@@ -77,43 +121,123 @@ class RecognitionEngine:
                          float(self.lib.krk_plan_layer_flops(s.plan.handle, i))) for i in range(n)])
         return out
 
-    def submit(self, x: torch.Tensor, lens: Optional[np.ndarray] = None) -> int:
+    # ------------------------------------------------------------------ submission
+    def free_slots(self) -> int:
+        return sum(not s.busy for s in self.slots)
+
+    def in_flight(self) -> int:
+        return len(self._inflight)
+
+    def _free_slot(self) -> _Slot:
+        slot = self.slots[self._next]
+        if slot.busy:
+            raise RuntimeError('all slots busy: collect() a ticket before submitting more')
+        return slot
+
+    def stage(self, n: int, w: int, height: Optional[int] = None) -> np.ndarray:
+        """
+        Zeroed pinned host array (n, C, H, w) of the next free slot; fill it in place and call ``submit_staged``.
+        ``height`` overrides the model's input height (variable-height specs: one plan per height).
+        """
+        slot = self._free_slot()
+        c = self.in_channels
+        h = self.in_height if height is None else height
+        slot.ensure_stage(n * c * h * w)
+        slot.staged = (n, c, h, w)
+        arr = slot.stage_host[:n * c * h * w].numpy().reshape(n, c, h, w)
+        arr.fill(0.0)
+        return arr
+
+    def upload_page(self, page: np.ndarray) -> torch.Tensor:
+        """uint8 page (H, W) or (H, W, 3) -> device tensor for ``submit_boxes`` (one upload per page)."""
+        t = torch.from_numpy(np.ascontiguousarray(page, dtype=np.uint8))
+        return t.to(f'cuda:{self.device}', non_blocking=False)
+
+    def submit_boxes(self, page_dev: torch.Tensor, boxes: np.ndarray, pad: int, want_probs: bool = False) -> int:
+        """
+        Recognises rectangular crops of an uploaded page: ``boxes`` int32 (n, 5) = x0, y0, x1, y1, resized width.  Crop,
+        fixed-height LANCZOS resize, white padding and inversion run on the device (``krk_prep_lines``), straight into
+        this slot's staging tensor -- the device-side counterpart of ``stage`` + ``submit_staged``.
+        """
+        slot = self._free_slot()
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32)
+        n = len(boxes)
+        c, h = self.in_channels, self.in_height
+        widths = boxes[:, 4] + 2 * pad
+        w = int(widths.max())
+        slot.ensure_stage(n * c * h * w, host=False)
+        slot.ensure_boxes(n)
+        slot.boxes_host[:n].copy_(torch.from_numpy(boxes))
+        ph, pw = int(page_dev.shape[0]), int(page_dev.shape[1])
+        pc = 1 if page_dev.dim() == 2 else int(page_dev.shape[2])
+        if pc != c:
+            raise ValueError(f'page has {pc} channels, the model takes {c}')
+        with torch.cuda.stream(slot.stream):
+            slot.boxes_dev[:n].copy_(slot.boxes_host[:n], non_blocking=True)
+            _lib.check(self.lib.krk_prep_lines(page_dev.data_ptr(), ph, pw, pc, slot.boxes_dev.data_ptr(), n,
+                                               int((boxes[:, 3] - boxes[:, 1]).max()), h, int(pad), w,
+                                               slot.stage_dev.data_ptr(), slot.flags_dev.data_ptr(), slot.stream.cuda_stream))
+            slot.flags_host[:n].copy_(slot.flags_dev[:n], non_blocking=True)
+        slot.has_flags = True
+        x = slot.stage_dev[:n * c * h * w].view(n, c, h, w)
+        slot.page_keep = page_dev
+        return self._launch(slot, x, widths.astype(np.int32), want_probs, wait_current=True)
+
+    def submit_staged(self, lens=None, want_probs: bool = False) -> int:
+        slot = self._free_slot()
+        n, c, h, w = slot.staged
+        k = n * c * h * w
+        with torch.cuda.stream(slot.stream):
+            slot.stage_dev[:k].copy_(slot.stage_host[:k], non_blocking=True)     # PCIe copy on the slot's own stream
+        x = slot.stage_dev[:k].view(n, c, h, w)
+        return self._launch(slot, x, lens, want_probs, wait_current=False)
+
+    def submit(self, x: torch.Tensor, lens: Optional[np.ndarray] = None, want_probs: bool = False) -> int:
         """
         x: (N, C, H, W) float32 tensor, resident on this device -- or a (preferably pinned) HOST tensor, which is copied
         to a per-slot staging buffer on the slot's own stream so that the PCIe transfer of batch k+1 overlaps the kernels of
         batch k.  Returns a ticket.
         """
-        slot_id = self._next
-        slot = self.slots[slot_id]
-        if slot.busy:
-            raise RuntimeError('all slots busy: collect() a ticket before submitting more')
+        slot = self._free_slot()
         if not x.is_cuda:
-            if slot.stage is None or slot.stage.shape != x.shape:
-                slot.stage = torch.empty(x.shape, dtype=torch.float32, device=f'cuda:{self.device}')
+            k = x.numel()
+            slot.ensure_stage(k)
             with torch.cuda.stream(slot.stream):
-                slot.stage.copy_(x, non_blocking=True)
-            x = slot.stage
-        N, _, _, W = x.shape
-        _, _, T = slot.plan.out_shape(W)
-        if N > slot.max_n or T > slot.max_t:
-            raise ValueError(f'batch {N}x{T} exceeds the engine capacity {slot.max_n}x{slot.max_t}')
-        nt = slot.max_n * slot.max_t
+                slot.stage_dev[:k].copy_(x.reshape(-1), non_blocking=True)
+            x = slot.stage_dev[:k].view(x.shape)
+            return self._launch(slot, x, lens, want_probs, wait_current=False)
+        return self._launch(slot, x, lens, want_probs, wait_current=True)
+
+    def _launch(self, slot: _Slot, x: torch.Tensor, lens, want_probs: bool, wait_current: bool) -> int:
+        slot_id = self._next
+        N, _, H, W = x.shape
+        plan = slot.plan
+        if H != self.in_height:
+            raise ValueError(f'engine built for input height {self.in_height}, got {H}')
+        _, _, T = plan.out_shape(W)
+        slot.ensure_results(N, T)
+        nt = slot.cap_n * slot.cap_t
         base = slot.dev_buf.data_ptr()
-        dec = _lib.KrkDecodeOut(base, base + 4 * nt, base + 8 * nt, base + 12 * nt, base + 16 * nt, slot.max_t)
+        dec = _lib.KrkDecodeOut(base, base + 4 * nt, base + 8 * nt, base + 12 * nt, base + 16 * nt, slot.cap_t)
         lens_arr = None
         if lens is not None:
             lens_arr = np.ascontiguousarray(np.asarray(lens, dtype=np.int32))
-        cur = torch.cuda.current_stream(self.device)
-        slot.stream.wait_stream(cur)   # the input may have been produced on the caller's stream
-        lag = int(os.environ.get('KRK_FRONT_LAG', '1'))
-        if self.chain_fronts and len(self._fronts) >= lag and len(self.slots) > 1:
-            _lib.check(self.lib.krk_plan_wait_front(slot.plan.handle, self._fronts[-lag]))
-        self._fronts.append(self.lib.krk_plan_front_event(slot.plan.handle))
+        if wait_current:
+            slot.stream.wait_stream(torch.cuda.current_stream(self.device))   # the input may have been produced there
+        if self.chain_fronts and len(self._fronts) >= self.front_lag and len(self.slots) > 1:
+            _lib.check(self.lib.krk_plan_wait_front(plan.handle, self._fronts[-self.front_lag]))
+        self._fronts.append(self.lib.krk_plan_front_event(plan.handle))
         del self._fronts[:-4]
+        slot.want_probs = bool(want_probs)
         with torch.cuda.stream(slot.stream):
-            _lib.check(self.lib.krk_recognize(slot.plan.handle, x.data_ptr(),
+            probs_ptr = None
+            if want_probs:
+                if slot.probs is None or slot.probs.numel() < N * T * self.classes:
+                    slot.probs = torch.empty(N * T * self.classes, dtype=torch.float32, device=x.device)
+                probs_ptr = slot.probs.data_ptr()
+            _lib.check(self.lib.krk_recognize(plan.handle, x.data_ptr(),
                                               lens_arr.ctypes.data if lens_arr is not None else None, N, W,
-                                              self.temperature, slot.stream.cuda_stream, None, None,
+                                              self.temperature, slot.stream.cuda_stream, None, probs_ptr,
                                               slot.olens.ctypes.data, C.byref(dec)))
             slot.host_buf.copy_(slot.dev_buf, non_blocking=True)
             slot.event.record(slot.stream)
@@ -122,6 +246,7 @@ class RecognitionEngine:
         self._inflight.append(slot_id)
         return slot_id
 
+    # ------------------------------------------------------------------ results
     def collect(self, ticket: Optional[int] = None) -> tuple[DecodedBatch, np.ndarray]:
         """Waits for the oldest (or the given) in-flight batch; returns (DecodedBatch, olens)."""
         if ticket is None:
@@ -130,17 +255,24 @@ class RecognitionEngine:
         slot = self.slots[ticket]
         slot.event.synchronize()
         _lib.check(self.lib.krk_plan_status(slot.plan.handle))     # a kernel that gave up waiting raises here, never hangs
-        nt = slot.max_n * slot.max_t
+        nt = slot.cap_n * slot.cap_t
         h = slot.host_buf.numpy()
-        n, t = slot.n, slot.max_t
-        view = lambda k: h[k * nt:(k + 1) * nt].reshape(slot.max_n, t)[:n]   # noqa: E731
+        n, t = slot.n, slot.cap_t
+        view = lambda k: h[k * nt:(k + 1) * nt].reshape(slot.cap_n, t)[:n]   # noqa: E731
         batch = DecodedBatch(view(0).copy(), view(1).copy(), view(2).copy(), view(3).copy().view(np.float32),
                              h[4 * nt:4 * nt + n].copy())
         slot.busy, slot.keep = False, None
+        self.last_slot = slot
+        self.last_flags = slot.flags_host[:n].numpy().copy() if slot.has_flags else None
+        slot.has_flags = False
         return batch, slot.olens[:n].copy()
 
-    def free_slots(self) -> int:
-        return sum(not s.busy for s in self.slots)
+    def last_probs(self) -> Optional[torch.Tensor]:
+        """(N, C, T) softmax of the batch returned by the last ``collect`` (device tensor; valid until that slot is reused)."""
+        slot = getattr(self, 'last_slot', None)
+        if slot is None or not slot.want_probs or slot.probs is None:
+            return None
+        return slot.probs[:slot.n * slot.t * self.classes].view(slot.n, slot.t, self.classes).permute(0, 2, 1)
 
     def close(self):
         for s in self.slots:

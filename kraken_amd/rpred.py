@@ -1,41 +1,56 @@
 """
-Legacy line-recognition generators on top of the HIP path.
+Line-recognition generators on top of the pipelined HIP engine.
 
-Drop-in for ``kraken.rpred.rpred`` / ``kraken.rpred.mm_rpred`` (reference kraken/rpred.py:57-370):
-same constructor arguments, the same iterator protocol (``len()``, ``next()`` yields one
-``ocr_record`` per line, in input order), per-tag model routing (``_resolve_type_to_model``
-:373-391), the same empty-record rules (ignored tags, failed extraction, zero-sized crops,
-failed tensor conversion, flat lines -- :193-223) and the same position arithmetic
-(``_scale_val`` :329-330).
+Two front ends of the reference funnel into the same three calls (``nn(x, lens)`` -> softmax -> decoder -> codec):
 
-What changes underneath: the reference runs ONE line per ``next()`` through torch on the CPU and
-copies the full softmax matrix to the host; here lines that share a model are queued and pushed
-through ``krk_recognize`` in width-sorted batches of ``batch_size`` lines.  Because the kernels
-implement masked padding, a line's result does not depend on its batch mates, so records are
-identical to per-line evaluation (tests/test_rpred_mirror.py).
+* the legacy ``kraken.rpred.rpred`` / ``mm_rpred`` generators (reference kraken/rpred.py:57-370): same constructor
+  arguments, the same iterator protocol (``len()``, ``next()`` yields one ``ocr_record`` per line, in input order),
+  per-tag model routing (``_resolve_type_to_model`` :373-391), the same empty-record rules (ignored tags, failed
+  extraction, zero-sized crops, failed tensor conversion, flat lines -- :193-223) and the same position arithmetic
+  (``_scale_val`` :329-330);
+* the batched API ``TorchVGSLModel.predict(im, segmentation)`` = ``VGSLRecognitionInference._recognition_pred``
+  (reference kraken/lib/vgsl/rpred.py:56-232): config-driven (``batch_size``, ``temperature``, ``padding``,
+  ``num_line_workers``, ``return_logits``, ``return_line_image``, ``bidi_reordering``, ``decoder``), records carry
+  ``logits`` / ``image`` when asked (``recognition_pred`` below).
 
-Line extraction: bounding-box lines are cropped here (the reference's
-``extract_polygons`` bbox branch, kraken/lib/segmentation.py:1630-1643); baseline/polygon
-extraction is CPU geometry outside the hot path and is delegated to kraken when it is installed.
-The module-level name ``extract_polygons`` is kept patchable like in the reference
-(tests/test_newpolygons.py:64-102 mocks it).
+What changes underneath: the reference runs one line (legacy) or one padded batch (new API) at a time through torch
+and decodes on the host.  Here both front ends drive a ``LinePipeline``: lines are prepared (crop, dewarp / resize,
+pad) on a pool of host threads one CHUNK ahead of the device, width-sorted into buckets so that a batch pads to a
+similar width (BASELINE config 4: "length bucketing + packed LSTM"), staged into pinned memory and submitted to a
+``RecognitionEngine`` that keeps several batches in flight; records are assembled from the compact label tuples with
+vectorised scaling.  Because the kernels implement masked padding, a line's result does not depend on its batch mates
+(it equals the reference's per-line ``rpred`` result), so the device batch size is a tuning knob of THIS implementation
+(``ENGINE_BATCH``) and not the caller's ``batch_size``.
+
+Line extraction: bounding-box lines are cropped here (the reference's ``extract_polygons`` bbox branch,
+kraken/lib/segmentation.py:1630-1643); baseline/polygon extraction is CPU geometry outside the hot path and is
+delegated to kraken when it is installed.  The module-level name ``extract_polygons`` is kept patchable like in the
+reference (tests/test_newpolygons.py:64-102 mocks it).
 """
 import dataclasses
 import logging
+import math
 import warnings
-from collections import defaultdict
+from collections import defaultdict, deque
+from concurrent.futures import ThreadPoolExecutor
 from functools import partial
 from typing import Optional, Union
 
 import numpy as np
 import torch
 
+from . import ctc_decoder as _ctc
 from .containers import BaselineOCRRecord, BBoxOCRRecord
 from .transforms import ImageInputTransforms
 
-__all__ = ['mm_rpred', 'rpred', 'extract_polygons']
+__all__ = ['mm_rpred', 'rpred', 'recognition_pred', 'extract_polygons', 'LinePipeline']
 
 logger = logging.getLogger(__name__)
+
+ENGINE_BATCH = 256     # lines per device batch (results do not depend on it: masked padding, see the module docstring)
+ENGINE_SLOTS = 3       # device batches in flight per recogniser
+DEVICE_PREP = True     # crop / resize / pad / invert eligible lines on the device (krk_prep_lines) instead of with PIL
+PREP_THREADS = 4       # host threads preparing line images when the caller does not say (``num_line_workers``)
 
 
 class KrakenInputException(Exception):
@@ -68,6 +83,9 @@ def extract_polygons(im, bounds, legacy: bool = False):
             logger.error('bbox {} is outside of image bounds {}'.format(box, im.size))
             raise ValueError('Line outside of image bounds')
         yield im.crop(box).rotate(angle, expand=True), line
+
+
+_EXTRACT_POLYGONS = extract_polygons      # a patched module attribute (tests mock it) switches the device-side crop off
 
 
 def _line_type(tags: Optional[dict], default: str = 'default') -> str:
@@ -106,15 +124,353 @@ class _Pending:
     line: object
     tag: str
     net: object
-    tensor: torch.Tensor
+    tensor: Optional[torch.Tensor]      # prepared on the host ... or None:
     box_size: tuple
+    image: object = None
+    width: int = 0                      # network input width (resized line + padding)
+    box: Optional[tuple] = None         # ... prepared on the device: (x0, y0, x1, y1, resized width) into the uploaded page
+    mode: str = ''                      # PIL mode of the page the device crops from
 
 
-class mm_rpred(object):
+@dataclasses.dataclass
+class LineResult:
+    """What the device path returns for one line: code points with their network-output positions."""
+    text: str
+    starts: np.ndarray        # network time steps (inclusive first / last step of every code point)
+    ends: np.ndarray
+    confs: np.ndarray         # float32
+    out_width: int            # valid output steps of this line (the reference's ``outputs.shape[2]`` / ``olen``)
+    probs: object = None      # (C, out_width) softmax (torch tensor) when asked for
+
+
+# ---------------------------------------------------------------------------------------------------- device side
+def _fused_ok(net) -> bool:
+    """The engine runs greedy best-path decoding on the device: only for recognisers whose decoder IS greedy_decoder."""
+    vgsl = getattr(net, 'nn', None)
+    hs = getattr(vgsl, 'nn', None)
+    if hs is None or not hasattr(hs, 'recognize'):
+        return False
+    return getattr(net, 'decoder', _ctc.greedy_decoder) is _ctc.greedy_decoder
+
+
+def _engine_for(net, temperature: float):
+    """The (cached) RecognitionEngine of a recogniser; None for models the engine does not take (variable height)."""
+    from .engine import RecognitionEngine
+    vgsl = net.nn
+    hs = vgsl.nn
+    if vgsl.input[2] <= 0:
+        return None
+    p = next(vgsl.parameters())
+    if not p.is_cuda:
+        vgsl.to('cuda')
+        p = next(vgsl.parameters())
+    dev = p.device.index if p.device.index is not None else torch.cuda.current_device()
+    key = (dev, hs.precision, hs._weights_version(), float(temperature))
+    cache = hs.__dict__.setdefault('_engines', {})
+    eng = cache.get(key)
+    if eng is None:
+        for old in cache.values():
+            old.close()
+        cache.clear()
+        eng = RecognitionEngine(vgsl, device=dev, max_batch=32, max_width=256, slots=ENGINE_SLOTS, temperature=temperature)
+        cache[key] = eng
+    return eng
+
+
+def _decode_lines(codec, batch, olens, probs=None) -> list:
+    """DecodedBatch -> LineResult per line.  Single-label codecs take the vectorised table path."""
+    n = len(batch.counts)
+    lut = codec._single_lut() if hasattr(codec, '_single_lut') else False
+    out = []
+    if lut is False:
+        for i, rec in enumerate(codec.decode_batch(batch) if hasattr(codec, 'decode_batch') else
+                                [codec.decode(t) for t in batch.tuples()]):
+            out.append(LineResult(''.join(x[0] for x in rec), np.array([x[1] for x in rec], dtype=np.int64),
+                                  np.array([x[2] for x in rec], dtype=np.int64),
+                                  np.array([x[3] for x in rec], dtype=np.float32), int(olens[i])))
+    else:
+        labels = np.asarray(batch.labels)
+        t = labels.shape[1] if labels.ndim == 2 else 0
+        counts = np.minimum(np.maximum(np.asarray(batch.counts), 0), t)
+        cps = np.where(labels < len(lut), lut[np.minimum(labels, len(lut) - 1)], 0).astype('<u4') if t else labels
+        for i in range(n):
+            k = int(counts[i])
+            c = cps[i, :k]
+            ok = c != 0                                    # undecodable labels are skipped (codec.decode, non-strict)
+            if getattr(codec, 'strict', False) and not ok.all():
+                codec.decode(batch.tuples()[i])            # raises the reference's exception
+            if ok.all():
+                s, e, cf = batch.starts[i, :k], batch.ends[i, :k], batch.confs[i, :k]
+            else:
+                c, s, e, cf = c[ok], batch.starts[i, :k][ok], batch.ends[i, :k][ok], batch.confs[i, :k][ok]
+            out.append(LineResult(c.tobytes().decode('utf-32-le'), s, e, cf, int(olens[i])))
+    if probs is not None:
+        for i, r in enumerate(out):
+            r.probs = probs[i, :, :r.out_width].clone()
+    return out
+
+
+class LinePipeline:
+    """
+    Recognises prepared line tensors of ONE recogniser: width-bucketed batches through its RecognitionEngine, several
+    batches in flight.  ``submit(items)`` takes ``(key, tensor (C, H, W))`` pairs and returns immediately;
+    ``drain(block)`` yields ``(key, LineResult)`` for finished batches.
+    """
+
+    def __init__(self, net, temperature: float = 1.0, batch_size: int = ENGINE_BATCH, want_probs: bool = False):
+        self.net = net
+        self.batch_size = max(1, int(batch_size))
+        self.want_probs = want_probs
+        self.temperature = float(temperature)
+        self.engine = _engine_for(net, temperature) if _fused_ok(net) else None
+        self._tickets = deque()       # (ticket, keys)
+        self._done = deque()
+
+    @property
+    def fused(self) -> bool:
+        return self.engine is not None
+
+    def submit(self, items: list):
+        """items: [(key, tensor)]; all tensors share (C, H).  Width-sorted so that a batch pads to similar widths."""
+        if not items:
+            return
+        if self.engine is None:
+            self._run_sync(items)
+            return
+        items = sorted(items, key=lambda kt: kt[1].shape[2])
+        for lo in range(0, len(items), self.batch_size):
+            part = items[lo:lo + self.batch_size]
+            while self.engine.free_slots() == 0:
+                self._collect_one()
+            widths = [t.shape[2] for _, t in part]
+            x = self.engine.stage(len(part), max(widths))
+            for i, (_, t) in enumerate(part):
+                x[i, :, :, :widths[i]] = t.numpy() if isinstance(t, torch.Tensor) else t
+            ticket = self.engine.submit_staged(np.asarray(widths, dtype=np.int32), want_probs=self.want_probs)
+            self._tickets.append((ticket, [k for k, _ in part]))
+
+    def submit_boxes(self, page_dev, items: list, pad: int):
+        """items: [(key, (x0, y0, x1, y1, resized width))]: crops of an uploaded page, prepared on the device."""
+        items = sorted(items, key=lambda kb: kb[1][4])
+        for lo in range(0, len(items), self.batch_size):
+            part = items[lo:lo + self.batch_size]
+            while self.engine.free_slots() == 0:
+                self._collect_one()
+            ticket = self.engine.submit_boxes(page_dev, np.asarray([b for _, b in part], dtype=np.int32), pad,
+                                              want_probs=self.want_probs)
+            self._tickets.append((ticket, [k for k, _ in part]))
+
+    def _collect_one(self):
+        ticket, keys = self._tickets.popleft()
+        batch, olens = self.engine.collect(ticket)
+        flags = self.engine.last_flags
+        probs = self.engine.last_probs() if self.want_probs else None
+        for i, (k, r) in enumerate(zip(keys, _decode_lines(self.net.codec, batch, olens, probs))):
+            # a line without a single non-white pixel is the reference's "flat line": empty record (kraken/rpred.py:221)
+            self._done.append((k, None if flags is not None and not flags[i] else r))
+
+    def _run_sync(self, items: list):
+        """Recognisers the engine does not take (custom decoder, variable height, foreign objects): per line, like the reference."""
+        for k, t in items:
+            preds = self.net.predict(t.unsqueeze(0))[0]
+            outw = self.net.outputs.shape[2]
+            probs = None
+            if self.want_probs:
+                o = self.net.outputs
+                probs = torch.as_tensor(o)[0, :, :outw].clone()
+            self._done.append((k, LineResult(''.join(x[0] for x in preds), np.array([x[1] for x in preds], dtype=np.int64),
+                                             np.array([x[2] for x in preds], dtype=np.int64),
+                                             np.array([x[3] for x in preds], dtype=np.float32), int(outw), probs)))
+
+    def pending(self) -> int:
+        return len(self._tickets)
+
+    def drain(self, block: bool = False):
+        """Yields finished (key, LineResult); with ``block`` waits for the oldest batch in flight first."""
+        if block and self._tickets:
+            self._collect_one()
+        while self._done:
+            yield self._done.popleft()
+
+
+# ------------------------------------------------------------------------------------------------------- host side
+class _RecognitionRun:
+    """Shared machinery of both front ends: chunked preparation, per-recogniser pipelines, record assembly."""
+
+    def _init_run(self, im, bounds, pad, bidi_reordering, temperature_of, want_probs=False, return_image=False,
+                  workers: int = PREP_THREADS, engine_batch: Optional[int] = None):
+        self.im, self.bounds, self.pad = im, bounds, pad
+        if hasattr(im, 'load'):
+            im.load()                                  # worker threads crop concurrently: decode the page once, up front
+        self.bidi_reordering = bidi_reordering
+        self.len = len(bounds.lines)
+        self._valid_norm = bounds.type != 'baselines'
+        self._record_cls = BBoxOCRRecord if bounds.type != 'baselines' else BaselineOCRRecord
+        self._results: dict[int, object] = {}
+        self._cursor = 0          # next line index to hand out
+        self._prepared = 0        # lines already extracted / queued
+        self._pipes: dict[int, LinePipeline] = {}
+        self._pending: dict[int, _Pending] = {}
+        self._temperature_of = temperature_of
+        self._want_probs = want_probs
+        self._return_image = return_image
+        self._pool = ThreadPoolExecutor(max_workers=workers) if workers and workers > 1 else None
+        # device batch: large enough to fill the chip, small enough that a page still splits into a few batches whose
+        # preparation overlaps the device work of their predecessors
+        b = engine_batch or ENGINE_BATCH
+        self._batch = int(min(b, max(32, math.ceil(self.len / (2 * ENGINE_SLOTS)))))
+        self._chunk = self._batch * ENGINE_SLOTS
+        self._pages: dict = {}     # PIL mode -> the page as a device tensor (device-side line preparation)
+
+    # -- device-side preparation (krk_prep_lines): rectangular crops of a fixed-height model, no dewarp ------------
+    def _device_prep_ok(self, net, ts) -> bool:
+        if not DEVICE_PREP or self.bounds.type == 'baselines' or not self.bounds.text_direction.startswith('horizontal'):
+            return False
+        pad = ts.pad
+        if not (isinstance(pad, (tuple, list)) and len(pad) == 2 and int(pad[0]) > 0 and int(pad[1]) == 0):
+            return False
+        if ts._center_norm or ts._perm != (0, 1, 2) or ts._mode not in ('L', 'RGB') or ts._scale[1] != 0 or \
+           not 1 <= ts._scale[0] <= 64:
+            return False
+        return _fused_ok(net) and net.nn.input[2] > 0      # (the engine itself is created on the main thread, _advance)
+
+    def _page_on_device(self, net, mode: str):
+        if mode not in self._pages:
+            arr = np.asarray(self.im.convert(mode))
+            self._pages[mode] = self._pipe(net).engine.upload_page(arr)
+        return self._pages[mode]
+
+    def _prepare_on_device(self, idx: int, line, tag: str, net, ts, want_image: bool = False):
+        """
+        The bbox branch of extract_polygons + the fixed-height transform as a crop descriptor for krk_prep_lines.
+        Returns an ocr_record (the reference's empty-record cases), a _Pending, or None: take the host path.
+        """
+        box = list(line.bbox)
+        W, H = self.im.size
+        # the reference's bounds test (lexicographic list comparison, kraken/lib/segmentation.py:1636-1640)
+        if box < [0, 0, 0, 0] or box[::2] >= [W, W] or box[1::2] >= [H, H] or box[2] < box[0] or box[3] < box[1]:
+            logger.warning(f'Extracting line failed: bbox {box} is outside of image bounds {self.im.size}')
+            return self._empty(line, [])
+        w, h = box[2] - box[0], box[3] - box[1]
+        if w == 0 or h == 0:
+            logger.warning(f'{line} with zero dimension. Emitting empty record.')
+            return self._empty(line)
+        out_h = ts._scale[0]
+        ow = int(w * out_h / h)
+        if ow <= 0:                                  # Image.resize raises on an empty target: "conversion failed"
+            logger.warning(f'Conversion of line {line} failed. Emitting empty record..')
+            return self._empty(line)
+        taps = lambda n_in, n_out: math.ceil(3.0 * max(1.0, n_in / n_out)) * 2 + 1      # noqa: E731
+        if h > 512 or taps(h, out_h) > 96 or taps(w, ow) > 96:
+            return None                              # outside the kernel's range
+        pad = int(ts.pad[0])
+        return _Pending(idx, line, tag, net, None, (w, h), image=self.im.crop(box) if want_image else None,
+                        width=ow + 2 * pad, box=(int(box[0]), int(box[1]), int(box[2]), int(box[3]), ow), mode=ts._mode)
+
+    # -- record assembly ----------------------------------------------------------------------------------
+    def _scale(self, val, net_scale, in_scale, max_val):
+        return int(round(min(max(((val * net_scale) - self.pad) * in_scale, 0), max_val - 1)))
+
+    def _scale_all(self, vals, net_scale, in_scale, max_val):
+        """Vectorised `_scale_val` (kraken/rpred.py:329-330): np.rint rounds half to even exactly like Python's round()."""
+        v = (np.asarray(vals, dtype=np.float64) * net_scale - self.pad) * in_scale
+        return np.rint(np.minimum(np.maximum(v, 0), max_val - 1)).astype(np.int64)
+
+    def _cuts(self, p: _Pending, r: LineResult):
+        net_scale = p.width / r.out_width
+        in_scale = p.box_size[0] / (p.width - 2 * self.pad)
+        n = len(r.starts)
+        if self._valid_norm:
+            coords = p.line.bbox
+            if self.bounds.text_direction.startswith('horizontal'):
+                lo = coords[0] + self._scale_all(r.starts, net_scale, in_scale, p.box_size[0])
+                hi = coords[0] + self._scale_all(r.ends, net_scale, in_scale, p.box_size[0])
+                y0, y1 = np.full(n, coords[1], dtype=np.int64), np.full(n, coords[3], dtype=np.int64)
+                pos = np.stack([np.stack([lo, y0], 1), np.stack([lo, y1], 1), np.stack([hi, y1], 1), np.stack([hi, y0], 1)], 1)
+            else:
+                lo = coords[1] + self._scale_all(r.starts, net_scale, in_scale, p.box_size[1])
+                hi = coords[1] + self._scale_all(r.ends, net_scale, in_scale, p.box_size[1])
+                x0, x1 = np.full(n, coords[0], dtype=np.int64), np.full(n, coords[2], dtype=np.int64)
+                pos = np.stack([np.stack([x0, lo], 1), np.stack([x1, lo], 1), np.stack([x1, hi], 1), np.stack([x0, hi], 1)], 1)
+            return pos.tolist() if n else []
+        lo = self._scale_all(r.starts, net_scale, in_scale, p.box_size[0])
+        hi = self._scale_all(r.ends, net_scale, in_scale, p.box_size[0])
+        return np.stack([lo, hi], 1).tolist() if n else []
+
+    def _order(self, rec):
+        if self.bidi_reordering:
+            return rec.logical_order(base_dir=self.bidi_reordering if self.bidi_reordering in ('L', 'R') else None)
+        return rec.display_order(None)
+
+    def _make_record(self, p: _Pending, r: LineResult):
+        return self._order(self._record_cls(r.text, self._cuts(p, r), r.confs.tolist(), p.line))
+
+    def _empty(self, line, cuts=()):
+        return self._record_cls('', cuts, cuts, line)
+
+    # -- pipeline -----------------------------------------------------------------------------------------
+    def _pipe(self, net) -> LinePipeline:
+        pipe = self._pipes.get(id(net))
+        if pipe is None:
+            pipe = LinePipeline(net, self._temperature_of(net), self._batch, want_probs=self._want_probs)
+            self._pipes[id(net)] = pipe
+        return pipe
+
+    def _absorb(self, block_pipe: Optional[LinePipeline] = None):
+        for pipe in self._pipes.values():
+            for idx, r in pipe.drain(block=pipe is block_pipe):
+                p = self._pending.pop(idx)
+                self._results[idx] = self._make_record(p, r) if r is not None else self._empty(p.line)
+
+    def _advance(self):
+        """Prepares + submits the next chunk (the device keeps working on earlier ones meanwhile), or waits for results."""
+        if self._prepared < self.len:
+            idxs = range(self._prepared, min(self._prepared + self._chunk, self.len))
+            items = list(self._pool.map(self._prepare, idxs)) if self._pool else [self._prepare(i) for i in idxs]
+            self._prepared = idxs[-1] + 1
+            groups: dict = {}
+            for i, item in zip(idxs, items):
+                if isinstance(item, _Pending):
+                    self._pending[i] = item
+                    shape = ('dev', item.mode) if item.tensor is None else tuple(item.tensor.shape[:2])
+                    groups.setdefault((id(item.net), shape), []).append(item)
+                else:
+                    self._results[i] = item
+            for (_, shape), group in groups.items():     # one (recogniser, line height) per batch: heights are never padded
+                if shape[0] == 'dev':
+                    net = group[0].net
+                    self._pipe(net).submit_boxes(self._page_on_device(net, shape[1]), [(p.idx, p.box) for p in group], self.pad)
+                else:
+                    self._pipe(group[0].net).submit([(p.idx, p.tensor) for p in group])
+            self._absorb()
+            return
+        busiest = max(self._pipes.values(), key=lambda p: p.pending(), default=None)
+        self._absorb(block_pipe=busiest)
+
+    def _fill(self):
+        while self._cursor not in self._results:
+            if self._prepared >= self.len and not self._pending:
+                raise RuntimeError(f'line {self._cursor} was never recognised')   # cannot happen: every line yields a record
+            self._advance()
+
+    def _next_record(self):
+        if self._cursor >= self.len:
+            if self._pool:
+                self._pool.shutdown(wait=False)
+                self._pool = None
+            raise StopIteration
+        self._fill()
+        rec = self._results.pop(self._cursor)
+        self._cursor += 1
+        return rec
+
+
+class mm_rpred(_RecognitionRun):
     """Multi-model recogniser iterator: ``for record in mm_rpred(nets, im, bounds): ...``"""
 
     def __init__(self, nets, im, bounds, pad: int = 16, bidi_reordering: Union[bool, str] = True,
-                 tags_ignore: Optional[list] = None, no_legacy_polygons: bool = False, batch_size: int = 32):
+                 tags_ignore: Optional[list] = None, no_legacy_polygons: bool = False, batch_size: Optional[int] = None,
+                 num_line_workers: int = PREP_THREADS):
         warnings.warn('`rpred.mm_rpred` is deprecated and will be removed with kraken 8. Use `RecognitionTaskModel` instead.',
                       DeprecationWarning)
         seg_types = set(r.seg_type for r in nets.values())
@@ -134,9 +490,8 @@ class mm_rpred(object):
         if '1' in modes and not _is_bitonal(im):
             logger.warning(f'Running binary models on non-binary input image (mode {im.mode}). This will result in '
                            'severely degraded performance')
-        self.len = len(bounds.lines)
-        self._valid_norm = bounds.type != 'baselines'
-        self._record_cls = BBoxOCRRecord if bounds.type != 'baselines' else BaselineOCRRecord
+        self._init_run(im, bounds, pad, bidi_reordering, lambda net: getattr(net, 'temperature', 1.0),
+                       workers=num_line_workers, engine_batch=batch_size)
 
         def _ts(network):
             batch, channels, height, width = network.nn.input
@@ -154,22 +509,13 @@ class mm_rpred(object):
             self.ts = {t: _ts(nets[t]) for t in tags if t not in tags_ignore}
         if not isinstance(self.ts, defaultdict) and not self.ts:
             raise ValueError('No tags in input data and no default model in mapping given.')
-
-        self.im, self.nets, self.bounds = im, nets, bounds
-        self.bidi_reordering = bidi_reordering
-        self.pad = pad
+        if isinstance(self.ts, defaultdict):
+            self.ts['default']                       # materialise before worker threads race on the factory
+        self.nets = nets
         self.tags_ignore = tags_ignore
         self.no_legacy_polygons = no_legacy_polygons
-        self.batch_size = max(1, int(batch_size))
-        self._results: dict[int, object] = {}
-        self._cursor = 0          # next line index to hand out
-        self._prepared = 0        # lines already extracted / queued
-        self._warned_legacy = False
 
     # ------------------------------------------------------------------ per-line preparation
-    def _empty(self, line, cuts=()):
-        return self._record_cls('', cuts, cuts, line)
-
     def _use_legacy_extractor(self, net) -> bool:
         if net.nn.use_legacy_polygons:
             if self.no_legacy_polygons:
@@ -190,10 +536,16 @@ class mm_rpred(object):
             logger.info(f'Ignoring line segment with type {_line_type(line.tags)}.')
             return self._empty(line)
         tag, net = _pick_model(line.tags, self.nets, self._default)
+        if extract_polygons is _EXTRACT_POLYGONS and self._device_prep_ok(net, self.ts[tag]):
+            item = self._prepare_on_device(idx, line, tag, net, self.ts[tag])
+            if item is not None:
+                return item
         legacy = self._use_legacy_extractor(net)
         seg = dataclasses.replace(self.bounds, lines=[line])
         try:
-            box, line = next(extract_polygons(self.im, seg, legacy=legacy))
+            box, line2 = next(extract_polygons(self.im, seg, legacy=legacy))
+            if self._valid_norm:
+                line = line2
         except ValueError as e:
             logger.warning(f'Extracting line failed: {e}')
             return self._empty(line, [])
@@ -208,88 +560,11 @@ class mm_rpred(object):
         if ts_box.max() == ts_box.min():
             logger.warning('Empty run. Emitting empty record.')
             return self._empty(line)
-        return _Pending(idx, line, tag, net, ts_box, box.size)
-
-    # --------------------------------------------------------------------- batched inference
-    def _scale(self, val, net_scale, in_scale, max_val):
-        return int(round(min(max(((val * net_scale) - self.pad) * in_scale, 0), max_val - 1)))
-
-    def _scale_all(self, vals, net_scale, in_scale, max_val):
-        """Vectorised `_scale` (kraken/rpred.py:329-330): np.rint rounds half to even exactly like Python's round()."""
-        v = (np.asarray(vals, dtype=np.float64) * net_scale - self.pad) * in_scale
-        return np.rint(np.minimum(np.maximum(v, 0), max_val - 1)).astype(np.int64).tolist()
-
-    def _finish(self, p: _Pending, preds, out_width: int):
-        net_scale = p.tensor.shape[2] / out_width
-        in_scale = p.box_size[0] / (p.tensor.shape[2] - 2 * self.pad)
-        text = ''.join(x[0] for x in preds)
-        conf = [x[3] for x in preds]
-        starts, ends = [x[1] for x in preds], [x[2] for x in preds]
-        if self._valid_norm:
-            coords = p.line.bbox
-            if self.bounds.text_direction.startswith('horizontal'):
-                lo = self._scale_all(starts, net_scale, in_scale, p.box_size[0])
-                hi = self._scale_all(ends, net_scale, in_scale, p.box_size[0])
-                x0, y0, y1 = coords[0], coords[1], coords[3]
-                pos = [[[x0 + a, y0], [x0 + a, y1], [x0 + b, y1], [x0 + b, y0]] for a, b in zip(lo, hi)]
-            else:
-                lo = self._scale_all(starts, net_scale, in_scale, p.box_size[1])
-                hi = self._scale_all(ends, net_scale, in_scale, p.box_size[1])
-                x0, x1, y0 = coords[0], coords[2], coords[1]
-                pos = [[[x0, y0 + a], [x1, y0 + a], [x1, y0 + b], [x0, y0 + b]] for a, b in zip(lo, hi)]
-        else:
-            lo = self._scale_all(starts, net_scale, in_scale, p.box_size[0])
-            hi = self._scale_all(ends, net_scale, in_scale, p.box_size[0])
-            pos = [[a, b] for a, b in zip(lo, hi)]
-        rec = self._record_cls(text, pos, conf, p.line)
-        if self.bidi_reordering:
-            return rec.logical_order(base_dir=self.bidi_reordering if self.bidi_reordering in ('L', 'R') else None)
-        return rec.display_order(None)
-
-    def _recognise(self, pending: list):
-        """Runs the queued lines of ONE recogniser as padded batches."""
-        net = pending[0].net
-        widths = [p.tensor.shape[2] for p in pending]
-        wmax = max(widths)
-        x = torch.zeros((len(pending),) + tuple(pending[0].tensor.shape[:2]) + (wmax,), dtype=torch.float32)
-        for i, p in enumerate(pending):
-            x[i, :, :, :widths[i]] = p.tensor
-        lens = torch.tensor(widths, dtype=torch.int32)
-        if hasattr(net.nn.nn, 'recognize'):          # kraken_amd recogniser: fused GPU path
-            batch, olens, _, _ = net.nn.nn.recognize(x, lens, temperature=getattr(net, 'temperature', 1.0))
-            decoded = net.codec.decode_batch(batch) if hasattr(net.codec, 'decode_batch') else \
-                [net.codec.decode(t) for t in batch.tuples()]
-            outw = [int(v) for v in olens]
-        else:                                        # any object with the reference's interface
-            decoded, outw = [], []
-            for i, p in enumerate(pending):
-                decoded.append(net.predict(p.tensor.unsqueeze(0))[0])
-                outw.append(net.outputs.shape[2])
-        for p, preds, ow in zip(pending, decoded, outw):
-            self._results[p.idx] = self._finish(p, preds, ow)
-
-    def _fill(self):
-        """Prepares and recognises lines until the record at the cursor is available."""
-        while self._cursor not in self._results and self._prepared < self.len:
-            queue: dict[int, list] = {}
-            while self._prepared < self.len and sum(map(len, queue.values())) < self.batch_size:
-                item = self._prepare(self._prepared)
-                if isinstance(item, _Pending):
-                    queue.setdefault(id(item.net), []).append(item)
-                else:
-                    self._results[self._prepared] = item
-                self._prepared += 1
-            for items in queue.values():
-                self._recognise(items)
+        return _Pending(idx, line, tag, net, ts_box, box.size, width=ts_box.shape[2])
 
     # ------------------------------------------------------------------------ iterator protocol
     def __next__(self):
-        if self._cursor >= self.len:
-            raise StopIteration
-        self._fill()
-        rec = self._results.pop(self._cursor)
-        self._cursor += 1
-        return rec
+        return self._next_record()
 
     def __iter__(self):
         return self
@@ -299,7 +574,101 @@ class mm_rpred(object):
 
 
 def rpred(network, im, bounds, pad: int = 16, bidi_reordering: Union[bool, str] = True,
-          no_legacy_polygons: bool = False, batch_size: int = 32):
+          no_legacy_polygons: bool = False, batch_size: Optional[int] = None, num_line_workers: int = PREP_THREADS):
     """Recognises the lines of `bounds` in `im` with one recogniser (kraken/rpred.py:344-370)."""
     return mm_rpred(defaultdict(lambda: network), im, bounds, pad, bidi_reordering,
-                    no_legacy_polygons=no_legacy_polygons, batch_size=batch_size)
+                    no_legacy_polygons=no_legacy_polygons, batch_size=batch_size, num_line_workers=num_line_workers)
+
+
+# ------------------------------------------------------------------------------------------- the batched (new) API
+class _ConfiguredRecognizer:
+    """What LinePipeline needs of a recogniser, built from a TorchVGSLModel + its inference config."""
+
+    def __init__(self, model, config):
+        self.nn = model
+        self.codec = model.codec
+        self.decoder = getattr(config, 'decoder', None) or _ctc.greedy_decoder
+        try:                                           # kraken's own greedy decoder is the same operator (seam B4)
+            from kraken.lib.ctc_decoder import greedy_decoder as _kgreedy
+            if self.decoder is _kgreedy:
+                self.decoder = _ctc.greedy_decoder
+        except Exception:
+            pass
+        self.temperature = float(getattr(config, 'temperature', 1.0) or 1.0)
+        self.outputs = None
+
+    def predict(self, line):
+        """Per-line path for custom decoders (reference _rec_predict, lib/vgsl/rpred.py:210-229)."""
+        logits, _ = self.nn.nn(line, None)
+        probs = (logits / self.temperature).softmax(1)
+        self.outputs = probs.detach().squeeze(2)
+        return [self.codec.decode(locs) for locs in self.decoder(self.outputs.cpu().numpy(), None)]
+
+
+class _PredRun(_RecognitionRun):
+    def __init__(self, model, im, segmentation, config):
+        self.model, self.config = model, config
+        pad = getattr(config, 'padding', 16)
+        workers = getattr(config, 'num_line_workers', PREP_THREADS)
+        self.net = _ConfiguredRecognizer(model, config)
+        self._init_run(im, segmentation, pad, getattr(config, 'bidi_reordering', True), lambda net: net.temperature,
+                       want_probs=bool(getattr(config, 'return_logits', False)) and segmentation.type == 'baselines',
+                       return_image=bool(getattr(config, 'return_line_image', False)),
+                       workers=workers if workers else 0)
+        batch, channels, height, width = model.input
+        self.ts = ImageInputTransforms(batch, height, width, channels, (pad, 0), self._valid_norm)
+        self.legacy = False
+        if model.use_legacy_polygons and segmentation.type == 'baselines':
+            if getattr(config, 'no_legacy_polygons', False):
+                warnings.warn('Enforcing use of the new polygon extractor for models trained with old version. Accuracy '
+                              'may be affected.')
+            else:
+                warnings.warn('Using legacy polygon extractor, as the model was not trained with the new method. Please '
+                              'retrain your model to get speed improvement.')
+                self.legacy = True
+
+    def _prepare(self, idx: int):
+        line = self.bounds.lines[idx]
+        if extract_polygons is _EXTRACT_POLYGONS and self._device_prep_ok(self.net, self.ts):
+            item = self._prepare_on_device(idx, line, 'default', self.net, self.ts, want_image=self._return_image)
+            if item is not None:
+                if not isinstance(item, _Pending):           # this API's empty records carry list cuts (lib/vgsl/rpred.py:105-116)
+                    return self._record_cls('', [], [], line)
+                return item
+        seg = dataclasses.replace(self.bounds, lines=[line])
+        try:
+            box, _ = next(extract_polygons(self.im, seg, legacy=self.legacy))
+        except ValueError:
+            return self._record_cls('', [], [], line)
+        if box is None or 0 in box.size:
+            return self._record_cls('', [], [], line)
+        try:
+            ts_box = self.ts(box)
+        except Exception:
+            return self._record_cls('', [], [], line)
+        if ts_box.max() == ts_box.min():
+            return self._record_cls('', [], [], line)
+        return _Pending(idx, line, 'default', self.net, ts_box, box.size, image=box, width=ts_box.shape[2])
+
+    def _make_record(self, p: _Pending, r: LineResult):
+        logits = None
+        if getattr(self.config, 'return_logits', False):
+            # the reference hands the decoded tuples to bbox records (lib/vgsl/rpred.py:157) and the probability slice
+            # to baseline records (:200)
+            logits = r.probs if not self._valid_norm else list(zip(r.text, r.starts.tolist(), r.ends.tolist(), r.confs.tolist()))
+        rec = self._record_cls(r.text, self._cuts(p, r), r.confs.tolist(), p.line, logits=logits,
+                               image=p.image if self._return_image else None)
+        return self._order(rec)
+
+
+def recognition_pred(model, im, segmentation, config=None):
+    """
+    Generator of ocr_records for the lines of `segmentation`, in input order: the batched recognition API
+    (``VGSLRecognitionInference._recognition_pred``, reference kraken/lib/vgsl/rpred.py:56-124) on the pipelined engine.
+    """
+    run = _PredRun(model, im, segmentation, config)
+    while True:
+        try:
+            yield run._next_record()
+        except StopIteration:
+            return

@@ -317,6 +317,12 @@ class _Plan:
             pass
 
 
+# kraken.registry.PRECISIONS -> plan (see HipSequential.precision_for_config)
+PRECISION_OF_CONFIG = {'64-true': 'f32', '32-true': 'bf16x3', '32': 'bf16x3', 'bf16-true': 'bf16x3', 'bf16-mixed': 'bf16x3',
+                       '16-true': 'bf16x3', '16-mixed': 'bf16x3', 'transformer-engine': 'bf16x3',
+                       'transformer-engine-float16': 'bf16x3'}
+
+
 class DecodedBatch:
     """Host copy of the compact greedy-decode result of one batch (see krk_decode_out)."""
 
@@ -355,13 +361,29 @@ class HipSequential(nn.Module):
         Arithmetic of the GEMM-shaped layers: 'f32' (exact f32 matrix cores, default) or 'bf16x3'
         (split-bf16 operands on the bf16 matrix cores, fp32-class results; conv/LSTM/linear networks only).
         """
-        table = {'f32': _lib.PREC_F32, 'fp32': _lib.PREC_F32, '32': _lib.PREC_F32, '32-true': _lib.PREC_F32,
+        table = {'f32': _lib.PREC_F32, 'fp32': _lib.PREC_F32, '32': _lib.PREC_F32,
                  _lib.PREC_F32: _lib.PREC_F32, 'bf16x3': _lib.PREC_BF16X3, _lib.PREC_BF16X3: _lib.PREC_BF16X3}
+        if precision in PRECISION_OF_CONFIG:
+            precision = self.precision_for_config(precision)
         if precision not in table:
-            raise ValueError(f'unknown precision {precision!r}; choose "f32" or "bf16x3"')
+            raise ValueError(f'unknown precision {precision!r}; choose "f32", "bf16x3" or one of kraken\'s precision '
+                             f'strings {sorted(PRECISION_OF_CONFIG)}')
         if table[precision] != self.precision:
             self.precision = table[precision]
             self.invalidate()
+
+    def precision_for_config(self, precision: str) -> str:
+        """
+        kraken's ``config.precision`` (kraken/configs/base.py:65, kraken/registry.py:22) -> arithmetic plan.  Every plan
+        keeps fp32-class results (the reduced-precision strings are requests for SPEED, which the split-bf16 plan
+        already provides at fp32 accuracy), so the mapping only decides between the two fp32-class plans:
+        'bf16x3' (3x the throughput, |d logit| ~1e-5) except where it has less margin to the 1e-3 parity gate --
+        networks with GroupNorm and '64-true' get the exact-f32 plan.
+        """
+        want = PRECISION_OF_CONFIG[precision]
+        if want == 'bf16x3' and self.has_layer('groupnorm'):
+            return 'f32'
+        return want
 
     def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -371,6 +393,11 @@ class HipSequential(nn.Module):
             self._plan.close()
         self._plan = None
         self._plan_key = None
+        for eng in self.__dict__.pop('_engines', {}).values():     # pipelined engines hold their own plans (rpred.py)
+            eng.close()
+
+    def has_layer(self, kind: str) -> bool:
+        return any(s.kind == kind for s in self._specs)
 
     def plan(self, device_index: int, height: Optional[int] = None) -> _Plan:
         # legacy [1,1,0,48]-style inputs keep the line height in the channel axis: C=48, H=1
@@ -554,9 +581,24 @@ class TorchVGSLModel(nn.Module):
         self.eval()
         self._inf_config = config
         dev = getattr(config, 'device', None) or 'cuda'
+        if isinstance(dev, (list, tuple)):
+            dev = dev[0] if dev else 'cuda'
+        if isinstance(dev, int):
+            dev = f'cuda:{dev}'
         if str(dev).startswith('cpu') or str(dev) == 'auto':
             dev = 'cuda'                      # this implementation has no CPU path
         self.to(dev)
+        precision = getattr(config, 'precision', None)
+        if precision is not None:
+            # kraken's strings and 'f32' / 'bf16x3' (reference: Fabric(precision=...), model.py:518-523).  A network the
+            # split-bf16 kernels do not cover (odd channel counts ...) keeps the exact-f32 plan instead of failing later.
+            self.nn.set_precision(precision)
+            if self.nn.precision != _lib.PREC_F32 and self.input[2] > 0:
+                p = next(self.parameters())
+                try:
+                    self.nn.plan(p.device.index if p.device.index is not None else torch.cuda.current_device())
+                except _lib.KrakenAmdError:
+                    self.nn.set_precision('f32')
         return self
 
     def predict(self, *args, **kwargs):
@@ -570,14 +612,10 @@ class TorchVGSLModel(nn.Module):
             from .blla import compute_segmentation_map
             return compute_segmentation_map(self, args[0] if args else kwargs['im'],
                                             input_padding=getattr(cfg, 'input_padding', 0))
-        from .models import TorchSeqRecognizer
-        from .rpred import rpred
+        from .rpred import recognition_pred
         im = args[0] if args else kwargs['im']
         segmentation = args[1] if len(args) > 1 else kwargs['segmentation']
-        rec = TorchSeqRecognizer(self, temperature=getattr(cfg, 'temperature', 1.0), device=str(next(self.parameters()).device))
-        return rpred(rec, im, segmentation, pad=getattr(cfg, 'padding', 16),
-                     bidi_reordering=getattr(cfg, 'bidi_reordering', True),
-                     batch_size=max(int(getattr(cfg, 'batch_size', 1) or 1), 1))
+        return recognition_pred(self, im, segmentation, cfg)
 
     # -- initialisation (reference model.py:450-479) ------------------------------------
     def init_weights(self) -> None:

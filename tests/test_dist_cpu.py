@@ -35,6 +35,13 @@ def test_pack_unpack_roundtrip():
         assert ol2.tolist() == ol.tolist()
 
 
+def test_concat_decoded_keeps_every_line():
+    parts = [_fake_batch(r, n, t) for r, (n, t) in enumerate(((5, 12), (0, 3), (7, 20)))]
+    b, ol = kdist.concat_decoded(parts)
+    assert b.tuples() == sum((p[0].tuples() for p in parts), [])
+    assert ol.tolist() == sum((p[1].tolist() for p in parts), [])
+
+
 def test_shard_bounds_cover_everything_once():
     for n, world in ((16384, 8), (10, 4), (3, 8), (0, 2)):
         seen = []

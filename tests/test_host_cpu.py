@@ -365,7 +365,7 @@ def test_vectorised_cut_scaling_equals_the_scalar_rule():
         for net_scale, in_scale, max_val in [(8.0, 1.0, 1200), (8.0, 0.5, 600), (1232 / 154, 2544 / 1200, 2544), (7.97, 3.25, 4000)]:
             vals = list(range(0, 160)) + rng.integers(0, 400, 64).tolist()
             want = [mm_rpred._scale(me, v, net_scale, in_scale, max_val) for v in vals]
-            assert mm_rpred._scale_all(me, vals, net_scale, in_scale, max_val) == want
+            assert mm_rpred._scale_all(me, vals, net_scale, in_scale, max_val).tolist() == want
 
 
 def test_identity_op_is_parsed_and_named_like_the_reference():

@@ -1,0 +1,196 @@
+"""
+Host logic of the recognition generators (kraken_amd/rpred.py) without a GPU: a recogniser object with the reference's
+legacy interface (``.nn.input``, ``.predict``, ``.outputs``, ``.codec`` -- SURVEY.md seam B5) takes the per-line path,
+so ordering, tag routing, ignore rules, empty-record rules, chunking and record arithmetic are checked on the CPU.
+Mirrors the behaviours the reference pins in tests/test_rpred.py:366-462.
+"""
+import types
+import warnings
+from collections import defaultdict
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from kraken_amd import rpred as R
+from kraken_amd.codec import PytorchCodec
+from kraken_amd.containers import BBoxLine, Segmentation
+from kraken_amd.vgsl import DecodedBatch
+
+
+class FakeNet:
+    """Emits one character per 16 input columns; remembers what it was called with."""
+
+    def __init__(self, char='a', height=48, channels=3, seg_type='bbox'):
+        self.nn = types.SimpleNamespace(input=(1, channels, height, 0), one_channel_mode='L', use_legacy_polygons=False)
+        self.seg_type = seg_type
+        self.char = char
+        self.calls = []
+        self.outputs = None
+        self.codec = None
+
+    def predict(self, x):
+        assert x.dim() == 4 and x.shape[0] == 1
+        w = x.shape[3]
+        t = max(w // 8, 1)
+        self.calls.append(tuple(x.shape))
+        self.outputs = np.zeros((1, 4, t), np.float32)
+        n = max(w // 16, 1)
+        return [[(self.char, 2 * i, min(2 * i + 1, t - 1), 0.5 + 0.01 * i) for i in range(n) if 2 * i < t]]
+
+
+def page(w=640, h=400, seed=0):
+    rng = np.random.default_rng(seed)
+    return Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8), 'RGB')
+
+
+def seg(boxes, tags=None, script_detection=False, direction='horizontal-lr'):
+    lines = [BBoxLine(id=f'l{i}', bbox=list(b), tags=None if tags is None else tags[i]) for i, b in enumerate(boxes)]
+    return Segmentation(type='bbox', imagename='p.png', lines=lines, text_direction=direction,
+                        script_detection=script_detection)
+
+
+def run(*a, **k):
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', DeprecationWarning)
+        return list(R.mm_rpred(*a, **k))
+
+
+def test_records_come_back_in_input_order_with_reference_cut_arithmetic():
+    boxes = [(0, 10 * i, 100 + 37 * i, 10 * i + 30) for i in range(11)]        # widths 100 .. 470, unsorted by design below
+    boxes = boxes[::2] + boxes[1::2]
+    net = FakeNet('a')
+    im = page()
+    recs = run(defaultdict(lambda: net), im, seg(boxes), pad=16, bidi_reordering=False, num_line_workers=3)
+    assert len(recs) == len(boxes) and [r.line.id for r in recs] == [f'l{i}' for i in range(len(boxes))]
+    for r, b in zip(recs, boxes):
+        bw, bh = b[2] - b[0], b[3] - b[1]
+        w_in = int(bw * 48 / bh) + 32                       # fixed-height resize + 16 px padding on both sides
+        t = w_in // 8
+        net_scale, in_scale = w_in / t, bw / (w_in - 32)
+        assert len(r.prediction) == max(w_in // 16, 1) or 2 * (len(r.prediction) - 1) < t
+        for k, cut in enumerate(r.cuts):
+            lo = int(round(min(max((2 * k * net_scale - 16) * in_scale, 0), bw - 1)))
+            hi = int(round(min(max((min(2 * k + 1, t - 1) * net_scale - 16) * in_scale, 0), bw - 1)))
+            assert cut == [[b[0] + lo, b[1]], [b[0] + lo, b[3]], [b[0] + hi, b[3]], [b[0] + hi, b[1]]]
+        np.testing.assert_allclose(r.confidences, [0.5 + 0.01 * k for k in range(len(r.prediction))], rtol=1e-6)
+
+
+def test_tag_routing_ignore_and_missing_models():
+    """reference tests/test_rpred.py:366-440: per-tag models, tags_ignore -> empty record, missing model -> error."""
+    boxes = [(0, 0, 200, 40), (0, 50, 300, 90), (0, 100, 250, 140)]
+    tags = [{'type': [{'type': 'foobar'}]}, {'type': [{'type': 'default'}]}, {'type': [{'type': 'foobar'}]}]
+    a, b = FakeNet('a'), FakeNet('b')
+    recs = run({'default': a, 'foobar': b}, page(), seg(boxes, tags, True), bidi_reordering=False)
+    assert [set(r.prediction) for r in recs] == [{'b'}, {'a'}, {'b'}]
+    assert len(a.calls) == 1 and len(b.calls) == 2
+    # ignored tag: empty record, its model is never called
+    a, b = FakeNet('a'), FakeNet('b')
+    recs = run({'default': a}, page(), seg(boxes, tags, True), bidi_reordering=False, tags_ignore=['foobar'])
+    assert [r.prediction for r in recs][0] == '' and recs[2].prediction == '' and set(recs[1].prediction) == {'a'}
+    assert recs[0].cuts == () or list(recs[0].cuts) == []
+    # default factory serves every tag
+    a = FakeNet('a')
+    recs = run(defaultdict(lambda: a), page(), seg(boxes, tags, True), bidi_reordering=False)
+    assert all(set(r.prediction) == {'a'} for r in recs) and len(a.calls) == 3
+    # a tag without a model and without a default
+    with pytest.raises(Exception):
+        run({'default': FakeNet()}, page(), seg(boxes, tags, True))
+    # no tags in the data and no default model (reference: ValueError)
+    with pytest.raises(ValueError):
+        run({('type', 'default'): FakeNet()}, page(), seg(boxes))
+
+
+def test_empty_record_rules_and_iterator_protocol():
+    im = page()
+    flat = Image.new('RGB', (640, 400), (255, 255, 255))
+    boxes = [(0, 0, 200, 40), (10, 10, 10, 50), (700, 0, 800, 40), (0, 60, 200, 100)]      # ok, zero width, outside (the reference's lexicographic test), ok
+    net = FakeNet('a')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', DeprecationWarning)
+        it = R.mm_rpred(defaultdict(lambda: net), im, seg(boxes), bidi_reordering=False)
+        assert len(it) == 4
+        recs = [next(it) for _ in range(4)]
+        with pytest.raises(StopIteration):
+            next(it)
+    assert [bool(r.prediction) for r in recs] == [True, False, False, True]
+    # a flat (all white) page gives only empty records: max == min after the transform (kraken/rpred.py:221)
+    recs = run(defaultdict(lambda: net), flat, seg(boxes[:1]), bidi_reordering=False)
+    assert recs[0].prediction == ''
+
+
+def test_lines_of_different_heights_are_never_padded_into_one_batch():
+    """variable-height specs ([1,0,0,1 ...]) keep each line's own height."""
+    net = FakeNet('a', height=0, channels=1)
+    boxes = [(0, 0, 200, 40), (0, 50, 300, 80), (0, 100, 250, 160)]
+    recs = run(defaultdict(lambda: net), page().convert('L'), seg(boxes), bidi_reordering=False)
+    assert [c[2] for c in net.calls] == [40, 30, 60]
+    assert all(r.prediction for r in recs)
+
+
+def test_many_lines_are_processed_in_chunks_and_stay_ordered(monkeypatch):
+    monkeypatch.setattr(R, 'ENGINE_SLOTS', 2)
+    rng = np.random.default_rng(3)
+    boxes = [(0, 0, int(w), 30) for w in rng.integers(40, 600, 300)]
+    net = FakeNet('a')
+    recs = run(defaultdict(lambda: net), page(), seg(boxes), bidi_reordering=False, batch_size=16)
+    assert [r.line.id for r in recs] == [f'l{i}' for i in range(300)]
+    assert len(net.calls) == 300
+
+
+def test_decode_lines_table_path_equals_the_codec():
+    from tests.specs import bench_codec
+    rng = np.random.default_rng(1)
+    n, t = 9, 21
+    counts = np.array([0, 21, 3, 0, 7, 1, 21, 0, 5], np.int32)
+    labels = rng.integers(1, 300, size=(n, t)).astype(np.int32)          # labels above 255 are not decodable: skipped
+    starts = np.sort(rng.integers(0, 150, size=(n, t)), axis=1).astype(np.int32)
+    ends = starts + 1
+    confs = rng.random((n, t)).astype(np.float32)
+    batch = DecodedBatch(labels, starts, ends, confs, counts)
+    olens = np.arange(100, 100 + n)
+    single = PytorchCodec(bench_codec())
+    got = R._decode_lines(single, batch, olens)
+    want = single.decode_batch(batch)
+    for g, w, ol in zip(got, want, olens):
+        assert g.text == ''.join(x[0] for x in w) and g.out_width == ol
+        assert g.starts.tolist() == [x[1] for x in w] and g.ends.tolist() == [x[2] for x in w]
+        np.testing.assert_allclose(g.confs, [x[3] for x in w], rtol=0, atol=0)
+    multi = PytorchCodec({'a': [1], 'bc': [2], 'd': [3, 4]})
+    small = DecodedBatch(np.array([[1, 2, 3, 4], [3, 1, 0, 0]], np.int32), np.array([[0, 2, 4, 6], [1, 3, 0, 0]], np.int32),
+                         np.array([[1, 3, 5, 7], [2, 4, 0, 0]], np.int32), np.full((2, 4), 0.5, np.float32), np.array([4, 2], np.int32))
+    got = R._decode_lines(multi, small, [8, 8])
+    assert [g.text for g in got] == ['abcd', 'a'] and got[0].starts.tolist() == [0, 2, 2, 4]
+
+
+def test_new_api_records_carry_logits_and_line_images():
+    """lib/vgsl/rpred.py:155-160: return_logits / return_line_image; custom decoders take the per-line path."""
+    calls = []
+
+    class Model:
+        input = (1, 3, 48, 0)
+        use_legacy_polygons = False
+        codec = types.SimpleNamespace(decode=lambda locs: [('x', s, e, c) for _, s, e, c in locs])
+
+        class nn:   # the network operator: logits (1, C, 1, T)
+            @staticmethod
+            def __call__(x, lens=None):
+                raise AssertionError
+
+        def __init__(self):
+            self.nn = lambda x, lens=None: (calls.append(tuple(x.shape)) or torch.zeros(x.shape[0], 5, 1, x.shape[3] // 8), None)
+
+    def my_decoder(outputs, lens):
+        return [[(1, 0, 1, 0.75), (2, 3, 4, 0.5)] for _ in range(outputs.shape[0])]
+
+    cfg = types.SimpleNamespace(batch_size=2, temperature=1.0, padding=16, bidi_reordering=False, num_line_workers=0,
+                                return_logits=True, return_line_image=True, decoder=my_decoder)
+    boxes = [(0, 0, 200, 40), (0, 50, 300, 90)]
+    recs = list(R.recognition_pred(Model(), page(), seg(boxes), cfg))
+    assert [r.prediction for r in recs] == ['xx', 'xx'] and len(calls) == 2
+    assert recs[0].logits == [('x', 0, 1, 0.75), ('x', 3, 4, 0.5)]
+    assert recs[1].image.size == (300, 40)
+    cfg.return_logits = cfg.return_line_image = False
+    recs = list(R.recognition_pred(Model(), page(), seg(boxes), cfg))
+    assert recs[0].logits is None and recs[0].image is None

@@ -3,7 +3,7 @@ import sys, time, torch
 sys.path.insert(0, '.')
 import kraken_amd
 from kraken_amd.engine import RecognitionEngine
-from tests.specs import BENCH_B, bench_codec
+from kraken_amd.specs import BENCH_B, bench_codec
 torch.manual_seed(0)
 m = kraken_amd.TorchVGSLModel(vgsl=BENCH_B, codec=bench_codec()).to('cuda')
 x = torch.rand(256, 1, 48, 1200, generator=torch.Generator().manual_seed(1)).cuda()

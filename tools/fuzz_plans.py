@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, '.')
 import kraken_amd  # noqa: E402
 from oracle.torch_port import CpuRecognizer  # noqa: E402
-from tests.specs import BENCH_A  # noqa: E402
+from kraken_amd.specs import BENCH_A  # noqa: E402
 
 SPECS = [
     BENCH_A,

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 sys.path.insert(0, '.')
-from tests.specs import BENCH_A as SPEC  # noqa: E402
+from kraken_amd.specs import BENCH_A as SPEC  # noqa: E402
 
 
 def child(N, T, dump):

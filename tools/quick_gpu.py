@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import kraken_amd
 from kraken_amd.vgsl import parse_vgsl
 from oracle.torch_port import CpuRecognizer
-from tests.specs import BENCH_A, BENCH_B
+from kraken_amd.specs import BENCH_A, BENCH_B
 for name, spec, N, W, lens in [('A-eq', BENCH_A, 3, 400, None), ('A-ragged', BENCH_A, 5, 400, [400, 307, 201, 399, 202]),
                                ('B-eq', BENCH_B, 3, 200, None), ('B-ragged', BENCH_B, 4, 200, [200,151,99,77]),
                                ('A-16', BENCH_A, 16, 800, None)]:

@@ -2,7 +2,7 @@ import sys, torch
 sys.path.insert(0, '.')
 import kraken_amd
 from oracle.torch_port import CpuRecognizer
-from tests.specs import BENCH_A
+from kraken_amd.specs import BENCH_A
 specs = [('A', BENCH_A, 4, 400, [400, 307, 201, 399], 48, 1),
          ('small', '[1,8,0,1 Cr3,3,16 Mp2,2 Cr3,5,32 S1(1x0)1,3 Lbx8 O1c12]', 3, 90, [90, 61, 17], 8, 1),
          ('nopool-tanh', '[1,6,0,3 Ct3,3,16 Cr3,7,48,1,2 Cl1,1,32 S1(1x0)1,3 Lfx16 Lbx8 O1c7]', 2, 77, None, 6, 3)]
