@@ -34,6 +34,8 @@ def init(backend: Optional[str] = None):
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('RANK', '0')            # a plain `python bench.py --force-dist` is a one-rank job
+    os.environ.setdefault('WORLD_SIZE', '1')
     # the host driver only supports dmabuf IPC (see the environment notes)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     td.init_process_group(backend=backend, init_method='env://')
@@ -90,15 +92,31 @@ def concat_decoded(batches) -> tuple[DecodedBatch, np.ndarray]:
             np.concatenate([np.asarray(o) for _, o in batches]))
 
 
-def gather_decoded(batch: DecodedBatch, olens, group=None, force: bool = False) -> list[DecodedBatch]:
-    """All ranks receive every rank's decoded lines, in rank order (`force`: run the collectives even alone)."""
+def gather_decoded(batch, olens=None, group=None, force: bool = False) -> list[DecodedBatch]:
+    """
+    All ranks receive every rank's decoded lines, in rank order (`force`: run the collectives even alone).
+    `batch` is one DecodedBatch with its `olens`, or a list of (DecodedBatch, olens) pairs -- all batches a rank decoded
+    travel in ONE exchange, each packed compactly (only the tuples that exist, not the padded rows).
+    """
+    if isinstance(batch, (list, tuple)):
+        parts = list(batch)
+    else:
+        parts = [(batch, olens)]
     if not td.is_initialized() or (td.get_world_size(group) == 1 and not force):
-        return [batch]
+        return [concat_decoded(parts)[0]] if len(parts) != 1 else [parts[0][0]]
     world = td.get_world_size(group)
     backend = td.get_backend(group)
     dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
-    flat = pack_decoded(batch, olens)
-    n, k = len(batch.counts), int(np.sum(batch.counts))
+    # [counts | olens | labels | starts | ends | conf bits] of all parts, field by field
+    counts = np.concatenate([np.asarray(b.counts, dtype=np.int32) for b, _ in parts])
+    packs = [pack_decoded(b, o) for b, o in parts]
+    ns = [len(b.counts) for b, _ in parts]
+    ks = [int(np.sum(b.counts)) for b, _ in parts]
+    n, k = int(sum(ns)), int(sum(ks))
+    fields = [counts, np.concatenate([p[m:2 * m] for p, m in zip(packs, ns)])]
+    for a in range(4):
+        fields.append(np.concatenate([p[2 * m + a * kk:2 * m + (a + 1) * kk] for p, m, kk in zip(packs, ns, ks)]))
+    flat = np.concatenate(fields).astype(np.int32)
     head = torch.tensor([n, k], dtype=torch.int64, device=dev)
     heads = [torch.empty_like(head) for _ in range(world)]
     td.all_gather(heads, head, group=group)

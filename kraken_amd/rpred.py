@@ -192,7 +192,8 @@ def _decode_lines(codec, batch, olens, probs=None) -> list:
         labels = np.asarray(batch.labels)
         t = labels.shape[1] if labels.ndim == 2 else 0
         counts = np.minimum(np.maximum(np.asarray(batch.counts), 0), t)
-        cps = np.where(labels < len(lut), lut[np.minimum(labels, len(lut) - 1)], 0).astype('<u4') if t else labels
+        # entries past a line's count are uninitialised device memory: clip before the table lookup
+        cps = np.where((labels >= 0) & (labels < len(lut)), lut[np.clip(labels, 0, len(lut) - 1)], 0).astype('<u4') if t else labels
         for i in range(n):
             k = int(counts[i])
             c = cps[i, :k]
@@ -334,11 +335,24 @@ class _RecognitionRun:
             return False
         return _fused_ok(net) and net.nn.input[2] > 0      # (the engine itself is created on the main thread, _advance)
 
-    def _page_on_device(self, net, mode: str):
-        if mode not in self._pages:
-            arr = np.asarray(self.im.convert(mode))
-            self._pages[mode] = self._pipe(net).engine.upload_page(arr)
-        return self._pages[mode]
+    def _strip_on_device(self, net, mode: str, boxes):
+        """
+        Device tensor holding the page rows the crops `boxes` touch, and its first row.  A chunk of lines usually spans a
+        band of the page: converting / uploading that band per chunk overlaps the device work of the previous chunk; when
+        the band is most of the page (lines in no particular order) the whole page goes up once and is reused.
+        """
+        W, H = self.im.size
+        y0 = max(min(b[1] for b in boxes), 0)
+        y1 = min(max(b[3] for b in boxes), H)
+        if mode in self._pages or (y1 - y0) > 0.6 * H:
+            if mode not in self._pages:
+                im = self.im if self.im.mode == mode else self.im.convert(mode)
+                self._pages[mode] = self._pipe(net).engine.upload_page(np.asarray(im))
+            return self._pages[mode], 0
+        band = self.im.crop((0, y0, W, y1))
+        if band.mode != mode:
+            band = band.convert(mode)
+        return self._pipe(net).engine.upload_page(np.asarray(band)), y0
 
     def _prepare_on_device(self, idx: int, line, tag: str, net, ts, want_image: bool = False):
         """
@@ -385,13 +399,19 @@ class _RecognitionRun:
             if self.bounds.text_direction.startswith('horizontal'):
                 lo = coords[0] + self._scale_all(r.starts, net_scale, in_scale, p.box_size[0])
                 hi = coords[0] + self._scale_all(r.ends, net_scale, in_scale, p.box_size[0])
-                y0, y1 = np.full(n, coords[1], dtype=np.int64), np.full(n, coords[3], dtype=np.int64)
-                pos = np.stack([np.stack([lo, y0], 1), np.stack([lo, y1], 1), np.stack([hi, y1], 1), np.stack([hi, y0], 1)], 1)
+                pos = np.empty((n, 4, 2), dtype=np.int64)          # [[lo, y0], [lo, y1], [hi, y1], [hi, y0]] per code point
+                pos[:, 0, 0] = pos[:, 1, 0] = lo
+                pos[:, 2, 0] = pos[:, 3, 0] = hi
+                pos[:, 0, 1] = pos[:, 3, 1] = coords[1]
+                pos[:, 1, 1] = pos[:, 2, 1] = coords[3]
             else:
                 lo = coords[1] + self._scale_all(r.starts, net_scale, in_scale, p.box_size[1])
                 hi = coords[1] + self._scale_all(r.ends, net_scale, in_scale, p.box_size[1])
-                x0, x1 = np.full(n, coords[0], dtype=np.int64), np.full(n, coords[2], dtype=np.int64)
-                pos = np.stack([np.stack([x0, lo], 1), np.stack([x1, lo], 1), np.stack([x1, hi], 1), np.stack([x0, hi], 1)], 1)
+                pos = np.empty((n, 4, 2), dtype=np.int64)          # [[x0, lo], [x1, lo], [x1, hi], [x0, hi]] per code point
+                pos[:, 0, 0] = pos[:, 3, 0] = coords[0]
+                pos[:, 1, 0] = pos[:, 2, 0] = coords[2]
+                pos[:, 0, 1] = pos[:, 1, 1] = lo
+                pos[:, 2, 1] = pos[:, 3, 1] = hi
             return pos.tolist() if n else []
         lo = self._scale_all(r.starts, net_scale, in_scale, p.box_size[0])
         hi = self._scale_all(r.ends, net_scale, in_scale, p.box_size[0])
@@ -439,7 +459,9 @@ class _RecognitionRun:
             for (_, shape), group in groups.items():     # one (recogniser, line height) per batch: heights are never padded
                 if shape[0] == 'dev':
                     net = group[0].net
-                    self._pipe(net).submit_boxes(self._page_on_device(net, shape[1]), [(p.idx, p.box) for p in group], self.pad)
+                    page_dev, top = self._strip_on_device(net, shape[1], [p.box for p in group])
+                    self._pipe(net).submit_boxes(page_dev, [(p.idx, (p.box[0], p.box[1] - top, p.box[2], p.box[3] - top, p.box[4]))
+                                                            for p in group], self.pad)
                 else:
                     self._pipe(group[0].net).submit([(p.idx, p.tensor) for p in group])
             self._absorb()

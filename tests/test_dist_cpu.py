@@ -72,6 +72,13 @@ for r in range(world):
     l, h = kdist.shard_bounds(11, world, r)
     want, _ = _fake_batch(r, h - l)
     assert got[r].tuples() == want.tuples(), (rank, r)
+# every batch a rank decoded travels in ONE exchange (bench.py: all steps of the timed region)
+mine = [_fake_batch(10 * rank + j, n, t) for j, (n, t) in enumerate(((4, 12), (0, 5), (6, 30 + rank)))]
+got = kdist.gather_decoded(mine)
+assert len(got) == world
+for r in range(world):
+    want = [_fake_batch(10 * r + j, n, t) for j, (n, t) in enumerate(((4, 12), (0, 5), (6, 30 + r)))]
+    assert got[r].tuples() == sum((w[0].tuples() for w in want), []), (rank, r)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 print('rank', rank, 'ok')
