@@ -14,7 +14,7 @@ Two ways to hand a batch over:
 
 * ``submit(x, lens)`` -- ``x`` resident on the device (bench.py) or any host tensor;
 * ``stage(n, w)`` -> pinned host array ``(n, C, H, w)`` of the next free slot, to be filled in place
-  (line k at ``[k, :, :, :w_k]``, zero elsewhere), then ``submit_staged(lens)``: what ``rpred`` /
+  (line k at ``[k, :, :, :w_k]``, zeros to its right), then ``submit_staged(lens)``: what ``rpred`` /
   ``TorchVGSLModel.predict`` use, so that padding a batch is its only host copy.
 
 Buffers grow on demand (batch size, width); nothing is sized by a guess that a page can exceed.
@@ -136,7 +136,8 @@ class RecognitionEngine:
 
     def stage(self, n: int, w: int, height: Optional[int] = None) -> np.ndarray:
         """
-        Zeroed pinned host array (n, C, H, w) of the next free slot; fill it in place and call ``submit_staged``.
+        Pinned host array (n, C, H, w) of the next free slot; fill it in place -- line k at ``[k, :, :, :w_k]`` and ZEROS to
+        its right (the array is reused, not cleared) -- and call ``submit_staged``.
         ``height`` overrides the model's input height (variable-height specs: one plan per height).
         """
         slot = self._free_slot()
@@ -144,9 +145,7 @@ class RecognitionEngine:
         h = self.in_height if height is None else height
         slot.ensure_stage(n * c * h * w)
         slot.staged = (n, c, h, w)
-        arr = slot.stage_host[:n * c * h * w].numpy().reshape(n, c, h, w)
-        arr.fill(0.0)
-        return arr
+        return slot.stage_host[:n * c * h * w].numpy().reshape(n, c, h, w)   # NOT cleared: the caller zeroes what it does not fill
 
     def upload_page(self, page: np.ndarray) -> torch.Tensor:
         """uint8 page (H, W) or (H, W, 3) -> device tensor for ``submit_boxes`` (one upload per page)."""

@@ -247,6 +247,7 @@ class LinePipeline:
             x = self.engine.stage(len(part), max(widths))
             for i, (_, t) in enumerate(part):
                 x[i, :, :, :widths[i]] = t.numpy() if isinstance(t, torch.Tensor) else t
+                x[i, :, :, widths[i]:] = 0.0                     # the staging array is reused: clear only the padding
             ticket = self.engine.submit_staged(np.asarray(widths, dtype=np.int32), want_probs=self.want_probs)
             self._tickets.append((ticket, [k for k, _ in part]))
 
@@ -349,10 +350,15 @@ class _RecognitionRun:
                 im = self.im if self.im.mode == mode else self.im.convert(mode)
                 self._pages[mode] = self._pipe(net).engine.upload_page(np.asarray(im))
             return self._pages[mode], 0
-        band = self.im.crop((0, y0, W, y1))
-        if band.mode != mode:
-            band = band.convert(mode)
-        return self._pipe(net).engine.upload_page(np.asarray(band)), y0
+        # PIL -> numpy copies at ~1 GB/s per thread: cut the band into sub-bands for the worker pool
+        step = max(256, -(-(y1 - y0) // 8))
+        cuts = list(range(y0, y1, step))
+
+        def part(ya):
+            sub = self.im.crop((0, ya, W, min(ya + step, y1)))
+            return np.asarray(sub if sub.mode == mode else sub.convert(mode))
+        parts = list(self._pool.map(part, cuts)) if self._pool and len(cuts) > 1 else [part(c) for c in cuts]
+        return self._pipe(net).engine.upload_page(parts[0] if len(parts) == 1 else np.concatenate(parts)), y0
 
     def _prepare_on_device(self, idx: int, line, tag: str, net, ts, want_image: bool = False):
         """
