@@ -22,7 +22,11 @@
 //   * the gather loads of the NEXT slot's group are issued at the start of a slot and checked optimistically in the middle
 //     of its MFMA stream (branch-free: the granules go to LDS whatever their tag; a lane that saw a stale tag only raises a
 //     flag), so the common case costs no wait at all; a flagged gather is polled at the start of the next slot;
-//   * xproj (HBM) is fetched one full step ahead, after the exchange loads in program order (vmcnt retires in order);
+//   * every vector-memory instruction of the time loop is inline assembly with hand-counted `s_waitcnt vmcnt(N)`: vmcnt
+//     retires in order and an sc1 (write-through) publish store takes ~1 us to be acknowledged, so a wait that is one count
+//     too strict stalls a slot behind the stores it just issued -- which is what the compiler's bookkeeping (conservative
+//     across the loop's branches) produced: 2.07 us per slot, 0.56 of it MFMA.  xproj lands in LDS (global_load_lds) two
+//     slots ahead, so no register is live across the loop edge while its load is in flight;
 //   * h_t leaves as K-blocked split planes for the next projection (gemm_x3.hip): after the gather every slice holds the
 //     whole h_t in LDS and writes a quarter of the lines, 16 bytes per lane, masked by the buffer bounds check.
 #include "common.h"
@@ -34,7 +38,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr unsigned kOOBws = 0x80000000u;   // voffset beyond every descriptor used here (all < 2 GiB): load = 0, store dropped
-constexpr int kAuxSC1 = 16;                // buffer op cache policy: sc1 = agent-scope write-through store / L1-bypassing load
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* p, unsigned bytes) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(p);
@@ -45,6 +48,36 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* p, unsigne
 }
 
 __device__ __forceinline__ bf16x8 ws_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// ---- vector memory by hand (see the header comment): the compiler neither sees nor counts these
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 ws_srd(const void* p, unsigned bytes) {       // raw buffer descriptor in SGPRs
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    i32x4 r;
+    r[0] = (int)__builtin_amdgcn_readfirstlane((unsigned)u);
+    r[1] = (int)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32) & 0xFFFFu);
+    r[2] = (int)__builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void vm_load_b64_sc1(u32x2& d, unsigned vo, const i32x4& srd, unsigned so) {
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=&v"(d) : "v"(vo), "s"(srd), "s"(so) : "memory");
+}
+__device__ __forceinline__ void vm_store_b64_sc1(const u32x2& d, unsigned vo, const i32x4& srd, unsigned so) {
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen sc1" : : "v"(d), "v"(vo), "s"(srd), "s"(so) : "memory");
+}
+__device__ __forceinline__ void vm_store_b128(const u32x4& d, unsigned vo, const i32x4& srd) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(d), "v"(vo), "s"(srd) : "memory");
+}
+__device__ __forceinline__ void vm_load_lds_b128(const float* gptr, unsigned lds_off) {   // 64 lanes x 16 B -> LDS [lds_off, +1 KB)
+    unsigned keep;                                                                        // M0 (LDS base of the copy) is saved and restored
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gptr), "s"(lds_off) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
 
 // NKB K blocks of 32, BPW gate-column blocks per wave
 template <int NKB, int BPW>
@@ -58,6 +91,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     int* lens_s = reinterpret_cast<int*>(smem8 + 4 * hbuf);         // [32]
     unsigned* misc = reinterpret_cast<unsigned*>(lens_s + 32);      // [0] ticket, [4..7] dump row for masked LDS writes
     const unsigned dump_off = (unsigned)(4 * hbuf + 32 * 4 + 16);
+    const unsigned xs_off = (unsigned)(4 * hbuf + 32 * 4 + 32);     // xproj landing zone [group 2][wave 8][BPW][64 lanes x 16 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -103,32 +137,27 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
 #pragma unroll
     for (int i = 0; i < BPW; ++i) bval[i] = (wave + 8 * i < BPC) && (slice * BPC + wave + 8 * i < a.NB);
 
-    // ---- xproj
-    const int nrows = min(a.N - n0, 32);
-    const unsigned xrow_bytes = (unsigned)a.xstride * 4u;
-    // rows are tile-time-major: this cluster's two 16-line groups are the tiles n0/16 and n0/16 + 1, each T*16 rows
-    const __amdgpu_buffer_rsrc_t xrs = ws_rsrc(a.xp + (size_t)n0 * a.T * a.xstride + (size_t)dir * a.G,
-                                               (unsigned)((size_t)(nrows > 16 ? 32 : 16) * a.T * xrow_bytes - (size_t)dir * a.G * 4));
-    unsigned xso[BPW];
+    // ---- xproj: rows are tile-time-major, this cluster's two 16-line groups are the tiles n0/16 and n0/16 + 1 of T*16 rows.
+    // HBM -> LDS directly (no bounds check on this path: lanes without a valid row -- finished lines, absent blocks, a group
+    // past N -- read row 0 of the cluster's first tile; whatever they compute stays in their own MFMA column / dump word).
+    const int ntiles = min((a.N - n0 + 15) / 16, 2);
+    const float* xbase = a.xp + (size_t)n0 * a.T * a.xstride + (size_t)dir * a.G + (size_t)line * a.xstride + us * 4;
+    unsigned xcol[BPW];
 #pragma unroll
-    for (int i = 0; i < BPW; ++i) xso[i] = (unsigned)(slice * BPC + wave + 8 * i) * 64u;
-    auto xvoff = [&](int g, int s) -> unsigned {
-        const bool on = s < mylen[g];
-        const int t = rev ? (mylen[g] - 1 - s) : s;
-        return on ? (((unsigned)g * (unsigned)a.T + (unsigned)t) * 16u + (unsigned)line) * xrow_bytes + (unsigned)us * 16u : kOOBws;
-    };
-    f32x4 xr[2][BPW];
+    for (int i = 0; i < BPW; ++i) xcol[i] = bval[i] ? (unsigned)(slice * BPC + wave + 8 * i) * 16u : 0u;
     auto load_x = [&](int g, int s) {
-        const unsigned vo = xvoff(g, s);
+        const int len = lens_s[16 * g + line];
+        const int t = rev ? (len - 1 - s) : s;
+        const size_t row = (s < len && g < ntiles) ? ((size_t)g * a.T + t) * 16 : 0;
+        const float* xr = xbase + row * a.xstride;
 #pragma unroll
-        for (int i = 0; i < BPW; ++i)
-            xr[g][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, bval[i] ? vo : kOOBws, xso[i], 2));
+        for (int i = 0; i < BPW; ++i) vm_load_lds_b128(xr + xcol[i], xs_off + (unsigned)(((g * 8 + wave) * BPW + i) * 1024));
     };
 
     // ---- exchange: granules [group][parity][slice][BPC*4 units][16 lines] of this cluster
     const unsigned slice_gran = (unsigned)BPC * 64u;              // granules one slice publishes per (group, step)
     const unsigned gp_bytes = 4u * slice_gran * 8u;               // bytes per (group, parity)
-    const __amdgpu_buffer_rsrc_t grs = ws_rsrc(reinterpret_cast<const unsigned char*>(a.gran) + (size_t)cluster * 4 * gp_bytes, 4u * gp_bytes);
+    const i32x4 grs = ws_srd(reinterpret_cast<const unsigned char*>(a.gran) + (size_t)cluster * 4 * gp_bytes, 4u * gp_bytes);
     const unsigned tagbase = (a.epoch & 0xFFFFu) << 16;
     // what this lane publishes for block i: unit_local = (wave + 8i)*4 + us, its own line
     unsigned pub_vo[BPW], own_lds[BPW];
@@ -157,10 +186,12 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     }
     u32x2 gd[NGI];
     bool dead = false;
-    auto gather_issue = [&](int g, int par) {
+    // `after`: a value the first load pretends to read, so that the request cannot be scheduled before it exists
+    auto gather_issue = [&](int g, int par, float after = 0.f) {
         const unsigned so = (unsigned)(g * 2 + par) * gp_bytes;
+        asm volatile("" : : "v"(after));
 #pragma unroll
-        for (int k = 0; k < NGI; ++k) gd[k] = __builtin_amdgcn_raw_buffer_load_b64(grs, g_vo[k], so, kAuxSC1);
+        for (int k = 0; k < NGI; ++k) vm_load_b64_sc1(gd[k], g_vo[k], grs, so);
     };
     auto gather_drop = [&](unsigned char* hb) {       // granule payloads -> LDS rows (masked items go to the dump word)
 #pragma unroll
@@ -171,9 +202,12 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             *reinterpret_cast<unsigned short*>(dst + ((g_lds[k] == dump_off) ? 2 : plane)) = (unsigned short)(v >> 16);
         }
     };
-    // branch-free: true if some granule of h(g, step) did not carry its tag yet; the payloads go to LDS either way
+    // waits for the gather loads (BPW publish stores were issued after them), then, branch-free: true if some granule of
+    // h(g, step) did not carry its tag yet; the payloads go to LDS either way
     auto gather_try = [&](int step, unsigned char* hb) -> bool {
         const unsigned want = tagbase | ((unsigned)(step + 1) & 0xFFFFu);
+        if constexpr (NGI == 3) asm volatile("s_waitcnt vmcnt(1)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]), "+v"(gd[4]), "+v"(gd[5]) : : "memory");
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NGI; ++k) ok = ok && (!g_ok[k] || gd[k][1] == want);
@@ -183,19 +217,16 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     // slow path: polls until every granule of h(g, step) carries its tag, then drops it into LDS buffer hb
     auto gather_poll = [&](int g, int par, int step, unsigned char* hb) {
         const unsigned want = tagbase | ((unsigned)(step + 1) & 0xFFFFu);
-        const unsigned so = (unsigned)(g * 2 + par) * gp_bytes;
         unsigned spins = 0;
-        gather_issue(g, par);
         while (!dead) {
+            gather_issue(g, par);
+            if constexpr (NGI == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]), "+v"(gd[4]), "+v"(gd[5]) : : "memory");
             bool ok = true;
 #pragma unroll
             for (int k = 0; k < NGI; ++k) ok = ok && (!g_ok[k] || gd[k][1] == want);
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(2);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < NGI; ++k)
-                if (g_ok[k] && gd[k][1] != want) gd[k] = __builtin_amdgcn_raw_buffer_load_b64(grs, g_vo[k], so, kAuxSC1);
             if (++spins > (1u << 21)) {          // ~ a second: give up, flag the plan, never wait again
                 dead = true;
                 if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -207,7 +238,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     // ---- output pass: this slice writes lines [4*slice, 4*slice+4) of a group, one 16-byte piece per lane
     const int per_line = a.H >> 3;
     const size_t rows_total = (size_t)a.N * a.T;
-    const __amdgpu_buffer_rsrc_t ors = ws_rsrc(a.out, (unsigned)((size_t)a.out_plane * 4));
+    const i32x4 ors = ws_srd(a.out, (unsigned)((size_t)a.out_plane * 4));
     unsigned sp_lds, sp_g0[2];
     int sp_len[2];
     {
@@ -224,11 +255,11 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         }
     }
     auto store_pass = [&](int g, int step, const unsigned char* hb) {
-        const bool on = step < sp_len[g];
+        const bool on = step >= 0 && step < sp_len[g];
         const int t = rev ? (sp_len[g] - 1 - step) : step;
         const unsigned vo = on ? sp_g0[g] + (unsigned)t * 16u : kOOBws;
         const u32x4 v = *reinterpret_cast<const u32x4*>(hb + sp_lds);
-        __builtin_amdgcn_raw_buffer_store_b128(v, ors, vo, 0, 0);
+        vm_store_b128(v, vo, ors);
     };
 
     float cst[2][BPW];
@@ -254,12 +285,18 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             hh[kb] = *reinterpret_cast<const bf16x8*>(hp);
             hl[kb] = *reinterpret_cast<const bf16x8*>(hp + plane);
         }
-        if (s > 0 && !KRK_DBGBIT(a, 16)) store_pass(g, s - 1, hb);
+        // xproj of this slot was requested two slots ago; since then this wave issued at least the BPW publish stores and the
+        // BPW xproj requests of the previous slot (its exchange loads were consumed there): everything older has landed
+        vm_wait<2 * BPW>();
+        f32x4 xv[BPW];
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) xv[i] = *reinterpret_cast<const f32x4*>(smem8 + xs_off + ((g * 8 + wave) * BPW + i) * 1024 + lane * 16);
+        if (!KRK_DBGBIT(a, 16)) store_pass(g, s - 1, hb);
         const unsigned want = tagbase | ((unsigned)(s + 1) & 0xFFFFu);
         const unsigned pso = (unsigned)(g * 2 + (par ^ 1)) * gp_bytes;
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
-            f32x4 acc0 = xr[g][i], acc1 = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc0 = xv[i], acc1 = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 if (KRK_DBGBIT(a, 4)) break;
@@ -269,7 +306,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             }
             // the peers finished publishing the other group about when this slot began and a granule needs ~0.5 us to become
             // visible: ask for them a block's worth of MFMAs into the slot, look at them at its end
-            if (i == 0 && nxt && !KRK_DBGBIT(a, 1)) gather_issue(1 - g, nxt_par);
+            if (i == 0 && nxt && !KRK_DBGBIT(a, 1)) gather_issue(1 - g, nxt_par, acc0[0] + acc1[0] + acc2[0]);
             if (KRK_DBGBIT(a, 2)) continue;
             const f32x4 z = acc0 + (acc1 + acc2);
             const float gi = krk_sigmoid(z[0]);
@@ -288,7 +325,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             u32x2 gran;
             gran[0] = (unsigned)hbits | ((unsigned)lbits << 16);
             gran[1] = want;
-            __builtin_amdgcn_raw_buffer_store_b64(gran, grs, pub_vo[i], pso, kAuxSC1);
+            vm_store_b64_sc1(gran, pub_vo[i], grs, pso);
         }
         if (nxt && !KRK_DBGBIT(a, 1)) pend[1 - g] = gather_try(nxt_step, hs + ((1 - g) * 2 + nxt_par) * hbuf);   // optimistic finish of the next slot's gather
     };
@@ -296,6 +333,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     // ---- prologue
     load_x(0, 0);
     load_x(1, 0);
+    vm_wait<0>();                                     // the counted wait inside a slot assumes a full previous slot behind it
     for (int s = 0; s < Lmax; ++s) {
         slot(0, s, s > 0, s & 1, s - 1);              // next: slot(1, s) needs h(1, s-1), parity s&1
         if (!KRK_DBGBIT(a, 8)) load_x(0, s + 1);
@@ -306,6 +344,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         const int par = Lmax & 1;
         unsigned char* hb0 = hs + (0 * 2 + par) * hbuf;
         if (__any(pend[0])) gather_poll(0, par, Lmax - 1, hb0);
+        vm_wait<0>();
         __syncthreads();
         store_pass(0, Lmax - 1, hb0);
         unsigned char* hb1 = hs + (1 * 2 + par) * hbuf;
@@ -318,7 +357,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
 template <int NKB, int BPW>
 int launch_ws(const LstmWsArgs& a, hipStream_t s) {
     const int nclusters = (a.N + 31) / 32 * a.ndir;
-    const size_t lds = (size_t)8 * 16 * a.hrow + 32 * sizeof(int) + 32;
+    const size_t lds = (size_t)8 * 16 * a.hrow + 32 * sizeof(int) + 32 + (size_t)2 * 8 * BPW * 1024;
     auto kfn = lstm_ws_kernel<NKB, BPW>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
