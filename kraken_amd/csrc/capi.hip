@@ -1362,7 +1362,11 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     // weight-stationary cluster kernel unless the shape is outside its range (then: the streaming kernel);
                     // KRK_LSTM_V=1 forces the streaming kernel (A/B probing, tools/lstm_probe.py)
                     if (s.d_wrecws && env_int("KRK_LSTM_V", 3) == 3) {
-                        const size_t gbytes = krk_lstm_ws_gran_bytes(N, s.ndir, s.ws_bpc);
+                        // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the
+                        // slot time does not move (1.78 vs 1.83 us: it is not exchange bound), so a launch takes twice as long
+                        // on half the CUs: same chip time, worse latency, 86 k vs 96 k lines/s.  KRK_LSTM_G=4 keeps it probeable.
+                        const int groups = env_int("KRK_LSTM_G", 2) == 4 ? 4 : 2;
+                        const size_t gbytes = std::max(krk_lstm_ws_gran_bytes(N, s.ndir, s.ws_bpc, 4), krk_lstm_ws_gran_bytes(N, s.ndir, s.ws_bpc, 2));
                         if (gbytes > s.ws_gran.cap) {
                             if (s.ws_gran.ensure(gbytes)) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
                             HIPCHK(hipMemsetAsync(s.ws_gran.p, 0, s.ws_gran.cap, stream));    // tags of a fresh buffer must not match
@@ -1379,8 +1383,8 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                         w.epoch = s.ws_epoch;
                         w.err = p->err_dev;
                         w.dbg = l.dbg;
-                        rc = krk_launch_lstm_ws(w, stream);
-                        if (rc == 0) s.ws_tickets += (unsigned)((N + 31) / 32 * s.ndir * 4);
+                        rc = krk_launch_lstm_ws(w, groups, stream);
+                        if (rc == 0) s.ws_tickets += (unsigned)(krk_lstm_ws_clusters(N, s.ndir, groups) * 4);
                     }
                     if (rc == -4) rc = krk_launch_lstm_x3(l, stream);
                     break;

@@ -196,7 +196,7 @@ struct LstmWsArgs {
     int xstride, ostride;
     int hrow;             // bytes per LDS row of h (one line, one plane) = NKB*64 + 16
     int BPC;              // gate-column blocks per cluster slice = ceil(NB/4)
-    unsigned long long* gran;   // exchange granules [cluster][group 2][parity 2][slice 4][BPC*4 units][16 lines], zeroed at allocation
+    unsigned long long* gran;   // exchange granules [cluster][group][parity 2][slice 4][BPC*4 units][16 lines], zeroed at allocation
     unsigned* ctrl;       // [0]: monotonic ticket counter (cluster membership is claimed at run time)
     unsigned ticket_base; // counter value before this launch (the host adds the grid size after every launch)
     unsigned epoch;       // launch number folded into the granule tags (never 0)
@@ -204,8 +204,9 @@ struct LstmWsArgs {
     int dbg;              // probe bits (-DKRK_ABLATE build, env KRK_LSTM_DBG): 1 no exchange reads, 2 no gate math / publish, 4 no MFMA, 8 no xproj loads, 16 no output pass, 32 no step barrier
 };
 bool krk_lstm_ws_supported(int H, int Hp);
-size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC);
-int krk_launch_lstm_ws(const LstmWsArgs& a, hipStream_t s);
+int krk_lstm_ws_clusters(int N, int ndir, int groups);
+size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC, int groups);
+int krk_launch_lstm_ws(const LstmWsArgs& a, int groups, hipStream_t s);
 
 // K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel
 int krk_lstm_kg(int M, int blocks_per_wave);

@@ -79,32 +79,32 @@ __device__ __forceinline__ void vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
 
-// NKB K blocks of 32, BPW gate-column blocks per wave
-template <int NKB, int BPW>
+// NKB K blocks of 32, BPW gate-column blocks per wave, NG groups of 16 lines per cluster (slots per time step; even)
+template <int NKB, int BPW, int NG>
 __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     constexpr int NGI = 3 * BPW;            // granules a lane gathers per (group, step): 3 peers x BPC*64 / 512, BPC <= 8*BPW
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     const int RS = a.hrow;                  // bytes per h row (one line, one plane)
     const int plane = 16 * RS;
     const int hbuf = 2 * plane;             // one (hi, lo) buffer of one group
-    unsigned char* hs = smem8;              // [group 2][parity 2][plane 2][16 lines][RS]
-    int* lens_s = reinterpret_cast<int*>(smem8 + 4 * hbuf);         // [32]
-    unsigned* misc = reinterpret_cast<unsigned*>(lens_s + 32);      // [0] ticket, [4..7] dump row for masked LDS writes
-    const unsigned dump_off = (unsigned)(4 * hbuf + 32 * 4 + 16);
-    const unsigned xs_off = (unsigned)(4 * hbuf + 32 * 4 + 32);     // xproj landing zone [group 2][wave 8][BPW][64 lanes x 16 B]
+    unsigned char* hs = smem8;              // [group NG][parity 2][plane 2][16 lines][RS]
+    int* lens_s = reinterpret_cast<int*>(smem8 + 2 * NG * hbuf);        // [16 * NG]
+    unsigned* misc = reinterpret_cast<unsigned*>(lens_s + 16 * NG);     // [0] ticket, [4..7] dump row for masked LDS writes
+    const unsigned dump_off = (unsigned)(2 * NG * hbuf + 16 * NG * 4 + 16);
+    const unsigned xs_off = (unsigned)(2 * NG * hbuf + 16 * NG * 4 + 32);   // xproj landing ring [slot parity 2][wave 8][BPW][64 lanes x 16 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) misc[0] = atomicAdd(a.ctrl, 1u) - a.ticket_base;
-    for (int e = tid; e < hbuf; e += 512) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // 4*hbuf bytes
+    for (int e = tid; e < NG * hbuf / 2; e += 512) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // 2*NG*hbuf bytes
     __syncthreads();
     const unsigned ticket = __builtin_amdgcn_readfirstlane(misc[0]);
     const int cluster = (int)(ticket >> 2), slice = (int)(ticket & 3);
     const int dir = cluster % a.ndir;
-    const int n0 = (cluster / a.ndir) * 32;
+    const int n0 = (cluster / a.ndir) * 16 * NG;
     const bool rev = (a.dirmode == 1) || (a.dirmode == 2 && dir == 1);
-    if (tid < 32) {
+    if (tid < 16 * NG) {
         const int n = n0 + tid;
         int l = 0;
         if (n < a.N) l = a.lens ? min(max(a.lens[n], 0), a.T) : a.T;
@@ -112,13 +112,10 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     }
     __syncthreads();
     int Lmax = 0;
-    for (int i = 0; i < 32; ++i) Lmax = max(Lmax, lens_s[i]);
+    for (int i = 0; i < 16 * NG; ++i) Lmax = max(Lmax, lens_s[i]);
 
     const int line = lane & 15, us = lane >> 4;
     const int BPC = a.BPC;
-    int mylen[2];
-    mylen[0] = lens_s[line];
-    mylen[1] = lens_s[16 + line];
 
     // ---- weights: resident for the whole launch.  [dir][slice][wave 8][i][kb][plane][lane][8]
     u32x4 whi[BPW][NKB], wlo[BPW][NKB];
@@ -137,27 +134,28 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
 #pragma unroll
     for (int i = 0; i < BPW; ++i) bval[i] = (wave + 8 * i < BPC) && (slice * BPC + wave + 8 * i < a.NB);
 
-    // ---- xproj: rows are tile-time-major, this cluster's two 16-line groups are the tiles n0/16 and n0/16 + 1 of T*16 rows.
+    // ---- xproj: rows are tile-time-major, this cluster's NG 16-line groups are NG consecutive tiles of T*16 rows.
     // HBM -> LDS directly (no bounds check on this path: lanes without a valid row -- finished lines, absent blocks, a group
     // past N -- read row 0 of the cluster's first tile; whatever they compute stays in their own MFMA column / dump word).
-    const int ntiles = min((a.N - n0 + 15) / 16, 2);
+    const int ntiles = min((a.N - n0 + 15) / 16, NG);
     const float* xbase = a.xp + (size_t)n0 * a.T * a.xstride + (size_t)dir * a.G + (size_t)line * a.xstride + us * 4;
     unsigned xcol[BPW];
 #pragma unroll
     for (int i = 0; i < BPW; ++i) xcol[i] = bval[i] ? (unsigned)(slice * BPC + wave + 8 * i) * 16u : 0u;
+    // `ring`: the landing buffer = parity of the slot that will consume it (slot index = s*NG + g, NG even: g & 1)
     auto load_x = [&](int g, int s) {
         const int len = lens_s[16 * g + line];
         const int t = rev ? (len - 1 - s) : s;
         const size_t row = (s < len && g < ntiles) ? ((size_t)g * a.T + t) * 16 : 0;
         const float* xr = xbase + row * a.xstride;
 #pragma unroll
-        for (int i = 0; i < BPW; ++i) vm_load_lds_b128(xr + xcol[i], xs_off + (unsigned)(((g * 8 + wave) * BPW + i) * 1024));
+        for (int i = 0; i < BPW; ++i) vm_load_lds_b128(xr + xcol[i], xs_off + (unsigned)((((g & 1) * 8 + wave) * BPW + i) * 1024));
     };
 
     // ---- exchange: granules [group][parity][slice][BPC*4 units][16 lines] of this cluster
     const unsigned slice_gran = (unsigned)BPC * 64u;              // granules one slice publishes per (group, step)
     const unsigned gp_bytes = 4u * slice_gran * 8u;               // bytes per (group, parity)
-    const i32x4 grs = ws_srd(reinterpret_cast<const unsigned char*>(a.gran) + (size_t)cluster * 4 * gp_bytes, 4u * gp_bytes);
+    const i32x4 grs = ws_srd(reinterpret_cast<const unsigned char*>(a.gran) + (size_t)cluster * (2 * NG) * gp_bytes, (unsigned)(2 * NG) * gp_bytes);
     const unsigned tagbase = (a.epoch & 0xFFFFu) << 16;
     // what this lane publishes for block i: unit_local = (wave + 8i)*4 + us, its own line
     unsigned pub_vo[BPW], own_lds[BPW];
@@ -169,9 +167,9 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         pub_vo[i] = ok ? ((unsigned)slice * slice_gran + (unsigned)ul * 16u + (unsigned)line) * 8u : kOOBws;
         own_lds[i] = (ok && unit < NKB * 32) ? (unsigned)(line * RS + unit * 2) : dump_off;
     }
-    // what this lane gathers: item e = tid + 512 k over [peer 3][BPC*4 units][16 lines]
-    unsigned g_vo[NGI], g_lds[NGI];
-    bool g_ok[NGI];
+    // what this lane gathers: item e = tid + 512 k over [peer 3][BPC*4 units][16 lines]; packed into one register: bit 31 =
+    // wanted, bits 16..30 = LDS offset / 2 (0x7FFF = nowhere: padding unit), bits 0..15 = granule index
+    unsigned g_item[NGI];
 #pragma unroll
     for (int k = 0; k < NGI; ++k) {
         const unsigned e = (unsigned)tid + 512u * k;
@@ -180,10 +178,10 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         const int ul = (int)(rem >> 4), ln = (int)(rem & 15);
         const int unit = sl * BPC * 4 + ul;
         const bool ok = p < 3 && (sl * BPC + (ul >> 2)) < a.NB;      // blocks beyond NB are never published
-        g_ok[k] = ok;
-        g_vo[k] = ok ? ((unsigned)sl * slice_gran + rem) * 8u : kOOBws;
-        g_lds[k] = (ok && unit < NKB * 32) ? (unsigned)(ln * RS + unit * 2) : dump_off;
+        const unsigned lo = (ok && unit < NKB * 32) ? ((unsigned)(ln * RS + unit * 2) >> 1) : 0x7FFFu;
+        g_item[k] = (ok ? 0x80000000u : 0u) | (lo << 16) | (((unsigned)sl * slice_gran + rem) & 0xFFFFu);
     }
+    auto g_vo = [&](int k) -> unsigned { return (g_item[k] >> 31) ? (g_item[k] & 0xFFFFu) * 8u : kOOBws; };
     u32x2 gd[NGI];
     bool dead = false;
     // `after`: a value the first load pretends to read, so that the request cannot be scheduled before it exists
@@ -191,15 +189,17 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         const unsigned so = (unsigned)(g * 2 + par) * gp_bytes;
         asm volatile("" : : "v"(after));
 #pragma unroll
-        for (int k = 0; k < NGI; ++k) vm_load_b64_sc1(gd[k], g_vo[k], grs, so);
+        for (int k = 0; k < NGI; ++k) vm_load_b64_sc1(gd[k], g_vo(k), grs, so);
     };
     auto gather_drop = [&](unsigned char* hb) {       // granule payloads -> LDS rows (masked items go to the dump word)
 #pragma unroll
         for (int k = 0; k < NGI; ++k) {
-            unsigned char* dst = (g_lds[k] == dump_off) ? smem8 + dump_off : hb + g_lds[k];
+            const unsigned lo = (g_item[k] >> 16) & 0x7FFFu;
+            const bool nowhere = lo == 0x7FFFu;
+            unsigned char* dst = nowhere ? smem8 + dump_off : hb + 2 * lo;
             const unsigned v = gd[k][0];
             *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(v & 0xFFFFu);
-            *reinterpret_cast<unsigned short*>(dst + ((g_lds[k] == dump_off) ? 2 : plane)) = (unsigned short)(v >> 16);
+            *reinterpret_cast<unsigned short*>(dst + (nowhere ? 2 : plane)) = (unsigned short)(v >> 16);
         }
     };
     // waits for the gather loads (BPW publish stores were issued after them), then, branch-free: true if some granule of
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         else asm volatile("s_waitcnt vmcnt(2)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]), "+v"(gd[4]), "+v"(gd[5]) : : "memory");
         bool ok = true;
 #pragma unroll
-        for (int k = 0; k < NGI; ++k) ok = ok && (!g_ok[k] || gd[k][1] == want);
+        for (int k = 0; k < NGI; ++k) ok = ok && (!(g_item[k] >> 31) || gd[k][1] == want);
         gather_drop(hb);
         return !ok;
     };
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]), "+v"(gd[4]), "+v"(gd[5]) : : "memory");
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < NGI; ++k) ok = ok && (!g_ok[k] || gd[k][1] == want);
+            for (int k = 0; k < NGI; ++k) ok = ok && (!(g_item[k] >> 31) || gd[k][1] == want);
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1u << 21)) {          // ~ a second: give up, flag the plan, never wait again
@@ -239,39 +239,37 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     const int per_line = a.H >> 3;
     const size_t rows_total = (size_t)a.N * a.T;
     const i32x4 ors = ws_srd(a.out, (unsigned)((size_t)a.out_plane * 4));
-    unsigned sp_lds, sp_g0[2];
-    int sp_len[2];
+    unsigned sp_lds, sp_g00;
+    int sp_ln;
     {
         const int e = tid;
         const int pl = e / (4 * per_line), r = e - pl * 4 * per_line;
         const int li = r / per_line, q = r - li * per_line;
-        const int ln = slice * 4 + li;
-        const bool ok = e < 8 * per_line;
-        sp_lds = ok ? (unsigned)(pl * plane + ln * RS + q * 16) : 0u;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            sp_g0[g] = (unsigned)((((size_t)(dir * per_line + q)) * rows_total + (size_t)(n0 + 16 * g + ln) * a.T) * 16 + (size_t)pl * a.out_plane * 2);
-            sp_len[g] = ok ? lens_s[16 * g + ln] : 0;
-        }
+        sp_ln = e < 8 * per_line ? slice * 4 + li : -1;
+        sp_lds = sp_ln >= 0 ? (unsigned)(pl * plane + sp_ln * RS + q * 16) : 0u;
+        sp_g00 = (unsigned)((((size_t)(dir * per_line + q)) * rows_total + (size_t)(n0 + max(sp_ln, 0)) * a.T) * 16 + (size_t)pl * a.out_plane * 2);
     }
     auto store_pass = [&](int g, int step, const unsigned char* hb) {
-        const bool on = step >= 0 && step < sp_len[g];
-        const int t = rev ? (sp_len[g] - 1 - step) : step;
-        const unsigned vo = on ? sp_g0[g] + (unsigned)t * 16u : kOOBws;
+        const int len = sp_ln >= 0 ? lens_s[16 * g + sp_ln] : 0;
+        const bool on = step >= 0 && step < len;
+        const int t = rev ? (len - 1 - step) : step;
+        const unsigned vo = on ? sp_g00 + ((unsigned)g * 16u * (unsigned)a.T + (unsigned)t) * 16u : kOOBws;
         const u32x4 v = *reinterpret_cast<const u32x4*>(hb + sp_lds);
         vm_store_b128(v, vo, ors);
     };
 
-    float cst[2][BPW];
+    float cst[NG][BPW];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int i = 0; i < BPW; ++i) cst[g][i] = 0.f;
 
     // one slot = one time step of one group.  `pend`: this wave's gather of h(g, s-1) met a stale tag (rare);
-    // `nxt`: 0 = no gather to start, else issue the gather of h(1-g, .) with parity nxt_par for the next slot
-    bool pend[2] = {false, false};
-    auto slot = [&](int g, int s, bool nxt, int nxt_par, int nxt_step) {
+    // `nxt`: start the gather of h(ng, nxt_step) (parity nxt_par), which the NEXT slot needs
+    bool pend[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) pend[g] = false;
+    auto slot = [&](int g, int s, bool nxt, int ng, int nxt_par, int nxt_step) {
         const int par = s & 1;
         unsigned char* hb = hs + (g * 2 + par) * hbuf;            // h(g, s-1): own rows written by our gates, the rest gathered
         unsigned char* hn = hs + (g * 2 + (par ^ 1)) * hbuf;      // h(g, s)
@@ -290,8 +288,10 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         vm_wait<2 * BPW>();
         f32x4 xv[BPW];
 #pragma unroll
-        for (int i = 0; i < BPW; ++i) xv[i] = *reinterpret_cast<const f32x4*>(smem8 + xs_off + ((g * 8 + wave) * BPW + i) * 1024 + lane * 16);
+        for (int i = 0; i < BPW; ++i) xv[i] = *reinterpret_cast<const f32x4*>(smem8 + xs_off + (((g & 1) * 8 + wave) * BPW + i) * 1024 + lane * 16);
         if (!KRK_DBGBIT(a, 16)) store_pass(g, s - 1, hb);
+        // NG > 2: the next slot's h was published NG-1 slots ago -- ask for it now, it lands under this slot's MFMAs
+        if (NG > 2 && nxt && !KRK_DBGBIT(a, 1)) gather_issue(ng, nxt_par);
         const unsigned want = tagbase | ((unsigned)(s + 1) & 0xFFFFu);
         const unsigned pso = (unsigned)(g * 2 + (par ^ 1)) * gp_bytes;
 #pragma unroll
@@ -304,9 +304,9 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(whi[i][kb]), hl[kb], acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(wlo[i][kb]), hh[kb], acc2, 0, 0, 0);
             }
-            // the peers finished publishing the other group about when this slot began and a granule needs ~0.5 us to become
-            // visible: ask for them a block's worth of MFMAs into the slot, look at them at its end
-            if (i == 0 && nxt && !KRK_DBGBIT(a, 1)) gather_issue(1 - g, nxt_par, acc0[0] + acc1[0] + acc2[0]);
+            // NG == 2: the peers finished publishing the other group about when this slot began and a granule needs ~0.5 us to
+            // become visible: ask for them a block's worth of MFMAs into the slot, look at them at its end
+            if (NG == 2 && i == 0 && nxt && !KRK_DBGBIT(a, 1)) gather_issue(ng, nxt_par, acc0[0] + acc1[0] + acc2[0]);
             if (KRK_DBGBIT(a, 2)) continue;
             const f32x4 z = acc0 + (acc1 + acc2);
             const float gi = krk_sigmoid(z[0]);
@@ -327,38 +327,44 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             gran[1] = want;
             vm_store_b64_sc1(gran, pub_vo[i], grs, pso);
         }
-        if (nxt && !KRK_DBGBIT(a, 1)) pend[1 - g] = gather_try(nxt_step, hs + ((1 - g) * 2 + nxt_par) * hbuf);   // optimistic finish of the next slot's gather
+        if (nxt && !KRK_DBGBIT(a, 1)) pend[ng] = gather_try(nxt_step, hs + (ng * 2 + nxt_par) * hbuf);   // optimistic finish of the next slot's gather
     };
 
-    // ---- prologue
+    // ---- prologue.  xproj of a slot is requested two slots ahead
     load_x(0, 0);
     load_x(1, 0);
     vm_wait<0>();                                     // the counted wait inside a slot assumes a full previous slot behind it
     for (int s = 0; s < Lmax; ++s) {
-        slot(0, s, s > 0, s & 1, s - 1);              // next: slot(1, s) needs h(1, s-1), parity s&1
-        if (!KRK_DBGBIT(a, 8)) load_x(0, s + 1);
-        slot(1, s, true, (s + 1) & 1, s);             // next: slot(0, s+1) (or the epilogue) needs h(0, s), parity (s+1)&1
-        if (!KRK_DBGBIT(a, 8)) load_x(1, s + 1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            // the next slot: (g+1, s) needs h(g+1, s-1), parity s&1 -- or (0, s+1) (also the epilogue) needs h(0, s), parity (s+1)&1
+            if (g + 1 < NG) slot(g, s, s > 0, g + 1, s & 1, s - 1);
+            else slot(g, s, true, 0, (s + 1) & 1, s);
+            if (!KRK_DBGBIT(a, 8)) load_x((g + 2) % NG, s + (g + 2) / NG);
+        }
     }
     if (Lmax > 0) {
         const int par = Lmax & 1;
-        unsigned char* hb0 = hs + (0 * 2 + par) * hbuf;
-        if (__any(pend[0])) gather_poll(0, par, Lmax - 1, hb0);
-        vm_wait<0>();
-        __syncthreads();
-        store_pass(0, Lmax - 1, hb0);
-        unsigned char* hb1 = hs + (1 * 2 + par) * hbuf;
-        if (!KRK_DBGBIT(a, 1)) gather_poll(1, par, Lmax - 1, hb1);
-        __syncthreads();
-        store_pass(1, Lmax - 1, hb1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            unsigned char* hb = hs + (g * 2 + par) * hbuf;
+            if (g == 0) {
+                if (__any(pend[0]) && !KRK_DBGBIT(a, 1)) gather_poll(0, par, Lmax - 1, hb);
+            } else if (!KRK_DBGBIT(a, 1)) {
+                gather_poll(g, par, Lmax - 1, hb);
+            }
+            vm_wait<0>();
+            __syncthreads();
+            store_pass(g, Lmax - 1, hb);
+        }
     }
 }
 
-template <int NKB, int BPW>
+template <int NKB, int BPW, int NG>
 int launch_ws(const LstmWsArgs& a, hipStream_t s) {
-    const int nclusters = (a.N + 31) / 32 * a.ndir;
-    const size_t lds = (size_t)8 * 16 * a.hrow + 32 * sizeof(int) + 32 + (size_t)2 * 8 * BPW * 1024;
-    auto kfn = lstm_ws_kernel<NKB, BPW>;
+    const int nclusters = (a.N + 16 * NG - 1) / (16 * NG) * a.ndir;
+    const size_t lds = (size_t)4 * NG * 16 * a.hrow + 16 * NG * sizeof(int) + 32 + (size_t)2 * 8 * BPW * 1024;
+    auto kfn = lstm_ws_kernel<NKB, BPW, NG>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3((unsigned)nclusters * 4), dim3(512), lds, s, a);
@@ -372,17 +378,21 @@ bool krk_lstm_ws_supported(int H, int Hp) {
     return (H % 8) == 0 && NKB >= 1 && NKB <= 7 && NB <= 64 && (NB + 3) / 4 <= 16;
 }
 
-size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC) {
-    return (size_t)((N + 31) / 32 * ndir) * 4 /* (group, parity) */ * 4 /* slices */ * (size_t)BPC * 64 * 8;
+int krk_lstm_ws_clusters(int N, int ndir, int groups) { return (N + 16 * groups - 1) / (16 * groups) * ndir; }
+
+size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC, int groups) {
+    return (size_t)krk_lstm_ws_clusters(N, ndir, groups) * (2 * groups) /* (group, parity) */ * 4 /* slices */ * (size_t)BPC * 64 * 8;
 }
 
-int krk_launch_lstm_ws(const LstmWsArgs& a, hipStream_t s) {
+// groups = 16-line groups a cluster advances in alternation: 2 (32 lines per 4 CUs: lowest latency, the exchange round trip
+// is about one slot) or 4 (64 lines per 4 CUs: half the CUs, the h of a group is three slots old when it is read)
+int krk_launch_lstm_ws(const LstmWsArgs& a, int groups, hipStream_t s) {
     if (!krk_lstm_ws_supported(a.H, a.Hp)) return -4;
     if ((size_t)a.out_plane * 4 >= 0x80000000ull) return -4;                 // 32-bit buffer offsets
-    if ((size_t)32 * a.T * a.xstride * 4 >= 0x80000000ull) return -4;
     if (a.T >= 0xFFFF) return -4;                                             // 16-bit step tags
+    if (3 * a.BPC * 64 > 0xFFFF) return -4;                                   // 16-bit granule index
     const int bpw = (a.BPC + 7) / 8;
-#define KRK_WS(NKB_, BPW_) if (a.NKB == NKB_ && bpw == BPW_) return launch_ws<NKB_, BPW_>(a, s)
+#define KRK_WS(NKB_, BPW_) if (a.NKB == NKB_ && bpw == BPW_) return groups == 4 ? launch_ws<NKB_, BPW_, 4>(a, s) : launch_ws<NKB_, BPW_, 2>(a, s)
     // NB = Hp/4 in (8(NKB-1), 8 NKB]; BPC = ceil(NB/4) in {2 NKB - 1, 2 NKB}; BPW = ceil(BPC/8)
     KRK_WS(1, 1); KRK_WS(2, 1); KRK_WS(3, 1); KRK_WS(4, 1); KRK_WS(5, 2); KRK_WS(6, 2); KRK_WS(7, 2);
 #undef KRK_WS
