@@ -1471,28 +1471,24 @@ int krk_greedy_decode(const float* scores_dev, long sn, long sc, long st, int N,
     if (!scores_dev || N <= 0 || C <= 0 || T <= 0) return fail(KRK_E_INVALID, "krk_greedy_decode: bad argument");
     if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_greedy_decode: no HIP device");
     hipStream_t s = (hipStream_t)stream;
-    int* d_labels = nullptr;
-    float* d_confs = nullptr;
-    int* d_olens = nullptr;
-    const size_t rows = (size_t)N * T;
-    HIPCHK(hipMallocAsync((void**)&d_labels, rows * sizeof(int), s));
-    HIPCHK(hipMallocAsync((void**)&d_confs, rows * sizeof(float), s));
-    if (olens_host) {
+    if (olens_host)
         for (int n = 0; n < N; ++n)
-            if (olens_host[n] < 0 || olens_host[n] > T) {
-                (void)hipFreeAsync(d_labels, s);
-                (void)hipFreeAsync(d_confs, s);
-                return fail(KRK_E_INVALID, "krk_greedy_decode: olens outside [0, T]");
-            }
-        HIPCHK(hipMallocAsync((void**)&d_olens, (size_t)N * sizeof(int), s));
-        HIPCHK(hipMemcpyAsync(d_olens, olens_host, (size_t)N * sizeof(int), hipMemcpyHostToDevice, s));
+            if (olens_host[n] < 0 || olens_host[n] > T) return fail(KRK_E_INVALID, "krk_greedy_decode: olens outside [0, T]");
+    // stream-ordered scratch, released on every path
+    struct Scratch {
+        hipStream_t s;
+        void* p[3] = {nullptr, nullptr, nullptr};
+        ~Scratch() { for (void* q : p) if (q) (void)hipFreeAsync(q, s); }
+    } sc{s};
+    const size_t rows = (size_t)N * T;
+    HIPCHK(hipMallocAsync(&sc.p[0], rows * sizeof(int), s));
+    HIPCHK(hipMallocAsync(&sc.p[1], rows * sizeof(float), s));
+    if (olens_host) {
+        HIPCHK(hipMallocAsync(&sc.p[2], (size_t)N * sizeof(int), s));
+        HIPCHK(hipMemcpyAsync(sc.p[2], olens_host, (size_t)N * sizeof(int), hipMemcpyHostToDevice, s));
     }
-    const int rc = decode_on_device(scores_dev, sn, sc, st, N, C, T, d_olens, softmax, temperature, probs_dev,
-                                    d_labels, d_confs, s, out);
-    (void)hipFreeAsync(d_labels, s);
-    (void)hipFreeAsync(d_confs, s);
-    if (d_olens) (void)hipFreeAsync(d_olens, s);
-    return rc;
+    return decode_on_device(scores_dev, sn, sc, st, N, C, T, (const int*)sc.p[2], softmax, temperature, probs_dev,
+                            (int*)sc.p[0], (float*)sc.p[1], s, out);
 }
 
 int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int channels, const int* boxes_dev, int n,

@@ -176,10 +176,13 @@ int krk_launch_gemm_x3(const GemmX3Args& a, hipStream_t s) {
     if (a.K % 16 || a.M <= 0) return a.M == 0 ? 0 : -1;
     const int slots = (a.ntiles + 7) / 8 * 8;
     const size_t lds = (size_t)3 * (A_Q + B_Q) * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the function object of the CURRENT device: once per device, not once per process
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)(slots * a.ncg)), dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -269,14 +269,14 @@ int launch_one(const LstmX3Args& a, hipStream_t s) {
 // a.NB = 4*Hp/16 column blocks of 16 gate columns; a.NKB = K-blocks of 32 (Hp padded to a multiple of 32).
 // Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs) once a wave would own more than 4 blocks -- the second
 // wave hides the L2 weight stream and the serial gate math of the first; 4 otherwise.
-// Lines per workgroup: 16, or (KRK_LSTM_G=2) 32 = two groups of 16 sharing every weight fragment: the per-CU weight
+// Lines per workgroup: 16, or (KRK_LSTM_STREAM_G=2) 32 = two groups of 16 sharing every weight fragment: the per-CU weight
 // stream is then paid once per 32 lines and the kernel holds half as many CUs (chip time per line -33 %), but a
 // launch takes 1.9 instead of 1.36 ms and the pipelined engine loses more to the longer per-batch chain.
 int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s) {
     int nw = a.NB > 16 && a.NB <= 64 ? 8 : 4;
-    if (const char* e = getenv("KRK_LSTM_NW")) nw = atoi(e) == 8 && a.NB <= 64 ? 8 : 4;
+    if (const char* e = getenv("KRK_LSTM_STREAM_NW")) nw = atoi(e) == 8 && a.NB <= 64 ? 8 : 4;
     int g = 1;   // 32-line tiles are opt-in: measured 80 k vs 91 k lines/s on the pipelined bench (longer per-batch chain)
-    if (const char* e = getenv("KRK_LSTM_G")) g = (atoi(e) == 2 && nw == 8 && a.NB <= 56) ? 2 : 1;
+    if (const char* e = getenv("KRK_LSTM_STREAM_G")) g = (atoi(e) == 2 && nw == 8 && a.NB <= 56) ? 2 : 1;
     if (nw == 8) {
         const int per_wave = (a.NB + 7) / 8;
         if (g == 2) {

@@ -37,6 +37,16 @@ except Exception:  # pragma: no cover
     pass
 
 
+class _ShapeOnly:
+    """``.outputs`` of a call that did not materialise the softmax: has the (N, C, T) shape, nothing else."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+    def __repr__(self):
+        return f'<softmax not materialised, shape {self.shape}; call forward() for the values>'
+
+
 class TorchSeqRecognizer(object):
     """A wrapper around a TorchVGSLModel for text recognition (GPU only)."""
 
@@ -71,8 +81,8 @@ class TorchSeqRecognizer(object):
     # ``outputs``: (N, C, T) float32 numpy array of softmax probabilities, like the reference.
     @property
     def outputs(self):
-        if self._probs is None:
-            return None
+        if self._probs is None or isinstance(self._probs, _ShapeOnly):
+            return self._probs
         if isinstance(self._probs, torch.Tensor):
             self._probs = self._probs.float().cpu().numpy()
         return self._probs
@@ -87,9 +97,13 @@ class TorchSeqRecognizer(object):
         c_out = self.nn.output[2] if self.nn.output else 1
         if c_out not in (0, 1):
             raise KrakenInputException('Expected dimension 3 to be 1, actual {}'.format(self.nn.output))
-        batch, olens, _, probs = self.nn.nn.recognize(line, lens, temperature=self.temperature, want_probs=True)
-        # keep the device tensor; the host copy happens only if someone reads .outputs
-        self._probs = probs
+        batch, olens, _, probs = self.nn.nn.recognize(line, lens, temperature=self.temperature, want_probs=want_probs)
+        if want_probs:
+            self._probs = probs           # device tensor; the host copy happens only if someone reads .outputs
+        else:
+            # rpred reads only `.outputs.shape[2]` (kraken/rpred.py:232): a shape-only stand-in keeps that contract
+            # without writing N*C*T floats per call
+            self._probs = _ShapeOnly((line.shape[0], self.nn.output[1] if self.nn.output else 0, int(max(olens)) if len(olens) else 0))
         return batch, olens
 
     def forward(self, line: torch.Tensor, lens: torch.Tensor = None):
@@ -102,7 +116,7 @@ class TorchSeqRecognizer(object):
         if self.decoder is not _ctc.greedy_decoder:
             o, olens = self.forward(line, lens)
             return [self.codec.decode(locs) for locs in self.decoder(o, olens)]
-        batch, _ = self._run(line, lens, False)
+        batch, _ = self._run(line, lens, True)       # the legacy callers of predict() read .outputs (kraken/align.py:66-71)
         return self.codec.decode_batch(batch)
 
     def predict_string(self, line: torch.Tensor, lens: Optional[torch.Tensor] = None) -> list[str]:

@@ -12,6 +12,8 @@ Nothing here runs on the GPU box; the fixtures travel instead.  What is pinned:
                    reproducing the test's exact strings through the reference's TorchVGSLModel +
                    TorchSeqRecognizer + rpred), the preprocessed line tensor, logits, softmax
                    outputs, greedy_decoder tuples, codec output and the expected strings.
+  overfit_models.npz  overfit_newpoly.mlmodel / overfit_bl{,_newpoly}.safetensors of the reference's test resources: the
+                   fixture line through both transform branches -> logits, softmax, greedy tuples, strings.
   bench_a.npz      BENCH-A, torch.manual_seed(0) + TorchVGSLModel init: state-dict digests,
   bench_b.npz      input digests, logits of selected lines, per-step argmax / max-prob and
                    greedy_decoder tuples for equal-width batches, and per-line (batch = 1) results for
@@ -306,6 +308,49 @@ def overfit_fixture(path):
     print('wrote', path, 'line tensor', tuple(ts.shape), 'T', logits.shape[-1])
 
 
+@torch.inference_mode()
+def overfit_models_fixture(path):
+    """
+    The three other recognisers among the reference's test resources (SURVEY.md 8c list item 1): overfit_newpoly.mlmodel,
+    overfit_bl.safetensors, overfit_bl_newpoly.safetensors.  Their own tests run them on baseline segmentations, whose
+    polygon extraction needs packages absent here; the network path is pinned instead: the fixture line through BOTH
+    transform branches (dewarp = bbox lines, fixed-height resize = what a baseline crop gets) -> the reference's logits,
+    softmax, greedy tuples and strings.
+    """
+    from PIL import Image
+    from kraken_amd.io import read_coreml, read_safetensors
+    im = Image.open(os.path.join(RES, '000236.png'))
+    box = im.crop([0, 0, 2544, 156])
+    out = {'files': json.dumps(['overfit_newpoly.mlmodel', 'overfit_bl.safetensors', 'overfit_bl_newpoly.safetensors'])}
+    for fi, fname in enumerate(json.loads(out['files'])):
+        p = os.path.join(RES, fname)
+        meta, sd = read_coreml(p) if fname.endswith('.mlmodel') else read_safetensors(p)[0]
+        kwargs = {k: v for k, v in meta.items() if k not in ('_model', 'model_type')}
+        net = ref_vgsl.TorchVGSLModel(**kwargs)
+        own = net.state_dict()
+        missing, unexpected = net.load_state_dict({k: v.to(own[k].dtype) for k, v in sd.items()}, strict=False)
+        assert not missing and not unexpected, (fname, missing, unexpected)
+        net.eval()
+        b, c, h, w = net.input
+        out[f'm{fi}_spec'] = kwargs['vgsl']
+        out[f'm{fi}_meta'] = json.dumps({k: v for k, v in kwargs.items() if k not in ('accuracy', 'metrics', 'hyper_params')}, default=str)
+        for k, v in sd.items():
+            out[f'm{fi}_sd/{k}'] = v.float().numpy()
+        for vn in (True, False):
+            ts = _ref_transforms(b, h, w, c, 16, vn)(box)
+            logits, _ = net.nn(ts.unsqueeze(0))
+            probs = logits.softmax(1).squeeze(2)
+            dec = ref_greedy(probs)
+            flat, counts = tuples_to_arr(dec)
+            chars = net.codec.decode(dec[0])
+            tag = f'm{fi}_{"dewarp" if vn else "resize"}'
+            out.update({f'{tag}_line': ts.numpy(), f'{tag}_logits': logits.squeeze(2).numpy(), f'{tag}_probs': probs.numpy(),
+                        f'{tag}_tuples': flat, f'{tag}_counts': counts, f'{tag}_string': ''.join(ch for ch, *_ in chars)})
+            print(fname, tag, tuple(ts.shape), 'T', logits.shape[-1], repr(out[f'{tag}_string'][:40]))
+    np.savez_compressed(path, **out)
+    print('wrote', path)
+
+
 def transforms_fixture(path):
     from PIL import Image
     rng = np.random.RandomState(7)
@@ -332,9 +377,11 @@ def transforms_fixture(path):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'codec', 'transforms']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'codec', 'transforms']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
+    if 'overfit_models' in which:
+        overfit_models_fixture(os.path.join(HERE, 'overfit_models.npz'))
     if 'bench_a' in which:
         bench_fixture(BENCH_A, os.path.join(HERE, 'bench_a.npz'))
     if 'bench_b' in which:

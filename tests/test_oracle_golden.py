@@ -139,6 +139,29 @@ def test_oracles_known_answer_overfit_model():
     assert str(z['string_rpred_pad1_bidi']) == 'ܡ ܘܡ ܗ ܡܕܐ ܐ ܐܐ ܡ ܗܗܐܐܐܕ'
 
 
+def test_oracles_on_the_other_reference_recognisers():
+    """overfit_newpoly.mlmodel, overfit_bl.safetensors, overfit_bl_newpoly.safetensors (SURVEY.md 8c list item 1):
+    reference logits / tuples / strings of the fixture line through both transform branches."""
+    z = load_golden('overfit_models.npz')
+    for fi, fname in enumerate(json.loads(str(z['files']))):
+        spec = str(z[f'm{fi}_spec'])
+        sd = {k.split('_sd/')[1]: z[k] for k in z.files if k.startswith(f'm{fi}_sd/')}
+        _, specs = parse_vgsl(spec)
+        meta = json.loads(str(z[f'm{fi}_meta']))
+        l2c = {tuple(v): k for k, v in meta['codec'].items()}
+        for br in ('dewarp', 'resize'):
+            tag = f'm{fi}_{br}'
+            line = z[f'{tag}_line'][None]
+            y, _ = CpuRecognizer(specs, sd).forward(line)
+            np.testing.assert_allclose(y.squeeze(2).numpy(), z[f'{tag}_logits'], atol=2e-5, err_msg=fname)
+            yn, _ = np_oracle.forward(specs, sd, line)
+            np.testing.assert_allclose(yn[:, :, 0, :], z[f'{tag}_logits'], atol=5e-4, err_msg=fname)
+            dec = np_oracle.greedy_decode(np_oracle.softmax_c(yn[:, :, 0, :]))[0]
+            want = arr_to_tuples(z[f'{tag}_tuples'], z[f'{tag}_counts'])[0]
+            assert [t[:3] for t in dec] == [t[:3] for t in want], fname
+            assert ''.join(c for c, *_ in np_oracle.codec_decode(l2c, dec)) == str(z[f'{tag}_string'])
+
+
 def test_np_greedy_decode_semantics():
     probs = np.array([[[0.1, 0.9, 0.9, 0.2, 0.2, 0.6],
                        [0.8, 0.05, 0.05, 0.7, 0.5, 0.3],
