@@ -84,14 +84,24 @@ template <int NKB, int BPW, int NG>
 __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     constexpr int NGI = 3 * BPW;            // granules a lane gathers per (group, step): 3 peers x BPC*64 / 512, BPC <= 8*BPW
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
-    const int RS = a.hrow;                  // bytes per h row (one line, one plane)
-    const int plane = 16 * RS;
-    const int hbuf = 2 * plane;             // one (hi, lo) buffer of one group
-    unsigned char* hs = smem8;              // [group NG][parity 2][plane 2][16 lines][RS]
+    // h in LDS, per (group, parity): [plane hi|lo][K octet 4][line 16][K block: 16 bytes each, padded to an odd count].
+    // A fragment read (lane = line + 16*octet) then touches 16 distinct lines of at most two octet planes per 16-lane
+    // group: conflict free.  (The [line][K] rows of the streaming kernel put two octets of different lines on the same
+    // banks: PMC showed 44 % of this kernel's LDS cycles as bank conflicts, all 8 waves reading right after the barrier.)
+    constexpr int RSO = 16 * (NKB | 1);     // bytes per (octet, line) row
+    constexpr int OS = 16 * RSO;            // one octet plane
+    constexpr int plane = 4 * OS;           // hi / lo plane
+    constexpr int hbuf = 2 * plane;         // one (hi, lo) buffer of one group
+    auto lds_of = [&](int ln, int unit) -> unsigned {        // byte offset of (line, unit) inside a buffer's hi plane
+        return (unsigned)(((unit & 31) >> 3) * OS + ln * RSO + (unit >> 5) * 16 + (unit & 7) * 2);
+    };
+    unsigned char* hs = smem8;              // [group NG][parity 2][hbuf]
     int* lens_s = reinterpret_cast<int*>(smem8 + 2 * NG * hbuf);        // [16 * NG]
-    unsigned* misc = reinterpret_cast<unsigned*>(lens_s + 16 * NG);     // [0] ticket, [4..7] dump row for masked LDS writes
-    const unsigned dump_off = (unsigned)(2 * NG * hbuf + 16 * NG * 4 + 16);
-    const unsigned xs_off = (unsigned)(2 * NG * hbuf + 16 * NG * 4 + 32);   // xproj landing ring [slot parity 2][wave 8][BPW][64 lanes x 16 B]
+    unsigned* misc = reinterpret_cast<unsigned*>(lens_s + 16 * NG);     // [0] ticket
+    // masked LDS writes (absent blocks, padding granules) land in a dump area, one dword per lane: 64 lanes hammering ONE
+    // dump word were the kernel's bank conflicts (PMC: 44 % of its LDS cycles, unchanged by the h layout)
+    const unsigned dump_base = (unsigned)(2 * NG * hbuf + 16 * NG * 4 + 16);
+    const unsigned xs_off = dump_base + 256;                             // xproj landing ring [slot parity 2][wave 8][BPW][64 lanes x 16 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,6 +125,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
     for (int i = 0; i < 16 * NG; ++i) Lmax = max(Lmax, lens_s[i]);
 
     const int line = lane & 15, us = lane >> 4;
+    const unsigned dump_off = dump_base + (unsigned)lane * 4u;
     const int BPC = a.BPC;
 
     // ---- weights: resident for the whole launch.  [dir][slice][wave 8][i][kb][plane][lane][8]
@@ -165,7 +176,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         const int unit = slice * BPC * 4 + ul;
         const bool ok = bval[i];
         pub_vo[i] = ok ? ((unsigned)slice * slice_gran + (unsigned)ul * 16u + (unsigned)line) * 8u : kOOBws;
-        own_lds[i] = (ok && unit < NKB * 32) ? (unsigned)(line * RS + unit * 2) : dump_off;
+        own_lds[i] = (ok && unit < NKB * 32) ? lds_of(line, unit) : dump_off;
     }
     // what this lane gathers: item e = tid + 512 k over [peer 3][BPC*4 units][16 lines]; packed into one register: bit 31 =
     // wanted, bits 16..30 = LDS offset / 2 (0x7FFF = nowhere: padding unit), bits 0..15 = granule index
@@ -178,7 +189,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         const int ul = (int)(rem >> 4), ln = (int)(rem & 15);
         const int unit = sl * BPC * 4 + ul;
         const bool ok = p < 3 && (sl * BPC + (ul >> 2)) < a.NB;      // blocks beyond NB are never published
-        const unsigned lo = (ok && unit < NKB * 32) ? ((unsigned)(ln * RS + unit * 2) >> 1) : 0x7FFFu;
+        const unsigned lo = (ok && unit < NKB * 32) ? (lds_of(ln, unit) >> 1) : 0x7FFFu;
         g_item[k] = (ok ? 0x80000000u : 0u) | (lo << 16) | (((unsigned)sl * slice_gran + rem) & 0xFFFFu);
     }
     auto g_vo = [&](int k) -> unsigned { return (g_item[k] >> 31) ? (g_item[k] & 0xFFFFu) * 8u : kOOBws; };
@@ -246,7 +257,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         const int pl = e / (4 * per_line), r = e - pl * 4 * per_line;
         const int li = r / per_line, q = r - li * per_line;
         sp_ln = e < 8 * per_line ? slice * 4 + li : -1;
-        sp_lds = sp_ln >= 0 ? (unsigned)(pl * plane + sp_ln * RS + q * 16) : 0u;
+        sp_lds = sp_ln >= 0 ? (unsigned)(pl * plane + (q & 3) * OS + sp_ln * RSO + (q >> 2) * 16) : 0u;   // piece q = units 8q..8q+7
         sp_g00 = (unsigned)((((size_t)(dir * per_line + q)) * rows_total + (size_t)(n0 + max(sp_ln, 0)) * a.T) * 16 + (size_t)pl * a.out_plane * 2);
     }
     auto store_pass = [&](int g, int step, const unsigned char* hb) {
@@ -279,7 +290,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         bf16x8 hh[NKB], hl[NKB];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const unsigned char* hp = hb + line * RS + (kb * 32 + us * 8) * 2;
+            const unsigned char* hp = hb + us * OS + line * RSO + kb * 16;
             hh[kb] = *reinterpret_cast<const bf16x8*>(hp);
             hl[kb] = *reinterpret_cast<const bf16x8*>(hp + plane);
         }
@@ -363,7 +374,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
 template <int NKB, int BPW, int NG>
 int launch_ws(const LstmWsArgs& a, hipStream_t s) {
     const int nclusters = (a.N + 16 * NG - 1) / (16 * NG) * a.ndir;
-    const size_t lds = (size_t)4 * NG * 16 * a.hrow + 16 * NG * sizeof(int) + 32 + (size_t)2 * 8 * BPW * 1024;
+    const size_t lds = (size_t)2 * NG * 2 * 4 * 16 * 16 * (NKB | 1) + 16 * NG * sizeof(int) + 16 + 256 + (size_t)2 * 8 * BPW * 1024;
     auto kfn = lstm_ws_kernel<NKB, BPW, NG>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
