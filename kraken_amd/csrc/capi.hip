@@ -99,7 +99,7 @@ struct ConvGeom {
 };
 
 // row pitch (elements) of the "NHCW" planes between conv1_x3 and conv_taps_x3: whole 16-byte pieces
-int nhcw_pitch(int w) { return (w + 7) / 8 * 8; }
+int nhcw_pitch(int w) { return (w + 63) / 64 * 64; }   // whole 128-byte lines per (row, channel): a column tile of conv1_x3 stores exactly one line (with the 16-byte pitch of round 1 every 128-byte store straddled two lines: 615 MB written for 472)
 
 int conv_out(int L, int k, int s, int d, int p) { return floordiv(L + 2 * p - d * (k - 1) - 1, s) + 1; }
 
