@@ -77,7 +77,9 @@ extern "C" {
 
 /* arithmetic modes */
 #define KRK_PREC_F32      0   /* exact f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4) */
-#define KRK_PREC_BF16     1   /* plain bf16 operands (not implemented: misses the 1e-3 logit gate) */
+#define KRK_PREC_BF16     1   /* OPT-IN: the KRK_PREC_BF16X3 kernels with the two cross terms dropped = plain bf16 operands, one MFMA
+                               per product, f32 accumulate.  |d logit| ~1e-2: outside the 1e-3 parity gate, gated instead
+                               on identical greedy strings on the fixtures; never what a precision string maps to */
 #define KRK_PREC_BF16X3   2   /* split-bf16 operands (hi+lo), 3 bf16 MFMAs per product, f32 accumulate: fp32-class
                                results (|d logit| ~ 2e-5) at ~5x the f32 matrix rate; conv/projection layers only,
                                networks of the form conv(+pool) x n -> reshape -> LSTM* -> linear */

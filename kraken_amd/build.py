@@ -16,6 +16,8 @@ CSRC = os.path.join(HERE, 'csrc')
 BUILD = os.path.join(CSRC, '_build')
 LIB = os.path.join(HERE, 'libkraken_amd.so')
 SOURCES = ['conv_mfma.hip', 'conv_x3.hip', 'conv1_x3.hip', 'conv_taps_x3.hip', 'gemm_x3.hip', 'norm_x3.hip', 'lstm_rec.hip', 'lstm_small.hip', 'lstm_x3.hip', 'lstm_ws.hip', 'misc_kernels.hip', 'prep_lines.hip', 'capi.hip']
+# sources compiled a second time with -DKRK_BF16_ONE: the plain-bf16 plan's launchers (name_b1), see csrc/common.h
+ONE_TERM = ['conv1_x3.hip', 'conv_taps_x3.hip', 'conv_x3.hip', 'gemm_x3.hip', 'lstm_ws.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'kraken_amd.h')]
 ARCH = 'gfx950'
@@ -57,6 +59,11 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
         objs.append(obj)
         if force or _stale(obj, [sp] + HEADERS + [os.path.abspath(__file__)]):
             jobs.append([hipcc, *flags, '-c', sp, '-o', obj])
+        if src in ONE_TERM:
+            obj1 = os.path.join(bdir, src.replace('.hip', '_b1.o'))
+            objs.append(obj1)
+            if force or _stale(obj1, [sp] + HEADERS + [os.path.abspath(__file__)]):
+                jobs.append([hipcc, *flags, '-DKRK_BF16_ONE', '-c', sp, '-o', obj1])
 
     def run(cmd):
         if verbose:
@@ -74,4 +81,9 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True, ablate='--ablate' in sys.argv))
+    try:
+        print(build(force='--force' in sys.argv, verbose=True, ablate='--ablate' in sys.argv))
+    except Exception as e:                      # a failed build must be the LAST thing on the screen, not a stale .so
+        print(str(e)[-3000:], file=sys.stderr)
+        print('BUILD FAILED', flush=True)
+        sys.exit(1)

@@ -566,9 +566,10 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
     if (!layers || n_layers <= 0 || !out) return fail(KRK_E_INVALID, "krk_plan_create: null/empty layer list");
     if (in_channels <= 0 || in_height <= 0)
         return fail(KRK_E_UNSUPPORTED, "krk_plan_create: input channels/height must be fixed and positive");
-    if (precision != KRK_PREC_F32 && precision != KRK_PREC_BF16X3)
-        return fail(KRK_E_UNSUPPORTED, "krk_plan_create: precision must be KRK_PREC_F32 or KRK_PREC_BF16X3");
-    bool x3 = precision == KRK_PREC_BF16X3;   // cleared by leave_x3() when the rest of the network needs f32-only layers
+    if (precision != KRK_PREC_F32 && precision != KRK_PREC_BF16X3 && precision != KRK_PREC_BF16)
+        return fail(KRK_E_UNSUPPORTED, "krk_plan_create: precision must be KRK_PREC_F32, KRK_PREC_BF16X3 or KRK_PREC_BF16");
+    // KRK_PREC_BF16 = the split-bf16 plan with the cross terms dropped (one MFMA per product): same layouts, same kernels
+    bool x3 = precision == KRK_PREC_BF16X3 || precision == KRK_PREC_BF16;   // cleared by leave_x3() when the rest of the network needs f32-only layers
     if (krk_device_count() <= device)
         return fail(KRK_E_HIP, "krk_plan_create: no HIP device " + std::to_string(device));
     HIPCHK(hipSetDevice(device));
@@ -1022,6 +1023,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
     if (!p || !x_dev) return fail(KRK_E_INVALID, "forward: null plan or input");
     if (N <= 0 || W <= 0) return fail(KRK_E_INVALID, "forward: N and W must be positive");
     HIPCHK(hipSetDevice(p->device));
+    const bool one = p->precision == KRK_PREC_BF16;    // plain-bf16 plan: the _b1 launchers (cross terms compiled out)
     p->last_N = N;
     p->last_W = W;
     if (p->front_wait) {   // one-shot: this batch's convolution block starts after the other plan's has finished
@@ -1170,7 +1172,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
                     s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
                     if (mark("conv_taps_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
-                    rc = krk_launch_conv_taps(a, g.pool, stream);
+                    rc = one ? krk_launch_conv_taps_b1(a, g.pool, stream) : krk_launch_conv_taps(a, g.pool, stream);
                     break;
                 }
                 if (s.cg.x3) {
@@ -1184,7 +1186,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     }
                     s.flops = 2.0 * N * (double)s.cg.Ho * a.Wo * s.cg.Cout * s.cg.Cin * s.cg.kh * s.cg.kw;
                     if (mark("conv_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
-                    rc = krk_launch_conv_x3(a, false, s.cg.pool, stream);
+                    rc = one ? krk_launch_conv_x3_b1(a, false, s.cg.pool, stream) : krk_launch_conv_x3(a, false, s.cg.pool, stream);
                     break;
                 }
                 if (s.cg.c1x3) {
@@ -1204,7 +1206,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     a.dbg = env_int("KRK_X3_DBG");
                     s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
                     if (mark("conv1_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
-                    rc = krk_launch_conv1_x3(a, g.pool, stream);
+                    rc = one ? krk_launch_conv1_x3_b1(a, g.pool, stream) : krk_launch_conv1_x3(a, g.pool, stream);
                     break;
                 }
                 ConvArgs a;
@@ -1294,7 +1296,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     GemmX3Args a;
                     fill_gemm(s.cg, a, xin, in_elems, (float*)outp, N * Win);
                     mark("linear_x3", s.flops);
-                    rc = krk_launch_gemm_x3(a, stream);
+                    rc = one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
                     break;
                 }
                 ConvArgs a;
@@ -1328,7 +1330,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                     fill_gemm(s.cg, a, xin, in_elems, (float*)s.aux.p, N * T);
                     a.tileT = s.rec_x3 ? T : 0;
                     mark("lstm_xproj_x3", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin);
-                    rc = krk_launch_gemm_x3(a, stream);
+                    rc = one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
                 } else {
                     ConvArgs a;
                     fill_conv(s.cg, a, cur, (float*)s.aux.p, 1, N * T, nullptr, nullptr);
@@ -1383,7 +1385,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
                         w.epoch = s.ws_epoch;
                         w.err = p->err_dev;
                         w.dbg = l.dbg;
-                        rc = krk_launch_lstm_ws(w, groups, stream);
+                        rc = one ? krk_launch_lstm_ws_b1(w, groups, stream) : krk_launch_lstm_ws(w, groups, stream);
                         if (rc == 0) s.ws_tickets += (unsigned)(krk_lstm_ws_clusters(N, s.ndir, groups) * 4);
                     }
                     if (rc == -4) rc = krk_launch_lstm_x3(l, stream);
@@ -1479,16 +1481,16 @@ int krk_greedy_decode(const float* scores_dev, long sn, long sc, long st, int N,
         hipStream_t s;
         void* p[3] = {nullptr, nullptr, nullptr};
         ~Scratch() { for (void* q : p) if (q) (void)hipFreeAsync(q, s); }
-    } sc{s};
+    } tmp{s};
     const size_t rows = (size_t)N * T;
-    HIPCHK(hipMallocAsync(&sc.p[0], rows * sizeof(int), s));
-    HIPCHK(hipMallocAsync(&sc.p[1], rows * sizeof(float), s));
+    HIPCHK(hipMallocAsync(&tmp.p[0], rows * sizeof(int), s));
+    HIPCHK(hipMallocAsync(&tmp.p[1], rows * sizeof(float), s));
     if (olens_host) {
-        HIPCHK(hipMallocAsync(&sc.p[2], (size_t)N * sizeof(int), s));
-        HIPCHK(hipMemcpyAsync(sc.p[2], olens_host, (size_t)N * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMallocAsync(&tmp.p[2], (size_t)N * sizeof(int), s));
+        HIPCHK(hipMemcpyAsync(tmp.p[2], olens_host, (size_t)N * sizeof(int), hipMemcpyHostToDevice, s));
     }
-    return decode_on_device(scores_dev, sn, sc, st, N, C, T, (const int*)sc.p[2], softmax, temperature, probs_dev,
-                            (int*)sc.p[0], (float*)sc.p[1], s, out);
+    return decode_on_device(scores_dev, sn, sc, st, N, C, T, (const int*)tmp.p[2], softmax, temperature, probs_dev,
+                            (int*)tmp.p[0], (float*)tmp.p[1], s, out);
 }
 
 int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int channels, const int* boxes_dev, int n,

@@ -14,6 +14,17 @@
 #define KRK_DBGBIT(a, bit) (false)
 #endif
 
+// The split-bf16 kernel sources are compiled twice: as written ("bf16x3": a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) and with
+// -DKRK_BF16_ONE, which drops the two cross terms (KRK_CROSS) and renames the launchers (KRK_FN: name_b1): the opt-in
+// plain-bf16 plan (KRK_PREC_BF16), one MFMA per product.  Same layouts, same code path, a third of the matrix work.
+#ifdef KRK_BF16_ONE
+#define KRK_CROSS(...)
+#define KRK_FN(name) name##_b1
+#else
+#define KRK_CROSS(...) __VA_ARGS__
+#define KRK_FN(name) name
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -114,6 +125,7 @@ struct Conv1Args {
 };
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
 int krk_launch_conv1_x3(const Conv1Args& a, bool pool, hipStream_t s);
+int krk_launch_conv1_x3_b1(const Conv1Args& a, bool pool, hipStream_t s);
 
 // wide-kernel convolution with taps as the K axis (conv_taps_x3.hip)
 struct ConvTapArgs {
@@ -133,6 +145,7 @@ struct ConvTapArgs {
 };
 bool krk_conv_taps_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
 int krk_launch_conv_taps(const ConvTapArgs& a, bool pool, hipStream_t s);
+int krk_launch_conv_taps_b1(const ConvTapArgs& a, bool pool, hipStream_t s);
 
 // split-bf16 row projection (gemm_x3.hip): Y[M][Cout] = X[M][K] . W^T + b
 struct GemmX3Args {
@@ -148,6 +161,7 @@ struct GemmX3Args {
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no MFMA, 2 no copies, 4 no stores, 8 no LDS reads
 };
 int krk_launch_gemm_x3(const GemmX3Args& a, hipStream_t s);
+int krk_launch_gemm_x3_b1(const GemmX3Args& a, hipStream_t s);
 
 // ----------------------------------------------------------------------- LSTM
 struct LstmArgs {
@@ -207,6 +221,7 @@ bool krk_lstm_ws_supported(int H, int Hp);
 int krk_lstm_ws_clusters(int N, int ndir, int groups);
 size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC, int groups);
 int krk_launch_lstm_ws(const LstmWsArgs& a, int groups, hipStream_t s);
+int krk_launch_lstm_ws_b1(const LstmWsArgs& a, int groups, hipStream_t s);
 
 // K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel
 int krk_lstm_kg(int M, int blocks_per_wave);
@@ -219,6 +234,7 @@ int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, int
 int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);
 int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
+int krk_launch_conv_x3_b1(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
 int krk_launch_split(const float* x, void* hi, size_t plane_elems, size_t n, hipStream_t s);
 // fp32 rows [M][K] -> K-blocked split planes [K/8][M][8] (hi, lo at + M*K elements)
 int krk_launch_split_rows(const float* x, void* hi, int M, int K, hipStream_t s);

@@ -128,8 +128,8 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         acc[o][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], f[0][s], acc[o][s], 0, 0, 0);
-                        acc[o][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], f[1][s], acc[o][s], 0, 0, 0);
-                        acc[o][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[dy], f[0][s], acc[o][s], 0, 0, 0);
+                        KRK_CROSS(acc[o][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], f[1][s], acc[o][s], 0, 0, 0);
+                                  acc[o][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[dy], f[0][s], acc[o][s], 0, 0, 0);)
                     }
                 }
             }
@@ -278,12 +278,15 @@ int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
 
 }  // namespace
 
+#ifndef KRK_BF16_ONE
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw) {
     return Cin == 1 && Cout <= 32 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5) && kw >= 1 && kw <= 16 && sh == 1 &&
            sw == 1 && dh == 1 && dw == 1;
 }
 
-int krk_launch_conv1_x3(const Conv1Args& a, bool pool, hipStream_t s) {
+#endif
+
+int KRK_FN(krk_launch_conv1_x3)(const Conv1Args& a, bool pool, hipStream_t s) {
     if (a.N <= 0) return 0;
     switch (a.kh) {
         case 1: return launch_kh<1>(a, pool, s);

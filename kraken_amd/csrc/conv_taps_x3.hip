@@ -140,10 +140,10 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
                 if (dy < 0 || dy >= KH) continue;
                 acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fh0, acc[o][0], 0, 0, 0);
                 acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fh1, acc[o][1], 0, 0, 0);
-                acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fl0, acc[o][0], 0, 0, 0);
-                acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fl1, acc[o][1], 0, 0, 0);
-                acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[dy], fh0, acc[o][0], 0, 0, 0);
-                acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[dy], fh1, acc[o][1], 0, 0, 0);
+                KRK_CROSS(acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fl0, acc[o][0], 0, 0, 0);
+                          acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[dy], fl1, acc[o][1], 0, 0, 0);
+                          acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[dy], fh0, acc[o][0], 0, 0, 0);
+                          acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[dy], fh1, acc[o][1], 0, 0, 0);)
             }
         }
     };
@@ -255,12 +255,15 @@ int launch_pw(const ConvTapArgs& a, bool pool, hipStream_t s) {
 
 }  // namespace
 
+#ifndef KRK_BF16_ONE
 bool krk_conv_taps_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw) {
     return Cin % 4 == 0 && Cin >= 4 && Cout <= 32 && Cout % 4 == 0 && kh == 3 && kw >= 11 && kw <= 16 && sh == 1 && sw == 1 &&
            dh == 1 && dw == 1;
 }
 
-int krk_launch_conv_taps(const ConvTapArgs& a, bool pool, hipStream_t s) {
+#endif
+
+int KRK_FN(krk_launch_conv_taps)(const ConvTapArgs& a, bool pool, hipStream_t s) {
     if (a.N <= 0) return 0;
     switch (a.pw) {
         case 5: return launch_pw<5>(a, pool, s);

@@ -192,12 +192,12 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
                         for (int sg = 0; sg < 2; ++sg) {
                             if (OUT_F32) {   // D[pixel][filter]
                                 acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[sg], wh[cb], acc[cb][sg], 0, 0, 0);
-                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[sg], wh[cb], acc[cb][sg], 0, 0, 0);
-                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[sg], wl[cb], acc[cb][sg], 0, 0, 0);
+                                KRK_CROSS(acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[sg], wh[cb], acc[cb][sg], 0, 0, 0);
+                                          acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[sg], wl[cb], acc[cb][sg], 0, 0, 0);)
                             } else {         // D[filter][pixel]
                                 acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xh[sg], acc[cb][sg], 0, 0, 0);
-                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xl[sg], acc[cb][sg], 0, 0, 0);
-                                acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], xh[sg], acc[cb][sg], 0, 0, 0);
+                                KRK_CROSS(acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xl[sg], acc[cb][sg], 0, 0, 0);
+                                          acc[cb][sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], xh[sg], acc[cb][sg], 0, 0, 0);)
                             }
                         }
                 }
@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
 
 }  // namespace
 
+#ifndef KRK_BF16_ONE
 int krk_launch_split_rows(const float* x, void* hi, int M, int K, hipStream_t s) {
     if (K % 8) return -1;
     const size_t total = (size_t)M * (K / 8);
@@ -370,8 +371,9 @@ int krk_x3_cb(int Cout) {
     const int CB = (Cout + 31) / 32;
     return CB >= 4 ? 4 : (CB >= 2 ? 2 : 1);
 }
+#endif
 
-int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s) {
+int KRK_FN(krk_launch_conv_x3)(const X3Args& a, bool out_f32, bool pool, hipStream_t s) {
     const int CBt = (a.Cout + 31) / 32;
     const int cb = krk_x3_cb(a.Cout);
     dim3 grid((unsigned)(a.tiles_w * a.tiles_h * a.N), (unsigned)((CBt + cb - 1) / cb));
@@ -380,6 +382,7 @@ int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s) 
     return pool ? launch_cb<1, 0>(a, cb, grid, lds, s) : launch_cb<0, 0>(a, cb, grid, lds, s);
 }
 
+#ifndef KRK_BF16_ONE
 int krk_launch_split(const float* x, void* hi, size_t plane_elems, size_t n, hipStream_t s) {
     if (n % 8) return -1;
     const size_t n8 = n / 8;
@@ -389,3 +392,4 @@ int krk_launch_split(const float* x, void* hi, size_t plane_elems, size_t n, hip
                        reinterpret_cast<__bf16*>(hi) + plane_elems, n8);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+#endif

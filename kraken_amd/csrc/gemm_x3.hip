@@ -110,8 +110,8 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xh[s], acc[cb][s], 0, 0, 0);
-                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xl[s], acc[cb][s], 0, 0, 0);
-                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], xh[s], acc[cb][s], 0, 0, 0);
+                KRK_CROSS(acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xl[s], acc[cb][s], 0, 0, 0);
+                          acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], xh[s], acc[cb][s], 0, 0, 0);)
             }
         buf = buf == 2 ? 0 : buf + 1;
     }
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
 
 }  // namespace
 
-int krk_launch_gemm_x3(const GemmX3Args& a, hipStream_t s) {
+int KRK_FN(krk_launch_gemm_x3)(const GemmX3Args& a, hipStream_t s) {
     if (a.K % 16 || a.M <= 0) return a.M == 0 ? 0 : -1;
     const int slots = (a.ntiles + 7) / 8 * 8;
     const size_t lds = (size_t)3 * (A_Q + B_Q) * 16;

@@ -312,8 +312,8 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             for (int kb = 0; kb < NKB; ++kb) {
                 if (KRK_DBGBIT(a, 4)) break;
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(whi[i][kb]), hh[kb], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(whi[i][kb]), hl[kb], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(wlo[i][kb]), hh[kb], acc2, 0, 0, 0);
+                KRK_CROSS(acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(whi[i][kb]), hl[kb], acc1, 0, 0, 0);
+                          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(wlo[i][kb]), hh[kb], acc2, 0, 0, 0);)
             }
             // NG == 2: the peers finished publishing the other group about when this slot began and a granule needs ~0.5 us to
             // become visible: ask for them a block's worth of MFMAs into the slot, look at them at its end
@@ -384,6 +384,7 @@ int launch_ws(const LstmWsArgs& a, hipStream_t s) {
 
 }  // namespace
 
+#ifndef KRK_BF16_ONE
 bool krk_lstm_ws_supported(int H, int Hp) {
     const int NKB = (Hp + 31) / 32, NB = Hp / 4;
     return (H % 8) == 0 && NKB >= 1 && NKB <= 7 && NB <= 64 && (NB + 3) / 4 <= 16;
@@ -395,9 +396,11 @@ size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC, int groups) {
     return (size_t)krk_lstm_ws_clusters(N, ndir, groups) * (2 * groups) /* (group, parity) */ * 4 /* slices */ * (size_t)BPC * 64 * 8;
 }
 
+#endif
+
 // groups = 16-line groups a cluster advances in alternation: 2 (32 lines per 4 CUs: lowest latency, the exchange round trip
 // is about one slot) or 4 (64 lines per 4 CUs: half the CUs, the h of a group is three slots old when it is read)
-int krk_launch_lstm_ws(const LstmWsArgs& a, int groups, hipStream_t s) {
+int KRK_FN(krk_launch_lstm_ws)(const LstmWsArgs& a, int groups, hipStream_t s) {
     if (!krk_lstm_ws_supported(a.H, a.Hp)) return -4;
     if ((size_t)a.out_plane * 4 >= 0x80000000ull) return -4;                 // 32-bit buffer offsets
     if (a.T >= 0xFFFF) return -4;                                             // 16-bit step tags

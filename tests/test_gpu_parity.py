@@ -961,6 +961,39 @@ def test_predict_api_precision_logits_and_line_images(bench_a, monkeypatch):
     assert (probs[0, :, :recs[2].logits.shape[1]] - recs[2].logits).abs().max().item() < 1e-4
 
 
+def test_plain_bf16_plan_is_opt_in_and_string_identical(bench_a):
+    """KRK_PREC_BF16: the split-bf16 kernels with the cross terms dropped.  Outside the 1e-3 logit gate by
+    construction; its gate: the reference's known-answer strings, and on random-weight BENCH-A identical labels wherever the
+    fp32 top-2 margin exceeds 4x the measured logit error (SURVEY 8c policy), the rest counted as tie-sensitive."""
+    from kraken_amd import _lib
+    z = load_golden('overfit.npz')
+    meta = json.loads(str(z['meta']))
+    sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
+    m = build_model(str(z['spec']), sd, codec=meta['codec']).to('cuda')
+    m.nn.set_precision('bf16')
+    assert m.nn.precision == _lib.PREC_BF16
+    for pad in (1, 16):
+        line = torch.from_numpy(z[f'pad{pad}_line'])[None].cuda()
+        batch, _, logits, _ = m.nn.recognize(line, None, want_logits=True)
+        assert ''.join(c for c, *_ in m.codec.decode(batch.tuples()[0])) == str(z[f'pad{pad}_string_display'])
+    # BENCH-A, 64 lines: error level and label agreement
+    x = synth_input(64, 1200, seed=2024).cuda()
+    _, _, l32, _ = bench_a.nn.recognize(x, None, want_logits=True)
+    mb = build_model(BENCH_A, codec=bench_codec(), seed=0).to('cuda')
+    mb.nn.set_precision('bf16')
+    _, _, lb, _ = mb.nn.recognize(x, None, want_logits=True)
+    err = (lb - l32).abs().max().item()
+    assert 1e-4 < err < 0.25, err                          # not fp32-class (that is the point), but bounded
+    top2 = l32.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4 * err             # (N, T): steps whose fp32 decision cannot flip
+    same = lb.argmax(1) == l32.argmax(1)
+    assert bool(same[safe].all())
+    print(f'plain bf16 plan: max |d logit| {err:.3e}; {int((~same).sum())} of {same.numel()} argmax steps differ, all tie-sensitive '
+          f'({int((~safe).sum())} steps within the margin)')
+    # a precision STRING never selects it
+    assert mb.nn.precision_for_config('bf16-true') == 'bf16x3'
+
+
 def test_rccl_gather_on_the_device_single_rank():
     """The exchange step over RCCL with HBM buffers (one rank: the collectives still run, `force`); the N>1 logic is
     covered by the 2-process gloo test, tests/test_dist_cpu.py (RCCL refuses two ranks on one GPU)."""
