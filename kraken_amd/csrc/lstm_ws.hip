@@ -82,7 +82,10 @@ __device__ __forceinline__ void vm_wait() {
 // NKB K blocks of 32, BPW gate-column blocks per wave, NG groups of 16 lines per cluster (slots per time step; even)
 template <int NKB, int BPW, int NG>
 __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
-    constexpr int NGI = 3 * BPW;            // granules a lane gathers per (group, step): 3 peers x BPC*64 / 512, BPC <= 8*BPW
+    // a lane gathers NGP PAIRS of granules per (group, step): two adjacent units of one line -> one dword per plane in LDS
+    // (3 peers x BPC*32 pairs / 512 lanes, BPC <= 8*BPW)
+    constexpr int NGP = (3 * BPW + 1) / 2;
+    constexpr int NGI = 2 * NGP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     // h in LDS, per (group, parity): [plane hi|lo][K octet 4][line 16][K block: 16 bytes each, padded to an odd count].
     // A fragment read (lane = line + 16*octet) then touches 16 distinct lines of at most two octet planes per 16-lane
@@ -178,50 +181,53 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         pub_vo[i] = ok ? ((unsigned)slice * slice_gran + (unsigned)ul * 16u + (unsigned)line) * 8u : kOOBws;
         own_lds[i] = (ok && unit < NKB * 32) ? lds_of(line, unit) : dump_off;
     }
-    // what this lane gathers: item e = tid + 512 k over [peer 3][BPC*4 units][16 lines]; packed into one register: bit 31 =
-    // wanted, bits 16..30 = LDS offset / 2 (0x7FFF = nowhere: padding unit), bits 0..15 = granule index
-    unsigned g_item[NGI];
+    // what this lane gathers: pair q = tid + 512 k over [peer 3][BPC*2 unit pairs][16 lines]; packed into one register: bit 31 =
+    // wanted, bits 16..30 = LDS offset / 4 of the pair's dword (0x7FFF = nowhere: padding units), bits 0..15 = index of the
+    // first granule (the second one is 16 granules = one unit further)
+    const unsigned slice_pairs = slice_gran >> 1;
+    unsigned g_item[NGP];
 #pragma unroll
-    for (int k = 0; k < NGI; ++k) {
-        const unsigned e = (unsigned)tid + 512u * k;
-        const unsigned p = e / slice_gran, rem = e - p * slice_gran;
+    for (int k = 0; k < NGP; ++k) {
+        const unsigned q = (unsigned)tid + 512u * k;
+        const unsigned p = q / slice_pairs, rem = q - p * slice_pairs;
         const int sl = (slice + 1 + (int)p) & 3;
-        const int ul = (int)(rem >> 4), ln = (int)(rem & 15);
+        const int ul = 2 * (int)(rem >> 4), ln = (int)(rem & 15);
         const int unit = sl * BPC * 4 + ul;
         const bool ok = p < 3 && (sl * BPC + (ul >> 2)) < a.NB;      // blocks beyond NB are never published
-        const unsigned lo = (ok && unit < NKB * 32) ? (lds_of(ln, unit) >> 1) : 0x7FFFu;
-        g_item[k] = (ok ? 0x80000000u : 0u) | (lo << 16) | (((unsigned)sl * slice_gran + rem) & 0xFFFFu);
+        const unsigned lo = (ok && unit < NKB * 32) ? (lds_of(ln, unit) >> 2) : 0x7FFFu;
+        g_item[k] = (ok ? 0x80000000u : 0u) | (lo << 16) | (((unsigned)sl * slice_gran + (unsigned)ul * 16u + (unsigned)ln) & 0xFFFFu);
     }
-    auto g_vo = [&](int k) -> unsigned { return (g_item[k] >> 31) ? (g_item[k] & 0xFFFFu) * 8u : kOOBws; };
+    auto g_vo = [&](int k) -> unsigned { return (g_item[k >> 1] >> 31) ? ((g_item[k >> 1] & 0xFFFFu) + 16u * (k & 1)) * 8u : kOOBws; };
     u32x2 gd[NGI];
     bool dead = false;
     // `after`: a value the first load pretends to read, so that the request cannot be scheduled before it exists
     auto gather_issue = [&](int g, int par, float after = 0.f) {
         const unsigned so = (unsigned)(g * 2 + par) * gp_bytes;
-        asm volatile("" : : "v"(after));
+        asm volatile("; after %0" : : "v"(after));   // (an EMPTY asm string drops its operand: the request then floats to the slot start)
 #pragma unroll
         for (int k = 0; k < NGI; ++k) vm_load_b64_sc1(gd[k], g_vo(k), grs, so);
     };
-    auto gather_drop = [&](unsigned char* hb) {       // granule payloads -> LDS rows (masked items go to the dump word)
+    auto gather_drop = [&](unsigned char* hb) {       // granule payloads -> LDS rows (masked pairs go to the lane's dump word)
 #pragma unroll
-        for (int k = 0; k < NGI; ++k) {
+        for (int k = 0; k < NGP; ++k) {
             const unsigned lo = (g_item[k] >> 16) & 0x7FFFu;
             const bool nowhere = lo == 0x7FFFu;
-            unsigned char* dst = nowhere ? smem8 + dump_off : hb + 2 * lo;
-            const unsigned v = gd[k][0];
-            *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(v & 0xFFFFu);
-            *reinterpret_cast<unsigned short*>(dst + (nowhere ? 2 : plane)) = (unsigned short)(v >> 16);
+            unsigned char* dst = nowhere ? smem8 + dump_off : hb + 4 * lo;
+            const unsigned v0 = gd[2 * k][0], v1 = gd[2 * k + 1][0];          // (hi | lo << 16) of units u, u + 1
+            *reinterpret_cast<unsigned*>(dst) = (v0 & 0xFFFFu) | (v1 << 16);
+            *reinterpret_cast<unsigned*>(dst + (nowhere ? 0 : plane)) = (v0 >> 16) | (v1 & 0xFFFF0000u);
         }
     };
     // waits for the gather loads (BPW publish stores were issued after them), then, branch-free: true if some granule of
     // h(g, step) did not carry its tag yet; the payloads go to LDS either way
+    static_assert((NGI == 4 && BPW == 1) || (NGI == 6 && BPW == 2), "the waits below count BPW publish stores behind NGI loads");
     auto gather_try = [&](int step, unsigned char* hb) -> bool {
         const unsigned want = tagbase | ((unsigned)(step + 1) & 0xFFFFu);
-        if constexpr (NGI == 3) asm volatile("s_waitcnt vmcnt(1)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]) : : "memory");
+        if constexpr (NGI == 4) asm volatile("s_waitcnt vmcnt(1)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(2)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]), "+v"(gd[4]), "+v"(gd[5]) : : "memory");
         bool ok = true;
 #pragma unroll
-        for (int k = 0; k < NGI; ++k) ok = ok && (!(g_item[k] >> 31) || gd[k][1] == want);
+        for (int k = 0; k < NGI; ++k) ok = ok && (!(g_item[k >> 1] >> 31) || gd[k][1] == want);
         gather_drop(hb);
         return !ok;
     };
@@ -231,11 +237,11 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         unsigned spins = 0;
         while (!dead) {
             gather_issue(g, par);
-            if constexpr (NGI == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]) : : "memory");
+            if constexpr (NGI == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]) : : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]), "+v"(gd[4]), "+v"(gd[5]) : : "memory");
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < NGI; ++k) ok = ok && (!(g_item[k] >> 31) || gd[k][1] == want);
+            for (int k = 0; k < NGI; ++k) ok = ok && (!(g_item[k >> 1] >> 31) || gd[k][1] == want);
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1u << 21)) {          // ~ a second: give up, flag the plan, never wait again
@@ -260,12 +266,18 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         sp_lds = sp_ln >= 0 ? (unsigned)(pl * plane + (q & 3) * OS + sp_ln * RSO + (q >> 2) * 16) : 0u;   // piece q = units 8q..8q+7
         sp_g00 = (unsigned)((((size_t)(dir * per_line + q)) * rows_total + (size_t)(n0 + max(sp_ln, 0)) * a.T) * 16 + (size_t)pl * a.out_plane * 2);
     }
-    auto store_pass = [&](int g, int step, const unsigned char* hb) {
+    // two halves: the LDS read is issued FIRST in a slot (LDS returns in order: a store that waited for a read issued after the
+    // 14 fragment reads would hold the wave -- and its first MFMA -- until the whole fragment set had arrived)
+    auto store_read = [&](int g, int step, const unsigned char* hb, unsigned& vo) -> u32x4 {
         const int len = sp_ln >= 0 ? lens_s[16 * g + sp_ln] : 0;
         const bool on = step >= 0 && step < len;
         const int t = rev ? (len - 1 - step) : step;
-        const unsigned vo = on ? sp_g00 + ((unsigned)g * 16u * (unsigned)a.T + (unsigned)t) * 16u : kOOBws;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(hb + sp_lds);
+        vo = on ? sp_g00 + ((unsigned)g * 16u * (unsigned)a.T + (unsigned)t) * 16u : kOOBws;
+        return *reinterpret_cast<const u32x4*>(hb + sp_lds);
+    };
+    auto store_pass = [&](int g, int step, const unsigned char* hb) {
+        unsigned vo;
+        const u32x4 v = store_read(g, step, hb, vo);
         vm_store_b128(v, vo, ors);
     };
 
@@ -287,6 +299,18 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         if (__any(pend[g]) && !KRK_DBGBIT(a, 1)) gather_poll(g, par, s - 1, hb);
         pend[g] = false;
         if (!KRK_DBGBIT(a, 32)) __syncthreads();
+        // xproj of this slot was requested two slots ago; since then this wave issued at least the BPW publish stores and the
+        // BPW xproj requests of the previous slot (its exchange loads were consumed there): everything older has landed
+        vm_wait<2 * BPW>();
+        // LDS returns in order: the small reads first (xproj landing, the output piece of the previous step), then the 2*NKB
+        // fragments in the order the MFMAs consume them, so that the matrix pipe starts on the first pair while the other
+        // waves' reads are still queued (8 waves x 14 KB = 875 LDS cycles per slot)
+        f32x4 xv[BPW];
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) xv[i] = *reinterpret_cast<const f32x4*>(smem8 + xs_off + (((g & 1) * 8 + wave) * BPW + i) * 1024 + lane * 16);
+        unsigned sp_vo = kOOBws;
+        u32x4 sp_v = u32x4{0u, 0u, 0u, 0u};
+        if (!KRK_DBGBIT(a, 16)) sp_v = store_read(g, s - 1, hb, sp_vo);
         bf16x8 hh[NKB], hl[NKB];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -294,15 +318,9 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             hh[kb] = *reinterpret_cast<const bf16x8*>(hp);
             hl[kb] = *reinterpret_cast<const bf16x8*>(hp + plane);
         }
-        // xproj of this slot was requested two slots ago; since then this wave issued at least the BPW publish stores and the
-        // BPW xproj requests of the previous slot (its exchange loads were consumed there): everything older has landed
-        vm_wait<2 * BPW>();
-        f32x4 xv[BPW];
-#pragma unroll
-        for (int i = 0; i < BPW; ++i) xv[i] = *reinterpret_cast<const f32x4*>(smem8 + xs_off + (((g & 1) * 8 + wave) * BPW + i) * 1024 + lane * 16);
-        if (!KRK_DBGBIT(a, 16)) store_pass(g, s - 1, hb);
+        if (!KRK_DBGBIT(a, 16)) vm_store_b128(sp_v, sp_vo, ors);
         // NG > 2: the next slot's h was published NG-1 slots ago -- ask for it now, it lands under this slot's MFMAs
-        if (NG > 2 && nxt && !KRK_DBGBIT(a, 1)) gather_issue(ng, nxt_par);
+        if ((NG > 2 || KRK_DBGBIT(a, 64)) && nxt && !KRK_DBGBIT(a, 1)) gather_issue(ng, nxt_par);
         const unsigned want = tagbase | ((unsigned)(s + 1) & 0xFFFFu);
         const unsigned pso = (unsigned)(g * 2 + (par ^ 1)) * gp_bytes;
 #pragma unroll
@@ -317,7 +335,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             }
             // NG == 2: the peers finished publishing the other group about when this slot began and a granule needs ~0.5 us to
             // become visible: ask for them a block's worth of MFMAs into the slot, look at them at its end
-            if (NG == 2 && i == 0 && nxt && !KRK_DBGBIT(a, 1)) gather_issue(ng, nxt_par, acc0[0] + acc1[0] + acc2[0]);
+            if (NG == 2 && !KRK_DBGBIT(a, 64) && i == (KRK_DBGBIT(a, 128) ? BPW - 1 : 0) && nxt && !KRK_DBGBIT(a, 1)) gather_issue(ng, nxt_par, acc0[0] + acc1[0] + acc2[0]);
             if (KRK_DBGBIT(a, 2)) continue;
             const f32x4 z = acc0 + (acc1 + acc2);
             const float gi = krk_sigmoid(z[0]);

@@ -72,7 +72,16 @@ if __name__ == '__main__':
                 r = run(dict(env, KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
                 print('ablate', name, 'dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
         sys.exit(0)
-    for N, T in ((256, 150), (64, 150), (1024, 150), (40, 60), (7, 33)):
+    if '--quick' in sys.argv:          # correctness at three sizes + the phase prices of the default (g2) variant
+        lib = os.path.abspath('kraken_amd/libkraken_amd_ablate.so')
+        for dbg in (0, 64, 128, 4, 16, 32, 1):     # 1 no exchange, 4 no MFMA, 16 no output pass, 32 no barrier; gather asked at slot start (64) / after the last block (128)
+            r = run(dict(variants[1][1], KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
+            print('ablate ws g2 dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
+        variants = variants[:2]
+        sizes = ((256, 150), (40, 60), (7, 33))
+    else:
+        sizes = ((256, 150), (64, 150), (1024, 150), (40, 60), (7, 33))
+    for N, T in sizes:
         ref = None
         for name, env in variants:
             for ragged in (0, 1):
