@@ -36,8 +36,6 @@ const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "l
 
 
 
-// Probe / experiment switches (documented in DESIGN.md section 5.1 and in the kernels): read once per call site.
-// The test-suite flips a few of them between calls (monkeypatch), so they are looked up per call, not cached.
 static int env_int(const char* name, int dflt = 0) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -561,6 +559,369 @@ void krk_plan_destroy(krk_plan* plan) {
     delete plan;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Compiles a layer table into a plan's schedule.  State that travels from layer to layer: the activation's shape and
+// format (image / sequence, fp32 / split-bf16 planes), the length stage, and the lookahead index `i` (a convolution
+// swallows a directly following 2x2 max-pool and the height->channel reshape).
+struct PlanBuilder {
+    krk_plan* p;
+    const krk_layer* layers;
+    int n_layers;
+    bool x3;                  // split-bf16 kernels still in use (cleared by leave_x3 when the rest of the network needs f32-only layers)
+    int C, H;
+    bool seq = false;
+    bool split_fmt = false;   // bf16x3: the current activation is held as split bf16 planes
+    int stage = 0;
+    int i = 0;
+
+    void push_toseq() {
+        Step s;
+        s.kind = S_TOSEQ;
+        s.C = C;
+        s.H = H;
+        s.out_is_seq = true;
+        s.outC = C * H;
+        s.outH = 1;
+        s.len_in = s.len_out = stage;
+        p->steps.push_back(std::move(s));
+        seq = true;
+        C = C * H;
+        H = 1;
+    }
+
+    // bf16x3 plans cover what the split-operand kernels implement; a layer that only exists in the f32 plan (an LSTM over
+    // image rows/columns, GroupNorm on a channel count that is not a power of two, ...) does not reject the network:
+    // the activations are converted once (split NHWC -> fp32 NCHW) and the rest of the plan runs on the f32 kernels.
+    void leave_x3() {
+        if (split_fmt && !seq) {
+            Step u;
+            u.kind = S_UNSPLIT;
+            u.C = C; u.H = H;
+            u.outC = C; u.outH = H;
+            u.len_in = u.len_out = stage;
+            p->steps.push_back(std::move(u));
+        }
+        x3 = false;
+        split_fmt = false;
+    }
+
+    int conv(const krk_layer& L, const std::string& where);
+    int maxpool(const krk_layer& L, const std::string& where);
+    int groupnorm(const krk_layer& L, const std::string& where);
+    int reshape(const krk_layer& L, const std::string& where);
+    int recurrent_or_linear(const krk_layer& L, const std::string& where);
+    int linear(const krk_layer& L, const std::string& where, Step& s);
+    int lstm(const krk_layer& L, const std::string& where, Step& s);
+    int build();
+};
+
+// ActConv2D (reference layers.py:791-860), with a directly following 2x2/2 MaxPool and/or the S reshape fused in
+int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
+    if (seq) return fail(KRK_E_UNSUPPORTED, where + ": convolution after a sequence layer");
+    if (!L.w[0] || !L.w[1]) return fail(KRK_E_INVALID, where + ": conv weights missing");
+    if (L.cout <= 0 || L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0 || L.dh <= 0 || L.dw <= 0)
+        return fail(KRK_E_INVALID, where + ": bad conv geometry");
+    if (L.act < 0 || L.act > KRK_ACT_SIGMOID) return fail(KRK_E_UNSUPPORTED, where + ": activation");
+    if (x3 && split_fmt && C % 16) {   // conv_x3 wants 16-channel K blocks; the tap kernel takes multiples of 4 after conv1_x3
+        const bool taps_ok = !p->steps.empty() && p->steps.back().kind == S_CONV && p->steps.back().cg.c1x3 &&
+                             krk_conv_taps_supported(C, L.cout, L.kh, L.kw, L.sh, L.sw, L.dh, L.dw) &&
+                             !(i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC);
+        if (!taps_ok) leave_x3();
+    }
+    Step s;
+    s.kind = S_CONV;
+    s.C = C;
+    s.H = H;
+    ConvGeom& g = s.cg;
+    g.Cin = C;
+    g.H = H;
+    g.Cout = L.cout;
+    g.kh = L.kh; g.kw = L.kw; g.sh = L.sh; g.sw = L.sw; g.dh = L.dh; g.dw = L.dw;
+    g.ph = (L.dh * (L.kh - 1)) / 2;
+    g.pw = (L.dw * (L.kw - 1)) / 2;
+    g.act = map_act(L.act);
+    s.len_in = stage;
+    p->lenops.push_back({0, L.kw, L.sw, L.dw, g.pw});
+    ++stage;
+    const int Ho = conv_out(H, L.kh, L.sh, L.dh, g.ph);
+    if (Ho <= 0) return fail(KRK_E_INVALID, where + ": conv output height <= 0");
+    // fuse a directly following 2x2/2 max-pool, or the height->channel reshape
+    if (i + 1 < n_layers && layers[i + 1].op == KRK_OP_MAXPOOL && layers[i + 1].kh == 2 &&
+        layers[i + 1].kw == 2 && layers[i + 1].sh == 2 && layers[i + 1].sw == 2 && Ho >= 2 &&
+        monotone_act(L.act)) {
+        g.pool = true;
+        p->lenops.push_back({1, 2, 2, 1, 0});
+        ++stage;
+        ++i;
+        // bf16x3: conv_x3.hip can pool AND write the collapsed sequence rows in one epilogue
+        if (x3 && split_fmt && i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
+            g.out_seq = true;
+            ++i;
+        }
+    } else if (i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
+        g.out_seq = true;
+        ++i;
+    }
+    plan_conv_geom(g);
+    if (upload_conv_weights(g, L.w[0], L.w[1], nullptr, nullptr) != KRK_OK) return KRK_E_HIP;
+    if (x3) {
+        // the first convolution reads the caller's fp32 NCHW image on the f32 cores and hands
+        // over split channels-last planes; every later one runs on the bf16 cores
+        const bool first = !split_fmt;
+        const int feat = g.out_seq ? g.Hy * L.cout : L.cout;
+        if (feat % 4) return fail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs a multiple of 4 output channels");   // the consumer checks its own K granule
+        if (first && g.out_seq) return fail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs >= 2 convolutions before the reshape");
+        g.split_out = true;
+        s.in_split = !first;
+        if (!first && !g.out_seq && !p->steps.empty() && p->steps.back().kind == S_CONV && p->steps.back().cg.c1x3 &&
+            krk_conv_taps_supported(g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw) && !getenv("KRK_NO_CONV_TAPS")) {
+            g.taps = true;
+            p->steps.back().cg.out_nhcw = true;
+            if (upload_conv_taps_weights(g, L.w[0]) != KRK_OK) return KRK_E_HIP;
+        } else if (!first) {
+            g.x3 = true;
+            if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, L.w[0], nullptr) != KRK_OK) return KRK_E_UNSUPPORTED;
+        } else if (!g.out_seq && krk_conv1_x3_supported(g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw) &&
+                   !getenv("KRK_NO_CONV1_X3")) {
+            g.c1x3 = true;
+            if (upload_conv1_x3_weights(g, L.w[0]) != KRK_OK) return KRK_E_HIP;
+        }
+        split_fmt = true;
+    }
+    s.len_out = stage;
+    if (g.out_seq) {
+        s.out_is_seq = true;
+        s.outC = g.Hy * g.Cout;   // Hy == Ho unless a pool is fused in front of the reshape
+        s.outH = 1;
+        seq = true;
+        C = s.outC;
+        H = 1;
+    } else {
+        s.outC = g.Cout;
+        s.outH = g.Hy;
+        C = g.Cout;
+        H = g.Hy;
+    }
+    p->steps.push_back(std::move(s));
+    return KRK_OK;
+}
+
+// stand-alone MaxPool (reference layers.py:381-388): the ones a convolution could not swallow
+int PlanBuilder::maxpool(const krk_layer& L, const std::string& where) {
+    if (x3 && split_fmt && !seq && C % 8) leave_x3();
+    if (x3 && !split_fmt) x3 = false;          // nothing split yet (pool in front of the first convolution): f32 plan
+    if (seq) return fail(KRK_E_UNSUPPORTED, where + ": max-pool after a sequence layer");
+    if (L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0) return fail(KRK_E_INVALID, where + ": bad pool");
+    Step s;
+    s.kind = S_MAXPOOL;
+    s.C = C;
+    s.H = H;
+    s.kh = L.kh; s.kw = L.kw; s.sh = L.sh; s.sw = L.sw;
+    s.on_split = x3;
+    s.Ho = floordiv(H - (L.kh - 1) - 1, L.sh) + 1;
+    if (s.Ho <= 0) return fail(KRK_E_INVALID, where + ": pool output height <= 0");
+    s.len_in = stage;
+    p->lenops.push_back({1, L.kw, L.sw, 1, 0});
+    ++stage;
+    s.len_out = stage;
+    s.outC = C;
+    s.outH = s.Ho;
+    H = s.Ho;
+    p->steps.push_back(std::move(s));
+    return KRK_OK;
+}
+
+// GroupNorm (reference layers.py:967-984)
+int PlanBuilder::groupnorm(const krk_layer& L, const std::string& where) {
+    if (x3 && split_fmt && !seq && !krk_gn_x3_supported(C, L.cout)) leave_x3();
+    if (x3 && !split_fmt) x3 = false;
+    if (seq) return fail(KRK_E_UNSUPPORTED, where + ": group norm after a sequence layer");
+    if (L.cout <= 0 || C % L.cout) return fail(KRK_E_INVALID, where + ": groups must divide channels");
+    if (!L.w[0] || !L.w[1]) return fail(KRK_E_INVALID, where + ": group norm weights missing");
+    Step s;
+    s.kind = S_GN;
+    s.C = C;
+    s.H = H;
+    s.groups = L.cout;
+    s.on_split = x3;
+    if (x3 && !p->steps.empty() && p->steps.back().kind == S_CONV && !p->steps.back().cg.out_seq &&
+        (p->steps.back().cg.x3 || p->steps.back().cg.c1x3 || p->steps.back().cg.taps)) {
+        // the convolution in front hands over exact fp32 values instead of (hi, lo): see gn_x3_kernel
+        p->steps.back().cg.out_f32 = true;
+        s.in_f32 = true;
+    }
+    std::vector<float> ga(L.w[0], L.w[0] + C), be(L.w[1], L.w[1] + C);
+    if (upload(&s.d_gamma, ga) != KRK_OK || upload(&s.d_beta, be) != KRK_OK) return KRK_E_HIP;
+    s.len_in = s.len_out = stage;
+    s.outC = C;
+    s.outH = H;
+    p->steps.push_back(std::move(s));
+    return KRK_OK;
+}
+
+// S1(1x0)1,3: height folded into channels (reference layers.py:313-335) when no convolution fused it
+int PlanBuilder::reshape(const krk_layer& L, const std::string& where) {
+    (void)L;
+    if (x3 && split_fmt && !seq && C % 8) leave_x3();
+    if (x3 && !split_fmt) x3 = false;
+    if (seq) return fail(KRK_E_UNSUPPORTED, where + ": reshape after a sequence layer");
+    push_toseq();
+    p->steps.back().on_split = x3;   // writes the K-blocked split sequence rows gemm_x3.hip reads
+    return KRK_OK;
+}
+
+// LinSoftmax's projection (reference layers.py:710-722)
+int PlanBuilder::linear(const krk_layer& L, const std::string& where, Step& s) {
+    ConvGeom& g = s.cg;
+    if (L.cout <= 0 || !L.w[0] || !L.w[1]) return fail(KRK_E_INVALID, where + ": linear weights missing");
+    s.kind = S_LINEAR;
+    g.Cout = L.cout;
+    plan_conv_geom(g);
+    if (upload_conv_weights(g, L.w[0], L.w[1], nullptr, nullptr) != KRK_OK) return KRK_E_HIP;
+    if (x3) {
+        g.x3 = true;
+        s.in_split = split_fmt;
+        if (upload_gemm_x3_weights(g, L.w[0], nullptr) != KRK_OK) return KRK_E_UNSUPPORTED;
+        split_fmt = false;   // fp32 rows out
+    }
+    s.outC = L.cout;
+    C = L.cout;
+    return KRK_OK;
+}
+
+// torch.nn.LSTM inside TransposedSummarizingRNN (reference layers.py:467-547): input projection as one GEMM over all
+// steps + the recurrent weights in every kernel's fragment order
+int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
+    ConvGeom& g = s.cg;
+    s.kind = S_LSTM;
+    s.hidden = L.cout;
+    s.dirmode = L.direction;
+    if (L.cout <= 0 || L.direction < 0 || L.direction > 2) return fail(KRK_E_INVALID, where + ": bad LSTM");
+    s.ndir = (L.direction == KRK_DIR_BIDI) ? 2 : 1;
+    for (int k = 0; k < 4 * s.ndir; ++k)
+        if (!L.w[k]) return fail(KRK_E_INVALID, where + ": LSTM weights missing");
+    s.Hp = (s.hidden + 7) / 8 * 8;
+    if (s.Hp > 256)
+        return fail(KRK_E_UNSUPPORTED, where + ": hidden size > 256 not implemented by the recurrent kernel");
+    const int H_ = s.hidden, G = 4 * s.Hp;
+    g.Cout = s.ndir * G;
+    plan_conv_geom(g);
+    // packed projection column d*G + 4*u + gate  <-  torch row gate*H + u of direction d
+    std::vector<float> wih((size_t)g.Cout * C, 0.f), bsum(g.Cout, 0.f);
+    std::vector<int> rowmap(g.Cout, -1);
+    for (int d = 0; d < s.ndir; ++d)
+        for (int u = 0; u < H_; ++u)
+            for (int gt = 0; gt < 4; ++gt) {
+                const int col = d * G + 4 * u + gt, row = gt * H_ + u;
+                rowmap[col] = col;  // identity on the staged matrix below
+                std::memcpy(&wih[(size_t)col * C], L.w[4 * d + 0] + (size_t)row * C, (size_t)C * sizeof(float));
+                bsum[col] = L.w[4 * d + 2][row] + L.w[4 * d + 3][row];
+            }
+    if (upload_conv_weights(g, wih.data(), nullptr, &rowmap, &bsum) != KRK_OK) return KRK_E_HIP;
+    if (x3) {
+        g.x3 = true;
+        s.in_split = split_fmt;
+        if (upload_gemm_x3_weights(g, wih.data(), &rowmap) != KRK_OK) return KRK_E_UNSUPPORTED;
+        // all but a final LSTM run the recurrence on the bf16 cores and hand over split planes
+        s.rec_x3 = (i + 1 < n_layers) && (s.ndir * s.hidden) % 16 == 0;
+        split_fmt = s.rec_x3;
+    }
+    const float* whh[2] = {L.w[1], s.ndir == 2 ? L.w[5] : nullptr};
+    std::vector<float> pk;
+    pack_lstm_recurrent(s, whh, 32, pk);
+    if (upload(&s.d_wrec32, pk) != KRK_OK) return KRK_E_HIP;
+    pack_lstm_recurrent(s, whh, 16, pk);
+    if (upload(&s.d_wrec16, pk) != KRK_OK) return KRK_E_HIP;
+    if (s.rec_x3 && upload_lstm_x3(s, whh) != KRK_OK) return KRK_E_HIP;
+    if (!s.rec_x3 && krk_lstm_small_supported(s.Hp) && !getenv("KRK_NO_LSTM_SMALL")) {
+        pack_lstm_small(s, whh, pk);
+        if (upload(&s.d_wrecsm, pk) != KRK_OK) return KRK_E_HIP;
+    }
+    s.outC = s.ndir * s.hidden;
+    C = s.outC;
+    return KRK_OK;
+}
+
+int PlanBuilder::recurrent_or_linear(const krk_layer& L, const std::string& where) {
+    // LSTM over the rows (kw = 0) or columns (kw = 1) of an image: reference TransposedSummarizingRNN on a
+    // 4-D input (layers.py:519-547; the BLLA segmenter's Lbx/Lby pairs).  img2rows -> LSTM -> rows2img.
+    const bool img_lstm = L.op == KRK_OP_LSTM && !seq && (H != 1 || L.kw == 1);
+    const bool summarize = L.op == KRK_OP_LSTM && L.kh == 1;
+    if (summarize && !(img_lstm && L.kw == 1))
+        return fail(KRK_E_UNSUPPORTED, where + ": only column (y-axis) LSTMs can summarise");
+    const int Himg = H;   // image height in front of the layer
+    if (img_lstm) {
+        if (x3) leave_x3();   // LSTMs over image rows/columns exist in the f32 plan only
+        Step a;
+        a.kind = S_IMG2ROWS;
+        a.C = C; a.H = H; a.yaxis = L.kw == 1;
+        a.outC = C; a.outH = H;
+        a.len_in = a.len_out = stage;
+        p->steps.push_back(std::move(a));
+    }
+    if (L.op == KRK_OP_LSTM && seq && L.kw == 1)
+        return fail(KRK_E_UNSUPPORTED, where + ": y-axis LSTM after the height collapse");
+    if (!seq && !img_lstm) {
+        if (H != 1)
+            return fail(KRK_E_UNSUPPORTED, where + ": recurrent/linear layer on an input of height " +
+                                               std::to_string(H) + " (only height 1 is implemented)");
+        if (x3) return fail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs the reshape fused into a convolution");
+        push_toseq();
+    }
+    Step s;
+    s.C = C;
+    s.H = 1;
+    s.out_is_seq = !img_lstm;
+    s.outH = img_lstm ? H : 1;
+    s.img_axis = img_lstm ? (L.kw == 1 ? 2 : 1) : 0;
+    s.len_in = s.len_out = stage;
+    ConvGeom& g = s.cg;
+    g.Cin = C;
+    g.H = 1;
+    g.in_seq = g.out_seq = true;
+    g.act = ACT_LINEAR;
+    if (int rc = (L.op == KRK_OP_LINEAR) ? linear(L, where, s) : lstm(L, where, s)) return rc;
+    p->steps.push_back(std::move(s));
+    if (img_lstm) {
+        Step b;
+        b.kind = S_ROWS2IMG;
+        b.C = C; b.H = Himg; b.yaxis = L.kw == 1;
+        b.last_only = summarize;
+        b.outC = C; b.outH = summarize ? 1 : Himg;
+        b.len_in = b.len_out = stage;
+        p->steps.push_back(std::move(b));
+        if (summarize) H = 1;
+    }
+    return KRK_OK;
+}
+
+int PlanBuilder::build() {
+    for (i = 0; i < n_layers; ++i) {
+        const krk_layer& L = layers[i];
+        const std::string where = "layer " + std::to_string(i);
+        int rc;
+        switch (L.op) {
+            case KRK_OP_CONV: rc = conv(L, where); break;
+            case KRK_OP_MAXPOOL: rc = maxpool(L, where); break;
+            case KRK_OP_GROUPNORM: rc = groupnorm(L, where); break;
+            case KRK_OP_RESHAPE_HC: rc = reshape(L, where); break;
+            case KRK_OP_LSTM:
+            case KRK_OP_LINEAR: rc = recurrent_or_linear(L, where); break;
+            default: rc = fail(KRK_E_UNSUPPORTED, where + ": unknown op " + std::to_string(L.op));
+        }
+        if (rc) return rc;
+    }
+    p->nstages = stage + 1;
+    return KRK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int in_height, int precision,
                     int device, krk_plan** out) {
     if (!layers || n_layers <= 0 || !out) return fail(KRK_E_INVALID, "krk_plan_create: null/empty layer list");
@@ -568,8 +929,6 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
         return fail(KRK_E_UNSUPPORTED, "krk_plan_create: input channels/height must be fixed and positive");
     if (precision != KRK_PREC_F32 && precision != KRK_PREC_BF16X3 && precision != KRK_PREC_BF16)
         return fail(KRK_E_UNSUPPORTED, "krk_plan_create: precision must be KRK_PREC_F32, KRK_PREC_BF16X3 or KRK_PREC_BF16");
-    // KRK_PREC_BF16 = the split-bf16 plan with the cross terms dropped (one MFMA per product): same layouts, same kernels
-    bool x3 = precision == KRK_PREC_BF16X3 || precision == KRK_PREC_BF16;   // cleared by leave_x3() when the rest of the network needs f32-only layers
     if (krk_device_count() <= device)
         return fail(KRK_E_HIP, "krk_plan_create: no HIP device " + std::to_string(device));
     HIPCHK(hipSetDevice(device));
@@ -583,338 +942,12 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
         krk_plan_destroy(p);
         return fail(code, msg);
     };
-
-    bool seq = false;
-    bool split_fmt = false;   // bf16x3: the current activation is held as split bf16 planes
-    int C = in_channels, H = in_height;
-    int stage = 0;
-    auto push_toseq = [&]() {
-        Step s;
-        s.kind = S_TOSEQ;
-        s.C = C;
-        s.H = H;
-        s.out_is_seq = true;
-        s.outC = C * H;
-        s.outH = 1;
-        s.len_in = s.len_out = stage;
-        p->steps.push_back(std::move(s));
-        seq = true;
-        C = C * H;
-        H = 1;
-    };
-
-    // bf16x3 plans cover what the split-operand kernels implement; a layer that only exists in the f32 plan (an LSTM over
-    // image rows/columns, GroupNorm on a channel count that is not a power of two, ...) does not reject the network:
-    // the activations are converted once (split NHWC -> fp32 NCHW) and the rest of the plan runs on the f32 kernels.
-    auto leave_x3 = [&]() {
-        if (split_fmt && !seq) {
-            Step u;
-            u.kind = S_UNSPLIT;
-            u.C = C; u.H = H;
-            u.outC = C; u.outH = H;
-            u.len_in = u.len_out = stage;
-            p->steps.push_back(std::move(u));
-        }
-        x3 = false;
-        split_fmt = false;
-    };
-
-    for (int i = 0; i < n_layers; ++i) {
-        const krk_layer& L = layers[i];
-        const std::string where = "layer " + std::to_string(i);
-        switch (L.op) {
-            case KRK_OP_CONV: {
-                if (seq) return bail(KRK_E_UNSUPPORTED, where + ": convolution after a sequence layer");
-                if (!L.w[0] || !L.w[1]) return bail(KRK_E_INVALID, where + ": conv weights missing");
-                if (L.cout <= 0 || L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0 || L.dh <= 0 || L.dw <= 0)
-                    return bail(KRK_E_INVALID, where + ": bad conv geometry");
-                if (L.act < 0 || L.act > KRK_ACT_SIGMOID) return bail(KRK_E_UNSUPPORTED, where + ": activation");
-                if (x3 && split_fmt && C % 16) {   // conv_x3 wants 16-channel K blocks; the tap kernel takes multiples of 4 after conv1_x3
-                    const bool taps_ok = !p->steps.empty() && p->steps.back().kind == S_CONV && p->steps.back().cg.c1x3 &&
-                                         krk_conv_taps_supported(C, L.cout, L.kh, L.kw, L.sh, L.sw, L.dh, L.dw) &&
-                                         !(i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC);
-                    if (!taps_ok) leave_x3();
-                }
-                Step s;
-                s.kind = S_CONV;
-                s.C = C;
-                s.H = H;
-                ConvGeom& g = s.cg;
-                g.Cin = C;
-                g.H = H;
-                g.Cout = L.cout;
-                g.kh = L.kh; g.kw = L.kw; g.sh = L.sh; g.sw = L.sw; g.dh = L.dh; g.dw = L.dw;
-                g.ph = (L.dh * (L.kh - 1)) / 2;
-                g.pw = (L.dw * (L.kw - 1)) / 2;
-                g.act = map_act(L.act);
-                s.len_in = stage;
-                p->lenops.push_back({0, L.kw, L.sw, L.dw, g.pw});
-                ++stage;
-                const int Ho = conv_out(H, L.kh, L.sh, L.dh, g.ph);
-                if (Ho <= 0) return bail(KRK_E_INVALID, where + ": conv output height <= 0");
-                // fuse a directly following 2x2/2 max-pool, or the height->channel reshape
-                if (i + 1 < n_layers && layers[i + 1].op == KRK_OP_MAXPOOL && layers[i + 1].kh == 2 &&
-                    layers[i + 1].kw == 2 && layers[i + 1].sh == 2 && layers[i + 1].sw == 2 && Ho >= 2 &&
-                    monotone_act(L.act)) {
-                    g.pool = true;
-                    p->lenops.push_back({1, 2, 2, 1, 0});
-                    ++stage;
-                    ++i;
-                    // bf16x3: conv_x3.hip can pool AND write the collapsed sequence rows in one epilogue
-                    if (x3 && split_fmt && i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
-                        g.out_seq = true;
-                        ++i;
-                    }
-                } else if (i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
-                    g.out_seq = true;
-                    ++i;
-                }
-                plan_conv_geom(g);
-                if (upload_conv_weights(g, L.w[0], L.w[1], nullptr, nullptr) != KRK_OK) {
-                    krk_plan_destroy(p);
-                    return KRK_E_HIP;
-                }
-                if (x3) {
-                    // the first convolution reads the caller's fp32 NCHW image on the f32 cores and hands
-                    // over split channels-last planes; every later one runs on the bf16 cores
-                    const bool first = !split_fmt;
-                    const int feat = g.out_seq ? g.Hy * L.cout : L.cout;
-                    if (feat % 4) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs a multiple of 4 output channels");   // the consumer checks its own K granule
-                    if (first && g.out_seq) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs >= 2 convolutions before the reshape");
-                    g.split_out = true;
-                    s.in_split = !first;
-                    if (!first && !g.out_seq && !p->steps.empty() && p->steps.back().kind == S_CONV && p->steps.back().cg.c1x3 &&
-                        krk_conv_taps_supported(g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw) && !getenv("KRK_NO_CONV_TAPS")) {
-                        g.taps = true;
-                        p->steps.back().cg.out_nhcw = true;
-                        if (upload_conv_taps_weights(g, L.w[0]) != KRK_OK) {
-                            krk_plan_destroy(p);
-                            return KRK_E_HIP;
-                        }
-                    } else if (!first) {
-                        g.x3 = true;
-                        if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, L.w[0], nullptr) != KRK_OK) {
-                            krk_plan_destroy(p);
-                            return KRK_E_UNSUPPORTED;
-                        }
-                    } else if (!g.out_seq && krk_conv1_x3_supported(g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw) &&
-                               !getenv("KRK_NO_CONV1_X3")) {
-                        g.c1x3 = true;
-                        if (upload_conv1_x3_weights(g, L.w[0]) != KRK_OK) {
-                            krk_plan_destroy(p);
-                            return KRK_E_HIP;
-                        }
-                    }
-                    split_fmt = true;
-                }
-                s.len_out = stage;
-                if (g.out_seq) {
-                    s.out_is_seq = true;
-                    s.outC = g.Hy * g.Cout;   // Hy == Ho unless a pool is fused in front of the reshape
-                    s.outH = 1;
-                    seq = true;
-                    C = s.outC;
-                    H = 1;
-                } else {
-                    s.outC = g.Cout;
-                    s.outH = g.Hy;
-                    C = g.Cout;
-                    H = g.Hy;
-                }
-                p->steps.push_back(std::move(s));
-                break;
-            }
-            case KRK_OP_MAXPOOL: {
-                if (x3 && split_fmt && !seq && C % 8) leave_x3();
-                if (x3 && !split_fmt) x3 = false;          // nothing split yet (pool in front of the first convolution): f32 plan
-                if (seq) return bail(KRK_E_UNSUPPORTED, where + ": max-pool after a sequence layer");
-                if (L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0) return bail(KRK_E_INVALID, where + ": bad pool");
-                Step s;
-                s.kind = S_MAXPOOL;
-                s.C = C;
-                s.H = H;
-                s.kh = L.kh; s.kw = L.kw; s.sh = L.sh; s.sw = L.sw;
-                s.on_split = x3;
-                s.Ho = floordiv(H - (L.kh - 1) - 1, L.sh) + 1;
-                if (s.Ho <= 0) return bail(KRK_E_INVALID, where + ": pool output height <= 0");
-                s.len_in = stage;
-                p->lenops.push_back({1, L.kw, L.sw, 1, 0});
-                ++stage;
-                s.len_out = stage;
-                s.outC = C;
-                s.outH = s.Ho;
-                H = s.Ho;
-                p->steps.push_back(std::move(s));
-                break;
-            }
-            case KRK_OP_GROUPNORM: {
-                if (x3 && split_fmt && !seq && !krk_gn_x3_supported(C, L.cout)) leave_x3();
-                if (x3 && !split_fmt) x3 = false;
-                if (seq) return bail(KRK_E_UNSUPPORTED, where + ": group norm after a sequence layer");
-                if (L.cout <= 0 || C % L.cout) return bail(KRK_E_INVALID, where + ": groups must divide channels");
-                if (!L.w[0] || !L.w[1]) return bail(KRK_E_INVALID, where + ": group norm weights missing");
-                Step s;
-                s.kind = S_GN;
-                s.C = C;
-                s.H = H;
-                s.groups = L.cout;
-                s.on_split = x3;
-                if (x3 && !p->steps.empty() && p->steps.back().kind == S_CONV && !p->steps.back().cg.out_seq &&
-                    (p->steps.back().cg.x3 || p->steps.back().cg.c1x3 || p->steps.back().cg.taps)) {
-                    // the convolution in front hands over exact fp32 values instead of (hi, lo): see gn_x3_kernel
-                    p->steps.back().cg.out_f32 = true;
-                    s.in_f32 = true;
-                }
-                std::vector<float> ga(L.w[0], L.w[0] + C), be(L.w[1], L.w[1] + C);
-                if (upload(&s.d_gamma, ga) != KRK_OK || upload(&s.d_beta, be) != KRK_OK) {
-                    krk_plan_destroy(p);
-                    return KRK_E_HIP;
-                }
-                s.len_in = s.len_out = stage;
-                s.outC = C;
-                s.outH = H;
-                p->steps.push_back(std::move(s));
-                break;
-            }
-            case KRK_OP_RESHAPE_HC: {
-                if (x3 && split_fmt && !seq && C % 8) leave_x3();
-                if (x3 && !split_fmt) x3 = false;
-                if (seq) return bail(KRK_E_UNSUPPORTED, where + ": reshape after a sequence layer");
-                push_toseq();
-                p->steps.back().on_split = x3;   // writes the K-blocked split sequence rows gemm_x3.hip reads
-                break;
-            }
-            case KRK_OP_LSTM:
-            case KRK_OP_LINEAR: {
-                // LSTM over the rows (kw = 0) or columns (kw = 1) of an image: reference TransposedSummarizingRNN on a
-                // 4-D input (layers.py:519-547; the BLLA segmenter's Lbx/Lby pairs).  img2rows -> LSTM -> rows2img.
-                const bool img_lstm = L.op == KRK_OP_LSTM && !seq && (H != 1 || L.kw == 1);
-                const bool summarize = L.op == KRK_OP_LSTM && L.kh == 1;
-                if (summarize && !(img_lstm && L.kw == 1))
-                    return bail(KRK_E_UNSUPPORTED, where + ": only column (y-axis) LSTMs can summarise");
-                const int Himg = H;   // image height in front of the layer
-                if (img_lstm) {
-                    if (x3) leave_x3();   // LSTMs over image rows/columns exist in the f32 plan only
-                    Step a;
-                    a.kind = S_IMG2ROWS;
-                    a.C = C; a.H = H; a.yaxis = L.kw == 1;
-                    a.outC = C; a.outH = H;
-                    a.len_in = a.len_out = stage;
-                    p->steps.push_back(std::move(a));
-                }
-                if (L.op == KRK_OP_LSTM && seq && L.kw == 1)
-                    return bail(KRK_E_UNSUPPORTED, where + ": y-axis LSTM after the height collapse");
-                if (!seq && !img_lstm) {
-                    if (H != 1)
-                        return bail(KRK_E_UNSUPPORTED, where + ": recurrent/linear layer on an input of height " +
-                                                           std::to_string(H) + " (only height 1 is implemented)");
-                    if (x3) return bail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs the reshape fused into a convolution");
-                    push_toseq();
-                }
-                Step s;
-                s.C = C;
-                s.H = 1;
-                s.out_is_seq = !img_lstm;
-                s.outH = img_lstm ? H : 1;
-                s.img_axis = img_lstm ? (L.kw == 1 ? 2 : 1) : 0;
-                s.len_in = s.len_out = stage;
-                ConvGeom& g = s.cg;
-                g.Cin = C;
-                g.H = 1;
-                g.in_seq = g.out_seq = true;
-                g.act = ACT_LINEAR;
-                if (L.op == KRK_OP_LINEAR) {
-                    if (L.cout <= 0 || !L.w[0] || !L.w[1]) return bail(KRK_E_INVALID, where + ": linear weights missing");
-                    s.kind = S_LINEAR;
-                    g.Cout = L.cout;
-                    plan_conv_geom(g);
-                    if (upload_conv_weights(g, L.w[0], L.w[1], nullptr, nullptr) != KRK_OK) {
-                        krk_plan_destroy(p);
-                        return KRK_E_HIP;
-                    }
-                    if (x3) {
-                        g.x3 = true;
-                        s.in_split = split_fmt;
-                        if (upload_gemm_x3_weights(g, L.w[0], nullptr) != KRK_OK) {
-                            krk_plan_destroy(p);
-                            return KRK_E_UNSUPPORTED;
-                        }
-                        split_fmt = false;   // fp32 rows out
-                    }
-                    s.outC = L.cout;
-                    C = L.cout;
-                } else {
-                    s.kind = S_LSTM;
-                    s.hidden = L.cout;
-                    s.dirmode = L.direction;
-                    if (L.cout <= 0 || L.direction < 0 || L.direction > 2) return bail(KRK_E_INVALID, where + ": bad LSTM");
-                    s.ndir = (L.direction == KRK_DIR_BIDI) ? 2 : 1;
-                    for (int k = 0; k < 4 * s.ndir; ++k)
-                        if (!L.w[k]) return bail(KRK_E_INVALID, where + ": LSTM weights missing");
-                    s.Hp = (s.hidden + 7) / 8 * 8;
-                    if (s.Hp > 256)
-                        return bail(KRK_E_UNSUPPORTED, where + ": hidden size > 256 not implemented by the recurrent kernel");
-                    const int H_ = s.hidden, G = 4 * s.Hp;
-                    g.Cout = s.ndir * G;
-                    plan_conv_geom(g);
-                    // packed projection column d*G + 4*u + gate  <-  torch row gate*H + u of direction d
-                    std::vector<float> wih((size_t)g.Cout * C, 0.f), bsum(g.Cout, 0.f);
-                    std::vector<int> rowmap(g.Cout, -1);
-                    for (int d = 0; d < s.ndir; ++d)
-                        for (int u = 0; u < H_; ++u)
-                            for (int gt = 0; gt < 4; ++gt) {
-                                const int col = d * G + 4 * u + gt, row = gt * H_ + u;
-                                rowmap[col] = col;  // identity on the staged matrix below
-                                std::memcpy(&wih[(size_t)col * C], L.w[4 * d + 0] + (size_t)row * C, (size_t)C * sizeof(float));
-                                bsum[col] = L.w[4 * d + 2][row] + L.w[4 * d + 3][row];
-                            }
-                    if (upload_conv_weights(g, wih.data(), nullptr, &rowmap, &bsum) != KRK_OK) {
-                        krk_plan_destroy(p);
-                        return KRK_E_HIP;
-                    }
-                    if (x3) {
-                        g.x3 = true;
-                        s.in_split = split_fmt;
-                        if (upload_gemm_x3_weights(g, wih.data(), &rowmap) != KRK_OK) {
-                            krk_plan_destroy(p);
-                            return KRK_E_UNSUPPORTED;
-                        }
-                        // all but a final LSTM run the recurrence on the bf16 cores and hand over split planes
-                        s.rec_x3 = (i + 1 < n_layers) && (s.ndir * s.hidden) % 16 == 0;
-                        split_fmt = s.rec_x3;
-                    }
-                    const float* whh[2] = {L.w[1], s.ndir == 2 ? L.w[5] : nullptr};
-                    std::vector<float> pk;
-                    pack_lstm_recurrent(s, whh, 32, pk);
-                    if (upload(&s.d_wrec32, pk) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
-                    pack_lstm_recurrent(s, whh, 16, pk);
-                    if (upload(&s.d_wrec16, pk) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
-                    if (s.rec_x3 && upload_lstm_x3(s, whh) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
-                    if (!s.rec_x3 && krk_lstm_small_supported(s.Hp) && !getenv("KRK_NO_LSTM_SMALL")) {
-                        pack_lstm_small(s, whh, pk);
-                        if (upload(&s.d_wrecsm, pk) != KRK_OK) { krk_plan_destroy(p); return KRK_E_HIP; }
-                    }
-                    s.outC = s.ndir * s.hidden;
-                    C = s.outC;
-                }
-                p->steps.push_back(std::move(s));
-                if (img_lstm) {
-                    Step b;
-                    b.kind = S_ROWS2IMG;
-                    b.C = C; b.H = Himg; b.yaxis = L.kw == 1;
-                    b.last_only = summarize;
-                    b.outC = C; b.outH = summarize ? 1 : Himg;
-                    b.len_in = b.len_out = stage;
-                    p->steps.push_back(std::move(b));
-                    if (summarize) H = 1;
-                }
-                break;
-            }
-            default:
-                return bail(KRK_E_UNSUPPORTED, where + ": unknown op " + std::to_string(L.op));
-        }
+    // KRK_PREC_BF16 = the split-bf16 plan with the cross terms dropped (one MFMA per product): same layouts, same kernels
+    PlanBuilder b{p, layers, n_layers, precision == KRK_PREC_BF16X3 || precision == KRK_PREC_BF16, in_channels, in_height};
+    if (int rc = b.build()) {
+        krk_plan_destroy(p);
+        return rc;
     }
-    p->nstages = stage + 1;
     if (hipEventCreateWithFlags(&p->lens_ev, hipEventDisableTiming) != hipSuccess)
         return bail(KRK_E_HIP, "hipEventCreate failed");
     if (hipEventCreateWithFlags(&p->front_ev, hipEventDisableTiming) != hipSuccess)
@@ -1015,6 +1048,416 @@ int krk_plan_layer_ms(krk_plan* plan, float* ms_host, int cap) {
 
 namespace {
 
+// ---- kernel argument blocks from a step's geometry ------------------------------------------------------------------
+void fill_conv(const ConvGeom& g, ConvArgs& a, const float* xin, float* yout, int Nn, int Wn, const int* li, const int* lo) {
+    a.x = xin; a.y = yout; a.wpack = g.d_w; a.bias = g.d_b;
+    a.len_in = li; a.len_out = lo;
+    a.N = Nn; a.Cin = g.Cin; a.H = g.H; a.W = Wn;
+    a.Cout = g.Cout; a.CBpad = g.CBpad;
+    a.kh = g.kh; a.kw = g.kw; a.sh = g.sh; a.sw = g.sw; a.dh = g.dh; a.dw = g.dw; a.ph = g.ph; a.pw = g.pw;
+    a.Ho = g.Ho;
+    a.Wo = g.in_seq ? Wn : conv_out(Wn, g.kw, g.sw, g.dw, g.pw);
+    a.Hy = g.Hy;
+    a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
+    a.act = g.act;
+    a.cchunk = g.cchunk; a.nchunks = g.nchunks; a.Kc = g.Kc;
+    a.KSG = g.KSG; a.KSG_last = g.KSG_last; a.KSGpad = g.KSGpad; a.KS4 = g.KS4; a.vec4 = g.vec4;
+    a.IH = g.IH; a.IW = g.IW; a.RS = g.RS; a.PS = g.PS; a.SR = g.SR;
+    a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
+    a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
+    a.otab_floats = g.otab_floats;
+    a.y_split = nullptr; a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0;
+}
+
+void fill_x3(const ConvGeom& g, X3Args& a, const void* xin, size_t x_plane, void* yout, int Nn, int Wn, const int* li,
+             const int* lo, int dbg) {
+    a.x = (const __bf16*)xin; a.x_plane = x_plane; a.y = yout;
+    a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
+    a.len_in = li; a.len_out = lo;
+    a.N = Nn; a.Cin = g.Cin; a.H = g.H; a.W = Wn;
+    a.Cout = g.Cout; a.CBpad = g.CBpad;
+    a.kh = g.kh; a.kw = g.kw; a.sh = g.sh; a.sw = g.sw; a.dh = g.dh; a.dw = g.dw; a.ph = g.ph; a.pw = g.pw;
+    a.Ho = g.Ho;
+    a.Wo = g.in_seq ? Wn : conv_out(Wn, g.kw, g.sw, g.dw, g.pw);
+    a.Hy = g.Hy;
+    a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
+    a.act = g.act;
+    a.cchunk = g.xchunk; a.nchunks = g.xnchunks; a.KB = g.xKB; a.KB_last = g.xKB_last;
+    a.IH = g.IH; a.IW = g.IW; a.PSTR = g.xPSTR; a.lds_plane = g.xplane; a.SR = g.SR;
+    a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
+    a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
+    a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0; a.y_blkM = 0; a.y_cols = 0; a.y_f32 = g.out_f32;
+    a.dbg = dbg;
+}
+
+void fill_gemm(const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane, float* yout, int rows, int dbg) {
+    a.x = (const __bf16*)xin; a.x_plane = x_plane;
+    a.w = (const __bf16*)g.d_wx3; a.bias = g.d_b; a.y = yout;
+    a.M = rows; a.K = g.Cin; a.Cout = g.Cout;
+    a.ncg = (g.Cout + 127) / 128; a.ntiles = (rows + 255) / 256;
+    a.act = g.act;
+    a.tileT = 0;
+    a.dbg = dbg;
+}
+
+// strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
+void split_strides(const ConvGeom& g, int Wo_, int Wy_, long& sn, long& sr, long& sc) {
+    if (g.out_seq) { sn = (long)Wo_ * g.Ho * g.Cout; sc = (long)g.Ho * g.Cout; sr = g.Cout; }
+    else { sn = (long)g.Hy * Wy_ * g.Cout; sr = (long)Wy_ * g.Cout; sc = g.Cout; }
+}
+
+// Probe switches (not API): looked up once per forward call -- the tools and a few tests flip them
+// between calls on a live plan.
+struct Probes {
+    int x3_dbg = env_int("KRK_X3_DBG");          // ablation bits of the split-bf16 conv / projection kernels (-DKRK_ABLATE builds)
+    int lstm_dbg = env_int("KRK_LSTM_DBG");      // ablation bits of the recurrent kernels
+    int lstm_v = env_int("KRK_LSTM_V", 3);       // 1: streaming recurrent kernel instead of the weight-stationary one
+    int lstm_g = env_int("KRK_LSTM_G", 2);       // 4: four 16-line groups per cluster
+    int lstm_m = env_int("KRK_LSTM_M");          // f32 plan: force 16- or 32-line tiles
+};
+
+constexpr int kFailed = -100;     // a step hit a hard error: the KRK_E_* code is in Pass::err, the message in g_err
+
+// One forward call over a plan's schedule: what the steps share, and one method per step family.  The methods return a
+// launcher code (0 ok, -4 unsupported configuration, other: launch failed) or kFailed.
+struct Pass {
+    krk_plan* p;
+    int N;
+    hipStream_t stream;
+    const int* lens_host;
+    bool one;                         // plain-bf16 plan: the _b1 launchers (cross terms compiled out)
+    Probes probe;
+    std::vector<int> Ws;              // tensor width per length stage
+    const int* d_lens = nullptr;      // [stage][N] valid widths on the device (null: every line is full width)
+    bool front_done = false;
+    int err = KRK_OK;
+
+    const int* lens_at(int stage) const { return d_lens ? d_lens + (size_t)stage * N : nullptr; }
+    int hard(int code, const std::string& msg) { err = fail(code, msg); return kFailed; }
+    int nomem() { return hard(KRK_E_NOMEM, "forward: workspace allocation failed"); }
+    int hip(hipError_t e, const char* what) {
+        return e == hipSuccess ? 0 : hard(KRK_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+    // marks the start of a profiled launch group (HIP event on the caller's stream)
+    int mark(const char* name, double flops) {
+        if (!p->profiling || p->prof_n + 1 >= p->events.size()) return 0;
+        if (hipEventRecord(p->events[p->prof_n], stream) != hipSuccess) return hard(KRK_E_HIP, "hipEventRecord failed");
+        p->prof_names[p->prof_n] = name;
+        p->prof_flops[p->prof_n] = flops;
+        ++p->prof_n;
+        return 0;
+    }
+
+    int widths(int W);
+    int upload_lens(int W);
+    int conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win);
+    int layout(Step& s, const float* cur, float* outp, size_t out_elems, int Win, int Wout);
+    int split_input(Step& s, const float* cur, size_t in_elems, const void** xin);
+    int linear(Step& s, const float* cur, float* outp, int Win);
+    int lstm(Step& s, const float* cur, float* outp, size_t out_elems, int Win);
+    int recurrence_x3(Step& s, float* outp, size_t out_elems, int N, int T, int G);
+    int recurrence_f32(Step& s, float* outp, int N, int T, int G);
+};
+
+// per-stage tensor widths
+int Pass::widths(int W) {
+    Ws.assign(p->nstages, 0);
+    Ws[0] = W;
+    for (int s = 0; s + 1 < p->nstages; ++s) {
+        Ws[s + 1] = shape_after(p->lenops[s], Ws[s]);
+        if (Ws[s + 1] <= 0) return hard(KRK_E_INVALID, "forward: input width " + std::to_string(W) + " too small for this network");
+    }
+    return 0;
+}
+
+// per-line valid widths of every stage, computed on the host, one asynchronous upload through a pinned buffer
+int Pass::upload_lens(int W) {
+    if (!lens_host) return 0;
+    const size_t cnt = (size_t)p->nstages * N;
+    if (cnt > p->h_lens_cap) {
+        if (p->lens_ev_pending) { if (int r = hip(hipEventSynchronize(p->lens_ev), "hipEventSynchronize")) return r; p->lens_ev_pending = false; }
+        if (p->h_lens_pinned) (void)hipHostFree(p->h_lens_pinned);
+        p->h_lens_pinned = nullptr;
+        if (int r = hip(hipHostMalloc((void**)&p->h_lens_pinned, cnt * sizeof(int) * 2, hipHostMallocDefault), "hipHostMalloc")) return r;
+        p->h_lens_cap = cnt * 2;
+    }
+    if (p->d_lens.ensure(cnt * sizeof(int))) return hard(KRK_E_NOMEM, "forward: length table allocation failed");
+    // the pinned staging buffer may still be in flight from the previous call
+    if (p->lens_ev_pending) { if (int r = hip(hipEventSynchronize(p->lens_ev), "hipEventSynchronize")) return r; p->lens_ev_pending = false; }
+    int* hl = p->h_lens_pinned;
+    for (int n = 0; n < N; ++n) {
+        int l = lens_host[n];
+        if (l < 1 || l > W) return hard(KRK_E_INVALID, "forward: lens[" + std::to_string(n) + "] outside [1, W]");
+        hl[n] = l;
+        for (int s = 0; s + 1 < p->nstages; ++s) {
+            l = width_after(p->lenops[s], l);
+            hl[(size_t)(s + 1) * N + n] = std::max(0, std::min(l, Ws[s + 1]));
+        }
+    }
+    if (int r = hip(hipMemcpyAsync(p->d_lens.p, hl, cnt * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync")) return r;
+    if (int r = hip(hipEventRecord(p->lens_ev, stream), "hipEventRecord")) return r;
+    p->lens_ev_pending = true;
+    d_lens = (const int*)p->d_lens.p;
+    return 0;
+}
+
+// ActConv2D (+ fused MaxPool / reshape): tap-as-K, split-bf16 implicit GEMM, split-bf16 first layer, or exact f32
+int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win) {
+    const ConvGeom& g = s.cg;
+    if (g.taps) {
+        ConvTapArgs a;
+        a.pitch = nhcw_pitch(Win);
+        a.x = (const __bf16*)cur; a.x_plane = (size_t)N * s.C * s.H * a.pitch;
+        a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
+        a.y = (__bf16*)outp; a.y_plane = out_elems;
+        a.len_out = lens_at(s.len_out);
+        a.N = N; a.H = g.H; a.Cin = g.Cin; a.Cout = g.Cout; a.kh = g.kh; a.kw = g.kw; a.ph = g.ph; a.pw = g.pw;
+        a.Ho = g.Ho; a.Wo = conv_out(Win, g.kw, g.sw, g.dw, g.pw);
+        a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
+        a.act = g.act;
+        a.tiles_h = (g.Ho + 3) / 4; a.tiles_w = (a.Wo + 127) / 128;
+        a.y_f32 = g.out_f32;
+        a.dbg = probe.x3_dbg;
+        split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+        s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
+        if (mark("conv_taps_x3", s.flops)) return kFailed;
+        return one ? krk_launch_conv_taps_b1(a, g.pool, stream) : krk_launch_conv_taps(a, g.pool, stream);
+    }
+    if (g.x3) {
+        X3Args a;
+        fill_x3(g, a, cur, (size_t)N * s.C * s.H * Win, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out), probe.x3_dbg);
+        a.y_plane = out_elems;
+        split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+        if (g.out_seq) {   // sequence rows for the projection: K-blocked
+            a.y_cols = g.pool ? a.Wy : a.Wo;
+            a.y_blkM = N * a.y_cols;
+        }
+        s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
+        if (mark("conv_x3", s.flops)) return kFailed;
+        return one ? krk_launch_conv_x3_b1(a, false, g.pool, stream) : krk_launch_conv_x3(a, false, g.pool, stream);
+    }
+    if (g.c1x3) {
+        Conv1Args a;
+        a.x = cur; a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
+        a.y = (__bf16*)outp; a.y_plane = out_elems;
+        a.len_in = lens_at(s.len_in); a.len_out = lens_at(s.len_out);
+        a.N = N; a.H = g.H; a.W = Win; a.Cout = g.Cout; a.kh = g.kh; a.kw = g.kw; a.ph = g.ph; a.pw = g.pw;
+        a.Ho = g.Ho; a.Wo = conv_out(Win, g.kw, g.sw, g.dw, g.pw);
+        a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
+        a.act = g.act;
+        a.tiles_h = (g.Ho + 7) / 8; a.tiles_w = (a.Wo + 127) / 128;
+        split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+        a.y_pitch = g.out_nhcw ? nhcw_pitch(a.Wy) : 0;
+        a.y_f32 = g.out_f32;
+        a.dbg = probe.x3_dbg;
+        s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
+        if (mark("conv1_x3", s.flops)) return kFailed;
+        return one ? krk_launch_conv1_x3_b1(a, g.pool, stream) : krk_launch_conv1_x3(a, g.pool, stream);
+    }
+    ConvArgs a;
+    fill_conv(g, a, cur, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));
+    if (g.split_out) {
+        a.y_split = outp;
+        a.y_plane = out_elems;
+        split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+    }
+    s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
+    if (mark("conv", s.flops)) return kFailed;
+    return krk_launch_conv(a, false, g.out_seq, g.pool, stream);
+}
+
+// the steps without arithmetic of their own: MaxPool, GroupNorm, reshapes and layout changes
+int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int Win, int Wout) {
+    s.flops = 0;
+    switch (s.kind) {
+        case S_MAXPOOL:
+            if (s.on_split) {
+                if (mark("maxpool_x3", 0)) return kFailed;
+                return krk_launch_maxpool_x3(cur, (size_t)N * s.C * s.H * Win, outp, out_elems, lens_at(s.len_out), N, s.C, s.H, Win,
+                                             s.kh, s.kw, s.sh, s.sw, s.Ho, Wout, stream);
+            }
+            if (mark("maxpool", 0)) return kFailed;
+            return krk_launch_maxpool(cur, outp, lens_at(s.len_out), N, s.C, s.H, Win, s.kh, s.kw, s.sh, s.sw, s.Ho, Wout, stream);
+        case S_GN: {
+            if (s.on_split) {
+                const int chunks = krk_gn_x3_chunks(N, s.H, Win);
+                if (s.aux.ensure((size_t)2 * N * (chunks + 1) * s.C * sizeof(float))) return nomem();
+                if (mark("groupnorm_x3", 0)) return kFailed;
+                return krk_launch_gn_x3(cur, s.in_f32, outp, out_elems, s.d_gamma, s.d_beta, lens_at(s.len_in), (float*)s.aux.p, N, s.C,
+                                        s.H, Win, s.groups, 1e-5f, stream);
+            }
+            if (mark("groupnorm", 0)) return kFailed;
+            const int chunks = krk_groupnorm_chunks(N, s.C, s.H, Win, s.groups);
+            float* scratch = nullptr;
+            if (chunks > 1) {
+                if (s.aux.ensure((size_t)2 * N * s.groups * chunks * sizeof(float))) return nomem();
+                scratch = (float*)s.aux.p;
+            }
+            return krk_launch_groupnorm(cur, outp, s.d_gamma, s.d_beta, lens_at(s.len_in), N, s.C, s.H, Win, s.groups, 1e-5f,
+                                        scratch, stream);
+        }
+        case S_TOSEQ:
+            if (s.on_split) {
+                if (mark("to_seq_x3", 0)) return kFailed;
+                return krk_launch_toseq_x3(cur, outp, out_elems, N, s.C, s.H, Win, stream);
+            }
+            if (mark("to_seq", 0)) return kFailed;
+            return krk_launch_to_seq(cur, outp, N, s.C, s.H, Win, stream);
+        case S_UNSPLIT:
+            if (mark("unsplit", 0)) return kFailed;
+            return krk_launch_unsplit(cur, out_elems, outp, N, s.C, s.H, Win, stream);
+        case S_IMG2ROWS:
+            if (mark("img2rows", 0)) return kFailed;
+            return krk_launch_img2rows(cur, outp, N, s.C, s.H, Win, s.yaxis, stream);
+        case S_ROWS2IMG:
+            if (mark("rows2img", 0)) return kFailed;
+            return krk_launch_rows2img(cur, outp, N, s.C, s.H, Win, s.yaxis, s.yaxis ? lens_at(s.len_in) : nullptr, s.last_only, stream);
+        default:
+            return -4;
+    }
+}
+
+// fp32 rows (from an f32 producer) -> the split planes the bf16x3 projection reads; a no-op when they arrive split
+int Pass::split_input(Step& s, const float* cur, size_t in_elems, const void** xin) {
+    *xin = cur;
+    if (s.in_split) return 0;
+    if (s.aux2.ensure(in_elems * sizeof(float))) return nomem();
+    if (mark("split", 0)) return kFailed;
+    if (int rc = krk_launch_split_rows(cur, s.aux2.p, (int)(in_elems / s.cg.Cin), s.cg.Cin, stream)) return rc;
+    *xin = s.aux2.p;
+    return 0;
+}
+
+// LinSoftmax's projection (logits; the softmax belongs to the decode)
+int Pass::linear(Step& s, const float* cur, float* outp, int Win) {
+    s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
+    if (s.cg.x3) {
+        const size_t in_elems = (size_t)N * Win * s.cg.Cin;
+        const void* xin;
+        if (int rc = split_input(s, cur, in_elems, &xin)) return rc;
+        GemmX3Args a;
+        fill_gemm(s.cg, a, xin, in_elems, outp, N * Win, probe.x3_dbg);
+        if (mark("linear_x3", s.flops)) return kFailed;
+        return one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
+    }
+    ConvArgs a;
+    fill_conv(s.cg, a, cur, outp, 1, N * Win, nullptr, nullptr);
+    if (mark("linear", s.flops)) return kFailed;
+    return krk_launch_conv(a, true, true, false, stream);
+}
+
+// TransposedSummarizingRNN: the input projection of every step as one GEMM, then the recurrence
+int Pass::lstm(Step& s, const float* cur, float* outp, size_t out_elems, int Win) {
+    if (s.img_axis == 1 && lens_host)
+        return hard(KRK_E_UNSUPPORTED, "forward: seq_lens with an LSTM over image rows (the reference raises too, layers.py:528-530)");
+    // sequences and steps: plain (N, W); image rows (N*H, W); image columns (N*W, H)
+    const int Himg = s.outH;
+    const int T = s.img_axis == 2 ? Himg : Win;
+    const int Ns = s.img_axis == 1 ? N * Himg : (s.img_axis == 2 ? N * Win : N);
+    const int G = 4 * s.Hp;
+    // tile-time-major projections (bf16x3 recurrence) address whole 16-line tiles: pad the row count
+    const size_t xp_elems = (size_t)(s.rec_x3 ? (Ns + 15) / 16 * 16 : Ns) * T * s.ndir * G;
+    if (s.aux.ensure(xp_elems * sizeof(float))) return nomem();
+    const double xflops = 2.0 * Ns * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin;
+    int rc;
+    if (s.cg.x3) {
+        const size_t in_elems = (size_t)Ns * T * s.cg.Cin;
+        const void* xin;
+        if ((rc = split_input(s, cur, in_elems, &xin))) return rc;
+        GemmX3Args a;
+        fill_gemm(s.cg, a, xin, in_elems, (float*)s.aux.p, Ns * T, probe.x3_dbg);
+        a.tileT = s.rec_x3 ? T : 0;
+        if (mark("lstm_xproj_x3", xflops)) return kFailed;
+        rc = one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
+    } else {
+        ConvArgs a;
+        fill_conv(s.cg, a, cur, (float*)s.aux.p, 1, Ns * T, nullptr, nullptr);
+        if (mark("lstm_xproj", xflops)) return kFailed;
+        rc = krk_launch_conv(a, true, true, false, stream);
+    }
+    if (rc) return rc;
+    if (!front_done) {   // convolution block + first projection are enqueued: the next batch may start its own
+        if ((rc = hip(hipEventRecord(p->front_ev, stream), "hipEventRecord"))) return rc;
+        front_done = true;
+    }
+    if (mark(s.rec_x3 ? "lstm_rec_x3" : "lstm_rec", 2.0 * Ns * (double)T * s.ndir * 4.0 * s.hidden * s.hidden)) return kFailed;
+    if (lens_host && (rc = hip(hipMemsetAsync(outp, 0, out_elems * sizeof(float), stream), "hipMemsetAsync"))) return rc;
+    s.flops = 2.0 * Ns * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
+    return s.rec_x3 ? recurrence_x3(s, outp, out_elems, Ns, T, G) : recurrence_f32(s, outp, Ns, T, G);
+}
+
+// split-bf16 recurrence: the weight-stationary cluster kernel, or the streaming kernel for shapes outside its range
+int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, int G) {
+    LstmX3Args l;
+    l.xp = (const float*)s.aux.p;
+    l.wp = (const __bf16*)s.d_wrecx3;
+    l.out = (__bf16*)outp;
+    l.out_plane = out_elems;
+    l.lens = lens_at(s.len_in);
+    l.N = Ns; l.T = T; l.H = s.hidden; l.Hp = s.Hp; l.G = G;
+    l.NB = G / 16; l.NKB = (s.Hp + 31) / 32;
+    l.ndir = s.ndir; l.dirmode = s.dirmode;
+    l.xstride = s.ndir * G;
+    l.ostride = s.ndir * s.hidden;
+    l.hrow = l.NKB * 64 + 16;
+    l.xtiled = 1;
+    l.dbg = probe.lstm_dbg;
+    if (!s.d_wrecws || probe.lstm_v != 3) return krk_launch_lstm_x3(l, stream);
+    // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time does
+    // not move (1.78 vs 1.83 us: it is not exchange bound), so a launch takes twice as long on half the CUs: same chip time,
+    // worse latency, 86 k vs 96 k lines/s.  KRK_LSTM_G=4 keeps it probeable.
+    const int groups = probe.lstm_g == 4 ? 4 : 2;
+    const size_t gbytes = std::max(krk_lstm_ws_gran_bytes(Ns, s.ndir, s.ws_bpc, 4), krk_lstm_ws_gran_bytes(Ns, s.ndir, s.ws_bpc, 2));
+    if (gbytes > s.ws_gran.cap) {
+        if (s.ws_gran.ensure(gbytes)) return nomem();
+        if (int r = hip(hipMemsetAsync(s.ws_gran.p, 0, s.ws_gran.cap, stream), "hipMemsetAsync")) return r;   // tags of a fresh buffer must not match
+    }
+    LstmWsArgs w;
+    w.xp = l.xp; w.wp = (const __bf16*)s.d_wrecws; w.out = l.out; w.out_plane = l.out_plane; w.lens = l.lens;
+    w.N = l.N; w.T = l.T; w.H = l.H; w.Hp = l.Hp; w.NKB = l.NKB; w.NB = l.NB; w.G = l.G;
+    w.ndir = l.ndir; w.dirmode = l.dirmode; w.xstride = l.xstride; w.ostride = l.ostride; w.hrow = l.hrow;
+    w.BPC = s.ws_bpc;
+    w.gran = (unsigned long long*)s.ws_gran.p;
+    w.ctrl = s.ws_ctrl;
+    w.ticket_base = s.ws_tickets;
+    s.ws_epoch = s.ws_epoch % 65535u + 1u;
+    w.epoch = s.ws_epoch;
+    w.err = p->err_dev;
+    w.dbg = l.dbg;
+    int rc = one ? krk_launch_lstm_ws_b1(w, groups, stream) : krk_launch_lstm_ws(w, groups, stream);
+    if (rc == 0) s.ws_tickets += (unsigned)(krk_lstm_ws_clusters(Ns, s.ndir, groups) * 4);
+    if (rc == -4) rc = krk_launch_lstm_x3(l, stream);
+    return rc;
+}
+
+// exact-f32 recurrence: register-resident kernel for tiny hidden sizes, else 16- or 32-line MFMA tiles
+int Pass::recurrence_f32(Step& s, float* outp, int Ns, int T, int G) {
+    LstmArgs l;
+    l.xp = (const float*)s.aux.p;
+    l.out = outp;
+    l.lens = s.img_axis ? nullptr : lens_at(s.len_in);   // image columns/rows always run their full length
+    l.N = Ns; l.T = T; l.H = s.hidden; l.Hp = s.Hp; l.G = G;
+    l.ndir = s.ndir; l.dirmode = s.dirmode;
+    l.xstride = s.ndir * G;
+    l.ostride = s.ndir * s.hidden;
+    l.dbg = probe.lstm_dbg;
+    if (s.d_wrecsm) {   // hidden size <= 32: one wave per 16 sequences, weights / h / c in registers
+        l.wp = s.d_wrecsm;
+        l.NG = l.NB = 0;
+        return krk_launch_lstm_small(l, stream);
+    }
+    // 32-line tiles once they fill most of the 256 CUs, 16-line tiles below that
+    const int tiles32 = (Ns + 31) / 32 * s.ndir;
+    const int M_auto = tiles32 >= 192 ? 32 : 16;
+    const int M = (probe.lstm_m == 16 || probe.lstm_m == 32) ? probe.lstm_m : M_auto;
+    l.wp = (M == 32) ? s.d_wrec32 : s.d_wrec16;
+    const int ks = s.Hp / ((M == 32) ? 2 : 4);
+    const int kg = krk_lstm_kg(M, (G / M + 3) / 4);
+    l.NG = (ks + kg - 1) / kg;
+    l.NB = G / M;
+    return krk_launch_lstm(l, M, stream);
+}
+
 // Runs the schedule.  `final_out` (may be null) receives the last step's output.
 // On return *final_ptr points at the last step's output buffer and *d_olens at the
 // device copy of the final valid widths (or null when lens_host is null).
@@ -1023,51 +1466,14 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
     if (!p || !x_dev) return fail(KRK_E_INVALID, "forward: null plan or input");
     if (N <= 0 || W <= 0) return fail(KRK_E_INVALID, "forward: N and W must be positive");
     HIPCHK(hipSetDevice(p->device));
-    const bool one = p->precision == KRK_PREC_BF16;    // plain-bf16 plan: the _b1 launchers (cross terms compiled out)
     p->last_N = N;
     p->last_W = W;
     if (p->front_wait) {   // one-shot: this batch's convolution block starts after the other plan's has finished
         HIPCHK(hipStreamWaitEvent(stream, p->front_wait, 0));
         p->front_wait = nullptr;
     }
-    bool front_done = false;
-
-    // ---- per-stage widths (tensor extents) and per-line valid widths
-    std::vector<int> Ws(p->nstages);
-    Ws[0] = W;
-    for (int s = 0; s + 1 < p->nstages; ++s) {
-        Ws[s + 1] = shape_after(p->lenops[s], Ws[s]);
-        if (Ws[s + 1] <= 0) return fail(KRK_E_INVALID, "forward: input width " + std::to_string(W) + " too small for this network");
-    }
-    const int* d_lens = nullptr;
-    if (lens_host) {
-        const size_t cnt = (size_t)p->nstages * N;
-        if (cnt > p->h_lens_cap) {
-            if (p->lens_ev_pending) { HIPCHK(hipEventSynchronize(p->lens_ev)); p->lens_ev_pending = false; }
-            if (p->h_lens_pinned) (void)hipHostFree(p->h_lens_pinned);
-            p->h_lens_pinned = nullptr;
-            HIPCHK(hipHostMalloc((void**)&p->h_lens_pinned, cnt * sizeof(int) * 2, hipHostMallocDefault));
-            p->h_lens_cap = cnt * 2;
-        }
-        if (p->d_lens.ensure(cnt * sizeof(int))) return fail(KRK_E_NOMEM, "forward: length table allocation failed");
-        // the pinned staging buffer may still be in flight from the previous call
-        if (p->lens_ev_pending) { HIPCHK(hipEventSynchronize(p->lens_ev)); p->lens_ev_pending = false; }
-        int* hl = p->h_lens_pinned;
-        for (int n = 0; n < N; ++n) {
-            int l = lens_host[n];
-            if (l < 1 || l > W) return fail(KRK_E_INVALID, "forward: lens[" + std::to_string(n) + "] outside [1, W]");
-            hl[n] = l;
-            for (int s = 0; s + 1 < p->nstages; ++s) {
-                l = width_after(p->lenops[s], l);
-                hl[(size_t)(s + 1) * N + n] = std::max(0, std::min(l, Ws[s + 1]));
-            }
-        }
-        HIPCHK(hipMemcpyAsync(p->d_lens.p, hl, cnt * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipEventRecord(p->lens_ev, stream));
-        p->lens_ev_pending = true;
-        d_lens = (const int*)p->d_lens.p;
-    }
-    auto lens_at = [&](int stage) -> const int* { return d_lens ? d_lens + (size_t)stage * N : nullptr; };
+    Pass pass{p, N, stream, lens_host, p->precision == KRK_PREC_BF16};
+    if (pass.widths(W) || pass.upload_lens(W)) return pass.err;
 
     const float* cur = x_dev;
     const size_t nsteps = p->steps.size();
@@ -1076,18 +1482,9 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         p->prof_names.assign(p->events.size(), nullptr);
         p->prof_flops.assign(p->events.size(), 0.0);
     }
-    // marks the start of a profiled launch group (HIP event on the caller's stream)
-    auto mark = [&](const char* name, double flops) -> int {
-        if (!p->profiling || p->prof_n + 1 >= p->events.size()) return 0;
-        if (hipEventRecord(p->events[p->prof_n], stream) != hipSuccess) return -1;
-        p->prof_names[p->prof_n] = name;
-        p->prof_flops[p->prof_n] = flops;
-        ++p->prof_n;
-        return 0;
-    };
     for (size_t si = 0; si < nsteps; ++si) {
         Step& s = p->steps[si];
-        const int Win = Ws[s.len_in], Wout = Ws[s.len_out];
+        const int Win = pass.Ws[s.len_in], Wout = pass.Ws[s.len_out];
         const bool is_last = (si + 1 == nsteps);
         size_t out_elems = (size_t)N * s.outC * s.outH * Wout;
         if (s.kind == S_CONV && s.cg.out_nhcw) out_elems = (size_t)N * s.outC * s.outH * nhcw_pitch(Wout);
@@ -1097,347 +1494,24 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
             if (s.out.ensure(out_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
             outp = (float*)s.out.p;
         }
-        auto fill_conv = [&](const ConvGeom& g, ConvArgs& a, const float* xin, float* yout, int Nn, int Wn,
-                             const int* li, const int* lo) {
-            a.x = xin; a.y = yout; a.wpack = g.d_w; a.bias = g.d_b;
-            a.len_in = li; a.len_out = lo;
-            a.N = Nn; a.Cin = g.Cin; a.H = g.H; a.W = Wn;
-            a.Cout = g.Cout; a.CBpad = g.CBpad;
-            a.kh = g.kh; a.kw = g.kw; a.sh = g.sh; a.sw = g.sw; a.dh = g.dh; a.dw = g.dw; a.ph = g.ph; a.pw = g.pw;
-            a.Ho = g.Ho;
-            a.Wo = g.in_seq ? Wn : conv_out(Wn, g.kw, g.sw, g.dw, g.pw);
-            a.Hy = g.Hy;
-            a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
-            a.act = g.act;
-            a.cchunk = g.cchunk; a.nchunks = g.nchunks; a.Kc = g.Kc;
-            a.KSG = g.KSG; a.KSG_last = g.KSG_last; a.KSGpad = g.KSGpad; a.KS4 = g.KS4; a.vec4 = g.vec4;
-            a.IH = g.IH; a.IW = g.IW; a.RS = g.RS; a.PS = g.PS; a.SR = g.SR;
-            a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
-            a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
-            a.otab_floats = g.otab_floats;
-            a.y_split = nullptr; a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0;
-        };
-        auto fill_x3 = [&](const ConvGeom& g, X3Args& a, const void* xin, size_t x_plane, void* yout, int Nn, int Wn,
-                           const int* li, const int* lo) {
-            a.x = (const __bf16*)xin; a.x_plane = x_plane; a.y = yout;
-            a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
-            a.len_in = li; a.len_out = lo;
-            a.N = Nn; a.Cin = g.Cin; a.H = g.H; a.W = Wn;
-            a.Cout = g.Cout; a.CBpad = g.CBpad;
-            a.kh = g.kh; a.kw = g.kw; a.sh = g.sh; a.sw = g.sw; a.dh = g.dh; a.dw = g.dw; a.ph = g.ph; a.pw = g.pw;
-            a.Ho = g.Ho;
-            a.Wo = g.in_seq ? Wn : conv_out(Wn, g.kw, g.sw, g.dw, g.pw);
-            a.Hy = g.Hy;
-            a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
-            a.act = g.act;
-            a.cchunk = g.xchunk; a.nchunks = g.xnchunks; a.KB = g.xKB; a.KB_last = g.xKB_last;
-            a.IH = g.IH; a.IW = g.IW; a.PSTR = g.xPSTR; a.lds_plane = g.xplane; a.SR = g.SR;
-            a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
-            a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
-            a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0; a.y_blkM = 0; a.y_cols = 0; a.y_f32 = g.out_f32;
-            a.dbg = env_int("KRK_X3_DBG");
-        };
-        auto fill_gemm = [&](const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane, float* yout, int rows) {
-            a.x = (const __bf16*)xin; a.x_plane = x_plane;
-            a.w = (const __bf16*)g.d_wx3; a.bias = g.d_b; a.y = yout;
-            a.M = rows; a.K = g.Cin; a.Cout = g.Cout;
-            a.ncg = (g.Cout + 127) / 128; a.ntiles = (rows + 255) / 256;
-            a.act = g.act;
-            a.tileT = 0;
-            a.dbg = env_int("KRK_X3_DBG");
-        };
-        // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
-        auto split_strides = [&](const ConvGeom& g, int Wo_, int Wy_, long& sn, long& sr, long& sc) {
-            if (g.out_seq) { sn = (long)Wo_ * g.Ho * g.Cout; sc = (long)g.Ho * g.Cout; sr = g.Cout; }
-            else { sn = (long)g.Hy * Wy_ * g.Cout; sr = (long)Wy_ * g.Cout; sc = g.Cout; }
-        };
-        int rc = 0;
+        int rc;
         switch (s.kind) {
-            case S_CONV: {
-                if (s.cg.taps) {
-                    const ConvGeom& g = s.cg;
-                    ConvTapArgs a;
-                    a.pitch = nhcw_pitch(Win);
-                    a.x = (const __bf16*)cur; a.x_plane = (size_t)N * s.C * s.H * a.pitch;
-                    a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
-                    a.y = (__bf16*)outp; a.y_plane = out_elems;
-                    a.len_out = lens_at(s.len_out);
-                    a.N = N; a.H = g.H; a.Cin = g.Cin; a.Cout = g.Cout; a.kh = g.kh; a.kw = g.kw; a.ph = g.ph; a.pw = g.pw;
-                    a.Ho = g.Ho; a.Wo = conv_out(Win, g.kw, g.sw, g.dw, g.pw);
-                    a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
-                    a.act = g.act;
-                    a.tiles_h = (g.Ho + 3) / 4; a.tiles_w = (a.Wo + 127) / 128;
-                    a.y_f32 = g.out_f32;
-                    a.dbg = env_int("KRK_X3_DBG");
-                    split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
-                    s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
-                    if (mark("conv_taps_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
-                    rc = one ? krk_launch_conv_taps_b1(a, g.pool, stream) : krk_launch_conv_taps(a, g.pool, stream);
-                    break;
-                }
-                if (s.cg.x3) {
-                    X3Args a;
-                    fill_x3(s.cg, a, cur, (size_t)N * s.C * s.H * Win, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));
-                    a.y_plane = out_elems;
-                    split_strides(s.cg, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
-                    if (s.cg.out_seq) {   // sequence rows for the projection: K-blocked
-                        a.y_cols = s.cg.pool ? a.Wy : a.Wo;
-                        a.y_blkM = N * a.y_cols;
-                    }
-                    s.flops = 2.0 * N * (double)s.cg.Ho * a.Wo * s.cg.Cout * s.cg.Cin * s.cg.kh * s.cg.kw;
-                    if (mark("conv_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
-                    rc = one ? krk_launch_conv_x3_b1(a, false, s.cg.pool, stream) : krk_launch_conv_x3(a, false, s.cg.pool, stream);
-                    break;
-                }
-                if (s.cg.c1x3) {
-                    const ConvGeom& g = s.cg;
-                    Conv1Args a;
-                    a.x = cur; a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
-                    a.y = (__bf16*)outp; a.y_plane = out_elems;
-                    a.len_in = lens_at(s.len_in); a.len_out = lens_at(s.len_out);
-                    a.N = N; a.H = g.H; a.W = Win; a.Cout = g.Cout; a.kh = g.kh; a.kw = g.kw; a.ph = g.ph; a.pw = g.pw;
-                    a.Ho = g.Ho; a.Wo = conv_out(Win, g.kw, g.sw, g.dw, g.pw);
-                    a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
-                    a.act = g.act;
-                    a.tiles_h = (g.Ho + 7) / 8; a.tiles_w = (a.Wo + 127) / 128;
-                    split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
-                    a.y_pitch = g.out_nhcw ? nhcw_pitch(a.Wy) : 0;
-                    a.y_f32 = g.out_f32;
-                    a.dbg = env_int("KRK_X3_DBG");
-                    s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
-                    if (mark("conv1_x3", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
-                    rc = one ? krk_launch_conv1_x3_b1(a, g.pool, stream) : krk_launch_conv1_x3(a, g.pool, stream);
-                    break;
-                }
-                ConvArgs a;
-                fill_conv(s.cg, a, cur, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));
-                if (s.cg.split_out) {
-                    a.y_split = outp;
-                    a.y_plane = out_elems;
-                    split_strides(s.cg, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
-                }
-                s.flops = 2.0 * N * (double)s.cg.Ho * a.Wo * s.cg.Cout * s.cg.Cin * s.cg.kh * s.cg.kw;
-                if (mark("conv", s.flops)) return fail(KRK_E_HIP, "hipEventRecord failed");
-                rc = krk_launch_conv(a, false, s.cg.out_seq, s.cg.pool, stream);
-                break;
-            }
-            case S_MAXPOOL:
-                s.flops = 0;
-                if (s.on_split) {
-                    mark("maxpool_x3", 0);
-                    rc = krk_launch_maxpool_x3(cur, (size_t)N * s.C * s.H * Win, outp, out_elems, lens_at(s.len_out), N, s.C, s.H, Win,
-                                               s.kh, s.kw, s.sh, s.sw, s.Ho, Wout, stream);
-                    break;
-                }
-                mark("maxpool", 0);
-                rc = krk_launch_maxpool(cur, outp, lens_at(s.len_out), N, s.C, s.H, Win, s.kh, s.kw, s.sh, s.sw, s.Ho,
-                                        Wout, stream);
-                break;
-            case S_GN:
-                s.flops = 0;
-                if (s.on_split) {
-                    const int chunks = krk_gn_x3_chunks(N, s.H, Win);
-                    if (s.aux.ensure((size_t)2 * N * (chunks + 1) * s.C * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
-                    mark("groupnorm_x3", 0);
-                    rc = krk_launch_gn_x3(cur, s.in_f32, outp, out_elems, s.d_gamma, s.d_beta, lens_at(s.len_in), (float*)s.aux.p, N, s.C,
-                                          s.H, Win, s.groups, 1e-5f, stream);
-                    break;
-                }
-                mark("groupnorm", 0);
-                {
-                    const int chunks = krk_groupnorm_chunks(N, s.C, s.H, Win, s.groups);
-                    float* scratch = nullptr;
-                    if (chunks > 1) {
-                        if (s.aux.ensure((size_t)2 * N * s.groups * chunks * sizeof(float)))
-                            return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
-                        scratch = (float*)s.aux.p;
-                    }
-                    rc = krk_launch_groupnorm(cur, outp, s.d_gamma, s.d_beta, lens_at(s.len_in), N, s.C, s.H, Win, s.groups,
-                                              1e-5f, scratch, stream);
-                }
-                break;
-            case S_TOSEQ:
-                s.flops = 0;
-                if (s.on_split) {
-                    mark("to_seq_x3", 0);
-                    rc = krk_launch_toseq_x3(cur, outp, out_elems, N, s.C, s.H, Win, stream);
-                    break;
-                }
-                mark("to_seq", 0);
-                rc = krk_launch_to_seq(cur, outp, N, s.C, s.H, Win, stream);
-                break;
-            case S_UNSPLIT:
-                s.flops = 0;
-                mark("unsplit", 0);
-                rc = krk_launch_unsplit(cur, out_elems, outp, N, s.C, s.H, Win, stream);
-                break;
-            case S_IMG2ROWS:
-                s.flops = 0;
-                mark("img2rows", 0);
-                rc = krk_launch_img2rows(cur, outp, N, s.C, s.H, Win, s.yaxis, stream);
-                break;
-            case S_ROWS2IMG:
-                s.flops = 0;
-                mark("rows2img", 0);
-                rc = krk_launch_rows2img(cur, outp, N, s.C, s.H, Win, s.yaxis, s.yaxis ? lens_at(s.len_in) : nullptr, s.last_only, stream);
-                break;
-            case S_LINEAR: {
-                s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
-                if (s.cg.x3) {
-                    const size_t in_elems = (size_t)N * Win * s.cg.Cin;
-                    const void* xin = cur;
-                    if (!s.in_split) {   // fp32 rows from the recurrent kernel -> split planes
-                        if (s.aux2.ensure(in_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
-                        mark("split", 0);
-                        rc = krk_launch_split_rows(cur, s.aux2.p, (int)(in_elems / s.cg.Cin), s.cg.Cin, stream);
-                        if (rc) break;
-                        xin = s.aux2.p;
-                    }
-                    GemmX3Args a;
-                    fill_gemm(s.cg, a, xin, in_elems, (float*)outp, N * Win);
-                    mark("linear_x3", s.flops);
-                    rc = one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
-                    break;
-                }
-                ConvArgs a;
-                fill_conv(s.cg, a, cur, outp, 1, N * Win, nullptr, nullptr);
-                mark("linear", s.flops);
-                rc = krk_launch_conv(a, true, true, false, stream);
-                break;
-            }
-            case S_LSTM: {
-                if (s.img_axis == 1 && lens_host)
-                    return fail(KRK_E_UNSUPPORTED, "forward: seq_lens with an LSTM over image rows (the reference raises too, layers.py:528-530)");
-                // sequences and steps: plain (N, W); image rows (N*H, W); image columns (N*W, H)
-                const int Nimg = N, Himg = s.outH;
-                const int T = s.img_axis == 2 ? Himg : Win;
-                const int N = s.img_axis == 1 ? Nimg * Himg : (s.img_axis == 2 ? Nimg * Win : Nimg);
-                const int G = 4 * s.Hp;
-                // tile-time-major projections (bf16x3 recurrence) address whole 16-line tiles: pad the row count
-                const size_t xp_elems = (size_t)(s.rec_x3 ? (N + 15) / 16 * 16 : N) * T * s.ndir * G;
-                if (s.aux.ensure(xp_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
-                if (s.cg.x3) {
-                    const size_t in_elems = (size_t)N * T * s.cg.Cin;
-                    const void* xin = cur;
-                    if (!s.in_split) {
-                        if (s.aux2.ensure(in_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
-                        mark("split", 0);
-                        rc = krk_launch_split_rows(cur, s.aux2.p, (int)(in_elems / s.cg.Cin), s.cg.Cin, stream);
-                        if (rc) break;
-                        xin = s.aux2.p;
-                    }
-                    GemmX3Args a;
-                    fill_gemm(s.cg, a, xin, in_elems, (float*)s.aux.p, N * T);
-                    a.tileT = s.rec_x3 ? T : 0;
-                    mark("lstm_xproj_x3", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin);
-                    rc = one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
-                } else {
-                    ConvArgs a;
-                    fill_conv(s.cg, a, cur, (float*)s.aux.p, 1, N * T, nullptr, nullptr);
-                    mark("lstm_xproj", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin);
-                    rc = krk_launch_conv(a, true, true, false, stream);
-                }
-                if (rc) break;
-                if (!front_done) {   // convolution block + first projection are enqueued: the next batch may start its own
-                    HIPCHK(hipEventRecord(p->front_ev, stream));
-                    front_done = true;
-                }
-                mark(s.rec_x3 ? "lstm_rec_x3" : "lstm_rec", 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * s.hidden);
-                if (lens_host) HIPCHK(hipMemsetAsync(outp, 0, out_elems * sizeof(float), stream));
-                if (s.rec_x3) {
-                    LstmX3Args l;
-                    l.xp = (const float*)s.aux.p;
-                    l.wp = (const __bf16*)s.d_wrecx3;
-                    l.out = (__bf16*)outp;
-                    l.out_plane = out_elems;
-                    l.lens = lens_at(s.len_in);
-                    l.N = N; l.T = T; l.H = s.hidden; l.Hp = s.Hp; l.G = G;
-                    l.NB = G / 16; l.NKB = (s.Hp + 31) / 32;
-                    l.ndir = s.ndir; l.dirmode = s.dirmode;
-                    l.xstride = s.ndir * G;
-                    l.ostride = s.ndir * s.hidden;
-                    l.hrow = l.NKB * 64 + 16;
-                    l.xtiled = 1;
-                    l.dbg = env_int("KRK_LSTM_DBG");
-                    s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
-                    rc = -4;
-                    // weight-stationary cluster kernel unless the shape is outside its range (then: the streaming kernel);
-                    // KRK_LSTM_V=1 forces the streaming kernel (A/B probing, tools/lstm_probe.py)
-                    if (s.d_wrecws && env_int("KRK_LSTM_V", 3) == 3) {
-                        // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the
-                        // slot time does not move (1.78 vs 1.83 us: it is not exchange bound), so a launch takes twice as long
-                        // on half the CUs: same chip time, worse latency, 86 k vs 96 k lines/s.  KRK_LSTM_G=4 keeps it probeable.
-                        const int groups = env_int("KRK_LSTM_G", 2) == 4 ? 4 : 2;
-                        const size_t gbytes = std::max(krk_lstm_ws_gran_bytes(N, s.ndir, s.ws_bpc, 4), krk_lstm_ws_gran_bytes(N, s.ndir, s.ws_bpc, 2));
-                        if (gbytes > s.ws_gran.cap) {
-                            if (s.ws_gran.ensure(gbytes)) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
-                            HIPCHK(hipMemsetAsync(s.ws_gran.p, 0, s.ws_gran.cap, stream));    // tags of a fresh buffer must not match
-                        }
-                        LstmWsArgs w;
-                        w.xp = l.xp; w.wp = (const __bf16*)s.d_wrecws; w.out = l.out; w.out_plane = l.out_plane; w.lens = l.lens;
-                        w.N = l.N; w.T = l.T; w.H = l.H; w.Hp = l.Hp; w.NKB = l.NKB; w.NB = l.NB; w.G = l.G;
-                        w.ndir = l.ndir; w.dirmode = l.dirmode; w.xstride = l.xstride; w.ostride = l.ostride; w.hrow = l.hrow;
-                        w.BPC = s.ws_bpc;
-                        w.gran = (unsigned long long*)s.ws_gran.p;
-                        w.ctrl = s.ws_ctrl;
-                        w.ticket_base = s.ws_tickets;
-                        s.ws_epoch = s.ws_epoch % 65535u + 1u;
-                        w.epoch = s.ws_epoch;
-                        w.err = p->err_dev;
-                        w.dbg = l.dbg;
-                        rc = one ? krk_launch_lstm_ws_b1(w, groups, stream) : krk_launch_lstm_ws(w, groups, stream);
-                        if (rc == 0) s.ws_tickets += (unsigned)(krk_lstm_ws_clusters(N, s.ndir, groups) * 4);
-                    }
-                    if (rc == -4) rc = krk_launch_lstm_x3(l, stream);
-                    break;
-                }
-                LstmArgs l;
-                l.xp = (const float*)s.aux.p;
-                l.out = outp;
-                l.lens = s.img_axis ? nullptr : lens_at(s.len_in);   // image columns/rows always run their full length
-                l.N = N; l.T = T; l.H = s.hidden; l.Hp = s.Hp; l.G = G;
-                l.ndir = s.ndir; l.dirmode = s.dirmode;
-                l.xstride = s.ndir * G;
-                l.ostride = s.ndir * s.hidden;
-                {
-                    const char* dbg = getenv("KRK_LSTM_DBG");
-                    l.dbg = dbg ? atoi(dbg) : 0;
-                }
-                if (s.d_wrecsm) {   // hidden size <= 32: one wave per 16 sequences, weights / h / c in registers
-                    l.wp = s.d_wrecsm;
-                    l.NG = l.NB = 0;
-                    s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
-                    rc = krk_launch_lstm_small(l, stream);
-                    break;
-                }
-                // 32-line tiles once they fill most of the 256 CUs, 16-line tiles below that
-                const int tiles32 = (N + 31) / 32 * s.ndir;
-                int forced_m = 0;
-                if (const char* fm = getenv("KRK_LSTM_M")) forced_m = atoi(fm);
-                const int M_auto = tiles32 >= 192 ? 32 : 16;
-                const int M = (forced_m == 16 || forced_m == 32) ? forced_m : M_auto;
-                l.wp = (M == 32) ? s.d_wrec32 : s.d_wrec16;
-                {
-                    const int ks = s.Hp / ((M == 32) ? 2 : 4);
-                    const int kg = krk_lstm_kg(M, (G / M + 3) / 4);
-                    l.NG = (ks + kg - 1) / kg;
-                }
-                l.NB = G / M;
-                s.flops = 2.0 * N * (double)T * s.ndir * 4.0 * s.hidden * ((double)s.cg.Cin + s.hidden);
-                rc = krk_launch_lstm(l, M, stream);
-                break;
-            }
+            case S_CONV: rc = pass.conv(s, cur, outp, out_elems, Win); break;
+            case S_LINEAR: rc = pass.linear(s, cur, outp, Win); break;
+            case S_LSTM: rc = pass.lstm(s, cur, outp, out_elems, Win); break;
+            default: rc = pass.layout(s, cur, outp, out_elems, Win, Wout); break;
         }
+        if (rc == kFailed) return pass.err;
         if (rc == -4) return fail(KRK_E_UNSUPPORTED, std::string("forward: unsupported kernel configuration in ") + kStepNames[s.kind]);
         if (rc) return fail(KRK_E_HIP, std::string("forward: launch of ") + kStepNames[s.kind] + " failed: " +
                                            hipGetErrorString(hipGetLastError()));
         cur = outp;
     }
-    if (!front_done) HIPCHK(hipEventRecord(p->front_ev, stream));
+    if (!pass.front_done) HIPCHK(hipEventRecord(p->front_ev, stream));
     if (p->profiling) HIPCHK(hipEventRecord(p->events[p->prof_n], stream));
     if (final_ptr) *final_ptr = cur;
-    if (d_olens) *d_olens = lens_at(p->nstages - 1);
-    if (T_out) *T_out = Ws[p->nstages - 1];
+    if (d_olens) *d_olens = pass.lens_at(p->nstages - 1);
+    if (T_out) *T_out = pass.Ws[p->nstages - 1];
     return KRK_OK;
 }
 

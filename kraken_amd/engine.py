@@ -152,6 +152,38 @@ class RecognitionEngine:
         t = torch.from_numpy(np.ascontiguousarray(page, dtype=np.uint8))
         return t.to(f'cuda:{self.device}', non_blocking=False)
 
+    def page_buffer(self, shape) -> np.ndarray:
+        """
+        Pinned host memory for a page (or a band of one), shape (rows, width[, 3]) uint8: the caller's threads convert the
+        image straight into it, ``upload_page_buffer`` then starts ONE asynchronous DMA -- no intermediate array, no pageable
+        copy.  Two buffers alternate, so band k+1 is filled while band k is still on its way.
+        """
+        if not hasattr(self, '_pg_host'):
+            self._pg_host, self._pg_ev, self._pg_i = [None, None], [None, None], 0
+            self._pg_stream = torch.cuda.Stream(device=self.device)
+        self._pg_i ^= 1
+        i, need = self._pg_i, int(np.prod(shape))
+        if self._pg_ev[i] is not None:
+            self._pg_ev[i].synchronize()              # the upload that last used this buffer has finished
+        if self._pg_host[i] is None or self._pg_host[i].numel() < need:
+            self._pg_host[i] = torch.empty(need + need // 4, dtype=torch.uint8, pin_memory=True)
+        self._pg_shape = tuple(int(v) for v in shape)
+        return self._pg_host[i][:need].numpy().reshape(self._pg_shape)
+
+    def upload_page_buffer(self) -> torch.Tensor:
+        """Starts the upload of the buffer ``page_buffer`` handed out last; the crops wait for it on the device (``submit_boxes``)."""
+        i, need = self._pg_i, int(np.prod(self._pg_shape))
+        dev = torch.empty(self._pg_shape, dtype=torch.uint8, device=f'cuda:{self.device}')
+        self._pg_stream.wait_stream(torch.cuda.current_stream(self.device))      # `dev` may recycle a block still in use there
+        with torch.cuda.stream(self._pg_stream):
+            dev.view(-1).copy_(self._pg_host[i][:need], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._pg_stream)
+        dev.record_stream(self._pg_stream)
+        self._pg_ev[i] = ev
+        dev._krk_ready = ev
+        return dev
+
     def submit_boxes(self, page_dev: torch.Tensor, boxes: np.ndarray, pad: int, want_probs: bool = False) -> int:
         """
         Recognises rectangular crops of an uploaded page: ``boxes`` int32 (n, 5) = x0, y0, x1, y1, resized width.  Crop,
@@ -171,7 +203,11 @@ class RecognitionEngine:
         pc = 1 if page_dev.dim() == 2 else int(page_dev.shape[2])
         if pc != c:
             raise ValueError(f'page has {pc} channels, the model takes {c}')
+        page_dev.record_stream(slot.stream)          # the caller may drop the page before this slot's crops have run
+        ready = getattr(page_dev, '_krk_ready', None)
         with torch.cuda.stream(slot.stream):
+            if ready is not None:
+                slot.stream.wait_event(ready)
             slot.boxes_dev[:n].copy_(slot.boxes_host[:n], non_blocking=True)
             _lib.check(self.lib.krk_prep_lines(page_dev.data_ptr(), ph, pw, pc, slot.boxes_dev.data_ptr(), n,
                                                int((boxes[:, 3] - boxes[:, 1]).max()), h, int(pad), w,

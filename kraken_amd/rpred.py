@@ -27,6 +27,7 @@ kraken/lib/segmentation.py:1630-1643); baseline/polygon extraction is CPU geomet
 delegated to kraken when it is installed.  The module-level name ``extract_polygons`` is kept patchable like in the
 reference (tests/test_newpolygons.py:64-102 mocks it).
 """
+import collections.abc
 import dataclasses
 import logging
 import math
@@ -130,6 +131,43 @@ class _Pending:
     width: int = 0                      # network input width (resized line + padding)
     box: Optional[tuple] = None         # ... prepared on the device: (x0, y0, x1, y1, resized width) into the uploaded page
     mode: str = ''                      # PIL mode of the page the device crops from
+
+
+class LazyList(collections.abc.Sequence):
+    """
+    A read-only list that is computed on first use.  The per-code-point ``cuts`` of a record are ~13 Python objects per
+    code point (a list of four [x, y] pairs each): built eagerly they cost more host time per line than everything else the
+    API path does, and most consumers (text export, string comparison) never look at them.  Behaves like the list the
+    reference stores (indexing, slicing, iteration, len, ==, pickling as a plain list).
+    """
+    __slots__ = ('_make', '_n', '_items')
+
+    def __init__(self, make, n: int):
+        self._make, self._n, self._items = make, n, None
+
+    def _get(self) -> list:
+        if self._items is None:
+            self._items = self._make()
+            self._make = None
+        return self._items
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __eq__(self, other):
+        return self._get() == (other._get() if isinstance(other, LazyList) else other)
+
+    def __repr__(self):
+        return repr(self._get())
+
+    def __reduce__(self):
+        return (list, (self._get(),))
 
 
 @dataclasses.dataclass
@@ -316,6 +354,7 @@ class _RecognitionRun:
         self._temperature_of = temperature_of
         self._want_probs = want_probs
         self._return_image = return_image
+        self._workers = max(1, int(workers or 1))
         self._pool = ThreadPoolExecutor(max_workers=workers) if workers and workers > 1 else None
         # device batch: large enough to fill the chip, small enough that a page still splits into a few batches whose
         # preparation overlaps the device work of their predecessors
@@ -345,20 +384,31 @@ class _RecognitionRun:
         W, H = self.im.size
         y0 = max(min(b[1] for b in boxes), 0)
         y1 = min(max(b[3] for b in boxes), H)
-        if mode in self._pages or (y1 - y0) > 0.6 * H:
-            if mode not in self._pages:
-                im = self.im if self.im.mode == mode else self.im.convert(mode)
-                self._pages[mode] = self._pipe(net).engine.upload_page(np.asarray(im))
+        whole = mode in self._pages or (y1 - y0) > 0.6 * H
+        if mode in self._pages:
             return self._pages[mode], 0
-        # PIL -> numpy copies at ~1 GB/s per thread: cut the band into sub-bands for the worker pool
-        step = max(256, -(-(y1 - y0) // 8))
-        cuts = list(range(y0, y1, step))
+        if whole:
+            y0, y1 = 0, H
+        # PIL -> numpy runs at ~1 GB/s per thread: the band is converted in 256-row pieces by the worker pool, every piece
+        # straight into the engine's pinned upload buffer
+        eng = self._pipe(net).engine
+        buf = eng.page_buffer((y1 - y0, W) if mode == 'L' else (y1 - y0, W, 3))
+        step = 256
 
         def part(ya):
-            sub = self.im.crop((0, ya, W, min(ya + step, y1)))
-            return np.asarray(sub if sub.mode == mode else sub.convert(mode))
-        parts = list(self._pool.map(part, cuts)) if self._pool and len(cuts) > 1 else [part(c) for c in cuts]
-        return self._pipe(net).engine.upload_page(parts[0] if len(parts) == 1 else np.concatenate(parts)), y0
+            yb = min(ya + step, y1)
+            sub = self.im.crop((0, ya, W, yb))
+            buf[ya - y0:yb - y0] = np.asarray(sub if sub.mode == mode else sub.convert(mode))
+        cuts = range(y0, y1, step)
+        if self._pool and len(cuts) > 1:
+            list(self._pool.map(part, cuts))
+        else:
+            for c in cuts:
+                part(c)
+        dev = eng.upload_page_buffer()
+        if whole:
+            self._pages[mode] = dev
+        return dev, y0
 
     def _prepare_on_device(self, idx: int, line, tag: str, net, ts, want_image: bool = False):
         """
@@ -429,7 +479,10 @@ class _RecognitionRun:
         return rec.display_order(None)
 
     def _make_record(self, p: _Pending, r: LineResult):
-        return self._order(self._record_cls(r.text, self._cuts(p, r), r.confs.tolist(), p.line))
+        n = len(r.starts)
+        if self.bidi_reordering or n == 0:      # reordering walks the lists right away: build them
+            return self._order(self._record_cls(r.text, self._cuts(p, r), r.confs.tolist(), p.line))
+        return self._order(self._record_cls(r.text, LazyList(partial(self._cuts, p, r), n), LazyList(r.confs.tolist, n), p.line))
 
     def _empty(self, line, cuts=()):
         return self._record_cls('', cuts, cuts, line)
@@ -452,7 +505,13 @@ class _RecognitionRun:
         """Prepares + submits the next chunk (the device keeps working on earlier ones meanwhile), or waits for results."""
         if self._prepared < self.len:
             idxs = range(self._prepared, min(self._prepared + self._chunk, self.len))
-            items = list(self._pool.map(self._prepare, idxs)) if self._pool else [self._prepare(i) for i in idxs]
+            if self._pool and len(idxs) > 1:
+                # a future per line costs more than a crop descriptor does: hand the pool a few slices per worker instead
+                k = max(1, len(idxs) // (4 * self._workers))
+                parts = self._pool.map(lambda lo: [self._prepare(i) for i in idxs[lo:lo + k]], range(0, len(idxs), k))
+                items = [it for part in parts for it in part]
+            else:
+                items = [self._prepare(i) for i in idxs]
             self._prepared = idxs[-1] + 1
             groups: dict = {}
             for i, item in zip(idxs, items):

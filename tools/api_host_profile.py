@@ -38,6 +38,13 @@ class StubEngine:
     def upload_page(self, arr):
         return arr
 
+    def page_buffer(self, shape):
+        self.buf = np.empty(shape, np.uint8)
+        return self.buf
+
+    def upload_page_buffer(self):
+        return self.buf
+
     def submit_boxes(self, page, boxes, pad, want_probs=False):
         self.k += 1
         self.q[self.k] = len(boxes)
