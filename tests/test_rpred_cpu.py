@@ -194,3 +194,29 @@ def test_new_api_records_carry_logits_and_line_images():
     cfg.return_logits = cfg.return_line_image = False
     recs = list(R.recognition_pred(Model(), page(), seg(boxes), cfg))
     assert recs[0].logits is None and recs[0].image is None
+
+
+def test_lazy_lists_behave_like_the_lists_the_reference_stores():
+    """cuts / confidences are computed on first use (kraken_amd.rpred.LazyList): same values, list semantics for readers."""
+    import pickle
+    calls = []
+
+    def make():
+        calls.append(1)
+        return [[[0, 1], [0, 5], [3, 5], [3, 1]], [[4, 1], [4, 5], [9, 5], [9, 1]], [[10, 1], [10, 5], [12, 5], [12, 1]]]
+    lz = R.LazyList(make, 3)
+    assert len(lz) == 3 and bool(lz) and not calls                      # length and truthiness do not build anything
+    assert lz[1] == [[4, 1], [4, 5], [9, 5], [9, 1]] and len(calls) == 1
+    assert lz[0:2] == make()[0:2] and lz[-1][0] == [10, 1]               # slices (kraken/serialization.py:211) and negatives
+    assert [c[0][0] for c in lz] == [0, 4, 10] and lz == make()
+    assert len(calls) == 3                                               # the two explicit make() calls above, not the reads
+    assert pickle.loads(pickle.dumps(lz)) == make() and isinstance(pickle.loads(pickle.dumps(lz)), list)
+    assert not R.LazyList(list, 0) and list(R.LazyList(list, 0)) == []
+    # through the generator: lazy without bidi reordering, plain lists with it (reordering walks them right away)
+    boxes = [(0, 0, 200, 30), (0, 40, 300, 70)]
+    net = FakeNet('a')
+    for bidi in (False, True):
+        recs = run(defaultdict(lambda: net), page(), seg(boxes), pad=16, bidi_reordering=bidi)
+        assert all(len(r.cuts) == len(r.prediction) == len(r.confidences) for r in recs)
+        assert all(isinstance(r.cuts, R.LazyList) != bidi for r in recs)
+        assert [list(r.cuts) for r in recs] == [[list(c) for c in r.cuts] for r in recs]
