@@ -90,6 +90,7 @@ struct ConvGeom {
     bool split_out = false;   // write the output as split channels-last bf16 planes
     int xchunk = 16, xnchunks = 1, xKB = 1, xKB_last = 1, xPSTR = 48, xplane = 0;
     void* d_wx3 = nullptr;
+    void* d_wx5 = nullptr;    // conv_taps_x3.hip, five-group packing (kw <= 13)
     bool c1x3 = false;        // one-channel first convolution on the bf16 cores (conv1_x3.hip); weights in d_wx3
     bool taps = false;        // wide-kernel convolution with taps as K (conv_taps_x3.hip); reads NHCW planes
     bool out_nhcw = false;    // conv1_x3 writes [N][H][C][pitch] planes for a following taps convolution
@@ -300,6 +301,38 @@ int upload_conv_taps_weights(ConvGeom& g, const float* w) {
                 }
     HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // Five-group packing (conv_taps_x3.hip header): [channel pair][kernel row][fragment 4][lane][8]; lane = filter + 32*half,
+    // half = channel of the pair; fragment 0 = w_hi taps 0..7, 1 = w_lo taps 0..7, 2 = w_hi 8..12 | w_hi 8..10,
+    // 3 = w_hi 11..12 | w_lo 8..12 | 0.  KRK_NO_TAPS5 keeps the six-group kernel (A/B probing).
+    if (g.kw > 13 || g.kh != 3 || g.Cin % 2 || getenv("KRK_NO_TAPS5")) return KRK_OK;
+    std::vector<uint16_t> p5((size_t)(g.Cin / 2) * g.kh * 4 * 64 * 8, 0);
+    for (int pr = 0; pr < g.Cin / 2; ++pr)
+        for (int dy = 0; dy < g.kh; ++dy)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int f = lane & 31, ch = 2 * pr + (lane >> 5);
+                if (f >= g.Cout) continue;
+                auto split = [&](int dx, uint16_t& hi, uint16_t& lo) {
+                    hi = lo = 0;
+                    if (dx >= g.kw) return;
+                    const float v = w[(((size_t)f * g.Cin + ch) * g.kh + dy) * g.kw + dx];
+                    hi = f2bf(v);
+                    lo = f2bf(v - bf2f(hi));
+                };
+                uint16_t* q = &p5[(((size_t)(pr * g.kh + dy) * 4) * 64 + lane) * 8];
+                const size_t FR = 64 * 8;
+                for (int e = 0; e < 8; ++e) {
+                    uint16_t hi, lo;
+                    split(e, hi, lo);
+                    q[0 * FR + e] = hi;
+                    q[1 * FR + e] = lo;
+                    split(e < 5 ? 8 + e : 8 + (e - 5), hi, lo);          // Gd: hi x hi taps 8..12, then hi x lo taps 8..10
+                    q[2 * FR + e] = hi;
+                    if (e < 2) { split(11 + e, hi, lo); q[3 * FR + e] = hi; }        // Ge: hi x lo taps 11..12 ...
+                    else if (e < 7) { split(8 + (e - 2), hi, lo); q[3 * FR + e] = lo; }   // ... lo x hi taps 8..12, slot 7 idle
+                }
+            }
+    HIPCHK(hipMalloc(&g.d_wx5, p5.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(g.d_wx5, p5.data(), p5.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return KRK_OK;
 }
 
@@ -507,6 +540,7 @@ void free_step(Step& s) {
     if (s.cg.d_w) (void)hipFree(s.cg.d_w);
     if (s.cg.d_b) (void)hipFree(s.cg.d_b);
     if (s.cg.d_wx3) (void)hipFree(s.cg.d_wx3);
+    if (s.cg.d_wx5) (void)hipFree(s.cg.d_wx5);
     if (s.d_wrecsm) (void)hipFree(s.d_wrecsm);
     if (s.d_gamma) (void)hipFree(s.d_gamma);
     if (s.d_beta) (void)hipFree(s.d_beta);
@@ -1208,7 +1242,7 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         ConvTapArgs a;
         a.pitch = nhcw_pitch(Win);
         a.x = (const __bf16*)cur; a.x_plane = (size_t)N * s.C * s.H * a.pitch;
-        a.wpack = (const __bf16*)g.d_wx3; a.bias = g.d_b;
+        a.wpack = (const __bf16*)g.d_wx3; a.wpack5 = (const __bf16*)g.d_wx5; a.bias = g.d_b;
         a.y = (__bf16*)outp; a.y_plane = out_elems;
         a.len_out = lens_at(s.len_out);
         a.N = N; a.H = g.H; a.Cin = g.Cin; a.Cout = g.Cout; a.kh = g.kh; a.kw = g.kw; a.ph = g.ph; a.pw = g.pw;

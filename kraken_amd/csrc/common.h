@@ -132,6 +132,7 @@ struct ConvTapArgs {
     const __bf16* x;      // hi plane [N][H][Cin][pitch]; lo plane at + x_plane elements
     size_t x_plane;
     const __bf16* wpack;  // [Cin][kh][plane][64 lanes][8]
+    const __bf16* wpack5; // [Cin/2][kh][4 fragments][64 lanes][8]: the five-group packing (kw <= 13), or null
     const float* bias;    // [32]
     __bf16* y;            // split NHWC output (strides below), lo plane at + y_plane
     size_t y_plane;
@@ -141,7 +142,7 @@ struct ConvTapArgs {
     int Ho, Wo, Hy, Wy;
     int act, tiles_h, tiles_w;
     int y_f32;            // 1: write fp32 NHWC instead of split planes (GroupNorm consumer)
-    int dbg;              // probe bits (env KRK_X3_DBG): 1 no K loop, 4 no staging loads, 16 no stores
+    int dbg;              // probe bits (env KRK_X3_DBG): 1 no K loop, 2 no weight refresh (FIVE), 4 no staging loads, 16 no stores
 };
 bool krk_conv_taps_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
 int krk_launch_conv_taps(const ConvTapArgs& a, bool pool, hipStream_t s);

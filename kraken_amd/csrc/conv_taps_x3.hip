@@ -15,7 +15,22 @@
 //   LDS       [plane][4 channels][kh+3 rows][152 columns], two buffers, register-staged one chunk ahead
 //   weights   [Cin][kh][plane][lane][8] A fragments straight from L2, prefetched one channel ahead
 //   epilogue  2x2 max-pool inside a lane, bias + activation, length mask, split NHWC planes (for conv_x3.hip)
+//
+// FIVE (kw <= 13, the split-operand build only): 13 taps x 3 product terms = 39 K slots, which the scheme above spreads over
+// 3 MFMAs of 16 (taps 13..15 idle in each: 16/13 of the algorithmic MFMA work).  The slot <-> (term, tap) assignment is free as
+// long as the weights are packed to match, so the 39 slots of one (channel, kernel row) are packed into FIVE groups of 8 and the
+// groups of TWO channels share an MFMA (lane half = channel): 5 MFMAs per channel pair instead of 6.
+//     group   B operand (8 consecutive K slots of a lane)                     A operand
+//     Ga      hi pixels 0..7                                                  w_hi taps 0..7   (hi x hi)
+//     Ga      (the same registers)                                            w_lo taps 0..7   (lo x hi)
+//     Gc      lo pixels 0..7                                                  w_hi taps 0..7   (hi x lo: the fragment of row 1)
+//     Gd      hi pixels 8..12 | lo pixels 8..10                               w_hi taps 8..12 | w_hi taps 8..10
+//     Ge      lo pixels 11..12 | hi pixels 8..12 | (pad)                      w_hi taps 11..12 | w_lo taps 8..12 | 0
+// A lane reads ONE 16-pixel window per plane of ITS channel (half as much LDS traffic as above) and assembles the mixed groups
+// with v_alignbyte / v_perm; the 4 distinct weight fragments of a kernel row are refreshed in place for the next channel pair
+// as soon as the row that used them last is done (no second register set).
 #include "common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -39,7 +54,25 @@ __device__ __forceinline__ bf16x8 window8(const unsigned (&d)[6]) {
     }
 }
 
-template <int KH, int PW, bool POOL>
+// ---- FIVE: pieces of a window held as dwords W[k] = pixels (2k, 2k+1)
+template <int J, int NW>
+__device__ __forceinline__ unsigned px2(const unsigned (&W)[NW]) {             // pixels (J, J+1)
+    if constexpr (J % 2 == 0) return W[J / 2];
+    else return __builtin_amdgcn_alignbyte(W[J / 2 + 1], W[J / 2], 2);
+}
+template <int JA, int JB, int NW>
+__device__ __forceinline__ unsigned mix2(const unsigned (&A)[NW], const unsigned (&B)[NW]) {   // (pixel JA of A, pixel JB of B)
+    constexpr unsigned lo_sel = (JA % 2 == 0) ? 0x0100u : 0x0302u;             // v_perm_b32: selector bytes 0..3 = src1, 4..7 = src0
+    constexpr unsigned hi_sel = (JB % 2 == 0) ? 0x0504u : 0x0706u;
+    return __builtin_amdgcn_perm(B[JB / 2], A[JA / 2], (hi_sel << 16) | lo_sel);
+}
+template <int J, int NW>
+__device__ __forceinline__ unsigned px1(const unsigned (&W)[NW]) {             // (pixel J, some finite value: its weight is zero)
+    if constexpr (J % 2 == 0) return W[J / 2];
+    else return W[J / 2] >> 16;
+}
+
+template <int KH, int PW, bool POOL, bool FIVE>
 __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) {
     constexpr int IH = TH + KH - 1;
     constexpr int SHIFT = 8 - PW;                    // LDS column 0 is image column w0 - 8
@@ -114,10 +147,11 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
     const bool live = (w0 + 64 * chalf) < wlim;      // this wave's columns are inside the line
     const int nchunks = a.Cin / CC;
 
-    bf16x8 wha[KH], wla[KH], whb[KH], wlb[KH];
     gload(0);
-    wload(0, wha, wla);
     lstore(0);
+    if constexpr (!FIVE) {
+    bf16x8 wha[KH], wla[KH], whb[KH], wlb[KH];
+    wload(0, wha, wla);
     __syncthreads();
 
     // one channel: KH+1 input rows, each window feeds both output rows of the pair
@@ -165,6 +199,74 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
         }
         if (k + 1 < nchunks) lstore(buf ^ 1);
         __syncthreads();
+    }
+    } else {
+#ifndef KRK_BF16_ONE
+    // ---- FIVE: see the header.  wq[dy][f]: f = 0 w_hi taps 0..7, 1 w_lo taps 0..7, 2 the Gd weights, 3 the Ge weights
+    static_assert(KH == 3 && CC == 4 && (SHIFT == 2 || SHIFT == 3), "FIVE: 3 kernel rows, 2 channel pairs per chunk, kw 11..13");
+    constexpr int NW = SHIFT == 2 ? 8 : 9;
+    const bf16x8* w5 = reinterpret_cast<const bf16x8*>(a.wpack5) + lane;
+    const int npairs = a.Cin >> 1;
+    bf16x8 wq[KH][4];
+    auto wload5 = [&](int pair, int dy) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) wq[dy][f] = w5[((size_t)(pair * KH + dy) * 4 + f) * 64];
+    };
+#pragma unroll
+    for (int dy = 0; dy < KH; ++dy) wload5(0, dy);
+    __syncthreads();
+
+    // one channel pair (this lane: channel 2*pp + half of the chunk): KH+1 input rows
+    auto pair_rows = [&](int buf, int pp, int next_pair) {
+        const int ch = 2 * pp + half;
+#pragma unroll
+        for (int i = 0; i < KH + 1; ++i) {
+            unsigned Wh[NW], Wl[NW];
+            const unsigned* ph = reinterpret_cast<const unsigned*>(&tile[buf][0][ch][2 * rp + i][64 * chalf + 2 * c]);
+            const unsigned* pl = reinterpret_cast<const unsigned*>(&tile[buf][1][ch][2 * rp + i][64 * chalf + 2 * c]);
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                Wh[k] = ph[k];
+                Wl[k] = pl[k];
+            }
+            auto groups = [&](auto R, bf16x8& Ga, bf16x8& Gc, bf16x8& Gd, bf16x8& Ge) {
+                constexpr int r = decltype(R)::value;        // window pixel of tap 0
+                Ga = __builtin_bit_cast(bf16x8, u32x4{px2<r, NW>(Wh), px2<r + 2, NW>(Wh), px2<r + 4, NW>(Wh), px2<r + 6, NW>(Wh)});
+                Gc = __builtin_bit_cast(bf16x8, u32x4{px2<r, NW>(Wl), px2<r + 2, NW>(Wl), px2<r + 4, NW>(Wl), px2<r + 6, NW>(Wl)});
+                Gd = __builtin_bit_cast(bf16x8, u32x4{px2<r + 8, NW>(Wh), px2<r + 10, NW>(Wh), mix2<r + 12, r + 8, NW>(Wh, Wl), px2<r + 9, NW>(Wl)});
+                Ge = __builtin_bit_cast(bf16x8, u32x4{px2<r + 11, NW>(Wl), px2<r + 8, NW>(Wh), px2<r + 10, NW>(Wh), px1<r + 12, NW>(Wh)});
+            };
+            bf16x8 Ga[2], Gc[2], Gd[2], Ge[2];
+            groups(std::integral_constant<int, SHIFT>{}, Ga[0], Gc[0], Gd[0], Ge[0]);
+            groups(std::integral_constant<int, SHIFT + 1>{}, Ga[1], Gc[1], Gd[1], Ge[1]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int dy = i - o;
+                if (dy < 0 || dy >= KH) continue;
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    acc[o][sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[dy][0], Ga[sx], acc[o][sx], 0, 0, 0);
+                    acc[o][sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[dy][1], Ga[sx], acc[o][sx], 0, 0, 0);
+                    acc[o][sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[dy][0], Gc[sx], acc[o][sx], 0, 0, 0);
+                    acc[o][sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[dy][2], Gd[sx], acc[o][sx], 0, 0, 0);
+                    acc[o][sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[dy][3], Ge[sx], acc[o][sx], 0, 0, 0);
+                }
+            }
+            if (i >= 1 && !KRK_DBGBIT(a, 2)) wload5(next_pair, i - 1);      // kernel row i-1 was used for the last time: fetch the next pair's
+        }
+    };
+
+    for (int k = 0; k < nchunks; ++k) {
+        const int buf = k & 1;
+        if (k + 1 < nchunks) gload((k + 1) * CC);
+        if (live && !KRK_DBGBIT(a, 1)) {
+            pair_rows(buf, 0, 2 * k + 1);
+            pair_rows(buf, 1, min(2 * k + 2, npairs - 1));
+        }
+        if (k + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#endif
     }
 
     // ---- epilogue: lane = pixels w0 + 64*chalf + 2c + s of rows h0 + 2*rp + o; register 4j+i = filter 8j + 4*half + i
@@ -248,8 +350,17 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
 template <int PW>
 int launch_pw(const ConvTapArgs& a, bool pool, hipStream_t s) {
     dim3 grid((unsigned)(a.N * a.tiles_h * a.tiles_w));
-    if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false>), grid, dim3(256), 0, s, a);
+#ifndef KRK_BF16_ONE
+    if constexpr (PW == 5 || PW == 6) {
+        if (a.wpack5 && a.kw <= 13) {
+            if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, true>), grid, dim3(256), 0, s, a);
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
+    }
+#endif
+    if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, false>), grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
