@@ -38,7 +38,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int LW = 152;   // LDS row: 8 (aligned left margin) + 128 + 15, rounded to 16-byte pieces
+constexpr int LW6 = 152;  // LDS row of the six-group kernel: 8 (aligned left margin) + 128 + 15, rounded to 16-byte pieces
+constexpr int LW5 = 144;  // five-group kernel: 8 + 128 + 8 (its windows end at column 143)
+constexpr int WPAIR = 3 * 4 * 64 * 16;   // bytes of the weight fragments of one channel pair (five-group kernel)
 constexpr int CC = 4;     // channels per LDS chunk
 constexpr int TW = 128, TH = 4;
 
@@ -76,10 +78,13 @@ template <int KH, int PW, bool POOL, bool FIVE>
 __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) {
     constexpr int IH = TH + KH - 1;
     constexpr int SHIFT = 8 - PW;                    // LDS column 0 is image column w0 - 8
+    constexpr int LW = FIVE ? LW5 : LW6;
     constexpr int ROWS = 2 * CC * IH;                // LDS rows per chunk (both planes)
     constexpr int PIECES = ROWS * (LW / 8);          // 16-byte pieces per chunk
     constexpr int NST = (PIECES + 255) / 256;
-    __shared__ __attribute__((aligned(16))) __bf16 tile[2][2][CC][IH][LW];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_taps[];
+    auto tile = reinterpret_cast<__bf16 (*)[2][CC][IH][LW]>(smem_taps);           // [buffer 2][plane 2][CC][IH][LW]
+    [[maybe_unused]] unsigned char* wts = smem_taps + sizeof(__bf16) * 2 * 2 * CC * IH * LW;   // FIVE: [chunk buffer 2][pair 2][WPAIR]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -205,20 +210,37 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
     // ---- FIVE: see the header.  wq[dy][f]: f = 0 w_hi taps 0..7, 1 w_lo taps 0..7, 2 the Gd weights, 3 the Ge weights
     static_assert(KH == 3 && CC == 4 && (SHIFT == 2 || SHIFT == 3), "FIVE: 3 kernel rows, 2 channel pairs per chunk, kw 11..13");
     constexpr int NW = SHIFT == 2 ? 8 : 9;
-    const bf16x8* w5 = reinterpret_cast<const bf16x8*>(a.wpack5) + lane;
+    // The four waves of a workgroup use the SAME weight fragments: fetched once per workgroup into LDS by asynchronous
+    // global -> LDS copies, one chunk ahead (per-wave loads of 24 KB per chunk ran the CU's 64 B/clk vector-memory path
+    // at ~80 %, in order with the tile staging loads: 0.59 ms without the weight traffic against 0.75 ms with it)
     const int npairs = a.Cin >> 1;
-    bf16x8 wq[KH][4];
-    auto wload5 = [&](int pair, int dy) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto wdma = [&](int chunk, int wb) {       // this wave's quarter of the chunk's (two channel pairs) fragments -> weight buffer wb
+        if (KRK_DBGBIT(a, 2)) return;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.wpack5) + (size_t)chunk * (2 * WPAIR) + wave * (WPAIR / 2) + lane * 16;
+        unsigned char* dst = wts + wb * (2 * WPAIR) + wave * (WPAIR / 2);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) wq[dy][f] = w5[((size_t)(pair * KH + dy) * 4 + f) * 64];
+        for (int j = 0; j < WPAIR / 2 / 1024; ++j)
+            __builtin_amdgcn_global_load_lds((const void*)(src + j * 1024), (lds_ptr)(dst + j * 1024), 16, 0, 0);
     };
-#pragma unroll
-    for (int dy = 0; dy < KH; ++dy) wload5(0, dy);
-    __syncthreads();
+    auto landed = [&]() {                       // my copies are in LDS; after the barrier: everyone's, and the other buffers are free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    wdma(0, 0);
+    landed();
 
     // one channel pair (this lane: channel 2*pp + half of the chunk): KH+1 input rows
-    auto pair_rows = [&](int buf, int pp, int next_pair) {
+    auto pair_rows = [&](int buf, int pp, int wb) {
         const int ch = 2 * pp + half;
+        bf16x8 wq[KH][4];
+        {
+            const bf16x8* wl = reinterpret_cast<const bf16x8*>(wts + wb * WPAIR) + lane;      // wb = 2 * (chunk buffer) + pair of the chunk
+#pragma unroll
+            for (int dy = 0; dy < KH; ++dy)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) wq[dy][f] = wl[(dy * 4 + f) * 64];
+        }
 #pragma unroll
         for (int i = 0; i < KH + 1; ++i) {
             unsigned Wh[NW], Wl[NW];
@@ -252,19 +274,24 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
                     acc[o][sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[dy][3], Ge[sx], acc[o][sx], 0, 0, 0);
                 }
             }
-            if (i >= 1 && !KRK_DBGBIT(a, 2)) wload5(next_pair, i - 1);      // kernel row i-1 was used for the last time: fetch the next pair's
         }
     };
 
+    const bool work = live && !KRK_DBGBIT(a, 1);
     for (int k = 0; k < nchunks; ++k) {
         const int buf = k & 1;
-        if (k + 1 < nchunks) gload((k + 1) * CC);
-        if (live && !KRK_DBGBIT(a, 1)) {
-            pair_rows(buf, 0, 2 * k + 1);
-            pair_rows(buf, 1, min(2 * k + 2, npairs - 1));
+        // everything the NEXT chunk needs is requested now and waited for at the end of this chunk: a whole chunk of MFMAs
+        // (~3.5 us) covers the HBM latency of the tile loads and the copies of the weight fragments alike
+        if (k + 1 < nchunks) {
+            wdma(k + 1, buf ^ 1);
+            gload((k + 1) * CC);
+        }
+        if (work) {
+            pair_rows(buf, 0, 2 * buf);
+            pair_rows(buf, 1, 2 * buf + 1);
         }
         if (k + 1 < nchunks) lstore(buf ^ 1);
-        __syncthreads();
+        landed();
     }
 #endif
     }
@@ -350,17 +377,29 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
 template <int PW>
 int launch_pw(const ConvTapArgs& a, bool pool, hipStream_t s) {
     dim3 grid((unsigned)(a.N * a.tiles_h * a.tiles_w));
+    constexpr size_t tile6 = sizeof(__bf16) * 2 * 2 * CC * (TH + 2) * LW6;
 #ifndef KRK_BF16_ONE
     if constexpr (PW == 5 || PW == 6) {
         if (a.wpack5 && a.kw <= 13) {
-            if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, true>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, true>), grid, dim3(256), 0, s, a);
+            constexpr size_t lds5 = sizeof(__bf16) * 2 * 2 * CC * (TH + 2) * LW5 + 4 * WPAIR;     // 27 KB of tiles + 48 KB of weights: two workgroups per CU
+            // more than the 64 KB a kernel gets by default: raise the limit once per device (the attribute belongs to the
+            // function object of the CURRENT device)
+            static bool attr_set[64] = {false};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taps_kernel<3, PW, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taps_kernel<3, PW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+                if (dev >= 0 && dev < 64) attr_set[dev] = true;
+            }
+            if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, true>), grid, dim3(256), lds5, s, a);
+            else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, true>), grid, dim3(256), lds5, s, a);
             return hipGetLastError() == hipSuccess ? 0 : -2;
         }
     }
 #endif
-    if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, false>), grid, dim3(256), 0, s, a);
+    if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, false>), grid, dim3(256), tile6, s, a);
+    else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, false>), grid, dim3(256), tile6, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
