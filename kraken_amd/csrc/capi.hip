@@ -401,6 +401,9 @@ struct Step {
     // per-call
     DevBuf out, aux, aux2;
     bool in_split = false;    // input arrives as split bf16 planes (bf16x3 mode)
+    // split-bf16 LSTM -> LSTM / linear: the rows between them stay tile-time-major (16-line tiles, ceil(N/16)*16*T rows):
+    // the recurrent kernel writes whole 256-byte runs and gemm_x3 needs no permutation (the linear layer undoes it)
+    bool out_tiled = false, in_tiled = false;
     double flops = 0.0;
 };
 
@@ -917,6 +920,11 @@ int PlanBuilder::recurrent_or_linear(const krk_layer& L, const std::string& wher
     g.H = 1;
     g.in_seq = g.out_seq = true;
     g.act = ACT_LINEAR;
+    if (x3 && split_fmt && !img_lstm && !p->steps.empty() && p->steps.back().kind == S_LSTM && p->steps.back().rec_x3 &&
+        !getenv("KRK_NO_TILED_ROWS")) {
+        p->steps.back().out_tiled = true;
+        s.in_tiled = true;
+    }
     if (int rc = (L.op == KRK_OP_LINEAR) ? linear(L, where, s) : lstm(L, where, s)) return rc;
     p->steps.push_back(std::move(s));
     if (img_lstm) {
@@ -1131,6 +1139,7 @@ void fill_gemm(const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane
     a.ncg = (g.Cout + 127) / 128; a.ntiles = (rows + 255) / 256;
     a.act = g.act;
     a.tileT = 0;
+    a.nlines = 0;
     a.dbg = dbg;
 }
 
@@ -1366,11 +1375,13 @@ int Pass::split_input(Step& s, const float* cur, size_t in_elems, const void** x
 int Pass::linear(Step& s, const float* cur, float* outp, int Win) {
     s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
     if (s.cg.x3) {
-        const size_t in_elems = (size_t)N * Win * s.cg.Cin;
+        const int Nr = s.in_tiled ? (N + 15) / 16 * 16 : N;      // tile-time-major rows come in whole 16-line tiles
+        const size_t in_elems = (size_t)Nr * Win * s.cg.Cin;
         const void* xin;
         if (int rc = split_input(s, cur, in_elems, &xin)) return rc;
         GemmX3Args a;
-        fill_gemm(s.cg, a, xin, in_elems, outp, N * Win, probe.x3_dbg);
+        fill_gemm(s.cg, a, xin, in_elems, outp, Nr * Win, probe.x3_dbg);
+        if (s.in_tiled) { a.tileT = -Win; a.nlines = N; }          // back to line-major rows for the decode
         if (mark("linear_x3", s.flops)) return kFailed;
         return one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
     }
@@ -1395,12 +1406,16 @@ int Pass::lstm(Step& s, const float* cur, float* outp, size_t out_elems, int Win
     const double xflops = 2.0 * Ns * (double)T * s.ndir * 4.0 * s.hidden * s.cg.Cin;
     int rc;
     if (s.cg.x3) {
-        const size_t in_elems = (size_t)Ns * T * s.cg.Cin;
+        const int Nr = s.in_tiled ? (Ns + 15) / 16 * 16 : Ns;
+        const size_t in_elems = (size_t)Nr * T * s.cg.Cin;
         const void* xin;
         if ((rc = split_input(s, cur, in_elems, &xin))) return rc;
         GemmX3Args a;
-        fill_gemm(s.cg, a, xin, in_elems, (float*)s.aux.p, Ns * T, probe.x3_dbg);
-        a.tileT = s.rec_x3 ? T : 0;
+        fill_gemm(s.cg, a, xin, in_elems, (float*)s.aux.p, Nr * T, probe.x3_dbg);
+        // projection rows for the split-bf16 recurrence are tile-time-major: permute line-major input rows, keep tiled ones;
+        // an f32 recurrence behind tiled input gets its line-major rows back
+        a.tileT = s.rec_x3 ? (s.in_tiled ? 0 : T) : (s.in_tiled ? -T : 0);
+        a.nlines = Ns;
         if (mark("lstm_xproj_x3", xflops)) return kFailed;
         rc = one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
     } else {
@@ -1435,6 +1450,7 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     l.ostride = s.ndir * s.hidden;
     l.hrow = l.NKB * 64 + 16;
     l.xtiled = 1;
+    l.otiled = s.out_tiled ? 1 : 0;
     l.dbg = probe.lstm_dbg;
     if (!s.d_wrecws || probe.lstm_v != 3) return krk_launch_lstm_x3(l, stream);
     // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time does
@@ -1457,6 +1473,7 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     s.ws_epoch = s.ws_epoch % 65535u + 1u;
     w.epoch = s.ws_epoch;
     w.err = p->err_dev;
+    w.otiled = l.otiled;
     w.dbg = l.dbg;
     int rc = one ? krk_launch_lstm_ws_b1(w, groups, stream) : krk_launch_lstm_ws(w, groups, stream);
     if (rc == 0) s.ws_tickets += (unsigned)(krk_lstm_ws_clusters(Ns, s.ndir, groups) * 4);
@@ -1522,6 +1539,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         const bool is_last = (si + 1 == nsteps);
         size_t out_elems = (size_t)N * s.outC * s.outH * Wout;
         if (s.kind == S_CONV && s.cg.out_nhcw) out_elems = (size_t)N * s.outC * s.outH * nhcw_pitch(Wout);
+        if (s.kind == S_LSTM && s.out_tiled) out_elems = (size_t)((N + 15) / 16 * 16) * s.outC * s.outH * Wout;
         float* outp;
         if (is_last && final_out) outp = final_out;
         else {

@@ -158,6 +158,8 @@ struct GemmX3Args {
     int M, K, Cout;
     int ncg, ntiles;      // column groups of 128, row tiles of 256
     int tileT;            // > 0: rows are (line, step) with tileT steps per line; store row n*T+t at ((n/16)*T + t)*16 + n%16
+                          // < 0: the INPUT rows are tile-time-major with -tileT steps per line: store row ((n/16)*T + t)*16 + n%16 at n*T+t
+    int nlines;           // tileT < 0: lines that exist (rows of the padding lines of the last 16-line tile are dropped)
     int act;
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no MFMA, 2 no copies, 4 no stores, 8 no LDS reads
 };
@@ -194,6 +196,7 @@ struct LstmX3Args {
     int xstride, ostride;
     int hrow;             // bytes per LDS row of h (one line, one plane) = NKB*64 + 16
     int xtiled;           // 1: xp rows are tile-time-major (see gemm_x3.hip): row of (line n, step t) = ((n/16)*T + t)*16 + n%16
+    int otiled;           // 1: the OUTPUT rows are tile-time-major too (ceil(N/16)*16*T rows per piece): the consumer is gemm_x3
     int dbg;              // probe bits (env KRK_LSTM_DBG): 1 no weight loads, 2 no gate math, 4 no MFMA, 8 no x prefetch
 };
 int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s);
@@ -216,6 +219,7 @@ struct LstmWsArgs {
     unsigned ticket_base; // counter value before this launch (the host adds the grid size after every launch)
     unsigned epoch;       // launch number folded into the granule tags (never 0)
     unsigned* err;        // mapped host word: set to 1 if an exchange wait timed out
+    int otiled;           // 1: output rows tile-time-major (ceil(N/16)*16*T rows per piece), whole 256-byte runs per (piece, step)
     int dbg;              // probe bits (-DKRK_ABLATE build, env KRK_LSTM_DBG): 1 no exchange reads, 2 no gate math / publish, 4 no MFMA, 8 no xproj loads, 16 no output pass, 32 no step barrier
 };
 bool krk_lstm_ws_supported(int H, int Hp);

@@ -139,9 +139,14 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
             }
         const int rbase = row0 + wave * 64 + 32 * s;
         int ln = 0, tt = 0;                                // (line, step) of row rbase + half (tile-time-major output only)
+        int tl = 0, rem = 0;                               // (16-line tile, row inside it) of row rbase + half (tile-time-major input)
+        const int T16 = 16 * (a.tileT < 0 ? -a.tileT : 1);
         if (a.tileT > 0) {
             ln = (rbase + half) / a.tileT;
             tt = (rbase + half) - ln * a.tileT;
+        } else if (a.tileT < 0) {
+            tl = (rbase + half) / T16;
+            rem = (rbase + half) - tl * T16;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -149,12 +154,19 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(T + r * RSTR + 4 * px);
             const int row = rbase + r, col = col0 + 4 * px;
             size_t orow = (size_t)row;
+            bool keep = true;
             if (a.tileT > 0) {
                 orow = ((size_t)(ln >> 4) * a.tileT + tt) * 16 + (ln & 15);
                 tt += 2;
                 while (tt >= a.tileT) { tt -= a.tileT; ++ln; }
+            } else if (a.tileT < 0) {
+                const int n = tl * 16 + (rem & 15);
+                keep = n < a.nlines;
+                orow = (size_t)n * (size_t)(-a.tileT) + (rem >> 4);
+                rem += 2;
+                if (rem >= T16) { rem -= T16; ++tl; }
             }
-            if (row < a.M && !nostore) {
+            if (row < a.M && keep && !nostore) {
                 float* yp = a.y + orow * a.Cout + col;
                 if (vec) {
                     if (col < a.Cout) {

@@ -252,27 +252,40 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         gather_drop(hb);
     };
 
-    // ---- output pass: this slice writes lines [4*slice, 4*slice+4) of a group, one 16-byte piece per lane
+    // ---- output pass, one 16-byte piece per lane.  Line-major rows: this slice writes lines [4*slice, 4*slice+4) of a group (200
+    // different 128-byte lines per slot: a piece's rows of one step lie T rows apart).  Tile-time-major rows (a.otiled: the
+    // consumer is gemm_x3, which keeps the order): the 16 lines of a group at one step are 16 consecutive rows, so this slice
+    // takes every fourth (plane, piece) combination for ALL 16 lines -- whole 256-byte runs, 26 lines per slot.
     const int per_line = a.H >> 3;
-    const size_t rows_total = (size_t)a.N * a.T;
+    const size_t rows_total = a.otiled ? (size_t)((a.N + 15) / 16 * 16) * a.T : (size_t)a.N * a.T;
     const i32x4 ors = ws_srd(a.out, (unsigned)((size_t)a.out_plane * 4));
-    unsigned sp_lds, sp_g00;
+    unsigned sp_lds, sp_g00, sp_tmul;
     int sp_ln;
-    {
+    if (a.otiled) {
+        const int cmb = slice + 4 * (tid >> 4);                 // (plane, piece) combination, plane-major
+        const int pl = cmb / per_line, q = cmb - pl * per_line;
+        sp_ln = cmb < 2 * per_line ? (tid & 15) : -1;
+        sp_lds = sp_ln >= 0 ? (unsigned)(pl * plane + (q & 3) * OS + sp_ln * RSO + (q >> 2) * 16) : 0u;
+        sp_g00 = (unsigned)((((size_t)(dir * per_line + q)) * rows_total + (size_t)(n0 >> 4) * a.T * 16 + (size_t)max(sp_ln, 0)) * 16 + (size_t)pl * a.out_plane * 2);
+        sp_tmul = 16u * 16u;                                      // bytes per time step: 16 rows
+    } else {
         const int e = tid;
         const int pl = e / (4 * per_line), r = e - pl * 4 * per_line;
         const int li = r / per_line, q = r - li * per_line;
         sp_ln = e < 8 * per_line ? slice * 4 + li : -1;
         sp_lds = sp_ln >= 0 ? (unsigned)(pl * plane + (q & 3) * OS + sp_ln * RSO + (q >> 2) * 16) : 0u;   // piece q = units 8q..8q+7
         sp_g00 = (unsigned)((((size_t)(dir * per_line + q)) * rows_total + (size_t)(n0 + max(sp_ln, 0)) * a.T) * 16 + (size_t)pl * a.out_plane * 2);
+        sp_tmul = 16u;                                            // consecutive steps of a line are consecutive rows
     }
+    // group g of the cluster: line-major 16 lines = 16*T rows further, tile-time-major the next tile = 16*T rows further too
+    const unsigned sp_gmul = 16u * (unsigned)a.T * 16u;
     // two halves: the LDS read is issued FIRST in a slot (LDS returns in order: a store that waited for a read issued after the
     // 14 fragment reads would hold the wave -- and its first MFMA -- until the whole fragment set had arrived)
     auto store_read = [&](int g, int step, const unsigned char* hb, unsigned& vo) -> u32x4 {
         const int len = sp_ln >= 0 ? lens_s[16 * g + sp_ln] : 0;
         const bool on = step >= 0 && step < len;
         const int t = rev ? (len - 1 - step) : step;
-        vo = on ? sp_g00 + ((unsigned)g * 16u * (unsigned)a.T + (unsigned)t) * 16u : kOOBws;
+        vo = on ? sp_g00 + (unsigned)g * sp_gmul + (unsigned)t * sp_tmul : kOOBws;
         return *reinterpret_cast<const u32x4*>(hb + sp_lds);
     };
     auto store_pass = [&](int g, int step, const unsigned char* hb) {

@@ -30,6 +30,11 @@ __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigne
                                               int wave, int lane, int dir, bool rev, int n0) {
     constexpr int LPW = M / NW;                          // lines each wave copies out
     const int RS = a.hrow, plane = M * RS;
+    // row of (line n, step t): line-major, or tile-time-major (16-line tiles) for a gemm_x3 consumer that keeps that order
+    const size_t rows = a.otiled ? (size_t)((a.N + 15) / 16 * 16) * a.T : (size_t)a.N * a.T;
+    auto row_of = [&](int n, int t) -> size_t {
+        return a.otiled ? ((size_t)(n >> 4) * a.T + t) * 16 + (n & 15) : (size_t)n * a.T + t;
+    };
     if ((a.H & 7) == 0) {
         const int per_line = a.H >> 3;                   // 16-byte pieces per line per plane
         const int total = LPW * per_line * 2;            // this wave: LPW lines x 2 planes
@@ -41,7 +46,7 @@ __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigne
             if (s < len) {
                 const int t = rev ? (len - 1 - s) : s;
                 // K-blocked sequence rows [feature/8][line*T + t][8] (what gemm_x3.hip streams)
-                const size_t o = ((size_t)(dir * per_line + q) * ((size_t)a.N * a.T) + (size_t)(n0 + i) * a.T + t) * 8;
+                const size_t o = ((size_t)(dir * per_line + q) * rows + row_of(n0 + i, t)) * 8;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(hnext + pl * plane + i * RS + q * 16);
                 *reinterpret_cast<f32x4*>(a.out + pl * a.out_plane + o) = v;
             }
@@ -51,7 +56,7 @@ __device__ __forceinline__ void lstm_x3_store(const LstmX3Args& a, const unsigne
             const int len = lens_s[i];
             if (s < len) {
                 const int t = rev ? (len - 1 - s) : s;
-                const size_t rowi = (size_t)(n0 + i) * a.T + t, rows = (size_t)a.N * a.T;
+                const size_t rowi = row_of(n0 + i, t);
                 const __bf16* src = reinterpret_cast<const __bf16*>(hnext + i * RS);
                 for (int k = lane; k < a.H; k += 64) {
                     const int f = dir * a.H + k;

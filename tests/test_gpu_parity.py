@@ -654,6 +654,29 @@ def test_x3_plan_uses_the_specialised_kernels(bench_a_x3):
     assert names[-1] == 'linear_x3' or 'linear_x3' in names
 
 
+def test_tap_kernel_packings_agree(bench_a_x3, monkeypatch):
+    """conv_taps_x3: the five-group K packing (40 slots for 13 taps x 3 terms, two channels per MFMA, weights through LDS) and
+    the six-group one (3 x 16 slots per channel) evaluate the same products; only the fp32 summation order differs."""
+    x = synth_input(5, 1200, seed=77).cuda()
+    lens = torch.tensor([1200, 1199, 640, 130, 9])
+    _, _, l5, _ = bench_a_x3.nn.recognize(x, lens, want_logits=True)
+    monkeypatch.setenv('KRK_NO_TAPS5', '1')                       # read when the plan is created
+    m6 = build_model(BENCH_A, codec=bench_codec(), seed=0).to('cuda')
+    m6.nn.set_precision('bf16x3')
+    _, _, l6, _ = m6.nn.recognize(x, lens, want_logits=True)
+    monkeypatch.delenv('KRK_NO_TAPS5')
+    t = [int(v) // 8 for v in lens]
+    d = max((l5[i, :, :t[i]] - l6[i, :, :t[i]]).abs().max().item() for i in range(5))
+    assert 0 < d < 2e-5, d            # not the same instruction stream (d > 0), the same arithmetic
+    # row order between the recurrent layers (tile-time-major vs line-major): pure data movement, bit-identical logits
+    monkeypatch.setenv('KRK_NO_TILED_ROWS', '1')
+    ml = build_model(BENCH_A, codec=bench_codec(), seed=0).to('cuda')
+    ml.nn.set_precision('bf16x3')
+    _, _, ll, _ = ml.nn.recognize(x, lens, want_logits=True)
+    monkeypatch.delenv('KRK_NO_TILED_ROWS')
+    assert all(torch.equal(l5[i, :, :t[i]], ll[i, :, :t[i]]) for i in range(5))
+
+
 def test_recurrent_kernel_variants_agree(bench_a_x3, monkeypatch):
     """The weight-stationary cluster kernel (2 or 4 line groups per cluster), the streaming kernel and its 32-line tiles
     are execution choices, not numerical ones."""
