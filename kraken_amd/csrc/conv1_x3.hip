@@ -30,11 +30,13 @@ constexpr int LW = 144;     // LDS row: 128 output columns + 15 taps, padded to 
 constexpr int TW = 128;     // output columns per tile
 constexpr int TH = 8;       // output rows per tile (2 per wave)
 
-template <int KH, bool POOL, bool NHCW>
+// RELU: the activation is ReLU (every kraken recogniser): chosen at launch, so the epilogue is straight-line code
+template <int KH, bool POOL, bool NHCW, bool RELU>
 __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
     constexpr int IH = TH + KH - 1;
     constexpr int NST = (IH * LW + 255) / 256;
     __shared__ __attribute__((aligned(16))) __bf16 tile[2][2][IH][LW];   // [buffer][plane][row][column]
+    __shared__ __attribute__((aligned(16))) float bias_s[32];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -66,13 +68,18 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
         s_off[i] = gh * a.W + iw - a.pw;
         s_iw[i] = ok ? iw - a.pw : -(1 << 28);
     }
+    // Vector memory of the tile loop is BRANCH-FREE (buffer instructions: an out-of-range offset reads 0 / drops the store):
+    // with loads and stores under exec-mask branches the compiler cannot count what is in flight and waits with vmcnt(0) --
+    // which, vmcnt retiring in order INCLUDING stores, holds the next tile until this tile's stores are acknowledged.
+    constexpr unsigned kOOB = 0x7FFFF000u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, a.H * a.W * (int)sizeof(float), 0x00020000);
     float st[NST];
     auto gload = [&](int w0) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int gw = w0 + s_iw[i];
-            st[i] = 0.f;
-            if (gw >= 0 && gw < len_in && !KRK_DBGBIT(a, 2)) st[i] = xin[s_off[i] + w0];
+            const bool ok = gw >= 0 && gw < len_in && !KRK_DBGBIT(a, 2);
+            st[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? (unsigned)(s_off[i] + w0) * 4u : kOOB, 0, 0));
         }
     };
     auto lstore = [&](int buf) {
@@ -88,6 +95,11 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
         }
     };
 
+    if (tid < 32) bias_s[tid] = a.bias[tid];
+    // NHCW output: one descriptor per plane for THIS line's [Hy][Cout][pitch] block
+    [[maybe_unused]] const int yline_b = a.Hy * a.Cout * a.y_pitch * (int)sizeof(__bf16);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t yrs_h = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.Hy * a.Cout * a.y_pitch, 0, yline_b, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t yrs_l = __builtin_amdgcn_make_buffer_rsrc(a.y + a.y_plane + (size_t)n * a.Hy * a.Cout * a.y_pitch, 0, yline_b, 0x00020000);
     gload(0);
     lstore(0);
     __syncthreads();
@@ -138,9 +150,12 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
         // ---- epilogue: lane = pixels w0 + 4c + s of rows h0 + 2*wave + o; register 4j+i = filter 8j + 4*half + i
         __bf16* yh = a.y;
         __bf16* yl = a.y + a.y_plane;
-        f32x4 bias4[4];   // (re)loaded per tile: 16 VGPRs the K loop does not have to carry
+        // (re)read per tile: 16 VGPRs the K loop does not have to carry.  From LDS, not from memory: a vector-memory load here
+        // would put `s_waitcnt vmcnt(small)` between the stores below, and vmcnt retires in order INCLUDING stores -- the wait for
+        // a bias value then is a wait for the previous tile's stores to be acknowledged
+        f32x4 bias4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + 8 * j + 4 * half);
+        for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(bias_s + 8 * j + 4 * half);
         if constexpr (NHCW) {
             // "NHCW" planes [N][Hy][Cout][pitch]: a lane owns 2 (pooled) or 4 consecutive columns of each of its 16
             // filters -> one 4/8-byte store per filter, 128/256 bytes contiguous across the wave.  Columns between
@@ -153,15 +168,17 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
                 for (int o = 0; o < NO; ++o) {
                     const int row = POOL ? (h0 >> 1) + wave : h0 + 2 * wave + o;
                     const int col0 = POOL ? (w0 >> 1) + 2 * c : w0 + 4 * c;
-                    if (row >= a.Hy || col0 >= a.y_pitch || KRK_DBGBIT(a, 4)) continue;
                     const int lim = min(len_out, a.Wy);
-                    // 64-bit base once, 32-bit filter offsets: filter f of this row starts f * pitch elements further
-                    __bf16* rowh = yh + ((size_t)n * a.Hy + row) * a.Cout * a.y_pitch + col0;
-                    __bf16* rowl = rowh + a.y_plane;
+                    // buffer stores on per-line descriptors (hi and lo plane): 32-bit offsets inside one line's planes, a lane
+                    // without an output (filter >= Cout, row / column outside) gets the out-of-range offset -- no branch, and
+                    // no per-filter 64-bit address in vector registers across the K loop (hoisted there they cost 32 VGPRs
+                    // and spilled: a scratch reload + vmcnt(0) in the middle of every tile's stores)
+                    const unsigned lane_off = (unsigned)(((row * a.Cout + 4 * half) * a.y_pitch + col0) * (int)sizeof(__bf16));
+                    const bool lane_ok = !(row >= a.Hy || col0 >= a.y_pitch || KRK_DBGBIT(a, 4));
+                    const unsigned pitch_b = (unsigned)a.y_pitch * (unsigned)sizeof(__bf16);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (f >= a.Cout) continue;
+                        const int f0 = (r & 3) + 8 * (r >> 2);             // this register's filter of lane half 0
                         __bf16 hv[NV], lv[NV];
 #pragma unroll
                         for (int e = 0; e < NV; ++e) {
@@ -173,19 +190,19 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
                             hv[e] = (__bf16)v;
                             lv[e] = (__bf16)(v - (float)hv[e]);
                         }
-                        const int off = f * a.y_pitch;
+                        const unsigned vo = (lane_ok && f0 + 4 * half < a.Cout) ? lane_off + (unsigned)f0 * pitch_b : kOOB;
                         if (POOL) {
                             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                            *reinterpret_cast<bf16x2*>(rowh + off) = bf16x2{hv[0], hv[1]};
-                            *reinterpret_cast<bf16x2*>(rowl + off) = bf16x2{lv[0], lv[1]};
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bf16x2{hv[0], hv[1]}), yrs_h, vo, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bf16x2{lv[0], lv[1]}), yrs_l, vo, 0, 0);
                         } else {
-                            *reinterpret_cast<bf16x4*>(rowh + off) = bf16x4{hv[0], hv[1], hv[2], hv[3]};
-                            *reinterpret_cast<bf16x4*>(rowl + off) = bf16x4{lv[0], lv[1], lv[2], lv[3]};
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, bf16x4{hv[0], hv[1], hv[2], hv[3]}), yrs_h, vo, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, bf16x4{lv[0], lv[1], lv[2], lv[3]}), yrs_l, vo, 0, 0);
                         }
                     }
                 }
             };
-            if (a.act == ACT_RELU) store_tile([](float v) { return fmaxf(v, 0.f); });
+            if constexpr (RELU) store_tile([](float v) { return fmaxf(v, 0.f); });
             else store_tile([&](float v) { return krk_act(v, a.act); });
         } else if constexpr (POOL) {
             const int prow = (h0 >> 1) + wave;
@@ -261,7 +278,12 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
         }
 
         if (tw + 1 < a.tiles_w) lstore(buf ^ 1);
-        __syncthreads();
+        // LDS hand-over only.  __syncthreads() would put a full vmcnt(0) in front of the barrier, i.e. wait until this tile's
+        // 32 stores per lane are acknowledged by memory before the next tile may start: the 503 MB this kernel writes then
+        // drain with the matrix pipe idle (ablation: 0.127 ms without stores + 0.116 ms of stores = the 0.243 ms measured)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -269,10 +291,13 @@ template <int KH>
 int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
     dim3 grid((unsigned)(a.N * a.tiles_h));
     const bool nhcw = a.y_pitch > 0;
-    if (pool && nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true>), grid, dim3(256), 0, s, a);
-    else if (pool) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, false>), grid, dim3(256), 0, s, a);
-    else if (nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv1_x3_kernel<KH, false, false>), grid, dim3(256), 0, s, a);
+    const bool relu = a.act == ACT_RELU;
+    if (pool && nhcw && relu) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true, true>), grid, dim3(256), 0, s, a);
+    else if (pool && nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true, false>), grid, dim3(256), 0, s, a);
+    else if (pool) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, false, false>), grid, dim3(256), 0, s, a);
+    else if (nhcw && relu) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true, true>), grid, dim3(256), 0, s, a);
+    else if (nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv1_x3_kernel<KH, false, false, false>), grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
