@@ -103,7 +103,10 @@ __global__ void __launch_bounds__(256, KRK_X3_OCC) conv_x3_kernel(const X3Args a
     for (int ci = 0; ci < a.nchunks; ++ci) {
         // ---------------------------------------------------------------- stage chunk ci (16-byte copies)
         __syncthreads();   // previous chunk fully consumed
-        constexpr int SB = 8;
+#ifndef KRK_X3_SB
+#define KRK_X3_SB 8
+#endif
+        constexpr int SB = KRK_X3_SB;
         for (int i0 = 0; i0 * 256 < items; i0 += SB) {
             f32x4 v[SB];
             int dst[SB];
