@@ -317,6 +317,19 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.KrkDecodeOut) == 5 * 8 + 8
 
 
+def test_library_is_not_older_than_its_sources():
+    """A failed rebuild must not go unnoticed behind a stale libkraken_amd.so (it happened: a compile error hidden by a
+    truncated build log, and several GPU runs measured the previous library).  Here, where the sources are edited and the
+    library is built; on the GPU box the snapshot's modification times say nothing."""
+    from kraken_amd import build
+    if not os.path.isdir(os.path.join(ROOT, '.git')):
+        pytest.skip('a snapshot without history: modification times are not meaningful')
+    lib_time = os.path.getmtime(build.LIB)
+    newer = [s for s in [os.path.join(build.CSRC, f) for f in build.SOURCES] + build.HEADERS if os.path.getmtime(s) > lib_time]
+    assert not newer, f'{[os.path.basename(s) for s in newer]} changed after the library was built: run `python -m kraken_amd.build`'
+    assert build.build() == build.LIB          # and a rebuild is a no-op that succeeds
+
+
 def test_error_reporting_without_compute():
     lib = _lib.load()
     handle = ctypes.c_void_p()
