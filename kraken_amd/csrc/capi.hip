@@ -1453,9 +1453,9 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     l.otiled = s.out_tiled ? 1 : 0;
     l.dbg = probe.lstm_dbg;
     if (!s.d_wrecws || probe.lstm_v != 3) return krk_launch_lstm_x3(l, stream);
-    // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time does
-    // not move (1.78 vs 1.83 us: it is not exchange bound), so a launch takes twice as long on half the CUs: same chip time,
-    // worse latency, 86 k vs 96 k lines/s.  KRK_LSTM_G=4 keeps it probeable.
+    // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time barely
+    // moves (it is not exchange bound), so a launch takes twice as long on half the CUs: same chip time, worse latency, fewer
+    // lines/s through the pipelined engine.  KRK_LSTM_G=4 keeps it probeable.
     const int groups = probe.lstm_g == 4 ? 4 : 2;
     const size_t gbytes = std::max(krk_lstm_ws_gran_bytes(Ns, s.ndir, s.ws_bpc, 4), krk_lstm_ws_gran_bytes(Ns, s.ndir, s.ws_bpc, 2));
     if (gbytes > s.ws_gran.cap) {

@@ -19,16 +19,22 @@
 //   * cluster membership is claimed at run time (ticket = atomicAdd): any four workgroups that have STARTED form a
 //     cluster, so a partially resident grid cannot deadlock whatever the dispatch order; every spin is bounded and a
 //     timeout raises the plan's error word (mapped host memory) instead of hanging the device;
-//   * the gather loads of the NEXT slot's group are issued at the start of a slot and checked optimistically in the middle
-//     of its MFMA stream (branch-free: the granules go to LDS whatever their tag; a lane that saw a stale tag only raises a
-//     flag), so the common case costs no wait at all; a flagged gather is polled at the start of the next slot;
+//   * the gather loads of the NEXT slot's group are issued one block of MFMAs into a slot (the peers published that group about
+//     when the slot began; a granule needs ~0.5 us to become visible) and checked optimistically at its end (branch-free: the
+//     granules go to LDS whatever their tag; a lane that saw a stale tag only raises a flag), so the common case costs no wait
+//     at all; a flagged gather is polled at the start of the next slot.  A lane gathers PAIRS of adjacent units of one line:
+//     two 8-byte loads -> one dword LDS write per plane;
+//   * inside a slot LDS returns in order: the small reads (xproj landing, output piece) first, then the 2*NKB fragments in the
+//     order the MFMAs consume them, so the matrix pipe starts on the first pair while the other waves' reads are queued;
 //   * every vector-memory instruction of the time loop is inline assembly with hand-counted `s_waitcnt vmcnt(N)`: vmcnt
 //     retires in order and an sc1 (write-through) publish store takes ~1 us to be acknowledged, so a wait that is one count
 //     too strict stalls a slot behind the stores it just issued -- which is what the compiler's bookkeeping (conservative
 //     across the loop's branches) produced: 2.07 us per slot, 0.56 of it MFMA.  xproj lands in LDS (global_load_lds) two
 //     slots ahead, so no register is live across the loop edge while its load is in flight;
 //   * h_t leaves as K-blocked split planes for the next projection (gemm_x3.hip): after the gather every slice holds the
-//     whole h_t in LDS and writes a quarter of the lines, 16 bytes per lane, masked by the buffer bounds check.
+//     whole h_t in LDS.  Rows tile-time-major (a.otiled, the rows between recurrent layers): a slice writes every fourth
+//     (plane, piece) combination for all 16 lines of the group -- whole 256-byte runs; line-major rows (other consumers): a
+//     quarter of the lines, 16 bytes per lane, each in a different 128-byte line.  Masked by the buffer bounds check.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -38,14 +44,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr unsigned kOOBws = 0x80000000u;   // voffset beyond every descriptor used here (all < 2 GiB): load = 0, store dropped
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* p, unsigned bytes) {
-    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
 
 __device__ __forceinline__ bf16x8 ws_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 

@@ -20,6 +20,12 @@ SPECS = [
     '[1,16,0,3 Ct3,3,16 Cr3,7,48,1,2 Cl1,1,32 S1(1x0)1,3 Lbx8 O1c7]',
     '[1,32,0,1 Cr3,3,16 Gn4 Mp2,2 Cr3,5,32 Gn8 Mp2,2 S1(1x0)1,3 Lbx16 O1c9]',
     '[1,24,0,1 Cr3,3,16 Mp3,2,2,3 Cr3,3,16 Gn2 S1(1x0)1,3 Lfx16 O1c5]',
+    # five-group tap kernel: kw 11 / 12 / 13 (window shifts 2 and 3), channel counts 8..28, with and without the fused pool,
+    # a GroupNorm consumer (fp32 hand-over); tile-time-major rows through stacks of recurrent layers (f / r / b, 2 and 3 deep)
+    '[1,20,0,1 Cr3,13,8 Cr3,13,12 Mp2,2 Cr3,5,32 S1(1x0)1,3 Lfx40 Lrx24 Lbx16 O1c21]',
+    '[1,16,0,1 Cr3,11,20 Mp2,2 Cr3,11,28 Cr3,3,16 S1(1x0)1,3 Lbx56 Lbx104 O1c40]',
+    '[1,12,0,1 Cr3,12,16 Cr3,12,32 Gn8 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx16 Lfx32 O1c8]',
+    '[1,48,0,1 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,64 Mp2,2 Cr3,9,64 S1(1x0)1,3 Lbx200 Lbx200 O1c50]',
 ]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()) if '--time-seed' in sys.argv else 0)
