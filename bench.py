@@ -65,7 +65,7 @@ def parse():
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the gather even with one rank (smoke test)')
     ap.add_argument('--cpu-lines', type=int, default=32, help='lines in the CPU baseline sample')
     ap.add_argument('--api-lines', type=int, default=2048, help='--mode api: bbox lines on the synthetic page')
-    ap.add_argument('--api-workers', type=int, default=16, help='--mode api: host threads preparing lines')
+    ap.add_argument('--api-workers', type=int, default=6, help='--mode api: host threads preparing lines (PIL conversions hold the GIL: more than ~6 threads only contend, 16 cost 40 %)')
     return ap.parse_args()
 
 
@@ -287,7 +287,10 @@ def mode_api(args, rank, local_rank):
                 with warnings.catch_warnings():
                     warnings.simplefilter('ignore')
                     t0 = time.perf_counter()
-                    recs = list(R.rpred(net, page, seg, bidi_reordering=False, num_line_workers=args.api_workers))
+                    # host-prepared lines (PIL resize / scipy dewarp, mostly outside the GIL) take more threads than the
+                    # device-prepared case, whose only host work is the GIL-bound page conversion
+                    workers = args.api_workers if (dev_prep and mode == 'RGB') else max(16, args.api_workers)
+                    recs = list(R.rpred(net, page, seg, bidi_reordering=False, num_line_workers=workers))
                     dt = time.perf_counter() - t0
                 assert len(recs) == n and all(r.prediction for r in recs)
                 best = max(best, n / dt)
