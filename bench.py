@@ -372,9 +372,11 @@ def mode_config4(args, model, local_rank):
     eng.close()
     # (b) host tensors through the API's pipeline
     net = TorchSeqRecognizer(model, device=dev)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(8)
     best = None
     for rep in range(3):
-        pipe = R.LinePipeline(net, batch_size=args.batch)
+        pipe = R.LinePipeline(net, batch_size=args.batch, pool=pool)
         t0 = time.perf_counter()
         pipe.submit(list(enumerate(lines)))
         got = {}
