@@ -140,6 +140,18 @@ IMAGE_LSTM_CASES = {
 }
 
 
+X3_NETWORK_CASES = {
+    # whole small networks for the split-bf16 kernels, outputs made by the REFERENCE's modules: the tap-as-K convolutions
+    # (first layer; five-group packing at kw 11 / 12 / 13 = window shifts 2 and 3; six-group at kw 15), channel counts that are
+    # not powers of two, fused pools, a GroupNorm consumer, and stacks of recurrent layers (tile-time-major rows between them)
+    'x3_taps13':    ('[1,20,0,1 Cr3,13,8 Cr3,13,12 Mp2,2 Cr3,5,32 S1(1x0)1,3 Lfx40 Lrx24 Lbx16 O1c21]', 3, 150, [150, 97, 40]),
+    'x3_taps11':    ('[1,16,0,1 Cr3,11,20 Mp2,2 Cr3,11,28 Cr3,3,16 S1(1x0)1,3 Lbx24 Lbx40 O1c40]', 3, 261, [261, 260, 131]),
+    'x3_taps12_gn': ('[1,12,0,1 Cr3,12,16 Cr3,12,32 Gn8 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx16 Lfx32 O1c8]', 2, 133, [133, 70]),
+    'x3_taps15':    ('[1,8,0,1 Ct1,3,4 Cs3,15,16 Cl3,3,16 S1(1x0)1,3 Lfx16 O1c5]', 2, 96, None),
+    'x3_c32_taps':  ('[1,24,0,1 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,32 S1(1x0)1,3 Lbx56 Lbx24 O1c50]', 2, 400, [400, 233]),
+}
+
+
 @torch.inference_mode()
 def layer_fixture(path, cases=None):
     cases = cases or {
@@ -377,7 +389,7 @@ def transforms_fixture(path):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'codec', 'transforms']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'codec', 'transforms']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -391,6 +403,8 @@ if __name__ == '__main__':
         layer_fixture(os.path.join(HERE, 'layers.npz'))
     if 'image_lstm' in which:
         layer_fixture(os.path.join(HERE, 'image_lstm.npz'), IMAGE_LSTM_CASES)
+    if 'x3_networks' in which:
+        layer_fixture(os.path.join(HERE, 'x3_networks.npz'), X3_NETWORK_CASES)
     if 'codec' in which:
         codec_fixture(os.path.join(HERE, 'codec.npz'))
     if 'transforms' in which:

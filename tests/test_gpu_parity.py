@@ -71,6 +71,34 @@ def test_layers_against_reference_golden(name):
                 assert np.all(y[i, ..., w:] == 0), 'padding must be zero after every non-linear-output layer'
 
 
+X3_NETS = layer_cases('x3_networks.npz')
+
+
+@pytest.mark.parametrize('name', sorted(X3_NETS))
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+def test_x3_kernels_against_reference_golden(name, prec):
+    """Small whole networks whose outputs the REFERENCE's own modules produced (tests/golden/make_golden.py, X3_NETWORK_CASES):
+    tap-as-K convolutions incl. the five-group packing at kw 11 / 12 / 13, odd channel counts, a GroupNorm consumer, stacks of
+    recurrent layers with tile-time-major rows between them; ragged batches against the reference's per-line results."""
+    c = X3_NETS[name]
+    m = build_model(c['spec'], c['sd']).to('cuda')
+    m.nn.set_precision(prec)
+    tol = 2e-5 if prec == 'f32' else (1e-3 if 'Gn' in c['spec'] else 2e-4)
+    x = torch.from_numpy(c['x'])
+    if c['lens'] is None:
+        y, _ = m.nn(x.cuda())
+        assert float((y.cpu() - torch.from_numpy(c['y'])).abs().max()) < tol
+    else:
+        for i, L in enumerate(c['lens']):
+            x[i, ..., L:] = 0
+        y, olens = m.nn(x.cuda(), torch.tensor(c['lens']))
+        y = y.cpu()
+        assert olens.tolist() == c['olens'].tolist()
+        for i, want in enumerate(c['ys']):
+            w = want.shape[3]
+            assert float((y[i:i + 1, ..., :w] - torch.from_numpy(want)).abs().max()) < tol, (name, prec, i)
+
+
 # ------------------------------------------------------------- (1) golden: benchmark networks
 @pytest.mark.parametrize('which', ['a', 'b'])
 def test_bench_networks_against_reference_golden(which, bench_a, bench_b):

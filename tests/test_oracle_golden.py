@@ -44,9 +44,12 @@ def test_np_oracle_layers(name):
             assert list(olens) == c['olens'].tolist()
 
 
-@pytest.mark.parametrize('name', sorted(CASES))
+X3_NETS = layer_cases('x3_networks.npz')     # whole small networks for the split-bf16 kernels, made by the reference's modules
+
+
+@pytest.mark.parametrize('name', sorted(CASES) + sorted(X3_NETS))
 def test_torch_port_layers(name):
-    c = CASES[name]
+    c = CASES[name] if name in CASES else X3_NETS[name]
     _, specs = parse_vgsl(c['spec'])
     ref = CpuRecognizer(specs, c['sd'])
     if c['lens'] is None:
