@@ -13,7 +13,6 @@ import numpy as np
 import pytest
 import torch
 
-from kraken_amd.vgsl import parse_vgsl
 from oracle import np_oracle
 from oracle.torch_port import CpuRecognizer
 from tests.helpers import arr_to_tuples, build_model, layer_cases, load_golden, synth_input

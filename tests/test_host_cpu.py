@@ -16,7 +16,7 @@ import kraken_amd
 from kraken_amd import _lib
 from kraken_amd.codec import KrakenCodecException, KrakenEncodeException, PytorchCodec
 from kraken_amd.vgsl import parse_vgsl
-from tests.helpers import GOLDEN, load_golden
+from tests.helpers import load_golden
 from tests.specs import BENCH_A, BENCH_B, bench_codec
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

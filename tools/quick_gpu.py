@@ -1,7 +1,6 @@
-import sys, time, torch, numpy as np
+import sys, time, torch
 sys.path.insert(0, '.')
 import kraken_amd
-from kraken_amd.vgsl import parse_vgsl
 from oracle.torch_port import CpuRecognizer
 from kraken_amd.specs import BENCH_A, BENCH_B
 for name, spec, N, W, lens in [('A-eq', BENCH_A, 3, 400, None), ('A-ragged', BENCH_A, 5, 400, [400, 307, 201, 399, 202]),
