@@ -64,6 +64,9 @@ def parse():
                     help='hand every batch over as a pinned HOST tensor (PCIe-inclusive rate; DESIGN.md quotes it, `value` never does)')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the gather even with one rank (smoke test)')
     ap.add_argument('--cpu-lines', type=int, default=32, help='lines in the CPU baseline sample')
+    ap.add_argument('--stub-engine', action='store_true',
+                    help='TEST ONLY (tests/test_dist_cpu.py): replace the device engine by a host stub and RCCL by gloo, to run the '
+                         'launcher / sharding / gather plumbing on a box without GPUs; the JSON line says so and its value is meaningless')
     ap.add_argument('--api-lines', type=int, default=2048, help='--mode api: bbox lines on the synthetic page')
     ap.add_argument('--api-workers', type=int, default=6, help='--mode api: host threads preparing lines (PIL conversions hold the GIL: more than ~6 threads only contend, 16 cost 40 %)')
     return ap.parse_args()
@@ -102,6 +105,8 @@ def cpu_baseline(model, width, n_lines):
     legacy = k / (time.perf_counter() - t0)
     torch.set_num_threads(saved)
     return {'value': round(sweep[best_t], 2), 'unit': 'lines/s', 'cores': best_t, 'host_cpus': ncpu, 'kind': 'port',
+            'why_port': 'kraken itself (/root/reference) is not importable on the GPU box; the port runs the same torch-CPU operators and is '
+                        'checked bit-for-bit against kraken in the authoring container (tests/golden/make_golden.py, tests/test_oracle_golden.py)',
             'thread_sweep': {str(t): round(v, 2) for t, v in sweep.items()},
             'legacy_one_line_per_call': round(legacy, 2),
             'sample': f'{n_lines} lines 1x48x{width} in one batch, fp32, best of the thread sweep: torch-CPU forward + softmax + '
@@ -162,75 +167,110 @@ def roofline_of(engine, precision):
                                 for k, v in groups.items()}
 
 
+class _StubEngine:
+    """Host stand-in for RecognitionEngine (--stub-engine: plumbing tests without a GPU).  Every line decodes to its rank-tagged index."""
+
+    def __init__(self, rank, slots):
+        self.slots, self.q, self.rank, self.k = [None] * slots, [], rank, 0
+
+    def free_slots(self):
+        return len(self.slots) - len(self.q)
+
+    def submit(self, x, lens=None):
+        assert self.free_slots() > 0
+        self.q.append(int(x.shape[0]))
+
+    def collect(self):
+        from kraken_amd.vgsl import DecodedBatch
+        n = self.q.pop(0)
+        lab = (np.arange(n, dtype=np.int32)[:, None] + self.k) % 250 + 1
+        self.k += n
+        return (DecodedBatch(np.repeat(lab, 2, 1), np.zeros((n, 2), np.int32), np.ones((n, 2), np.int32),
+                             np.full((n, 2), 0.5, np.float32), np.full(n, 1 + self.rank % 2, np.int32)), np.full(n, 150, np.int32))
+
+    def set_profiling(self, on):
+        pass
+
+    def layer_times(self):
+        return []
+
+    def close(self):
+        pass
+
+
 def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
-    from kraken_amd.engine import RecognitionEngine
-    dev = torch.device(f'cuda:{local_rank}')
+    stub = args.stub_engine
+    dev = torch.device('cpu') if stub else torch.device(f'cuda:{local_rank}')
     N, W = args.batch, args.width
     g = torch.Generator().manual_seed(1234 + rank)
-    xs = [torch.rand(N, 1, 48, W, generator=g).to(dev) for _ in range(4)]   # resident in HBM before timing; rotated
-    engine = RecognitionEngine(model, device=local_rank, max_batch=N, max_width=W, slots=args.slots)
+    xs = [torch.rand(N, 1, 48, W, generator=g).to(dev) for _ in range(1 if stub else 4)]   # resident in HBM before timing; rotated
+    # the product's sharded recogniser (kraken_amd/dist.py): one pipelined engine per rank, one gather of decoded tuples
+    sr = kdist.ShardedRecognizer(model, device=local_rank, batch=N, slots=args.slots, max_width=W,
+                                 engine_factory=(lambda: _StubEngine(rank, args.slots)) if stub else None)
+    engine = sr.engine
     if args.host_input:
         xs = [x.cpu().pin_memory() for x in xs]
     codec = model.codec
     n_chars = [0]
-    done = []
 
-    def to_text(item):
-        strings = codec.decode_strings(item[0])        # host codec: label tuples -> text, inside the timed region
+    def to_text(decoded, olens):
+        strings = codec.decode_strings(decoded)        # host codec: label tuples -> text, inside the timed region
         n_chars[0] += sum(map(len, strings))
-        done.append(item)
-
-    def run(steps):
-        for i in range(steps):
-            item = engine.collect() if engine.free_slots() == 0 else None
-            engine.submit(xs[i % len(xs)])             # the freed slot goes straight back to work ...
-            if item is not None:
-                to_text(item)                          # ... while the host turns the collected batch into text
-        while engine.free_slots() < len(engine.slots):
-            to_text(engine.collect())
 
     def barrier():
         if use_dist:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
-    run(args.warmup)
+    done = sr.stream((xs[i % len(xs)] for i in range(args.warmup)), to_text)
     if use_dist:
-        kdist.gather_decoded(done[-2:], force=args.force_dist)      # untimed: RCCL builds its communicator on first use
+        sr.gather(done[-2:], force=args.force_dist)      # untimed: RCCL builds its communicator on first use
     engine.set_profiling(True)
-    done.clear()
     n_chars[0] = 0
     barrier()
     t0 = time.perf_counter()
-    run(args.steps)
+    done = sr.stream((xs[i % len(xs)] for i in range(args.steps)), to_text)
     # every line this rank decoded in the timed region travels in one exchange (RCCL all_gather of compact tuples)
-    gathered_lines = (sum(len(b.counts) for b in kdist.gather_decoded(done, force=args.force_dist)) if use_dist
-                      else sum(len(b.counts) for b, _ in done))
+    gathered = sr.gather(done, force=args.force_dist) if use_dist else None
+    gathered_lines = sum(len(b.counts) for b in gathered) if use_dist else sum(len(b.counts) for b, _ in done)
     barrier()
     dt = time.perf_counter() - t0
+    gather_ms = sr.gather_ms if use_dist else 0.0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, gather_ms], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    roofline, launches, groups = roofline_of(engine, args.precision)
+        dt, gather_ms = float(t[0].item()), float(t[1].item())
     lines = N * args.steps * world
     value = lines / dt
     gathered_lines = int(gathered_lines)
     assert gathered_lines == lines, (gathered_lines, lines)
-    return {
+    ranks_seen = torch.distributed.get_world_size() if use_dist else 1
+    assert ranks_seen == world, (ranks_seen, world)
+    out = {
         'metric': METRIC, 'value': round(value, 1), 'unit': 'lines/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': DTYPES[args.precision],
         'data': 'synthetic' + (' (pinned host input per step: PCIe-inclusive)' if args.host_input else ''),
         'config': {'workload': f'BENCH-A VGSL recogniser (3.17M params, random init seed 0), {N} lines 1x48x{W} per GPU '
                                f'per step, greedy CTC decode, label tuples to host, host codec to strings',
+                   'inputs': 'pinned host tensors, copied per step (PCIe-inclusive)' if args.host_input else 'resident in HBM before the timed region',
                    'lines_per_gpu_step': N, 'width': W, 'slots': args.slots, 'precision': args.precision,
                    'parallelism': f'dp{world}', 'whole_path_tflops': round(value * 2.778e-3 * (W / 1200.0), 2)},
+        'ranks_in_collective': ranks_seen, 'collective_backend': torch.distributed.get_backend() if use_dist else None,
+        'gather_ms': round(gather_ms, 3), 'gathered_lines': gathered_lines, 'decoded_chars': int(n_chars[0]),
+    }
+    if stub:
+        out['data'] = 'STUB ENGINE -- plumbing test without a GPU, no device work: `value` is meaningless'
+        out['dtype'] = 'none (stub)'
+        return out
+    roofline, launches, groups = roofline_of(engine, args.precision)
+    out.update({
         'roofline': roofline,
         'launches': [{'name': l['name'], 'ms': round(l['ms'], 3), 'tflops': round(l['gflop'] / l['ms'], 1) if l['ms'] > 0 else 0}
                      for l in launches],
-        'groups': groups, 'gathered_lines': gathered_lines, 'decoded_chars': int(n_chars[0]),
-    }
+        'groups': groups})
+    return out
 
 
 def _page_of_lines(n, w, h, mode, seed=7):
@@ -398,34 +438,80 @@ def mode_config4(args, model, local_rank):
                                'note': f'host float tensors -> LinePipeline (bucketing, pinned staging, {R.ENGINE_SLOTS} batches in flight)'}}
 
 
+def launch_ranks(args) -> int:
+    """
+    `python bench.py --gpus N` without a launcher: become the launcher.  Spawns N copies of this command, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), rank 0 prints the JSON line.
+    Refuses (exit 3) when fewer than N devices are visible -- never a silent 1-GPU run labelled as N.
+    """
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.stub_engine:
+        from kraken_amd import _lib
+        have = _lib.device_count()
+        if have < n:
+            print(f'bench.py: --gpus {n} but only {have} HIP device(s) visible; refusing to run', file=sys.stderr)
+            return 3
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+            if rc:
+                break
+    finally:
+        for p in procs:                    # a rank that died must not leave its peers waiting in a collective
+            if p.poll() is None:
+                p.terminate()
+    return rc
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     import kraken_amd
     from kraken_amd import _lib, dist as kdist
     from kraken_amd.specs import BENCH_A, bench_codec
 
-    _lib.require_gpu()
-    torch.cuda.set_device(local_rank)
+    stub = args.stub_engine
+    if stub and args.mode != 'engine':
+        raise SystemExit('--stub-engine is a plumbing test of the default mode only')
+    if not stub:
+        _lib.require_gpu()
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f'rank {rank}: LOCAL_RANK={local_rank} but {torch.cuda.device_count()} device(s) visible')
+        torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        kdist.init(backend='nccl')
+        kdist.init(backend='gloo' if stub else 'nccl')
 
     torch.manual_seed(0)
     model = kraken_amd.TorchVGSLModel(vgsl=BENCH_A, codec=bench_codec())
-    model.to(torch.device(f'cuda:{local_rank}'))
-    model.nn.set_precision(args.precision)
+    if not stub:
+        model.to(torch.device(f'cuda:{local_rank}'))
+        model.nn.set_precision(args.precision)
     if args.mode == 'api':
         out = mode_api(args, rank, local_rank)
     elif args.mode == 'config4':
         out = mode_config4(args, model, local_rank)
     else:
         out = mode_engine(args, model, rank, world, local_rank, use_dist, kdist)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'engine':
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'engine' and not stub:
         out['cpu_baseline'] = cpu_baseline(model, args.width, args.cpu_lines)
     if use_dist:
         torch.distributed.destroy_process_group()

@@ -23,7 +23,8 @@ import torch.distributed as td
 
 from .vgsl import DecodedBatch
 
-__all__ = ['init', 'shard_bounds', 'shard_indices', 'gather_decoded', 'pack_decoded', 'unpack_decoded', 'concat_decoded']
+__all__ = ['init', 'shard_bounds', 'shard_indices', 'gather_decoded', 'pack_decoded', 'unpack_decoded', 'concat_decoded',
+           'ShardedRecognizer', 'recognize_lines']
 
 
 def init(backend: Optional[str] = None):
@@ -94,7 +95,8 @@ def concat_decoded(batches) -> tuple[DecodedBatch, np.ndarray]:
 
 def gather_decoded(batch, olens=None, group=None, force: bool = False) -> list[DecodedBatch]:
     """
-    All ranks receive every rank's decoded lines, in rank order (`force`: run the collectives even alone).
+    All ranks receive every rank's decoded lines, in rank order (`force`: run the collectives even alone); each returned
+    DecodedBatch carries the lines' valid output widths as ``.olens``.
     `batch` is one DecodedBatch with its `olens`, or a list of (DecodedBatch, olens) pairs -- all batches a rank decoded
     travel in ONE exchange, each packed compactly (only the tuples that exist, not the padded rows).
     """
@@ -102,8 +104,13 @@ def gather_decoded(batch, olens=None, group=None, force: bool = False) -> list[D
         parts = list(batch)
     else:
         parts = [(batch, olens)]
+    if not parts:                                   # a rank without lines still takes part in the exchange
+        z = np.zeros((0, 1), dtype=np.int32)
+        parts = [(DecodedBatch(z, z.copy(), z.copy(), z.view(np.float32).copy(), np.zeros(0, np.int32)), np.zeros(0, np.int32))]
     if not td.is_initialized() or (td.get_world_size(group) == 1 and not force):
-        return [concat_decoded(parts)[0]] if len(parts) != 1 else [parts[0][0]]
+        b, o = concat_decoded(parts) if len(parts) != 1 else parts[0]
+        b.olens = None if o is None else np.asarray(o)
+        return [b]
     world = td.get_world_size(group)
     backend = td.get_backend(group)
     dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
@@ -122,8 +129,128 @@ def gather_decoded(batch, olens=None, group=None, force: bool = False) -> list[D
     td.all_gather(heads, head, group=group)
     sizes = [(int(h[0]), int(h[1])) for h in heads]
     longest = max(2 * a + 4 * b for a, b in sizes)
+    # The tuples are already on the host (the engine copies the compact result back for the codec), so a rank's message
+    # goes host -> device -> xGMI -> device -> host: one extra PCIe round trip of <= 5 MB per exchange, against the
+    # alternative of keeping every slot's device result buffers alive until the end of the run.
     buf = torch.zeros(max(longest, 1), dtype=torch.int32, device=dev)
     buf[:flat.size] = torch.from_numpy(flat).to(dev)
     bufs = [torch.empty_like(buf) for _ in range(world)]
     td.all_gather(bufs, buf, group=group)
-    return [unpack_decoded(b.cpu().numpy(), a, c)[0] for b, (a, c) in zip(bufs, sizes)]
+    out = []
+    for b, (a, c) in zip(bufs, sizes):
+        batch, ol = unpack_decoded(b.cpu().numpy(), a, c)
+        batch.olens = ol                       # valid output steps per line travel with the tuples
+        out.append(batch)
+    return out
+
+
+class ShardedRecognizer:
+    """
+    Recognition of independent text lines on the GPUs of one node -- BASELINE config 3 ("lines sharded over xGMI, RCCL gather
+    of decoded strings") as a product call.  One instance per rank (= per GPU, one process each): weights replicated, a
+    pipelined ``RecognitionEngine`` per rank, no data-path collective; the single exchange is ``gather``.
+
+        sr = ShardedRecognizer(model)                       # every rank, after dist.init()
+        texts = sr.recognize_lines(lines)                   # the same list of (C, H, W) line tensors on every rank
+                                                            # -> list of LineResult in INPUT order, on every rank
+
+    ``engine_factory`` replaces the device engine in the CPU test-suite (the plumbing is identical).
+    """
+
+    def __init__(self, model, device: Optional[int] = None, batch: int = 256, slots: int = 3, max_width: int = 2400,
+                 temperature: float = 1.0, group=None, engine_factory=None):
+        self.model, self.batch, self.group = model, int(batch), group
+        self.rank = td.get_rank(group) if td.is_initialized() else 0
+        self.world = td.get_world_size(group) if td.is_initialized() else 1
+        if engine_factory is None:
+            from .engine import RecognitionEngine
+            if device is None:
+                device = torch.cuda.current_device()
+            self.engine = RecognitionEngine(model, device=device, max_batch=self.batch, max_width=max_width, slots=slots,
+                                            temperature=temperature)
+        else:
+            self.engine = engine_factory()
+        self.gather_ms = 0.0
+
+    # -- this rank's share of the work -----------------------------------------------------------------------------
+    def stream(self, batches, on_batch=None) -> list:
+        """
+        Runs ``batches`` -- an iterable of ``x`` or ``(x, lens)``, device-resident or host tensors -- through the engine with
+        all its slots in flight: a freed slot is resubmitted BEFORE the host turns the collected batch into text
+        (``on_batch(decoded, olens)``, e.g. the codec).  Returns [(DecodedBatch, olens)] in submission order.
+        """
+        eng, done = self.engine, []
+
+        def finish(item):
+            if on_batch is not None:
+                on_batch(*item)
+            done.append(item)
+
+        for b in batches:
+            x, lens = b if isinstance(b, tuple) else (b, None)
+            item = eng.collect() if eng.free_slots() == 0 else None
+            eng.submit(x, lens)
+            if item is not None:
+                finish(item)
+        while eng.free_slots() < len(eng.slots):
+            finish(eng.collect())
+        return done
+
+    def gather(self, done, force: bool = False) -> list:
+        """The exchange step: every rank's decoded lines to every rank, in rank order (one RCCL all_gather of compact tuples)."""
+        import time
+        t0 = time.perf_counter()
+        out = gather_decoded(done, group=self.group, force=force)
+        self.gather_ms = 1e3 * (time.perf_counter() - t0)
+        return out
+
+    # -- the whole job -------------------------------------------------------------------------------------------
+    def recognize_lines(self, lines: Sequence, codec=None) -> list:
+        """
+        ``lines``: the job's line tensors ``(C, H, W_i)`` (host or device), the same list on every rank.  Lines are dealt to
+        the ranks width-balanced (``shard_indices``), each rank width-sorts its share into batches of ``batch`` lines
+        (zero-padded to the batch's widest line, true widths passed as ``lens``: masked kernels make a line's result
+        independent of its batch mates), recognises them, and the decoded tuples of all ranks are gathered.  Returns one
+        ``rpred.LineResult`` per input line, in input order, on every rank.
+        """
+        from .rpred import _decode_lines
+        codec = codec or self.model.codec
+        widths = np.asarray([int(t.shape[-1]) for t in lines], dtype=np.int64)
+        shards = [shard_indices(widths, self.world, r) for r in range(self.world)]
+        mine = shards[self.rank]
+        order = [mine[np.argsort(widths[mine], kind='stable')]] if len(mine) else []
+        batches = [order[0][lo:lo + self.batch] for lo in range(0, len(mine), self.batch)] if len(mine) else []
+
+        def padded(idx):
+            w = int(widths[idx].max())
+            first = lines[int(idx[0])]
+            x = torch.zeros((len(idx),) + tuple(first.shape[:-1]) + (w,), dtype=torch.float32, device=first.device)
+            for j, i in enumerate(idx):
+                x[j, ..., :int(widths[i])] = lines[int(i)]
+            return x, widths[idx].astype(np.int32)
+
+        done = self.stream(padded(idx) for idx in batches)
+        parts = self.gather(done)                                   # rank r's lines, in ITS batch order
+        results = [None] * len(lines)
+        for r, part in enumerate(parts):
+            rank_order = shards[r][np.argsort(widths[shards[r]], kind='stable')]
+            if len(part.counts) != len(rank_order):
+                raise RuntimeError(f'rank {r} returned {len(part.counts)} lines for a shard of {len(rank_order)}')
+            olens = getattr(part, 'olens', None)
+            for i, res in zip(rank_order, _decode_lines(codec, part, olens if olens is not None else np.zeros(len(rank_order), np.int32))):
+                results[int(i)] = res
+        return results
+
+    def close(self):
+        self.engine.close()
+
+
+def recognize_lines(model, lines: Sequence, **kw) -> list:
+    """One-call form of ``ShardedRecognizer(model, **kw).recognize_lines(lines)`` (initialises torch.distributed from the launcher's environment)."""
+    if 'WORLD_SIZE' in os.environ and not td.is_initialized():
+        init()
+    sr = ShardedRecognizer(model, **kw)
+    try:
+        return sr.recognize_lines(lines)
+    finally:
+        sr.close()

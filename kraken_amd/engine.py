@@ -97,6 +97,8 @@ class RecognitionEngine:
                 s.ensure_results(max_batch, max_t)
         self._next = 0
         self._inflight = deque()
+        self.in_use = False          # held by a LinePipeline (rpred.py: one consumer per engine at a time)
+        self.closed = False
         # front event of the batch submitted last: the next batch's convolution block queues behind it, so the
         # full-chip convolution blocks of different batches run one after another (no convoy of all slots doing
         # convolutions together and then all doing recurrences together) -- see include/kraken_amd.h
@@ -257,8 +259,10 @@ class RecognitionEngine:
         lens_arr = None
         if lens is not None:
             lens_arr = np.ascontiguousarray(np.asarray(lens, dtype=np.int32))
-        if wait_current:
-            slot.stream.wait_stream(torch.cuda.current_stream(self.device))   # the input may have been produced there
+        if wait_current or slot.want_probs:
+            # the input may have been produced on the current stream; and when the slot's previous batch exposed its softmax
+            # (`last_probs`), the consumer's clones were enqueued there too: order them before this batch's overwrite
+            slot.stream.wait_stream(torch.cuda.current_stream(self.device))
         if self.chain_fronts and len(self._fronts) >= self.front_lag and len(self.slots) > 1:
             _lib.check(self.lib.krk_plan_wait_front(plan.handle, self._fronts[-self.front_lag]))
         self._fronts.append(self.lib.krk_plan_front_event(plan.handle))
@@ -289,6 +293,7 @@ class RecognitionEngine:
         self._inflight.remove(ticket)
         slot = self.slots[ticket]
         slot.event.synchronize()
+        slot.busy, slot.keep = False, None                         # the slot is free again whatever the status below says
         _lib.check(self.lib.krk_plan_status(slot.plan.handle))     # a kernel that gave up waiting raises here, never hangs
         nt = slot.cap_n * slot.cap_t
         h = slot.host_buf.numpy()
@@ -296,7 +301,6 @@ class RecognitionEngine:
         view = lambda k: h[k * nt:(k + 1) * nt].reshape(slot.cap_n, t)[:n]   # noqa: E731
         batch = DecodedBatch(view(0).copy(), view(1).copy(), view(2).copy(), view(3).copy().view(np.float32),
                              h[4 * nt:4 * nt + n].copy())
-        slot.busy, slot.keep = False, None
         self.last_slot = slot
         self.last_flags = slot.flags_host[:n].numpy().copy() if slot.has_flags else None
         slot.has_flags = False
@@ -309,6 +313,26 @@ class RecognitionEngine:
             return None
         return slot.probs[:slot.n * slot.t * self.classes].view(slot.n, slot.t, self.classes).permute(0, 2, 1)
 
-    def close(self):
+    def reset(self):
+        """
+        Abandons whatever is in flight (a consumer that stopped iterating, an exception between submit and collect): waits for
+        the slots' streams, frees every slot and clears a stale status word, so that the next run starts from a clean engine.
+        """
         for s in self.slots:
+            if s.busy:
+                s.stream.synchronize()
+            s.busy, s.keep, s.staged, s.has_flags, s.want_probs = False, None, None, False, False
+            if s.plan.handle:
+                self.lib.krk_plan_status(s.plan.handle)            # reading the word clears it
+        self._inflight.clear()
+        self._fronts.clear()
+        self._next = 0
+        self.last_slot = None
+        self.last_flags = None
+
+    def close(self):
+        self.closed = True
+        for s in self.slots:
+            if s.busy:
+                s.stream.synchronize()
             s.plan.close()

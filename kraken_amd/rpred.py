@@ -193,7 +193,13 @@ def _fused_ok(net) -> bool:
 
 
 def _engine_for(net, temperature: float):
-    """The (cached) RecognitionEngine of a recogniser; None for models the engine does not take (variable height)."""
+    """
+    Checks out a RecognitionEngine of a recogniser for ONE consumer (a LinePipeline); None for models the engine does not take
+    (variable height).  Engines are cached on the model per (device, arithmetic, weights version) -- the softmax temperature is
+    an argument of every call, not a property of the plans -- and handed out exclusively: a second live pipeline on the same
+    model gets an engine of its own, and an engine that comes back from an abandoned run (generator dropped mid-page, exception
+    between submit and collect) is reset before it is reused.  ``_release_engine`` hands it back.
+    """
     from .engine import RecognitionEngine
     vgsl = net.nn
     hs = vgsl.nn
@@ -204,16 +210,36 @@ def _engine_for(net, temperature: float):
         vgsl.to('cuda')
         p = next(vgsl.parameters())
     dev = p.device.index if p.device.index is not None else torch.cuda.current_device()
-    key = (dev, hs.precision, hs._weights_version(), float(temperature))
+    key = (dev, hs.precision, hs._weights_version())
     cache = hs.__dict__.setdefault('_engines', {})
-    eng = cache.get(key)
+    for k in [k for k in cache if k != key]:          # weights updated in place / other arithmetic: those plans are stale
+        for old in cache.pop(k):
+            if old.in_use:
+                old.stale = True                      # closed by the pipeline that still holds it
+            else:
+                old.close()
+    pool = cache.setdefault(key, [])
+    eng = next((e for e in pool if not e.in_use and not e.closed), None)
     if eng is None:
-        for old in cache.values():
-            old.close()
-        cache.clear()
         eng = RecognitionEngine(vgsl, device=dev, max_batch=32, max_width=256, slots=ENGINE_SLOTS, temperature=temperature)
-        cache[key] = eng
+        eng.stale = False
+        pool.append(eng)
+        del pool[:-4]                                 # engines still held elsewhere stay alive through their holders
+    else:
+        eng.reset()
+    eng.temperature = float(temperature)
+    eng.in_use = True
     return eng
+
+
+def _release_engine(eng):
+    if eng is None or not eng.in_use:
+        return
+    eng.in_use = False
+    if getattr(eng, 'stale', False):
+        eng.close()
+    elif not eng.closed:
+        eng.reset()
 
 
 def _decode_lines(codec, batch, olens, probs=None) -> list:
@@ -270,6 +296,18 @@ class LinePipeline:
     @property
     def fused(self) -> bool:
         return self.engine is not None
+
+    def close(self):
+        """Hands the engine back (abandoning batches still in flight); the pipeline cannot be used afterwards."""
+        eng, self.engine = self.__dict__.get('engine'), None
+        self.__dict__.get('_tickets', deque()).clear()
+        try:
+            _release_engine(eng)
+        except Exception:      # interpreter shutdown, device already gone
+            pass
+
+    def __del__(self):
+        self.close()
 
     def submit(self, items: list):
         """items: [(key, tensor)]; all tensors share (C, H).  Width-sorted so that a batch pads to similar widths."""
@@ -551,13 +589,30 @@ class _RecognitionRun:
                 raise RuntimeError(f'line {self._cursor} was never recognised')   # cannot happen: every line yields a record
             self._advance()
 
+    def close(self):
+        """Ends the run: engines go back to their models (batches still in flight are abandoned), the thread pool stops."""
+        for pipe in self.__dict__.get('_pipes', {}).values():
+            pipe.close()
+        self.__dict__.get('_pipes', {}).clear()
+        pool, self._pool = self.__dict__.get('_pool'), None
+        if pool:
+            pool.shutdown(wait=False)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _next_record(self):
         if self._cursor >= self.len:
-            if self._pool:
-                self._pool.shutdown(wait=False)
-                self._pool = None
+            self.close()
             raise StopIteration
-        self._fill()
+        try:
+            self._fill()
+        except BaseException:
+            self.close()          # a failed batch must not leave its engine's slots busy for the next page (engines are cached)
+            raise
         rec = self._results.pop(self._cursor)
         self._cursor += 1
         return rec
@@ -765,8 +820,11 @@ def recognition_pred(model, im, segmentation, config=None):
     (``VGSLRecognitionInference._recognition_pred``, reference kraken/lib/vgsl/rpred.py:56-124) on the pipelined engine.
     """
     run = _PredRun(model, im, segmentation, config)
-    while True:
-        try:
-            yield run._next_record()
-        except StopIteration:
-            return
+    try:
+        while True:
+            try:
+                yield run._next_record()
+            except StopIteration:
+                return
+    finally:                   # also on GeneratorExit: `next(model.predict(...))`, `break` in the consumer's loop
+        run.close()

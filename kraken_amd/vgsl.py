@@ -294,6 +294,9 @@ class _Plan:
         self.handle = handle
         self.device = device
         self._lib = lib
+        # plans with a recurrent layer on the split-bf16 kernels may run the cluster kernel (lstm_ws), whose only failure
+        # signal is the status word (krk_plan_status)
+        self.has_status = precision != _lib.PREC_F32 and any(s.kind == 'rnn' for s in specs)
 
     def out_shape(self, W: int):
         c, h, w = C.c_int(), C.c_int(), C.c_int()
@@ -351,8 +354,7 @@ class HipSequential(nn.Module):
         self._input = tuple(input_shape)
         for spec in specs:
             self.add_module(spec.name, _HOLDERS[spec.kind](spec) if spec.kind in _HOLDERS else _NoParams())
-        self._plan: Optional[_Plan] = None
-        self._plan_key = None
+        self._plans: dict = {}          # (device, precision, weights version, height) -> _Plan, a few heights at most
         self.precision = _lib.PREC_F32
 
     # -- plan management -------------------------------------------------------------
@@ -391,13 +393,30 @@ class HipSequential(nn.Module):
     def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def _drop_plans(self):
+        for plan in self._plans.values():
+            plan.close()
+        self._plans.clear()
+
+    @property
+    def _plan(self) -> Optional[_Plan]:
+        """The plan used last (diagnostics / tests)."""
+        return next(reversed(self._plans.values()), None)
+
     def invalidate(self):
-        if self._plan is not None:
-            self._plan.close()
-        self._plan = None
-        self._plan_key = None
-        for eng in self.__dict__.pop('_engines', {}).values():     # pipelined engines hold their own plans (rpred.py)
-            eng.close()
+        """
+        Weights, device or arithmetic changed: drops this module's own plans AND the pipelined engines built on them
+        (rpred.py).  A mere change of input height or device index of a direct call only adds a plan (``plan()``): it must
+        not take down the engines a running ``LinePipeline`` holds.  An engine a pipeline still holds is closed by that
+        pipeline when it lets go of it (``RecognitionEngine.in_use``), never underneath it.
+        """
+        self._drop_plans()
+        for engines in self.__dict__.pop('_engines', {}).values():     # pipelined engines hold their own plans (rpred.py)
+            for eng in engines:
+                if eng.in_use:
+                    eng.stale = True
+                else:
+                    eng.close()
 
     def has_layer(self, kind: str) -> bool:
         return any(s.kind == kind for s in self._specs)
@@ -409,11 +428,16 @@ class HipSequential(nn.Module):
             self._specs_for_height(height)   # raises if the weights do not fit that height
             h = height
         key = (device_index, self.precision, self._weights_version(), h)
-        if self._plan is None or self._plan_key != key:
-            self.invalidate()
-            self._plan = _Plan(self._specs, self, c, h, device_index, self.precision)
-            self._plan_key = key
-        return self._plan
+        plan = self._plans.get(key)
+        if plan is None:
+            if any(k[:3] != key[:3] for k in self._plans):       # in-place weight update, other device: everything is stale
+                self.invalidate()
+            while len(self._plans) >= 4:                         # variable-height models: a few heights stay planned
+                self._plans.pop(next(iter(self._plans))).close()
+            plan = self._plans[key] = _Plan(self._specs, self, c, h, device_index, self.precision)
+        else:
+            self._plans[key] = self._plans.pop(key)              # most recently used last
+        return plan
 
     def _specs_for_height(self, height: int):
         """
@@ -476,6 +500,11 @@ class HipSequential(nn.Module):
             stream = torch.cuda.current_stream().cuda_stream
             _lib.check(plan._lib.krk_forward(plan.handle, xd.data_ptr(), lens.ctypes.data if lens is not None else None,
                                              N, W, stream, out.data_ptr()))
+            if plan.has_status:
+                # the recurrent cluster kernel reports a timed-out exchange through the plan's status word only: callers of
+                # nn(x) (custom decoders, the segmenter) must not receive such logits silently
+                torch.cuda.current_stream().synchronize()
+                _lib.check(plan._lib.krk_plan_status(plan.handle))
         olens = None
         if lens is not None:
             olens = torch.from_numpy(plan.olens(lens))

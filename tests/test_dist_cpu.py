@@ -106,3 +106,96 @@ def test_gather_decoded_two_ranks_gloo(tmp_path):
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f'rank {rank} ok' in o
+
+
+# ---------------------------------------------------------------------------- sharded recognition as a product call
+SHARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from kraken_amd import dist as kdist
+from kraken_amd.codec import PytorchCodec
+from kraken_amd.vgsl import DecodedBatch
+kdist.init(backend='gloo')
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+
+class Stub:                                   # RecognitionEngine surface; a line decodes to chr(width % 50 + 1) x (1 + line sum % 3)
+    def __init__(self):
+        self.slots, self.q = [0, 0], []
+    def free_slots(self):
+        return 2 - len(self.q)
+    def submit(self, x, lens=None):
+        assert x.shape[0] == len(lens) and x.shape[-1] == int(max(lens))
+        for j, l in enumerate(lens):          # zero padding to the right of every line, the line itself intact
+            assert float(x[j, ..., l:].abs().sum()) == 0.0
+        self.q.append((x.clone(), np.asarray(lens)))
+    def collect(self):
+        x, lens = self.q.pop(0)
+        n = len(lens)
+        reps = np.array([1 + int(round(float(x[j].sum()))) % 3 for j in range(n)], np.int32)
+        lab = np.repeat((lens % 50 + 1).astype(np.int32)[:, None], 3, 1)
+        st = np.tile(np.arange(3, dtype=np.int32) * 2, (n, 1))
+        return DecodedBatch(lab, st, st + 1, np.full((n, 3), 0.25, np.float32), reps), (lens // 8).astype(np.int32)
+    def close(self):
+        pass
+
+rng = np.random.RandomState(5)
+widths = rng.randint(40, 400, size=int(sys.argv[2]))
+lines = [torch.full((1, 4, int(w)), float(i % 7) / (4 * int(w))) for i, w in enumerate(widths)]     # line sum = i % 7
+codec = PytorchCodec({chr(0x40 + k): [k] for k in range(1, 52)})
+model = type('M', (), {'codec': codec})()
+sr = kdist.ShardedRecognizer(model, batch=16, engine_factory=Stub)
+res = sr.recognize_lines(lines)
+assert len(res) == len(lines)
+for i, (r, w) in enumerate(zip(res, widths)):
+    assert r.text == chr(0x40 + w % 50 + 1) * (1 + (i % 7) % 3), (rank, i, r.text)
+    assert r.out_width == w // 8 and r.starts.tolist() == [0, 2, 4][:len(r.text)]
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print('rank', rank, 'ok', len(res))
+'''
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize('n_lines', [101, 1])
+def test_recognize_lines_sharded_over_two_ranks_returns_input_order(tmp_path, n_lines):
+    """BASELINE config 3 as a product call: shard -> per-rank pipelined engine -> gather -> results in input order on every rank."""
+    script = tmp_path / 'worker.py'
+    script.write_text(SHARD_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n_lines)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=170)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f'rank {rank} ok {n_lines}' in o
+
+
+@pytest.mark.timeout(240)
+def test_bench_launches_its_own_ranks_and_refuses_missing_devices():
+    """
+    `python bench.py --gpus N` without torchrun must be an N-rank job (VERDICT r2 #1): the launcher, the per-rank streaming loop
+    and the gather run here with 2 gloo ranks and a host stub in place of the device engine.
+    """
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                        '--stub-engine', '--batch', '8', '--width', '64'], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['n_gpus'] == 2 and out['ranks_in_collective'] == 2 and out['gathered_lines'] == 2 * 5 * 8
+    assert out['config']['parallelism'] == 'dp2' and 'STUB' in out['data'] and out['gather_ms'] > 0
+    # without the stub there is no device here: the launcher refuses instead of running one rank labelled as two
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env,
+                           capture_output=True, text=True, timeout=200)
+        assert r.returncode != 0 and 'refusing' in r.stderr and not r.stdout.strip()
+    # a launcher's WORLD_SIZE that contradicts --gpus is an error, not a relabelled run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub-engine'],
+                       env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=200)
+    assert r.returncode != 0

@@ -220,3 +220,120 @@ def test_lazy_lists_behave_like_the_lists_the_reference_stores():
         assert all(len(r.cuts) == len(r.prediction) == len(r.confidences) for r in recs)
         assert all(isinstance(r.cuts, R.LazyList) != bidi for r in recs)
         assert [list(r.cuts) for r in recs] == [[list(c) for c in r.cuts] for r in recs]
+
+
+# ------------------------------------------------------------------ engine ownership (abandoned runs, shared engines)
+class _StubEngine:
+    """The RecognitionEngine surface LinePipeline uses, on the host: submit_staged queues, collect answers one char per line."""
+    made = []
+
+    def __init__(self, model, device=0, max_batch=32, max_width=256, slots=3, temperature=1.0):
+        self.slots = [types.SimpleNamespace(busy=False) for _ in range(slots)]
+        self.temperature = temperature
+        self.in_use = self.closed = False
+        self.q, self.k, self.resets, self.last_flags = {}, 0, 0, None
+        self.fail_next_collect = False
+        _StubEngine.made.append(self)
+
+    def free_slots(self):
+        return len(self.slots) - len(self.q)
+
+    def stage(self, n, w, height=None):
+        self._staged = n
+        return np.zeros((n, 3, 48, w), np.float32)
+
+    def submit_staged(self, lens=None, want_probs=False):
+        assert self.free_slots() > 0, 'all slots busy'
+        self.k += 1
+        self.q[self.k] = np.asarray(lens)
+        return self.k
+
+    def collect(self, ticket):
+        lens = self.q.pop(ticket)
+        if self.fail_next_collect:
+            self.fail_next_collect = False
+            raise RuntimeError('device error')
+        n = len(lens)
+        one = np.ones((n, 1), np.int32)
+        return DecodedBatch(one, 0 * one, one, np.full((n, 1), 0.5, np.float32), np.ones(n, np.int32)), (lens // 8).astype(np.int32)
+
+    def last_probs(self):
+        return None
+
+    def reset(self):
+        self.q.clear()
+        self.resets += 1
+
+    def close(self):
+        self.closed = True
+
+
+def _stub_recogniser(monkeypatch):
+    import kraken_amd.engine as E
+    monkeypatch.setattr(E, 'RecognitionEngine', _StubEngine)
+    monkeypatch.setattr(R, '_fused_ok', lambda net: True)
+    monkeypatch.setattr(R, 'DEVICE_PREP', False)
+    _StubEngine.made.clear()
+    w = torch.nn.Parameter(torch.zeros(1))
+    hs = types.SimpleNamespace(precision=2, _weights_version=lambda: (w.data_ptr(), w._version), _engines={})
+    hs.__dict__['_engines'] = {}
+    vgsl = types.SimpleNamespace(nn=hs, input=(1, 3, 48, 0), one_channel_mode='L', use_legacy_polygons=False,
+                                 parameters=lambda: iter([types.SimpleNamespace(is_cuda=True, device=types.SimpleNamespace(index=0))]))
+    net = types.SimpleNamespace(nn=vgsl, seg_type='bbox', codec=PytorchCodec({'a': [1]}), temperature=1.0)
+    return net, hs, w
+
+
+def test_an_abandoned_run_hands_back_a_clean_engine(monkeypatch):
+    """A generator dropped mid-page (break / next(...) once) must not leave the model's cached engine with busy slots."""
+    net, hs, _ = _stub_recogniser(monkeypatch)
+    boxes = [(0, 0, 100 + i, 30) for i in range(200)]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', DeprecationWarning)
+        it = R.mm_rpred(defaultdict(lambda: net), page(), seg(boxes), bidi_reordering=False, batch_size=32)
+        assert next(it).prediction == 'a'
+        eng = _StubEngine.made[0]
+        assert eng.in_use and len(eng.q) > 0                  # batches still in flight
+        del it                                               # abandoned: the run's finaliser hands the engine back
+        import gc
+        gc.collect()                                         # (lazy cut lists refer back to the run: a cycle)
+        assert not eng.in_use and not eng.q and eng.resets >= 1
+        recs = list(R.mm_rpred(defaultdict(lambda: net), page(), seg(boxes), bidi_reordering=False, batch_size=32))
+    assert len(recs) == 200 and all(r.prediction == 'a' for r in recs)
+    assert len(_StubEngine.made) == 1 and not eng.in_use     # the same engine served the second page
+
+
+def test_two_live_runs_on_one_model_do_not_share_an_engine(monkeypatch):
+    net, hs, w = _stub_recogniser(monkeypatch)
+    boxes = [(0, 0, 100 + i, 30) for i in range(120)]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', DeprecationWarning)
+        a = R.mm_rpred(defaultdict(lambda: net), page(), seg(boxes), bidi_reordering=False, batch_size=32)
+        b = R.mm_rpred(defaultdict(lambda: net), page(), seg(boxes), bidi_reordering=False, batch_size=32)
+        ra, rb = [next(a)], [next(b)]
+        assert len(_StubEngine.made) == 2 and all(e.in_use for e in _StubEngine.made)
+        # a different temperature is an argument of the calls, not another engine
+        net.temperature = 0.5
+        ra += list(a)
+        rb += list(b)
+        assert len(ra) == len(rb) == 120
+        c = list(R.mm_rpred(defaultdict(lambda: net), page(), seg(boxes[:40]), bidi_reordering=False))
+        assert len(c) == 40 and len(_StubEngine.made) == 2 and _StubEngine.made[0].temperature == 0.5
+        # weights updated in place: the cached engines are stale -> closed, a fresh one is built
+        with torch.no_grad():
+            w.add_(1.0)
+        list(R.mm_rpred(defaultdict(lambda: net), page(), seg(boxes[:40]), bidi_reordering=False))
+    assert len(_StubEngine.made) == 3 and _StubEngine.made[0].closed and _StubEngine.made[1].closed
+
+
+def test_a_failed_batch_frees_the_engine(monkeypatch):
+    net, hs, _ = _stub_recogniser(monkeypatch)
+    boxes = [(0, 0, 100 + i, 30) for i in range(100)]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', DeprecationWarning)
+        it = R.mm_rpred(defaultdict(lambda: net), page(), seg(boxes), bidi_reordering=False, batch_size=32)
+        next(it)
+        _StubEngine.made[0].fail_next_collect = True
+        with pytest.raises(RuntimeError):
+            list(it)
+        assert not _StubEngine.made[0].in_use and not _StubEngine.made[0].q
+        assert len(list(R.mm_rpred(defaultdict(lambda: net), page(), seg(boxes), bidi_reordering=False))) == 100
