@@ -65,7 +65,8 @@ __device__ __forceinline__ void vm_store_b64_sc1(const u32x2& d, unsigned vo, co
     asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen sc1" : : "v"(d), "v"(vo), "s"(srd), "s"(so) : "memory");
 }
 __device__ __forceinline__ void vm_store_b128(const u32x4& d, unsigned vo, const i32x4& srd) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(d), "v"(vo), "s"(srd) : "memory");
+    // s_nop: wait states of the ">64-bit store data, then VALU write of those registers" hazard (invisible to the compiler here)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(d), "v"(vo), "s"(srd) : "memory");
 }
 __device__ __forceinline__ void vm_load_lds_b128(const float* gptr, unsigned lds_off) {   // 64 lanes x 16 B -> LDS [lds_off, +1 KB)
     unsigned keep;                                                                        // M0 (LDS base of the copy) is saved and restored

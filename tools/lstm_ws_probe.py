@@ -51,7 +51,10 @@ def child(N, T, dump):
 
 def run(env, N, T, dump=None):
     e = dict(os.environ, **{k: str(v) for k, v in env.items()})
-    out = subprocess.run([sys.executable, __file__, 'child', str(N), str(T), dump or ''], env=e, capture_output=True, text=True)
+    try:
+        out = subprocess.run([sys.executable, __file__, 'child', str(N), str(T), dump or ''], env=e, capture_output=True, text=True, timeout=150)
+    except subprocess.TimeoutExpired:
+        return {'error': 'timeout'}
     try:
         return json.loads(out.stdout.strip().splitlines()[-1])
     except Exception:
@@ -64,7 +67,7 @@ if __name__ == '__main__':
         sys.exit(0)
     import numpy as np
     os.makedirs('gpurun_out', exist_ok=True)
-    variants = [('v1', dict(KRK_LSTM_V=1)), ('ws g2', dict(KRK_LSTM_V=3, KRK_LSTM_G=2)), ('ws g4', dict(KRK_LSTM_V=3, KRK_LSTM_G=4))]
+    variants = [('v1', dict(KRK_LSTM_V=1)), ('ws g2', dict(KRK_LSTM_V=3, KRK_LSTM_G=2)), ('ws g4', dict(KRK_LSTM_V=3, KRK_LSTM_G=4)), ('wp', dict(KRK_LSTM_V=4))]
     if '--ablate' in sys.argv:
         lib = os.path.abspath('kraken_amd/libkraken_amd_ablate.so')
         for name, env in variants[1:]:
@@ -72,14 +75,17 @@ if __name__ == '__main__':
                 r = run(dict(env, KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
                 print('ablate', name, 'dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
         sys.exit(0)
-    if '--quick' in sys.argv:          # correctness at three sizes + the phase prices of the default (g2) variant
+    if '--wp' in sys.argv:             # round 3: the pipelined cluster kernel against the streaming and the round-2 cluster kernel
+        variants = [variants[0], variants[1], variants[3]]
+        sizes = ((256, 150), (40, 60), (7, 33), (1024, 150), (100, 300))
+    elif '--quick' in sys.argv:          # correctness at three sizes + the phase prices of the default (g2) variant
         lib = os.path.abspath('kraken_amd/libkraken_amd_ablate.so')
         for dbg in (0, 64, 128, 4, 16, 32, 1):     # 1 no exchange, 4 no MFMA, 16 no output pass, 32 no barrier; gather asked at slot start (64) / after the last block (128)
             r = run(dict(variants[1][1], KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
             print('ablate ws g2 dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
-        variants = variants[:2]
+        variants = [variants[0], variants[1], variants[3]]
         sizes = ((256, 150), (40, 60), (7, 33))
-    else:
+    elif '--wp' not in sys.argv:
         sizes = ((256, 150), (64, 150), (1024, 150), (40, 60), (7, 33))
     for N, T in sizes:
         ref = None
