@@ -1187,7 +1187,7 @@ void split_strides(const ConvGeom& g, int Wo_, int Wy_, long& sn, long& sr, long
 struct Probes {
     int x3_dbg = env_int("KRK_X3_DBG");          // ablation bits of the split-bf16 conv / projection kernels (-DKRK_ABLATE builds)
     int lstm_dbg = env_int("KRK_LSTM_DBG");      // ablation bits of the recurrent kernels
-    int lstm_v = env_int("KRK_LSTM_V", 4);       // 4: pipelined cluster kernel (lstm_wp.hip); 3: the round-2 cluster kernel (lstm_ws.hip); 1: streaming kernel
+    int lstm_v = env_int("KRK_LSTM_V", 0);       // 0: by hidden size (see recurrence_x3); 3: cluster kernel lstm_ws.hip; 4: pipelined XCD-local kernel lstm_wp.hip; 1: streaming kernel
     int lstm_g = env_int("KRK_LSTM_G", 2);       // 4: four 16-line groups per cluster
     int lstm_m = env_int("KRK_LSTM_M");          // f32 plan: force 16- or 32-line tiles
 };
@@ -1485,7 +1485,13 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     l.xtiled = 1;
     l.otiled = s.out_tiled ? 1 : 0;
     l.dbg = probe.lstm_dbg;
-    if (s.d_wrecwp && probe.lstm_v == 4) {
+    // Which cluster kernel: lstm_ws.hip (4-CU clusters, two blocks per wave, cross-XCD sc1 exchange) is the faster one on wide
+    // layers (H = 200: 0.46 vs 0.50 ms per layer at N = 256, T = 150); on narrow layers its time step is a handful of MFMAs and its
+    // optimistic exchange intermittently runs into its own one-second spin bound (tools/ws_flake.py: 5..50 timeouts in 100 forwards
+    // of a two-layer H = 8 net, in the round-2 build as well, hidden until forward() began to check the status word).  lstm_wp.hip
+    // (XCD-local clusters, dedicated gather waves, every wait behind a barrier) showed none in 900: it takes H <= 128.
+    const int lstm_v = probe.lstm_v ? probe.lstm_v : (l.NKB <= 4 ? 4 : 3);
+    if (s.d_wrecwp && lstm_v == 4) {
         const size_t gbytes = krk_lstm_wp_gran_bytes(Ns, s.ndir, s.Hp);
         if (gbytes > s.ws_gran.cap) {
             if (s.ws_gran.ensure(gbytes)) return nomem();
@@ -1523,7 +1529,7 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
         if (rc == 0) return 0;
         if (rc != -4) return rc;
     }
-    if (!s.d_wrecws || (probe.lstm_v != 3 && probe.lstm_v != 4)) return krk_launch_lstm_x3(l, stream);
+    if (!s.d_wrecws || (lstm_v != 3 && lstm_v != 4)) return krk_launch_lstm_x3(l, stream);
     // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time barely
     // moves (it is not exchange bound), so a launch takes twice as long on half the CUs: same chip time, worse latency, fewer
     // lines/s through the pipelined engine.  KRK_LSTM_G=4 keeps it probeable.
@@ -1539,15 +1545,17 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     w.ndir = l.ndir; w.dirmode = l.dirmode; w.xstride = l.xstride; w.ostride = l.ostride; w.hrow = l.hrow;
     w.BPC = s.ws_bpc;
     w.gran = (unsigned long long*)s.ws_gran.p;
+    // the ticket counter is zeroed before every launch (a 64-byte memset node): a monotonic counter mirrored on the host is one
+    // missed bump away from shifting every cluster of every later launch
+    if (int r = hip(hipMemsetAsync(s.ws_ctrl, 0, 64, stream), "hipMemsetAsync")) return r;
     w.ctrl = s.ws_ctrl;
-    w.ticket_base = s.ws_tickets;
+    w.ticket_base = 0;
     s.ws_epoch = s.ws_epoch % 65535u + 1u;
     w.epoch = s.ws_epoch;
     w.err = p->err_dev;
     w.otiled = l.otiled;
     w.dbg = l.dbg;
     int rc = one ? krk_launch_lstm_ws_b1(w, groups, stream) : krk_launch_lstm_ws(w, groups, stream);
-    if (rc == 0) s.ws_tickets += (unsigned)(krk_lstm_ws_clusters(Ns, s.ndir, groups) * 4);
     if (rc == -4) rc = krk_launch_lstm_x3(l, stream);
     return rc;
 }

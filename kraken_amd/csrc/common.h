@@ -42,6 +42,29 @@ __device__ __forceinline__ float krk_tanh(float x) {
     // tanh x = 2 sigma(2x) - 1; saturates cleanly to +-1 (e^-2x -> inf / 0)
     return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f;
 }
+// One LSTM cell update from the pre-activations z = (i, f, g, o) of a unit: 5 v_exp + 2 v_rcp (the textbook form: 5 + 5).
+//   c' = f c + i tanh(g) = [c (1+ei)(1+eg) + (1-eg)(1+ef)] / [(1+ei)(1+ef)(1+eg)],   ei = e^-zi, ef = e^-zf, eg = e^-2zg
+//   h  = o tanh(c')      = (1 - et) / [(1+eo)(1+et)],                                 eo = e^-zo, et = e^-2c'
+// Exponent arguments are clamped to +-20 (x log2 e): sigmoid / tanh are within 2e-9 of their limits there and the products
+// of the denominators stay below 2^88.
+__device__ __forceinline__ float krk_lstm_cell(const f32x4& z, float& c) {
+    constexpr float L2E = 1.4426950408889634f, LIM = 28.853900817779268f;   // 20 log2 e
+    const float ai = __builtin_amdgcn_fmed3f(-L2E * z[0], -LIM, LIM);
+    const float af = __builtin_amdgcn_fmed3f(-L2E * z[1], -LIM, LIM);
+    const float ag = __builtin_amdgcn_fmed3f(-2.f * L2E * z[2], -LIM, LIM);
+    const float ao = __builtin_amdgcn_fmed3f(-L2E * z[3], -LIM, LIM);
+    const float ei = __builtin_amdgcn_exp2f(ai), ef = __builtin_amdgcn_exp2f(af);
+    const float eg = __builtin_amdgcn_exp2f(ag), eo = __builtin_amdgcn_exp2f(ao);
+    const float pi = 1.f + ei, pf = 1.f + ef, pg = 1.f + eg, po = 1.f + eo;
+    const float pig = pi * pg;
+    const float num = __builtin_fmaf(c, pig, (1.f - eg) * pf);
+    const float cn = num * __builtin_amdgcn_rcpf(pig * pf);
+    c = cn;
+    const float at = __builtin_amdgcn_fmed3f(-2.f * L2E * cn, -LIM, LIM);
+    const float et = __builtin_amdgcn_exp2f(at);
+    return (1.f - et) * __builtin_amdgcn_rcpf(po * (1.f + et));
+}
+
 __device__ __forceinline__ float krk_act(float v, int act) {
     switch (act) {
         case ACT_RELU: return v > 0.f ? v : 0.f;

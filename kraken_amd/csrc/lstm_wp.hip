@@ -96,36 +96,11 @@ __device__ __forceinline__ void wp_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// One LSTM cell update from the pre-activations z = (i, f, g, o) of a unit: 5 v_exp + 2 v_rcp (lstm_ws: 5 + 5).
-//   c' = f c + i tanh(g) = [c (1+ei)(1+eg) + (1-eg)(1+ef)] / [(1+ei)(1+ef)(1+eg)],   ei = e^-zi, ef = e^-zf, eg = e^-2zg
-//   h  = o tanh(c')      = (1 - et) / [(1+eo)(1+et)],                                 eo = e^-zo, et = e^-2c'
-// Exponent arguments are clamped to +-20 (x log2 e): sigmoid / tanh are within 2e-9 of their limits there and the products
-// of the denominators stay below 2^88.
-__device__ __forceinline__ float wp_cell(const f32x4& z, float& c) {
-    constexpr float L2E = 1.4426950408889634f, LIM = 28.853900817779268f;   // 20 log2 e
-    const float ai = __builtin_amdgcn_fmed3f(-L2E * z[0], -LIM, LIM);
-    const float af = __builtin_amdgcn_fmed3f(-L2E * z[1], -LIM, LIM);
-    const float ag = __builtin_amdgcn_fmed3f(-2.f * L2E * z[2], -LIM, LIM);
-    const float ao = __builtin_amdgcn_fmed3f(-L2E * z[3], -LIM, LIM);
-    const float ei = __builtin_amdgcn_exp2f(ai), ef = __builtin_amdgcn_exp2f(af);
-    const float eg = __builtin_amdgcn_exp2f(ag), eo = __builtin_amdgcn_exp2f(ao);
-    const float pi = 1.f + ei, pf = 1.f + ef, pg = 1.f + eg, po = 1.f + eo;
-    const float pig = pi * pg;
-    const float num = __builtin_fmaf(c, pig, (1.f - eg) * pf);
-    const float cn = num * __builtin_amdgcn_rcpf(pig * pf);
-    c = cn;
-    const float at = __builtin_amdgcn_fmed3f(-2.f * L2E * cn, -LIM, LIM);
-    const float et = __builtin_amdgcn_exp2f(at);
-    return (1.f - et) * __builtin_amdgcn_rcpf(po * (1.f + et));
-}
-
 // NKB K blocks of 32; NG groups of 16 lines per cluster (stages per time step); CS slices (workgroups) per cluster.
 // 12 waves: 0..7 compute (one gate-column block each), 8..11 gather.
 template <int NKB, int NG, int CS>
 __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
-    constexpr int NGW = 4;                                        // gather waves
     constexpr int NPEER = CS - 1;
-    constexpr int NGP = (NPEER * 8 * 32 + 64 * NGW - 1) / (64 * NGW);   // granule PAIRS per gather lane (a slice publishes <= 8 blocks = 256 pairs)
     constexpr int RING = 4;                                       // xproj landing buffers (three stages ahead)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     // h in LDS, per (group, parity): [plane hi|lo][K octet 4][line 16][K block: 16 bytes each, padded to an odd count]
@@ -136,10 +111,10 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     auto lds_of = [&](int ln, int unit) -> unsigned {        // byte offset of (line, unit) inside a buffer's hi plane
         return (unsigned)(((unit & 31) >> 3) * OS + ln * RSO + (unit >> 5) * 16 + (unit & 7) * 2);
     };
-    unsigned char* hs = smem8;              // [group NG][parity 2][hbuf]
-    int* lens_s = reinterpret_cast<int*>(smem8 + 2 * NG * hbuf);        // [16 * NG]
+    unsigned char* hs = smem8;              // [group NG][hbuf]: ONE buffer per group (see the hazard note at the stage loop)
+    int* lens_s = reinterpret_cast<int*>(smem8 + NG * hbuf);            // [16 * NG]
     unsigned* misc = reinterpret_cast<unsigned*>(lens_s + 16 * NG);     // [0] cluster (work item), [1] slice
-    const unsigned dump_base = (unsigned)(2 * NG * hbuf + 16 * NG * 4 + 16);   // masked LDS writes: one dump dword per lane (two for gather lanes)
+    const unsigned dump_base = (unsigned)(NG * hbuf + 16 * NG * 4 + 16);   // masked LDS writes: one dump dword per lane (two for gather lanes)
     const unsigned xs_off = dump_base + 768u * 8u;                      // xproj landing ring [RING][wave 8][64 lanes x 16 B]
 
     const int tid = threadIdx.x;
@@ -191,7 +166,7 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
         misc[0] = c;
         misc[1] = sl;
     }
-    for (int e = tid; e < NG * hbuf / 2; e += 768) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // 2*NG*hbuf bytes
+    for (int e = tid; e < NG * hbuf / 4; e += 768) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // NG*hbuf bytes
     __syncthreads();
     const int cluster = (int)__builtin_amdgcn_readfirstlane(misc[0]), slice = (int)__builtin_amdgcn_readfirstlane(misc[1]);
     if (cluster >= a.nclusters) return;                          // surplus workgroup
@@ -220,6 +195,9 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
 
     if (wave >= 8) {
         // ======================================================================================== gather waves
+        constexpr int NGW = 4;
+        constexpr int NGP = (NPEER * 8 * 32 + 64 * NGW - 1) / (64 * NGW);   // granule PAIRS per gather lane (a slice publishes <= 8 blocks = 256 pairs)
+        static_assert(NGP == 3 || NGP == 7, "the vmcnt(0) asm below lists NGP registers");
         const int gl = tid - 512;                                 // 0 .. 64*NGW-1
         const unsigned slice_pairs = slice_gran >> 1;
         unsigned g_vo[NGP], g_lds[NGP];
@@ -237,17 +215,23 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
             g_lds[j] = (g_on[j] && unit < NKB * 32) ? lds_of(ln, unit) : 0xFFFFFFFFu;
         }
         bool dead = false;
-        // h(tg, ts - 1) -> LDS buffer [tg][ts & 1]: what the stage after this one consumes
-        unsigned gkk = 0;
-        auto gather = [&](int tg, int ts) {
-            const unsigned want = tagbase | ((unsigned)ts & 0xFFFFu);           // tag of step ts - 1
+        u32x4 gd[NGP];
+        auto issue = [&](int tg, int ts) {                        // granules of h(tg, ts - 1)
             const unsigned so = (unsigned)(tg * 2 + (ts & 1)) * gp_bytes;
-            unsigned char* hb = hs + (tg * 2 + (ts & 1)) * hbuf;
-            u32x4 gd[NGP];
+#pragma unroll
+            for (int j = 0; j < NGP; ++j) wp_load_b128_sc1(gd[j], g_vo[j], grs, so);
+        };
+        // h(tg, ts - 1) -> LDS buffer tg: what the stage after this one consumes.  `inflight`: the request went out at the end of
+        // the previous iteration (after that iteration's rows were written: the registers are free then, and nothing is in flight
+        // across the loop's back edge that the compiler could copy -- see DESIGN.md for the variants that did not work)
+        unsigned gkk = 0;
+        auto gather = [&](int tg, int ts, bool inflight) {
+            const unsigned want = tagbase | ((unsigned)ts & 0xFFFFu);           // tag of step ts - 1
+            unsigned char* hb = hs + tg * hbuf;
             unsigned spins = 0;
             while (true) {
-#pragma unroll
-                for (int j = 0; j < NGP; ++j) wp_load_b128_sc1(gd[j], g_vo[j], grs, so);
+                if (!inflight) issue(tg, ts);
+                inflight = false;
                 if constexpr (NGP == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]) : : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]), "+v"(gd[4]), "+v"(gd[5]), "+v"(gd[6]) : : "memory");
                 bool ok = true;
@@ -279,17 +263,22 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
                 *reinterpret_cast<unsigned*>(dst + (nowhere ? 4 : plane)) = (v0 >> 16) | (v1 & 0xFFFF0000u);
             }
         };
-        static_assert(NGP == 3 || NGP == 7, "the vmcnt(0) asm above lists NGP registers");
+        // iteration (s, g) runs beside compute stage (g, s) and prepares the input of the NEXT stage: (g+1, s) consumes
+        // h(g+1, s-1) -- or (0, s+1) consumes h(0, s); in the epilogue (s == Lmax) the "stages" only write h(., Lmax-1) out
+        bool pend = false;                                        // the loads of this iteration's target are already in flight
         for (int s = 0; s <= Lmax; ++s) {
 #pragma unroll
             for (int g = 0; g < NG; ++g, ++gkk) {
                 WP_STAMP(wave == 8, gkk, 7);
                 wp_barrier();
                 WP_STAMP(wave == 8, gkk, 4);
-                // the next stage is (g+1, s) and consumes h(g+1, s-1) -- or (0, s+1) and consumes h(0, s); in the epilogue
-                // (s == Lmax) the "stages" only write h(., Lmax-1) out
-                if (g + 1 < NG) { if (s > 0) gather(g + 1, s); }
-                else if (s < Lmax) gather(0, s + 1);
+                if (g + 1 < NG) { if (s > 0) gather(g + 1, s, pend); }
+                else if (s < Lmax) gather(0, s + 1, pend);
+                pend = false;
+                // the target of the next iteration was published during the stage before this one: ask for it now
+                if (g + 2 < NG) { if (s > 0) { issue(g + 2, s); pend = true; } }
+                else if (g + 2 == NG) { if (s < Lmax) { issue(0, s + 1); pend = true; } }
+                // (no request across the loop's back edge: the compiler may copy a register an unfinished load will write)
             }
         }
         return;
@@ -305,6 +294,9 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     u32x4 whi[NKB], wlo[NKB];
     {
         const __bf16* wb = a.wp + ((((size_t)dir * CS + slice) * 8 + wave) * NKB) * 1024 + lane * 8;
+        // pins these loads BELOW the role branch: hoisted above it (they are speculatable) they cost the gather waves 8 NKB
+        // registers they have no room for
+        asm volatile("; weights of the compute waves" : "+v"(wb));
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             whi[kb] = *reinterpret_cast<const u32x4*>(wb + (size_t)kb * 1024);
@@ -321,12 +313,21 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     int len_x[NG];                                                // length of this lane's line in every group (registers: no LDS round trip per stage)
     auto line_len = [&](int n) -> int { return n < a.N ? (a.lens ? min(max(a.lens[n], 0), a.T) : a.T) : 0; };
 #pragma unroll
-    for (int g = 0; g < NG; ++g) len_x[g] = line_len(n0 + 16 * g + line);
-    auto load_x = [&](int g, int s, unsigned ring) {
-        const int len = len_x[g];
-        const int t = rev ? (len - 1 - s) : s;
-        const size_t row = (s < len && g < ntiles) ? ((size_t)g * a.T + t) * 16 : 0;
-        wp_load_lds_b128(xbase + row * a.xstride + xcol, xs_off + (ring * 8u + (unsigned)wave) * 1024u);
+    for (int g = 0; g < NG; ++g) len_x[g] = (g < ntiles) ? line_len(n0 + 16 * g + line) : 0;
+    // the address of a group's NEXT xproj row is carried, not recomputed: one 64-bit add per load instead of two 64-bit
+    // multiplies (the stage is issue-bound: ~190 instructions per compute wave, 3 waves per SIMD)
+    const float* xdummy = xbase + xcol;                           // row 0 of the cluster's first tile: what lanes without a row read
+    const long long xstep = (long long)(rev ? -16 : 16) * a.xstride;          // floats per time step of a line
+    const float* xnext[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int t0 = rev ? (len_x[g] - 1) : 0;
+        xnext[g] = xbase + ((size_t)g * a.T + (size_t)max(t0, 0)) * 16 * a.xstride + xcol;
+    }
+    auto load_x = [&](int g, int s, unsigned ring) {              // must be called for s = 0, 1, 2, ... of a group, once each
+        const float* src = s < len_x[g] ? xnext[g] : xdummy;
+        xnext[g] += xstep;
+        wp_load_lds_b128(src, xs_off + (ring * 8u + (unsigned)wave) * 1024u);
     };
 
     // ---- what this lane publishes: unit_local ul = wave*4 + us of its own line
@@ -361,14 +362,19 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
         sp_tmul = 16u;                                            // consecutive steps of a line are consecutive rows
     }
     const unsigned sp_gmul = 16u * (unsigned)a.T * 16u;           // next group: 16*T rows further in both orders
+    // the store offset of a group's NEXT output step is carried the same way
     int len_sp[NG];
+    unsigned vnext[NG];
+    const unsigned vstep = rev ? 0u - sp_tmul : sp_tmul;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) len_sp[g] = sp_ln >= 0 ? line_len(n0 + 16 * g + sp_ln) : 0;
-    auto store_read = [&](int g, int step, const unsigned char* hb, unsigned& vo) -> u32x4 {
-        const int len = len_sp[g];
-        const bool on = step >= 0 && step < len;
-        const int t = rev ? (len - 1 - step) : step;
-        vo = on ? sp_g00 + (unsigned)g * sp_gmul + (unsigned)t * sp_tmul : kOOBwp;
+    for (int g = 0; g < NG; ++g) {
+        len_sp[g] = sp_ln >= 0 ? line_len(n0 + 16 * g + sp_ln) : 0;
+        vnext[g] = sp_g00 + (unsigned)g * sp_gmul + (unsigned)(rev ? max(len_sp[g] - 1, 0) : 0) * sp_tmul;
+    }
+    auto store_read = [&](int g, int step, const unsigned char* hb, unsigned& vo) -> u32x4 {       // step = -1, 0, 1, ... of a group, once each
+        const bool on = step >= 0 && step < len_sp[g];
+        vo = on ? vnext[g] : kOOBwp;
+        if (step >= 0) vnext[g] += vstep;
         return *reinterpret_cast<const u32x4*>(hb + sp_lds);
     };
 
@@ -380,7 +386,7 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     // the gates of stage (pg, ps): c, h (split into bf16 hi + lo) ...
     struct GateOut { unsigned short hbits, lbits; };
     auto gates = [&](int pg, int ps) -> GateOut {
-        const float h = wp_cell(zq, cst[pg]);
+        const float h = krk_lstm_cell(zq, cst[pg]);
         const __bf16 hb16 = (__bf16)h;
         const __bf16 lb16 = (__bf16)(h - (float)hb16);
         return GateOut{__builtin_bit_cast(unsigned short, hb16), __builtin_bit_cast(unsigned short, lb16)};
@@ -388,7 +394,7 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     // ... and where they go: own rows of h(pg, ps) in LDS buffer [pg][(ps+1)&1], the granule with tag ps+1
     auto publish = [&](const GateOut& go, int pg, int ps, bool real) {
         const bool nowhere = own_lds == 0xFFFFFFFFu;
-        unsigned char* dst = nowhere ? smem8 + dump_off : hs + (pg * 2 + ((ps + 1) & 1)) * hbuf + own_lds;
+        unsigned char* dst = nowhere ? smem8 + dump_off : hs + pg * hbuf + own_lds;
         *reinterpret_cast<unsigned short*>(dst) = go.hbits;
         *reinterpret_cast<unsigned short*>(dst + (nowhere ? 2 : plane)) = go.lbits;
         u32x2 gran;
@@ -410,8 +416,10 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     for (int s = 0; s < Lmax; ++s) {
 #pragma unroll
         for (int g = 0; g < NG; ++g, ++kk) {
-            const int par = s & 1;
-            const unsigned char* hb = hs + (g * 2 + par) * hbuf;    // h(g, s-1): own rows written by our gates, the rest gathered
+            // ONE h buffer per group is enough because the gates are deferred: buffer g holds h(g, s-1) while stage (g, s) reads it
+            // (fragments, output piece); our own rows of h(g, s) are written during the NEXT stage and the peers' rows during
+            // the stage before (g, s+1) -- both behind the barrier that ends this stage's reads.
+            const unsigned char* hb = hs + g * hbuf;                // h(g, s-1): own rows written by our gates, the rest gathered
             const int pg = (g + NG - 1) % NG, ps = g == 0 ? s - 1 : s;
             WP_STAMP(wave == 0, kk, 3);
             wp_barrier();
@@ -445,7 +453,6 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
                 if (NKB > 1) frag(1);
                 unsigned sp_vo;
                 const u32x4 sp_v = store_read(g, s - 1, hb, sp_vo);
-                load_x(g3, s3, (kk + 3u) & (RING - 1));
                 // stage (pg, ps)'s gate math: pure VALU on independent data, free to sink into the MFMA stream below (the
                 // scheduling barriers pin only the LDS reads and the MFMAs); its LDS rows and its granule leave after PUBK blocks
                 WP_STAMP(wave == 0, kk, 1);
@@ -457,13 +464,15 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_bf(whi[kb]), hh[kb], acc0, 0, 0, 0);
                     KRK_CROSS(acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_bf(whi[kb]), hl[kb], acc1, 0, 0, 0);
                               acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_bf(wlo[kb]), hh[kb], acc2, 0, 0, 0);)
-                    if (kb == 0) wp_store_b128(sp_v, sp_vo, ors);
+                    if (kb == 0) load_x(g3, s3, (kk + 3u) & (RING - 1));           // vector memory in the order [xproj, output, publish]
+                    if (kb == (NKB > 1 ? 1 : 0)) wp_store_b128(sp_v, sp_vo, ors);
                     if (kb == PUBK) publish(go, pg, ps, kk != 0);
                     __builtin_amdgcn_sched_barrier(0x406);          // VALU / SALU / transcendentals may cross; MFMA, LDS, VMEM may not
                 }
                 zq = acc0 + (acc1 + acc2);
                 WP_STAMP(wave == 0 && zq[0] != 123.f, kk, 2);
             } else {                                                // a wave without a block: its share of the output pass only
+                (void)g3; (void)s3;
                 unsigned sp_vo;
                 const u32x4 sp_v = store_read(g, s - 1, hb, sp_vo);
                 wp_store_b128(sp_v, sp_vo, ors);
@@ -472,10 +481,9 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     }
     // ---- epilogue: the gates of the last stage, then h(g, Lmax-1) of every group leaves (the gather waves complete it)
     {
-        const int par = Lmax & 1;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const unsigned char* hb = hs + (g * 2 + par) * hbuf;
+            const unsigned char* hb = hs + g * hbuf;
             wp_barrier();
             if (g == 0 && bval) publish(gates(NG - 1, Lmax - 1), NG - 1, Lmax - 1, true);
             unsigned sp_vo;
@@ -488,7 +496,7 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
 template <int NKB, int NG, int CS>
 int launch_wp(const LstmWsArgs& a, hipStream_t s) {
     const int nclusters = (a.N + 16 * NG - 1) / (16 * NG) * a.ndir;
-    const size_t lds = (size_t)2 * NG * 2 * 4 * 16 * 16 * (NKB | 1) + 16 * NG * sizeof(int) + 16 + 768 * 8 + (size_t)4 * 8 * 1024;
+    const size_t lds = (size_t)NG * 2 * 4 * 16 * 16 * (NKB | 1) + 16 * NG * sizeof(int) + 16 + 768 * 8 + (size_t)4 * 8 * 1024;
     auto kfn = lstm_wp_kernel<NKB, NG, CS>;
     if (lds > 160 * 1024) return -4;
     if (lds > 48 * 1024)

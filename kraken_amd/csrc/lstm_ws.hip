@@ -350,13 +350,7 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
             if (NG == 2 && !KRK_DBGBIT(a, 64) && i == (KRK_DBGBIT(a, 128) ? BPW - 1 : 0) && nxt && !KRK_DBGBIT(a, 1)) gather_issue(ng, nxt_par, acc0[0] + acc1[0] + acc2[0]);
             if (KRK_DBGBIT(a, 2)) continue;
             const f32x4 z = acc0 + (acc1 + acc2);
-            const float gi = krk_sigmoid(z[0]);
-            const float gf = krk_sigmoid(z[1]);
-            const float gg = krk_tanh(z[2]);
-            const float go = krk_sigmoid(z[3]);
-            const float c = gf * cst[g][i] + gi * gg;
-            cst[g][i] = c;
-            const float h = go * krk_tanh(c);
+            const float h = krk_lstm_cell(z, cst[g][i]);          // 7 transcendentals per unit instead of 10 (common.h)
             const __bf16 hb16 = (__bf16)h;
             const __bf16 lb16 = (__bf16)(h - (float)hb16);
             const unsigned short hbits = __builtin_bit_cast(unsigned short, hb16), lbits = __builtin_bit_cast(unsigned short, lb16);
