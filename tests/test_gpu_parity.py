@@ -721,7 +721,6 @@ def test_recurrent_kernel_variants_agree(bench_a_x3, monkeypatch):
         assert _max_conf_diff(got, base) < 1e-5, env
 
 
-@pytest.mark.parametrize('lens', [None, [400, 333]])
 def test_narrow_recurrent_layers_never_hit_the_exchange_timeout():
     """
     Round 3: forward() now reports the cluster kernels' exchange-timeout word, which showed that lstm_ws.hip intermittently runs
