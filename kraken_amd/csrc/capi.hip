@@ -637,12 +637,15 @@ struct PlanBuilder {
     krk_plan* p;
     const krk_layer* layers;
     int n_layers;
-    bool x3;                  // split-bf16 kernels still in use (cleared by leave_x3 when the rest of the network needs f32-only layers)
+    bool x3;                  // split-bf16 kernels in use for the layer being compiled (see build(): off up to the last GroupNorm)
     int C, H;
     bool seq = false;
     bool split_fmt = false;   // bf16x3: the current activation is held as split bf16 planes
     int stage = 0;
     int i = 0;
+    bool want_x3 = false;     // the plan's arithmetic is split-bf16 (KRK_PREC_BF16X3 / KRK_PREC_BF16)
+    bool left_x3 = false;     // a layer that exists in the f32 plan only was met: the rest of the network stays there
+    int last_gn = -1;         // index of the network's last GroupNorm layer
 
     void push_toseq() {
         Step s;
@@ -672,6 +675,7 @@ struct PlanBuilder {
             p->steps.push_back(std::move(u));
         }
         x3 = false;
+        left_x3 = true;
         split_fmt = false;
     }
 
@@ -779,7 +783,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
 // stand-alone MaxPool (reference layers.py:381-388): the ones a convolution could not swallow
 int PlanBuilder::maxpool(const krk_layer& L, const std::string& where) {
     if (x3 && split_fmt && !seq && C % 8) leave_x3();
-    if (x3 && !split_fmt) x3 = false;          // nothing split yet (pool in front of the first convolution): f32 plan
+    const bool x3 = this->x3 && split_fmt;     // nothing split yet (pool in front of the first split-bf16 layer): the f32 kernel
     if (seq) return fail(KRK_E_UNSUPPORTED, where + ": max-pool after a sequence layer");
     if (L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0) return fail(KRK_E_INVALID, where + ": bad pool");
     Step s;
@@ -804,7 +808,7 @@ int PlanBuilder::maxpool(const krk_layer& L, const std::string& where) {
 // GroupNorm (reference layers.py:967-984)
 int PlanBuilder::groupnorm(const krk_layer& L, const std::string& where) {
     if (x3 && split_fmt && !seq && !krk_gn_x3_supported(C, L.cout)) leave_x3();
-    if (x3 && !split_fmt) x3 = false;
+    const bool x3 = this->x3 && split_fmt;
     if (seq) return fail(KRK_E_UNSUPPORTED, where + ": group norm after a sequence layer");
     if (L.cout <= 0 || C % L.cout) return fail(KRK_E_INVALID, where + ": groups must divide channels");
     if (!L.w[0] || !L.w[1]) return fail(KRK_E_INVALID, where + ": group norm weights missing");
@@ -833,7 +837,7 @@ int PlanBuilder::groupnorm(const krk_layer& L, const std::string& where) {
 int PlanBuilder::reshape(const krk_layer& L, const std::string& where) {
     (void)L;
     if (x3 && split_fmt && !seq && C % 8) leave_x3();
-    if (x3 && !split_fmt) x3 = false;
+    const bool x3 = this->x3 && split_fmt;
     if (seq) return fail(KRK_E_UNSUPPORTED, where + ": reshape after a sequence layer");
     push_toseq();
     p->steps.back().on_split = x3;   // writes the K-blocked split sequence rows gemm_x3.hip reads
@@ -935,7 +939,7 @@ int PlanBuilder::recurrent_or_linear(const krk_layer& L, const std::string& wher
         if (H != 1)
             return fail(KRK_E_UNSUPPORTED, where + ": recurrent/linear layer on an input of height " +
                                                std::to_string(H) + " (only height 1 is implemented)");
-        if (x3) return fail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs the reshape fused into a convolution");
+        if (x3 && split_fmt) return fail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs the reshape fused into a convolution");
         push_toseq();
     }
     Step s;
@@ -971,9 +975,26 @@ int PlanBuilder::recurrent_or_linear(const krk_layer& L, const std::string& wher
 }
 
 int PlanBuilder::build() {
+    // Where the split-bf16 arithmetic may begin.  GroupNorm divides by the group's standard deviation and thereby amplifies the
+    // error its input carries by |x| / sigma -- on random-weight networks rare lines of an all-split plan reached 2.3e-3 against
+    // the 1e-3 parity gate (profiles/r02_fuzz_300s.txt); the error is that of the operands' 16-bit representation, so a fourth
+    // (lo x lo) MFMA term would not remove it.  Every layer up to and including the LAST GroupNorm therefore runs on the exact-f32
+    // matrix cores; the split-bf16 kernels take over behind it (the next convolution computes in f32 and hands over split planes;
+    // sequence layers split their fp32 rows on the way in), where the error is the ~1e-5 of a GroupNorm-free network.
+    want_x3 = x3;
+    for (int k = 0; k < n_layers; ++k)
+        if (layers[k].op == KRK_OP_GROUPNORM) last_gn = k;
     for (i = 0; i < n_layers; ++i) {
         const krk_layer& L = layers[i];
         const std::string where = "layer " + std::to_string(i);
+        x3 = want_x3 && !left_x3 && i > last_gn;
+        // a convolution that would be the first split-bf16 layer AND carry the height collapse has no split-plane hand-over
+        // (the f32 kernel writes split NHWC planes, not sequence rows): it stays f32, the sequence layers behind it split their rows
+        if (x3 && !split_fmt && !seq && L.op == KRK_OP_CONV) {
+            int j = i + 1;
+            if (j < n_layers && layers[j].op == KRK_OP_MAXPOOL) ++j;
+            if (j < n_layers && layers[j].op == KRK_OP_RESHAPE_HC) x3 = false;
+        }
         int rc;
         switch (L.op) {
             case KRK_OP_CONV: rc = conv(L, where); break;

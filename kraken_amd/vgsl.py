@@ -365,7 +365,7 @@ class HipSequential(nn.Module):
         kernels with the cross terms dropped: plain bf16 operands, logits ~1e-2 from fp32 -- outside the 1e-3 parity
         gate, never selected by `config.precision`; gate: identical strings on the fixtures).
         """
-        table = {'f32': _lib.PREC_F32, 'fp32': _lib.PREC_F32, '32': _lib.PREC_F32,
+        table = {'f32': _lib.PREC_F32, 'fp32': _lib.PREC_F32,
                  _lib.PREC_F32: _lib.PREC_F32, 'bf16x3': _lib.PREC_BF16X3, _lib.PREC_BF16X3: _lib.PREC_BF16X3,
                  'bf16': _lib.PREC_BF16, _lib.PREC_BF16: _lib.PREC_BF16}
         if precision in PRECISION_OF_CONFIG:
@@ -381,14 +381,11 @@ class HipSequential(nn.Module):
         """
         kraken's ``config.precision`` (kraken/configs/base.py:65, kraken/registry.py:22) -> arithmetic plan.  Every plan
         keeps fp32-class results (the reduced-precision strings are requests for SPEED, which the split-bf16 plan
-        already provides at fp32 accuracy), so the mapping only decides between the two fp32-class plans:
-        'bf16x3' (3x the throughput, |d logit| ~1e-5) except where it has less margin to the 1e-3 parity gate --
-        networks with GroupNorm and '64-true' get the exact-f32 plan.
+        already provides at fp32 accuracy), so the mapping only decides between the two fp32-class plans: 'bf16x3'
+        (|d logit| ~1e-5; layers up to and including a network's last GroupNorm run on the exact-f32 cores inside that
+        plan, see PlanBuilder::build in csrc/capi.hip) and, for '64-true', the all-f32 plan.
         """
-        want = PRECISION_OF_CONFIG[precision]
-        if want == 'bf16x3' and self.has_layer('groupnorm'):
-            return 'f32'
-        return want
+        return PRECISION_OF_CONFIG[precision]
 
     def _weights_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())

@@ -63,13 +63,9 @@ while time.time() - t0 < budget:
         d = (out['f32'][0][i, ..., :L] - out['bf16x3'][0][i, ..., :L]).abs().max().item()
         worst = max(worst, d)
         worst_by[spec[:40]] = max(worst_by.get(spec[:40], 0.0), d)
-        # GroupNorm divides by the group's standard deviation: it amplifies whatever error its input carries by |x| / sigma.
-        # On these RANDOM-weight GroupNorm networks even the f32 plan differs from the CPU by up to 9e-5 (3e-6 without
-        # GroupNorm); the split-bf16 operands are 2^7 coarser: median 3e-5, rare lines up to 1.2e-3 (the same line alone
-        # gives the same number: it is conditioning, not batching).  BENCH-B stays below 2e-4 (tests/test_gpu_parity.py).
-        # (sanity bound, not the parity gate: `config.precision` never selects bf16x3 for a GroupNorm network.  Seen so far on
-        # the two-GroupNorm random net: 1.4e-3, 1.6e-3, 2.3e-3 in runs of 2000-4500 cases)
-        assert d < (5e-3 if 'Gn' in spec else 2e-4), (spec, n, w, lens, i, d)
+        # GroupNorm networks: the layers up to the last GroupNorm run on the exact-f32 cores in BOTH plans (round 3), so the
+        # two plans differ only by what the sequence layers' split operands add; the 1e-3 bound is the parity gate itself
+        assert d < (1e-3 if 'Gn' in spec else 2e-4), (spec, n, w, lens, i, d)
         if check_cpu:
             dc = (out['f32'][0][i, ..., :L] - want[0][i, ..., :L]).abs().max().item()
             assert dc < (2e-4 if 'Gn' in spec else 5e-5), ('f32 vs cpu', spec, n, w, lens, i, dc)
