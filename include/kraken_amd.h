@@ -209,6 +209,19 @@ int krk_recognize(krk_plan* plan, const float* x_dev, const int* lens_host,
 int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int channels, const int* boxes_dev, int n,
                    int max_in_h, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream);
 
+/*
+ * The same preprocessing for line images that were cut out on the HOST (baseline / polygon extraction,
+ * kraken/lib/segmentation.py:extract_polygons -- CPU geometry outside this library; or any other producer of line images):
+ * the uint8 crops travel packed, 1 byte per pixel and channel, and are resized to the model height (the reference's
+ * `_fixed_resize`, kraken/lib/functional_im_transforms.py:66-82), padded, scaled and inverted on the device -- replaces the
+ * per-line PIL resize + float tensor of ImageInputTransforms.__call__ (kraken/lib/dataset/utils.py:93-152) without dewarping.
+ *   crops_dev  uint8 images back to back, image k = [h_k][w_k][channels] at byte offset desc[k][0]
+ *   desc_dev   int32 [n][4]: byte offset, w, h, resized width out_w = int(w * out_h / h)
+ * Everything else as krk_prep_lines.  Bit-exact against PIL + ImageInputTransforms (tests/test_gpu_parity.py).
+ */
+int krk_prep_crops(const unsigned char* crops_dev, int channels, const int* desc_dev, int n, int max_in_h, int out_h, int pad,
+                   int batch_w, float* x_dev, int* flags_dev, void* stream);
+
 /* Bytes of device workspace currently held by the plan (diagnostics). */
 long krk_plan_workspace_bytes(const krk_plan* plan);
 

@@ -1719,26 +1719,47 @@ int krk_greedy_decode(const float* scores_dev, long sn, long sc, long st, int N,
                             (int*)tmp.p[0], (float*)tmp.p[1], s, out);
 }
 
-int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int channels, const int* boxes_dev, int n,
-                   int max_in_h, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream) {
-    if (!page_dev || !boxes_dev || !x_dev || !flags_dev || n < 0 || batch_w <= 0)
-        return fail(KRK_E_INVALID, "krk_prep_lines: bad argument");
-    if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_prep_lines: no HIP device");
-    // uint8 -> float table of ToDtype(scale=True): v / 255 in fp32, one per device
+// uint8 -> float table of ToDtype(scale=True): v / 255 in fp32, one per device
+static int prep_lut(const char* who, float** out) {
     static float* luts[64] = {nullptr};
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return fail(KRK_E_INVALID, "krk_prep_lines: device index");
+    if (dev < 0 || dev >= 64) return fail(KRK_E_INVALID, std::string(who) + ": device index");
     if (!luts[dev]) {
         float h[256];
         for (int v = 0; v < 256; ++v) h[v] = (float)v / 255.0f;
         HIPCHK(hipMalloc((void**)&luts[dev], sizeof(h)));
         HIPCHK(hipMemcpy(luts[dev], h, sizeof(h), hipMemcpyHostToDevice));
     }
-    const int rc = krk_launch_prep_lines(page_dev, page_h, page_w, channels, boxes_dev, n, max_in_h, luts[dev], out_h, pad,
+    *out = luts[dev];
+    return KRK_OK;
+}
+
+int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int channels, const int* boxes_dev, int n,
+                   int max_in_h, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream) {
+    if (!page_dev || !boxes_dev || !x_dev || !flags_dev || n < 0 || batch_w <= 0)
+        return fail(KRK_E_INVALID, "krk_prep_lines: bad argument");
+    if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_prep_lines: no HIP device");
+    float* lut = nullptr;
+    if (int rc = prep_lut("krk_prep_lines", &lut)) return rc;
+    const int rc = krk_launch_prep_lines(page_dev, page_h, page_w, channels, boxes_dev, n, max_in_h, lut, out_h, pad,
                                          batch_w, x_dev, flags_dev, (hipStream_t)stream);
     if (rc == -4) return fail(KRK_E_UNSUPPORTED, "krk_prep_lines: line geometry outside the kernel's range (height, scale, padding)");
     if (rc) return fail(KRK_E_HIP, std::string("krk_prep_lines: launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return KRK_OK;
+}
+
+int krk_prep_crops(const unsigned char* crops_dev, int channels, const int* desc_dev, int n, int max_in_h, int out_h, int pad,
+                   int batch_w, float* x_dev, int* flags_dev, void* stream) {
+    if (!crops_dev || !desc_dev || !x_dev || !flags_dev || n < 0 || batch_w <= 0)
+        return fail(KRK_E_INVALID, "krk_prep_crops: bad argument");
+    if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_prep_crops: no HIP device");
+    float* lut = nullptr;
+    if (int rc = prep_lut("krk_prep_crops", &lut)) return rc;
+    const int rc = krk_launch_prep_crops(crops_dev, channels, desc_dev, n, max_in_h, lut, out_h, pad, batch_w, x_dev, flags_dev,
+                                         (hipStream_t)stream);
+    if (rc == -4) return fail(KRK_E_UNSUPPORTED, "krk_prep_crops: line geometry outside the kernel's range (height, scale, padding)");
+    if (rc) return fail(KRK_E_HIP, std::string("krk_prep_crops: launch failed: ") + hipGetErrorString(hipGetLastError()));
     return KRK_OK;
 }
 

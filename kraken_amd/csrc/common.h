@@ -270,6 +270,10 @@ int krk_lstm_kg(int M, int blocks_per_wave);
 int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, int ch, const int* boxes_dev, int n, int max_in_h,
                           const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
 
+// the same for a packed buffer of uint8 line images: desc_dev = [n][4] int32 (byte offset, width, height, out_w)
+int krk_launch_prep_crops(const unsigned char* crops, int ch, const int* desc_dev, int n, int max_in_h,
+                          const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
+
 // host-side launchers (implemented in the .hip files)
 int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);

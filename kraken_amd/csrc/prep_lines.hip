@@ -67,14 +67,27 @@ __device__ __forceinline__ unsigned clip8(int v) {
     return v < 0 ? 0u : (v > 255 ? 255u : (unsigned)v);
 }
 
+// PACKED = false: crops of ONE page, boxes [n][5] = x0 y0 x1 y1 out_w (krk_prep_lines).
+// PACKED = true: every line brings its own crop -- `page` is a packed buffer of uint8 images, boxes [n][4] = byte offset,
+//                width, height, out_w (krk_prep_crops): what a host-side line extractor (baseline / polygon extraction, any
+//                producer of line images) hands over, 1 byte per pixel over PCIe instead of the 4 of a float tensor.
+template <bool PACKED>
 __global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __restrict__ page, int page_h, int page_w, int ch,
-                                                         const int* __restrict__ boxes /* [n][5]: x0 y0 x1 y1 out_w */,
+                                                         const int* __restrict__ boxes,
                                                          const float* __restrict__ lut, int out_h, int pad, int batch_w,
                                                          float* __restrict__ out, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = blockIdx.y;
-    const int* b = boxes + 5 * n;
-    const int x0 = b[0], y0 = b[1], in_w = b[2] - b[0], in_h = b[3] - b[1], ow = b[4];
+    int x0, y0, in_w, in_h, ow;
+    if constexpr (PACKED) {
+        const int* b = boxes + 4 * n;
+        page += (size_t)(unsigned)b[0];
+        x0 = 0; y0 = 0; in_w = b[1]; in_h = b[2]; ow = b[3];
+        page_w = in_w; page_h = in_h;
+    } else {
+        const int* b = boxes + 5 * n;
+        x0 = b[0]; y0 = b[1]; in_w = b[2] - b[0]; in_h = b[3] - b[1]; ow = b[4];
+    }
     const int col0 = blockIdx.x * COLS;             // first column of this tile in the PADDED line [0, ow + 2*pad)
     const int line_w = ow + 2 * pad;
     const int tid = threadIdx.x;
@@ -161,9 +174,23 @@ int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, int
     if (out_h < 1 || out_h > 64 || pad < 1 || (ch != 1 && ch != 3) || max_in_h > MAX_ROWS) return -4;
     const size_t lds = (size_t)(out_h + COLS) * (MAX_K + 2) * sizeof(int) + (size_t)ch * (max_in_h + 2) * COLS;
     if (lds > 160 * 1024) return -4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_lines_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_lines_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), s);
     dim3 grid((unsigned)((batch_w + COLS - 1) / COLS), (unsigned)n);
-    hipLaunchKernelGGL(prep_lines_kernel, grid, dim3(256), lds, s, page, page_h, page_w, ch, boxes_dev, lut, out_h, pad, batch_w, out, flags);
+    hipLaunchKernelGGL(prep_lines_kernel<false>, grid, dim3(256), lds, s, page, page_h, page_w, ch, boxes_dev, lut, out_h, pad, batch_w, out, flags);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// packed crops: crops_dev = uint8 images back to back ([h][w][ch] each), desc_dev = [n][4] int32: byte offset, w, h, out_w
+int krk_launch_prep_crops(const unsigned char* crops, int ch, const int* desc_dev, int n, int max_in_h,
+                          const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (out_h < 1 || out_h > 64 || pad < 1 || (ch != 1 && ch != 3) || max_in_h > MAX_ROWS) return -4;
+    const size_t lds = (size_t)(out_h + COLS) * (MAX_K + 2) * sizeof(int) + (size_t)ch * (max_in_h + 2) * COLS;
+    if (lds > 160 * 1024) return -4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_lines_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), s);
+    dim3 grid((unsigned)((batch_w + COLS - 1) / COLS), (unsigned)n);
+    hipLaunchKernelGGL(prep_lines_kernel<true>, grid, dim3(256), lds, s, crops, 0, 0, ch, desc_dev, lut, out_h, pad, batch_w, out, flags);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -48,6 +48,7 @@ class _Slot:
         self.staged = None         # (n, c, h, w) of the batch being staged
         self.probs = None          # (n, t, classes) softmax of the last batch, when asked for
         self.want_probs = False
+        self.crops_host = self.crops_dev = None     # packed uint8 line crops (krk_prep_crops): pinned staging + device copy
         self.boxes_host = self.boxes_dev = None     # device-side line preprocessing (krk_prep_lines): crop boxes ...
         self.flags_dev = self.flags_host = None     # ... and the per-line "holds ink" flags it returns
         self.has_flags = False
@@ -70,6 +71,12 @@ class _Slot:
             self.stage_host = None
         if host and self.stage_host is None:
             self.stage_host = torch.empty(self.stage_dev.numel(), dtype=torch.float32).pin_memory()
+
+    def ensure_crops(self, nbytes: int):
+        if self.crops_host is None or self.crops_host.numel() < nbytes:
+            cap = int(nbytes * 1.25) + 4096
+            self.crops_host = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self.crops_dev = torch.empty(cap, dtype=torch.uint8, device=f'cuda:{self.dev}')
 
     def ensure_boxes(self, n: int):
         if self.boxes_host is None or self.boxes_host.shape[0] < n:
@@ -219,6 +226,54 @@ class RecognitionEngine:
         x = slot.stage_dev[:n * c * h * w].view(n, c, h, w)
         slot.page_keep = page_dev
         return self._launch(slot, x, widths.astype(np.int32), want_probs, wait_current=True)
+
+    def submit_crops(self, crops: list, pad: int, want_probs: bool = False, pool=None) -> int:
+        """
+        Recognises line images that were cut out on the host: ``crops`` = uint8 arrays ``(h, w)`` (1-channel models) or
+        ``(h, w, 3)``.  They travel packed, ONE byte per pixel and channel (a float tensor is four), and are resized to the
+        model height, padded, scaled and inverted on the device (``krk_prep_crops``) -- the counterpart of ``stage`` +
+        ``submit_staged`` for callers that have images, not tensors.  ``pool``: executor for the packing copies.
+        """
+        slot = self._free_slot()
+        c, h = self.in_channels, self.in_height
+        n = len(crops)
+        desc = np.empty((n, 5), dtype=np.int32)                  # offset, w, h, out_w (+ 1 unused: the box buffers are 5 wide)
+        off = 0
+        for k, a in enumerate(crops):
+            if a.dtype != np.uint8 or a.ndim != (2 if c == 1 else 3) or (c == 3 and a.shape[2] != 3):
+                raise ValueError(f'crop {k}: expected a uint8 array of shape (h, w{", 3" if c == 3 else ""}), got {a.dtype} {a.shape}')
+            ch, cw = int(a.shape[0]), int(a.shape[1])
+            desc[k] = (off, cw, ch, int(cw * h / ch) if ch else 0, 0)
+            off += (ch * cw * c + 15) & ~15                       # 16-byte aligned images
+        widths = desc[:, 3] + 2 * pad
+        w = int(widths.max())
+        slot.ensure_crops(off)
+        slot.ensure_stage(n * c * h * w, host=False)
+        slot.ensure_boxes(n)
+        buf = slot.crops_host.numpy()
+
+        def pack(lo_hi):
+            for k in range(*lo_hi):
+                a = crops[k]
+                buf[desc[k, 0]:desc[k, 0] + a.size] = np.ascontiguousarray(a).reshape(-1)
+        if pool is not None and n >= 32:
+            step = -(-n // 8)
+            list(pool.map(pack, [(a, min(a + step, n)) for a in range(0, n, step)]))
+        else:
+            pack((0, n))
+        slot.boxes_host[:n].copy_(torch.from_numpy(desc))
+        with torch.cuda.stream(slot.stream):
+            slot.crops_dev[:off].copy_(slot.crops_host[:off], non_blocking=True)          # PCIe copy on the slot's own stream
+            slot.boxes_dev[:n].copy_(slot.boxes_host[:n], non_blocking=True)
+            # krk_prep_crops reads 4-wide descriptors: compact them on the device side of the copy
+            d4 = slot.boxes_dev[:n, :4].contiguous()
+            _lib.check(self.lib.krk_prep_crops(slot.crops_dev.data_ptr(), c, d4.data_ptr(), n, int(desc[:, 2].max()), h, int(pad), w,
+                                               slot.stage_dev.data_ptr(), slot.flags_dev.data_ptr(), slot.stream.cuda_stream))
+            slot.flags_host[:n].copy_(slot.flags_dev[:n], non_blocking=True)
+            d4.record_stream(slot.stream)
+        slot.has_flags = True
+        x = slot.stage_dev[:n * c * h * w].view(n, c, h, w)
+        return self._launch(slot, x, widths.astype(np.int32), want_probs, wait_current=False)
 
     def submit_staged(self, lens=None, want_probs: bool = False) -> int:
         slot = self._free_slot()

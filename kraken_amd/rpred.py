@@ -132,6 +132,7 @@ class _Pending:
     width: int = 0                      # network input width (resized line + padding)
     box: Optional[tuple] = None         # ... prepared on the device: (x0, y0, x1, y1, resized width) into the uploaded page
     mode: str = ''                      # PIL mode of the page the device crops from
+    crop: object = None                 # ... or a uint8 line image cut out on the host, resized / padded / inverted on the device
 
 
 class LazyList(collections.abc.Sequence):
@@ -349,6 +350,17 @@ class LinePipeline:
                                               want_probs=self.want_probs)
             self._tickets.append((ticket, [k for k, _ in part]))
 
+    def submit_crops(self, items: list, pad: int):
+        """items: [(key, uint8 array (h, w[, 3]))]: line images cut out on the host, prepared (resize, pad, invert) on the device."""
+        h = self.engine.in_height
+        items = sorted(items, key=lambda ka: int(ka[1].shape[1] * h / max(ka[1].shape[0], 1)))
+        for lo in range(0, len(items), self.batch_size):
+            part = items[lo:lo + self.batch_size]
+            while self.engine.free_slots() == 0:
+                self._collect_one()
+            ticket = self.engine.submit_crops([a for _, a in part], pad, want_probs=self.want_probs, pool=self.pool)
+            self._tickets.append((ticket, [k for k, _ in part]))
+
     def _collect_one(self):
         ticket, keys = self._tickets.popleft()
         batch, olens = self.engine.collect(ticket)
@@ -413,16 +425,55 @@ class _RecognitionRun:
         self._pages: dict = {}     # PIL mode -> the page as a device tensor (device-side line preparation)
 
     # -- device-side preparation (krk_prep_lines): rectangular crops of a fixed-height model, no dewarp ------------
-    def _device_prep_ok(self, net, ts) -> bool:
-        if not DEVICE_PREP or self.bounds.type == 'baselines' or not self.bounds.text_direction.startswith('horizontal'):
-            return False
+    def _transform_on_device_ok(self, net, ts) -> bool:
+        """The transform is crop -> fixed-height LANCZOS resize -> white padding -> scale -> invert: what the device kernels do."""
+        if not DEVICE_PREP:
+            return self._host_path('device preparation is switched off (rpred.DEVICE_PREP)')
         pad = ts.pad
         if not (isinstance(pad, (tuple, list)) and len(pad) == 2 and int(pad[0]) > 0 and int(pad[1]) == 0):
+            return self._host_path('padding other than (n > 0, 0)')
+        if ts._center_norm:
+            return self._host_path('the model asks for the CenterNormalizer dewarp (1-channel model on a bbox segmentation)')
+        if ts._perm != (0, 1, 2) or ts._mode not in ('L', 'RGB') or ts._scale[1] != 0 or not 1 <= ts._scale[0] <= 64:
+            return self._host_path('input spec outside the kernel\'s range (legacy height-in-channels layout, height > 64, fixed width)')
+        if not (_fused_ok(net) and net.nn.input[2] > 0):
+            return self._host_path('recogniser without the fused engine (custom decoder, variable height)')
+        return True                                        # (the engine itself is created on the main thread, _advance)
+
+    def _host_path(self, why: str) -> bool:
+        """Says ONCE per run and reason that lines are prepared with PIL on the host: a 30x slower path the user should see."""
+        seen = self.__dict__.setdefault('_host_reasons', set())
+        if why not in seen:
+            seen.add(why)
+            logger.info(f'line images are prepared on the host, not on the device: {why}')
+        return False
+
+    def _device_prep_ok(self, net, ts) -> bool:
+        """Rectangular crops straight from the uploaded page (krk_prep_lines): bbox segmentations of horizontal text."""
+        if self.bounds.type == 'baselines' or not self.bounds.text_direction.startswith('horizontal'):
             return False
-        if ts._center_norm or ts._perm != (0, 1, 2) or ts._mode not in ('L', 'RGB') or ts._scale[1] != 0 or \
-           not 1 <= ts._scale[0] <= 64:
-            return False
-        return _fused_ok(net) and net.nn.input[2] > 0      # (the engine itself is created on the main thread, _advance)
+        return self._transform_on_device_ok(net, ts)
+
+    def _crop_for_device(self, idx: int, line, tag: str, net, ts, box, box_size, want_image: bool = False):
+        """
+        A line image that was cut out on the host (baseline / polygon extraction, vertical text ...) as a uint8 array for
+        krk_prep_crops -- or None: the reference's host transform takes it.  The flat-line rule is applied by the kernel's flags.
+        """
+        if not self._transform_on_device_ok(net, ts):
+            return None
+        w, h = box.size
+        out_h = ts._scale[0]
+        ow = int(w * out_h / h)
+        if ow <= 0:
+            return None                              # Image.resize raises on an empty target: the host path reports it
+        taps = lambda n_in, n_out: math.ceil(3.0 * max(1.0, n_in / n_out)) * 2 + 1      # noqa: E731
+        if h > 512 or taps(h, out_h) > 96 or taps(w, ow) > 96:
+            self._host_path('crop geometry outside the kernel\'s range (taller than 512 px or scaled by more than 15)')
+            return None
+        im = box if box.mode == ts._mode else box.convert(ts._mode)
+        arr = np.asarray(im, dtype=np.uint8)
+        return _Pending(idx, line, tag, net, None, box_size, image=box if want_image else None,
+                        width=ow + 2 * int(ts.pad[0]), mode=ts._mode, crop=arr)
 
     def _strip_on_device(self, net, mode: str, boxes):
         """
@@ -566,12 +617,15 @@ class _RecognitionRun:
             for i, item in zip(idxs, items):
                 if isinstance(item, _Pending):
                     self._pending[i] = item
-                    shape = ('dev', item.mode) if item.tensor is None else tuple(item.tensor.shape[:2])
+                    shape = (('crop', item.mode) if item.crop is not None else ('dev', item.mode)) if item.tensor is None \
+                        else tuple(item.tensor.shape[:2])
                     groups.setdefault((id(item.net), shape), []).append(item)
                 else:
                     self._results[i] = item
             for (_, shape), group in groups.items():     # one (recogniser, line height) per batch: heights are never padded
-                if shape[0] == 'dev':
+                if shape[0] == 'crop':
+                    self._pipe(group[0].net).submit_crops([(p.idx, p.crop) for p in group], self.pad)
+                elif shape[0] == 'dev':
                     net = group[0].net
                     page_dev, top = self._strip_on_device(net, shape[1], [p.box for p in group])
                     self._pipe(net).submit_boxes(page_dev, [(p.idx, (p.box[0], p.box[1] - top, p.box[2], p.box[3] - top, p.box[4]))
@@ -705,6 +759,9 @@ class mm_rpred(_RecognitionRun):
         if 0 in box.size:
             logger.warning(f'{line} with zero dimension. Emitting empty record.')
             return self._empty(line)
+        item = self._crop_for_device(idx, line, tag, net, self.ts[tag], box, box.size)
+        if item is not None:
+            return item
         try:
             ts_box = self.ts[tag](box)
         except Exception:
@@ -795,6 +852,9 @@ class _PredRun(_RecognitionRun):
             return self._record_cls('', [], [], line)
         if box is None or 0 in box.size:
             return self._record_cls('', [], [], line)
+        item = self._crop_for_device(idx, line, 'default', self.net, self.ts, box, box.size, want_image=self._return_image)
+        if item is not None:
+            return item
         try:
             ts_box = self.ts(box)
         except Exception:

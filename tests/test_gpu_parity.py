@@ -569,8 +569,9 @@ def test_x3_plan_keeps_everything_up_to_the_last_groupnorm_on_the_f32_cores():
 
 
 def test_x3_bench_b_groupnorm_network_against_reference_golden():
-    """BENCH-B (GroupNorm + stand-alone pools + stand-alone height collapse) on the bf16 matrix cores end to end:
-    groupnorm_x3 / maxpool_x3 / to_seq_x3 (norm_x3.hip) between conv1_x3, conv_x3, gemm_x3 and lstm_x3."""
+    """BENCH-B (GroupNorm + stand-alone pools + stand-alone height collapse) in the bf16x3 plan: the convolution / GroupNorm
+    stack runs on the exact-f32 cores (round 3: everything up to the last GroupNorm), the rows are split for gemm_x3 and the
+    recurrent kernel -- so the GroupNorm-free tolerance applies."""
     from kraken_amd.engine import RecognitionEngine
     m = build_model(BENCH_B, codec=bench_codec(), seed=0).to('cuda')
     m.nn.set_precision('bf16x3')
@@ -579,7 +580,7 @@ def test_x3_bench_b_groupnorm_network_against_reference_golden():
         n, w = int(tag[1:tag.index('w')]), int(tag[tag.index('w') + 1:])
         batch, olens, logits, _ = m.nn.recognize(synth_input(n, w).cuda(), torch.tensor([w] * n), want_logits=True)
         keep = z[f'{tag}_keep'].tolist()
-        assert np.abs(logits.cpu().numpy()[keep] - z[f'{tag}_logits']).max() < X3_TOL
+        assert np.abs(logits.cpu().numpy()[keep] - z[f'{tag}_logits']).max() < 2e-4
         assert _keys(batch.tuples()) == _keys(arr_to_tuples(z[f'{tag}_tuples'], z[f'{tag}_counts']))
     widths = z['ragged_widths'].tolist()          # masked GroupNorm statistics: ragged batch == per-line reference
     x = synth_input(len(widths), 800, seed=4321)
@@ -589,14 +590,15 @@ def test_x3_bench_b_groupnorm_network_against_reference_golden():
     for i in range(len(widths)):
         want = z[f'ragged{i}_logits']
         assert olens[i] == want.shape[1]
-        assert np.abs(logits.cpu().numpy()[i, :, :olens[i]] - want).max() < X3_TOL
+        assert np.abs(logits.cpu().numpy()[i, :, :olens[i]] - want).max() < 2e-4
     eng = RecognitionEngine(m, device=0, max_batch=4, max_width=256, slots=1)
     eng.set_profiling(True)
     eng.submit(synth_input(4, 256).cuda())
     eng.collect()
     names = [n_ for n_, _, _ in eng.layer_times()[0]]
     eng.close()
-    assert names[:7] == ['conv1_x3', 'groupnorm_x3', 'maxpool_x3', 'conv_x3', 'groupnorm_x3', 'maxpool_x3', 'to_seq_x3']
+    assert names[:7] == ['conv', 'groupnorm', 'maxpool', 'conv', 'groupnorm', 'maxpool', 'to_seq'], names
+    assert 'lstm_xproj_x3' in names and 'lstm_rec_x3' in names and 'linear_x3' in names, names
 
 
 def test_x3_full_size_batch_invariance(bench_a_x3, bench_a):
@@ -938,6 +940,95 @@ def test_device_line_preprocessing_is_bit_exact(mode):
         assert torch.equal(got[i, :, :, :w.shape[2]], w), (i, rows[i], (got[i, :, :, :w.shape[2]] - w).abs().max())
         assert got[i, :, :, w.shape[2]:].abs().sum() == 0
     assert flags.cpu().tolist() == [int(w.max() != w.min()) for w in want]
+
+
+@pytest.mark.parametrize('mode', ['L', 'RGB'])
+def test_device_preparation_of_host_cut_crops_is_bit_exact(mode):
+    """
+    krk_prep_crops (packed uint8 line images: what a host-side extractor -- baseline / polygon extraction -- hands over) ==
+    kraken's ImageInputTransforms on the same PIL images: fixed-height LANCZOS resize, white padding, scale, invert.  Through
+    the engine (RecognitionEngine.submit_crops stages the crops 1 byte per pixel) and through the C entry point directly.
+    """
+    from kraken_amd import _lib
+    from kraken_amd.transforms import ImageInputTransforms
+    page = _rgb_page().convert(mode)
+    ch = 1 if mode == 'L' else 3
+    boxes = _boxes(30, page, seed=5) + [(0, 0, 900, 48), (5, 5, 400, 29), (0, 100, 37, 612), (10, 10, 13, 300), (100, 0, 500, 1)]
+    ts = ImageInputTransforms(1, 48, 0, ch, (16, 0), valid_norm=False)
+    crops, want = [], []
+    for b in boxes:
+        im = page.crop(b)
+        if int(im.size[0] * 48 / im.size[1]) <= 0:
+            continue
+        crops.append(np.asarray(im, dtype=np.uint8))
+        want.append(ts(im))
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    desc, off = [], 0
+    for a in crops:
+        desc.append((off, a.shape[1], a.shape[0], int(a.shape[1] * 48 / a.shape[0])))
+        off += (a.size + 15) & ~15
+    buf = np.zeros(off, np.uint8)
+    for a, d in zip(crops, desc):
+        buf[d[0]:d[0] + a.size] = a.reshape(-1)
+    cb = torch.from_numpy(buf).to(dev)
+    dd = torch.tensor(desc, dtype=torch.int32, device=dev)
+    wmax = max(d[3] for d in desc) + 32
+    out = torch.full((len(crops), ch, 48, wmax), -7.0, device=dev)
+    flags = torch.full((len(crops),), -1, dtype=torch.int32, device=dev)
+    _lib.check(lib.krk_prep_crops(cb.data_ptr(), ch, dd.data_ptr(), len(crops), max(d[2] for d in desc), 48, 16, wmax,
+                                  out.data_ptr(), flags.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    got = out.cpu()
+    for i, w in enumerate(want):
+        assert tuple(w.shape) == (ch, 48, desc[i][3] + 32)
+        assert torch.equal(got[i, :, :, :w.shape[2]], w), (i, desc[i], (got[i, :, :, :w.shape[2]] - w).abs().max())
+        assert got[i, :, :, w.shape[2]:].abs().sum() == 0
+    assert flags.cpu().tolist() == [int(w.max() != w.min()) for w in want]
+
+
+def test_host_cut_line_images_are_prepared_on_the_device_and_give_the_host_records(monkeypatch):
+    """
+    The reference's baseline-segmentation path: lines are cut out on the host (extract_polygons: CPU geometry, here a stand-in
+    that crops rectangles) and resized / padded per line with PIL.  Here the crops travel as uint8 and krk_prep_crops does the
+    rest: same records (strings, cuts, confidences) as the PIL transform, and a log line says so when a model cannot take the
+    device path (1-channel model on a bbox segmentation: CenterNormalizer dewarp).
+    """
+    import logging
+    import warnings
+    from collections import defaultdict
+    from kraken_amd import rpred as R
+    from kraken_amd.containers import BaselineLine, BBoxLine, Segmentation
+    from kraken_amd.models import TorchSeqRecognizer
+    m = build_model(RGB_SPEC, codec={chr(0x61 + i): [i + 1] for i in range(26)}, seed=3)
+    m.seg_type, m.model_type = 'baselines', ['recognition']
+    m.use_legacy_polygons = False
+    net = TorchSeqRecognizer(m, device='cuda')
+    page = _rgb_page()
+    boxes = _boxes(90, page, seed=4)
+    lines = [BaselineLine(id=f'l{i}', baseline=[[b[0], b[3]], [b[2], b[3]]], boundary=[[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]])
+             for i, b in enumerate(boxes)]
+    seg = Segmentation(type='baselines', imagename='p', text_direction='horizontal-lr', script_detection=False, lines=lines)
+
+    def fake_extract(im, bounds, legacy=False):              # stand-in for kraken's polygon extractor: the boundary's bounding box
+        for ln in bounds.lines:
+            xs = [p[0] for p in ln.boundary]
+            ys = [p[1] for p in ln.boundary]
+            yield im.crop((min(xs), min(ys), max(xs), max(ys))), ln
+    monkeypatch.setattr(R, 'extract_polygons', fake_extract)
+    staged = []
+    from kraken_amd.engine import RecognitionEngine
+    real = RecognitionEngine.submit_crops
+    monkeypatch.setattr(RecognitionEngine, 'submit_crops', lambda self, crops, *a, **k: (staged.append(len(crops)), real(self, crops, *a, **k))[1])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        dev_recs = list(R.mm_rpred(defaultdict(lambda: net), page, seg, bidi_reordering=False))
+        monkeypatch.setattr(R, 'DEVICE_PREP', False)
+        host_recs = list(R.mm_rpred(defaultdict(lambda: net), page, seg, bidi_reordering=False))
+    assert sum(staged) == len(boxes)                         # every line went through krk_prep_crops
+    assert [r.prediction for r in dev_recs] == [r.prediction for r in host_recs] and any(r.prediction for r in dev_recs)
+    assert [list(r.cuts) for r in dev_recs] == [list(r.cuts) for r in host_recs]
+    for a, b in zip(dev_recs, host_recs):
+        np.testing.assert_allclose(a.confidences, b.confidences, atol=1e-6)
 
 
 def test_rpred_device_preparation_equals_host_preparation(monkeypatch):
