@@ -145,21 +145,29 @@ def roofline_of(engine, precision):
                 'gflop_per_launch': round(dom['gflop'] / dom['n'], 3),
                 'achieved': round(ach, 2), 'peak': peak_of(dom_name), 'unit': 'TFLOP/s',
                 'frac': round(ach / peak_of(dom_name), 4), 'traffic': None,
+                'clock': 'HIP events on the stream the kernels ran on (the rocprofv3 average of the same command is in profiles/)',
                 'note': ('algorithmic FLOPs of the launch group / its HIP-event time with the other batches in flight; the '
                          'split-operand kernels issue 3 bf16 MFMAs per algorithmic product'
                          if dom_name.endswith('_x3') else 'exact f32 MFMA')}
-    # HBM traffic of the dominant kernel from the committed PMC summary of this same command (separate
-    # rocprofv3 --pmc passes, see tools/summarize_pmc.py); null when no summary is available
+    # HBM traffic of the dominant kernel from the committed PMC summary of this same command (separate rocprofv3 --pmc passes at
+    # the benchmark's slot count, tools/profile_round.sh + tools/summarize_pmc.py); the NEWEST summary of this precision under
+    # profiles/ is used and named in `source`; null when there is none
     try:
-        tag = 'r02_bf16x3' if precision != 'f32' else 'r01'
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_summary.json')))['kernels']
+        import glob
+        pat = 'r*_bf16x3_pmc_summary*.json' if precision != 'f32' else 'r*_f32_pmc_summary*.json'
+        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)) or
+                       ([] if precision != 'f32' else glob.glob(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json'))))
+        cands = [c for c in cands if 'solo' not in c] or cands
+        summary = cands[-1]
+        tag = os.path.basename(summary)
+        pmc = json.load(open(summary))['kernels']
         kname = roofline['kernel'].split('<')[0]
         hit = [v for k, v in pmc.items() if k.startswith(kname) and 'hbm_write_MB_per_launch' in v]
         if hit:
             v = max(hit, key=lambda e: e.get('total_ms', 0))
             rd = v.get('hbm_read_MB_x2', v.get('hbm_read_MB_per_launch', 0.0))
             roofline['traffic'] = {'read_MB': rd, 'write_MB': v['hbm_write_MB_per_launch'], 'per': 'launch',
-                                   'source': f'profiles/{tag}_pmc_summary.json (FETCH_SIZE/WRITE_SIZE passes)'}
+                                   'source': f'profiles/{tag} (FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the guide for the wide streaming reads)'}
     except Exception:
         pass
     return roofline, launches, {k: {'ms': round(v['ms'], 3), 'tflops': round(v['gflop'] / v['ms'], 1) if v['ms'] > 0 else 0,

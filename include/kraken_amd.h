@@ -222,6 +222,13 @@ int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int ch
 int krk_prep_crops(const unsigned char* crops_dev, int channels, const int* desc_dev, int n, int max_in_h, int out_h, int pad,
                    int batch_w, float* x_dev, int* flags_dev, void* stream);
 
+/*
+ * Tail of the segmenter's forward (reference kraken/lib/vgsl/spred.py:268-272): the network's class logits (C, h, w) are
+ * brought to the scaled page's resolution by nearest-neighbour upsampling (F.interpolate(o, size=(H, W))) and squashed with a
+ * sigmoid; one pass, (C, H, W) float32 out.
+ */
+int krk_upsample_sigmoid(const float* x_dev, int C, int h, int w, int H, int W, float* y_dev, void* stream);
+
 /* Bytes of device workspace currently held by the plan (diagnostics). */
 long krk_plan_workspace_bytes(const krk_plan* plan);
 

@@ -5,7 +5,7 @@ Mirrors ``SegmentationTaskModel._compute_segmentation_map`` (reference kraken/li
 page goes through ``ImageInputTransforms(valid_norm=False)`` (resize to the network height, optional white
 padding, invert), the VGSL network (strided 7x7 / 3x3 convolutions, GroupNorm, LSTMs over image rows and
 columns, 1x1 heatmap head) runs in ``csrc/*.hip`` (f32 plan), and the logits are upsampled to the scaled page
-(``F.interpolate``, nearest) and squashed (``sigmoid``) on the GPU with torch.  Vectorisation / polygonisation of
+(nearest, like ``F.interpolate``) and squashed (``sigmoid``) by ``krk_upsample_sigmoid``.  Vectorisation / polygonisation of
 the heatmaps (``vectorize_lines`` etc.) is out of scope and stays in kraken.
 
 BASELINE.json config 5 ("blla.mlmodel baseline segmenter over 4k x 3k page, conv U-Net forward only").
@@ -14,7 +14,6 @@ from typing import Any, Sequence, Union
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from .transforms import ImageInputTransforms
 from .vgsl import TorchVGSLModel
@@ -45,8 +44,14 @@ def compute_segmentation_map(model: TorchVGSLModel, im, input_padding: Union[int
 
     model.to(device)
     o, _ = model.nn(tensor_im.unsqueeze(0).to(device))
-    o = F.interpolate(o, size=scal_im.shape)
-    o = torch.sigmoid(o)
+    # nearest upsampling to the scaled page + sigmoid: one HIP kernel (spred.py:268-272 runs F.interpolate + torch.sigmoid)
+    from . import _lib
+    o = o.contiguous()
+    _, nc, oh, ow = o.shape
+    H, W = int(scal_im.shape[0]), int(scal_im.shape[1])
+    up = torch.empty((1, nc, H, W), dtype=torch.float32, device=o.device)
+    _lib.check(_lib.load().krk_upsample_sigmoid(o.data_ptr(), nc, oh, ow, H, W, up.data_ptr(), torch.cuda.current_stream(o.device).cuda_stream))
+    o = up
     # remove padding (same index arithmetic as the reference, spred.py:272-277)
     pad = [p if p else None for p in padding]
     pad[1] = -pad[1] if pad[1] else None

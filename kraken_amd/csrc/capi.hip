@@ -1719,6 +1719,14 @@ int krk_greedy_decode(const float* scores_dev, long sn, long sc, long st, int N,
                             (int*)tmp.p[0], (float*)tmp.p[1], s, out);
 }
 
+int krk_upsample_sigmoid(const float* x_dev, int C, int h, int w, int H, int W, float* y_dev, void* stream) {
+    if (!x_dev || !y_dev || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return fail(KRK_E_INVALID, "krk_upsample_sigmoid: bad argument");
+    if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_upsample_sigmoid: no HIP device");
+    if (krk_launch_upsample_sigmoid(x_dev, y_dev, C, h, w, H, W, (hipStream_t)stream))
+        return fail(KRK_E_HIP, std::string("krk_upsample_sigmoid: launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return KRK_OK;
+}
+
 // uint8 -> float table of ToDtype(scale=True): v / 255 in fp32, one per device
 static int prep_lut(const char* who, float** out) {
     static float* luts[64] = {nullptr};

@@ -303,6 +303,8 @@ int krk_launch_unsplit(const void* x, size_t plane, float* y, int N, int C, int 
 // (N,C,H,W) <-> sequence rows [(n,h)][w][C] (yaxis = 0) or [(n,w)][h][C] (yaxis = 1) for LSTMs over image rows/columns
 int krk_launch_img2rows(const float* x, float* y, int N, int C, int H, int W, int yaxis, hipStream_t s);
 int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, int yaxis, const int* lens, int last, hipStream_t s);
+// nearest upsampling + sigmoid of the segmenter's heatmaps: (C, h, w) -> (C, H, W)
+int krk_launch_upsample_sigmoid(const float* x, float* y, int C, int h, int w, int H, int W, hipStream_t s);
 int krk_launch_rowmax(const float* scores, long sn, long sc, long st, int N, int C, int T,
                       int softmax, float temp, float* probs, int* labels, float* confs,
                       hipStream_t s);

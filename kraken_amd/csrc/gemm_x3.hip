@@ -77,44 +77,69 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][s][r] = 0.f;
 
-    // three LDS buffers, copies two K steps ahead: 6 copies per wave per step, so "vmcnt(6)" = this
-    // wave's copies of step kb have landed while those of step kb+1 are still in flight
+    // Three LDS buffers, copies two K steps ahead (6 copies per wave per step), and the FRAGMENTS one step ahead in registers
+    // (round 3): the twelve ds_read_b128 of step kb+1 are issued behind the barrier that publishes it and land while the 24
+    // MFMAs of step kb run.  Before, every step began with the reads and an `lgkmcnt(0)`: ~350 cycles of LDS latency in front
+    // of 768 cycles of MFMAs, hidden only as far as the CU's second workgroup happened to be out of phase
+    // (0.106 ms for the bare loop against 0.056 ms of MFMA time).
     const bool no_mma = KRK_DBGBIT(a, 1), no_copy = KRK_DBGBIT(a, 2), no_lds = KRK_DBGBIT(a, 8);
     if (!no_copy) { issue(0, 0);
     if (nkb > 1) issue(1, 1); }
 
     const int arow = wave * 64 + px;   // first segment's row inside the tile
-    int buf = 0;
-    for (int kb = 0; kb < nkb; ++kb) {
-        if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // everyone's copies of step kb landed; everyone finished reading step kb-1
-        bf16x8 xh[2] = {}, xl[2] = {}, wh[4] = {}, wl[4] = {};
+    struct Frag { bf16x8 xh[2], xl[2], wh[4], wl[4]; };
+    auto read = [&](int buf, Frag& f) {
         const f32x4* L = lds + buf * (A_Q + B_Q);
-        if (!no_lds) {
+        if (no_lds) return;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            xh[s] = __builtin_bit_cast(bf16x8, L[(0 + half) * TM + arow + 32 * s]);
-            xl[s] = __builtin_bit_cast(bf16x8, L[(2 + half) * TM + arow + 32 * s]);
+            f.xh[s] = __builtin_bit_cast(bf16x8, L[(0 + half) * TM + arow + 32 * s]);
+            f.xl[s] = __builtin_bit_cast(bf16x8, L[(2 + half) * TM + arow + 32 * s]);
         }
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            wh[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (0 + half) * TN + cb * 32 + px]);
-            wl[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (2 + half) * TN + cb * 32 + px]);
+            f.wh[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (0 + half) * TN + cb * 32 + px]);
+            f.wl[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (2 + half) * TN + cb * 32 + px]);
         }
-        }
-        if (kb + 2 < nkb && !no_copy) issue(kb + 2, buf == 0 ? 2 : buf - 1);   // into the buffer step kb-1 used
-        if (!no_mma)
+    };
+    auto mma = [&](const Frag& f) {
+        if (no_mma) return;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xh[s], acc[cb][s], 0, 0, 0);
-                KRK_CROSS(acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], xl[s], acc[cb][s], 0, 0, 0);
-                          acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], xh[s], acc[cb][s], 0, 0, 0);)
+                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[cb], f.xh[s], acc[cb][s], 0, 0, 0);
+                KRK_CROSS(acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[cb], f.xl[s], acc[cb][s], 0, 0, 0);
+                          acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wl[cb], f.xh[s], acc[cb][s], 0, 0, 0);)
             }
-        buf = buf == 2 ? 0 : buf + 1;
+    };
+    // one K step: publish step kb+1 (its copies landed, everyone is done reading step kb-1 ... kb), start its fragment reads,
+    // refill the buffer step kb used, then the MFMAs of step kb on the fragments read one step ago
+    auto step = [&](int kb, const Frag& cur, Frag& nxt) {
+        if (kb + 1 < nkb) {
+            if (kb + 2 < nkb) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // lgkmcnt(0) through the BUILTIN (vmcnt 63, expcnt 7, lgkmcnt 0): the compiler's own wait-count pass must know that
+            // the fragments of step kb have arrived, or it waits for them at the first MFMA -- behind the reads of step kb+1
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            read((kb + 1) % 3, nxt);
+            if (kb + 3 < nkb && !no_copy) issue(kb + 3, kb % 3);
+        }
+        mma(cur);
+    };
+    Frag fa = {}, fb = {};
+    if (nkb > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read(0, fa);
+    if (nkb > 2 && !no_copy) issue(2, 2);
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) {
+        step(kb, fa, fb);
+        step(kb + 1, fb, fa);
     }
+    if (kb < nkb) step(kb, fa, fb);
 
     // epilogue: D[column][row] (weights are the MFMA's A operand): lane = row px of its segment, registers
     // 4j..4j+3 = columns 8j + 4*half + 0..3 of the block.  The tile is transposed through LDS (the pipeline

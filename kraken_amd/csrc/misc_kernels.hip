@@ -458,6 +458,30 @@ int krk_launch_unsplit(const void* x, size_t plane, float* y, int N, int C, int 
     return last_ok();
 }
 
+namespace {
+// Heatmap tail of the segmenter (reference kraken/lib/vgsl/spred.py:268-272: F.interpolate(o, size) -- nearest -- then sigmoid):
+// (C, h, w) logits -> (C, H, W) probabilities in one pass.  Source index = min(floor(dst * (float)in / out), in - 1), in fp32
+// like ATen's nearest_idx, so that the same pixel is picked.  HBM-bound on the (C, H, W) fp32 write.
+__global__ void __launch_bounds__(256) upsample_sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int h, int w, int H, int W) {
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const size_t total = (size_t)C * H * W;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int X = (int)(e % W), Y = (int)((e / W) % H), c = (int)(e / ((size_t)W * H));
+        const int ys = min((int)floorf(Y * sy), h - 1), xs = min((int)floorf(X * sx), w - 1);
+        const float v = x[((size_t)c * h + ys) * w + xs];
+        y[e] = 1.0f / (1.0f + expf(-v));
+    }
+}
+}  // namespace
+
+int krk_launch_upsample_sigmoid(const float* x, float* y, int C, int h, int w, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)C * H * W;
+    if (!total) return 0;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(upsample_sigmoid_kernel, dim3(blocks), dim3(256), 0, s, x, y, C, h, w, H, W);
+    return last_ok();
+}
+
 int krk_launch_rowmax(const float* scores, long sn, long sc, long st, int N, int C, int T, int softmax,
                       float temp, float* probs, int* labels, float* confs, hipStream_t s) {
     const long rows = (long)N * T;

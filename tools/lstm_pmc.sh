@@ -26,7 +26,7 @@ for p in ('p1', 'p2'):
     if not f: print(p, 'no csv'); continue
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
-        if 'lstm' in r['Kernel_Name']:
+        if "lstm" in r["Kernel_Name"]:
             d[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in d.items():
         print(p, k)

@@ -3,7 +3,9 @@
 Condenses rocprofv3 outputs (kernel stats + separate --pmc passes) into a small JSON summary that
 is committed under profiles/.  Usage:
 
-    python tools/summarize_pmc.py <round tag> <stats dir> <FETCH_SIZE dir> <WRITE_SIZE dir> <MFMA dir>
+    python tools/summarize_pmc.py <round tag> <kernel_stats.csv> <FETCH_SIZE csv> <WRITE_SIZE csv> <MFMA csv>
+
+(files, not directories: tools/profile_round.sh passes the NEWEST file of each freshly emptied output directory)
 
 Counter conventions (/opt/skills/guides/MI355X_MICROARCH.md, sections HBM + rocprofv3): FETCH_SIZE / WRITE_SIZE are in
 KiB per dispatch and are reported RAW.  Calibration against known byte counts in these kernels:
@@ -21,7 +23,7 @@ import os
 import re
 import sys
 
-HALVED_READ_KERNELS = ('lstm_f32_kernel', 'lstm_x3_kernel', 'lstm_ws_kernel')   # calibrated: xproj stream reads half
+HALVED_READ_KERNELS = ('lstm_f32_kernel', 'lstm_x3_kernel', 'lstm_ws_kernel', 'lstm_wp_kernel')   # calibrated: xproj stream reads half
 
 
 def short(name):
@@ -31,17 +33,19 @@ def short(name):
 
 def pmc(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
-    f = [x for x in os.listdir(path) if x.endswith('counter_collection.csv')][0]
-    for r in csv.DictReader(open(os.path.join(path, f))):
+    for r in csv.DictReader(open(path)):
         d[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
     return d
 
 
 def main():
-    tag, stats_dir, fetch_dir, write_dir, mfma_dir = sys.argv[1:6]
-    out = {'round': tag, 'kernels': {}}
-    sf = [x for x in os.listdir(stats_dir) if x.endswith('kernel_stats.csv')][0]
-    for r in csv.DictReader(open(os.path.join(stats_dir, sf))):
+    tag, stats_file, fetch_dir, write_dir, mfma_dir = sys.argv[1:6]
+    out = {'round': tag, 'sources': {'kernel_stats': os.path.basename(stats_file), 'pmc': [os.path.basename(os.path.dirname(os.path.dirname(p))) or p
+                                                                                         for p in (fetch_dir, write_dir, mfma_dir)]},
+           'note': 'durations (avg_us) are from the kernel-trace run at the benchmark slot count; counters from the passes named in `sources` '
+                   '(solo = --slots 1, load = the benchmark slot count)',
+           'kernels': {}}
+    for r in csv.DictReader(open(stats_file)):
         k = short(r['Name'])
         out['kernels'][k] = {'calls': int(r['Calls']), 'avg_us': round(float(r['AverageNs']) / 1e3, 1),
                              'total_ms': round(float(r['TotalDurationNs']) / 1e6, 3), 'pct': float(r['Percentage'])}
