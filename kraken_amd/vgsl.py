@@ -164,6 +164,8 @@ def parse_vgsl(spec: str):
                 raise NotImplementedError(f'RNN variant "{block}" (x-axis summarising / legacy / GRU) is not supported '
                                           'by the HIP executor')
             hidden = int(g['out'])
+            if hidden > 256:
+                raise NotImplementedError(f'recurrent layer "{block}": hidden sizes above 256 are not supported by the HIP recurrent kernels')
             # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523);
             # 's' keeps only the last step of every column (:537-539): (N, C, H, W) -> (N, O, 1, W)
             p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'], summarize=bool(g['sum']))
@@ -174,8 +176,8 @@ def parse_vgsl(spec: str):
                 raise ValueError('categorical output not supported, yet.')
             if typ == 'c' and dim == 2:
                 raise ValueError('CTC not supported for heatmap output')
-            if g['aug']:
-                raise NotImplementedError('1-augmented output layers are not supported by the HIP executor')
+            if g['aug'] and dim == 2:
+                raise NotImplementedError(f'1-augmented heatmap output "{block}" is not supported by the HIP executor')
             if dim == 2:
                 if typ != 'l':
                     raise NotImplementedError('softmax heatmap outputs are not supported by the HIP executor')
@@ -184,7 +186,9 @@ def parse_vgsl(spec: str):
                          output_type=typ)
             else:
                 kind = 'linear'
-                p = dict(out=out, output_type=typ)
+                # 'a': LinSoftmax(augmentation=True) prepends a constant 1 to every input vector (layers.py:703-719); the extra
+                # weight column is folded into the bias when the plan is compiled
+                p = dict(out=out, output_type=typ, aug=bool(g['aug']))
             oshape = (n, out, h, w)
         layers.append(LayerSpec(kind, name, _named_block(block, name), p, shape, oshape))
         shape = oshape
@@ -217,7 +221,7 @@ class _RnnHolder(nn.Module):
 class _LinearHolder(nn.Module):
     def __init__(self, spec: LayerSpec):
         super().__init__()
-        self.lin = nn.Linear(spec.in_shape[1], spec.params['out'])
+        self.lin = nn.Linear(spec.in_shape[1] + (1 if spec.params.get('aug') else 0), spec.params['out'])
 
 
 class _NoParams(nn.Module):
@@ -281,7 +285,10 @@ class _Plan:
             elif spec.kind == 'linear':
                 d.op = _lib.OP_LINEAR
                 d.cout = p['out']
-                arrays = [_f32(mod.lin.weight), _f32(mod.lin.bias)]
+                w, b = _f32(mod.lin.weight), _f32(mod.lin.bias)
+                if p.get('aug'):       # y = W[:, 0] * 1 + W[:, 1:] x + b
+                    w, b = np.ascontiguousarray(w[:, 1:]), (b + w[:, 0]).astype(np.float32)
+                arrays = [w, b]
             else:
                 raise NotImplementedError(f'layer kind {spec.kind} is not supported by the HIP executor')
             for i, a in enumerate(arrays):

@@ -106,7 +106,10 @@ class CpuRecognizer:
                     o, _ = self.rnn[nm](seq)
                 x = o.reshape(h, n, w, -1).permute(1, 3, 0, 2)
             elif s.kind == 'linear':    # layers.py:710-722
-                x = F.linear(x.transpose(1, 3), self.sd[f'nn.{nm}.lin.weight'], self.sd[f'nn.{nm}.lin.bias']).transpose(1, 3)
+                xt = x.transpose(1, 3)
+                if s.params.get('aug'):     # 1-augmentation, layers.py:718-719
+                    xt = torch.cat([torch.ones(xt.shape[:3] + (1,)), xt], dim=3)
+                x = F.linear(xt, self.sd[f'nn.{nm}.lin.weight'], self.sd[f'nn.{nm}.lin.bias']).transpose(1, 3)
             else:
                 raise NotImplementedError(s.kind)
             if masked and s.kind != 'linear':

@@ -383,6 +383,20 @@ def transforms_fixture(path):
         out[f'im{i}'] = arr
         out[f'out{i}'] = t.numpy()
         cases.append({'height': height, 'valid_norm': valid_norm, 'pad': pad})
+    # round 3: 3-channel models (no dewarp: fixed-height LANCZOS resize of an RGB crop) -- up- and down-scaling, own generator so
+    # that the cases above stay bit-identical
+    rng3 = np.random.RandomState(11)
+    for h, w, height, pad in [(61, 410, 48, 16), (33, 257, 48, 16), (48, 120, 48, 8)]:
+        i = len(cases)
+        arr = rng3.randint(120, 256, size=(h, w, 3)).astype(np.uint8)
+        for x in range(0, w, 5):
+            if rng3.rand() < 0.5:
+                arr[h // 4:3 * h // 4, x:x + 2] = rng3.randint(0, 100, size=3)
+        im = Image.fromarray(arr, 'RGB')
+        t = _ref_transforms(1, height, 0, 3, pad, False)(im)
+        out[f'im{i}'] = arr
+        out[f'out{i}'] = t.numpy()
+        cases.append({'height': height, 'valid_norm': False, 'pad': pad, 'channels': 3})
     out['cases'] = json.dumps(cases)
     np.savez_compressed(path, **out)
     print('wrote', path)

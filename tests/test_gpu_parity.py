@@ -487,6 +487,7 @@ def test_x3_bench_a_against_reference_golden(bench_a_x3):
      'Lbx200 Do0.1,2 Lbx200 Do0.1,2 Lbx200 Do O1c133]', 4, 700, [700, 655, 301, 64]),
     # pool AND height collapse fused into one conv_x3 epilogue (Mp directly in front of S1)
     ('[1,32,0,1 Cr3,11,16 Cr3,15,32 Mp2,2 Cr5,5,32 Mp2,2 S1(1x0)1,3 Lfx48 Lbx16 O1c33]', 3, 203, [203, 150, 77]),
+    ('[1,16,0,1 Cr3,13,16 Cr3,3,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx24 O1ca19]', 3, 150, [150, 149, 40]),       # 1-augmented output layer
 ])
 def test_x3_matches_cpu_oracle_on_small_networks(spec, n, w, lens):
     """Strides, dilation, even kernels, tanh/leaky/linear activations, f/b LSTM stacks, hidden 200."""
@@ -620,6 +621,13 @@ def test_x3_full_size_batch_invariance(bench_a_x3, bench_a):
     assert _keys(bs.tuples()) == [tx3[i] for i in sub]
 
 
+def _min_top2_margin(ref, x, w) -> float:
+    """Smallest difference between the two largest logits over the steps of one line, from the CPU oracle's forward."""
+    logits, _ = ref.forward(x, [w])
+    top2 = logits[0, :, 0, :].topk(2, dim=0).values
+    return float((top2[0] - top2[1]).min())
+
+
 # ------------------------------------------------------- BASELINE.json configs 3 and 4 at full size
 @pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
 def test_config3_rank_shard_of_2048_lines(prec, bench_a, bench_a_x3):
@@ -641,7 +649,10 @@ def test_config3_rank_shard_of_2048_lines(prec, bench_a, bench_a_x3):
     if prec == 'f32':
         assert [t[i] for i in sample] == want
     else:       # split-bf16: identical except where the fp32 top-2 margin is below the split-operand error (tie-sensitive)
-        assert sum(t[i] != w for i, w in zip(sample, want)) <= 1
+        off = [i for i, w in zip(sample, want) if t[i] != w]
+        assert len(off) <= 1
+        for i in off:           # ... and the line that differs must BE tie-sensitive: some step's top-2 margin of the oracle's own logits
+            assert _min_top2_margin(ref, x[i:i + 1].cpu(), W) < 4 * X3_TOL, i
 
 
 @pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
@@ -669,12 +680,16 @@ def test_config4_1024_ragged_lines_width_sorted(prec, bench_a, bench_a_x3):
         assert _keys(one.tuples())[0] == [t[:3] for t in got[i]]
     # against the CPU oracle, each line on its own (the reference's per-line rpred result): 32 lines across the width range
     ref = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()})
-    bad = 0
+    bad = []
     for i in range(5, 1024, 32):
         w = int(widths[i])
         want = ref.predict_labels(base[i % 8:i % 8 + 1, ..., :w])
-        bad += [t[:3] for t in got[i]] != [t[:3] for t in want[0]]
-    assert bad == 0 if prec == 'f32' else bad <= 1
+        if [t[:3] for t in got[i]] != [t[:3] for t in want[0]]:
+            bad.append(i)
+    assert not bad if prec == 'f32' else len(bad) <= 1
+    for i in bad:               # a line may differ only where the oracle's own top-2 margin is inside the split-operand error
+        w = int(widths[i])
+        assert _min_top2_margin(ref, base[i % 8:i % 8 + 1, ..., :w], w) < 4 * X3_TOL, i
 
 
 def test_edge_shapes(bench_a, bench_a_x3):

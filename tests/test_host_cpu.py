@@ -70,6 +70,68 @@ def test_bad_or_unsupported_specs_raise(spec, exc):
         kraken_amd.TorchVGSLModel(vgsl=spec)
 
 
+# Every VGSL form the reference accepts (kraken/lib/vgsl/model.py:570-817) that the HIP executor does NOT
+# run: it must be refused when the model is BUILT (constructor / load_model), naming the offending block -- never at the first
+# forward call.  (Table in DESIGN.md section 7.)
+UNSUPPORTED_FORMS = [
+    ('[1,48,0,1 CTr3,3,32 O2l4]', 'transposed', 'model.py:701-712 (transposed convolution)'),
+    ('[1,48,0,1 Cm3,3,32 S1(1x0)1,3 O1c10]', 'softmax-activated', 'model.py:701 (channel-softmax convolution)'),
+    ('[1,48,0,1 Cr3,3,32 (Cr3,3,16 Cr5,5,16) S1(1x0)1,3 O1c10]', '(Cr3,3,16', 'model.py:876 (parallel block)'),
+    ('[1,48,0,1 Cr3,3,32 A1,2 S1(1x0)1,3 O1c10]', 'A1,2', 'model.py:622 (Addition)'),
+    ('[1,48,0,1 W0.5,10 S1(1x0)1,3 O1c10]', 'W0.5,10', 'model.py:677 (wav2vec mask)'),
+    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxs20 O1c10]', 'Lbxs20', 'model.py:579 (x-axis summarising)'),
+    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxc20 O1c10]', 'Lbxc20', 'layers.py:498 (legacy 1-augmented LSTM)'),
+    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxo20 O1c10]', 'Lbxo20', 'layers.py:146 (peephole LSTM)'),
+    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Gbx20 O1c10]', 'Gbx20', 'model.py:579 (G cell)'),
+    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbx300 O1c10]', 'Lbx300', 'hidden size above 256'),
+    ('[1,48,0,1 Cr3,3,32 S3(4x8)1,3 O1c10]', 'S3(4x8)1,3', 'model.py:748 (general reshape)'),
+    ('[1,48,0,1 Cr3,3,32 O2s4]', 'softmax heatmap', 'model.py:806 (softmax heatmap head)'),
+    ('[1,48,0,1 Cr3,3,32 O2la4]', 'O2la4', 'model.py:788 (1-augmented heatmap head)'),
+]
+
+
+@pytest.mark.parametrize('spec,token,what', UNSUPPORTED_FORMS)
+def test_unsupported_vgsl_forms_are_refused_at_construction_naming_the_block(spec, token, what):
+    with pytest.raises(NotImplementedError) as e:
+        kraken_amd.TorchVGSLModel(vgsl=spec)
+    assert token in str(e.value), (what, str(e.value))
+
+
+def test_one_augmented_output_layer_is_built_like_the_reference():
+    """`O1ca..`: LinSoftmax(augmentation=True) owns a weight of (out, in + 1) (layers.py:703-708)."""
+    m = kraken_amd.TorchVGSLModel(vgsl='[1,8,0,1 Cr3,3,16 Cr3,3,16 S1(1x0)1,3 O1ca12]')
+    assert tuple(m.state_dict()['nn.O_3.lin.weight'].shape) == (12, 8 * 16 + 1)
+    assert m.layer_specs[-1].params['aug'] is True and m.output[1] == 12
+
+
+def test_plugin_entry_points_resolve_through_importlib_metadata(tmp_path, monkeypatch):
+    """
+    kraken finds model classes and loaders through the `kraken.models` / `kraken.loaders` entry-point groups
+    (kraken/models/utils.py:12-31, kraken/models/loaders.py:27-43).  An installed distribution is simulated with a .dist-info
+    directory on sys.path holding THIS package's entry_points.txt (generated from pyproject.toml): the names must resolve to the
+    real objects.
+    """
+    import importlib.metadata as md
+    import tomli
+    proj = tomli.loads(open(os.path.join(ROOT, 'pyproject.toml')).read())['project']
+    di = tmp_path / f"{proj['name'].replace('-', '_')}-{proj.get('version', '0')}.dist-info"
+    di.mkdir()
+    (di / 'METADATA').write_text(f"Metadata-Version: 2.1\nName: {proj['name']}\nVersion: {proj.get('version', '0')}\n")
+    lines = []
+    for group, eps in proj['entry-points'].items():
+        lines.append(f'[{group}]')
+        lines += [f'{k} = {v}' for k, v in eps.items()]
+    (di / 'entry_points.txt').write_text('\n'.join(lines) + '\n')
+    monkeypatch.syspath_prepend(str(tmp_path))
+    md_eps = md.entry_points()
+    models = {e.name: e for e in md_eps.select(group='kraken.models')}
+    loaders = {e.name: e for e in md_eps.select(group='kraken.loaders')}
+    assert 'Mi355VGSLModel' in models and 'mi355' in loaders
+    assert models['Mi355VGSLModel'].load() is kraken_amd.TorchVGSLModel
+    from kraken_amd.io import load_models
+    assert loaders['mi355'].load() is load_models
+
+
 def test_missing_spec():
     with pytest.raises(ValueError):
         kraken_amd.TorchVGSLModel()
@@ -272,9 +334,12 @@ def test_transforms_match_reference_outputs():
     from PIL import Image
     from kraken_amd.transforms import ImageInputTransforms
     z = load_golden('transforms.npz')
-    for i, c in enumerate(json.loads(str(z['cases']))):
-        im = Image.fromarray(z[f'im{i}'], 'L')
-        t = ImageInputTransforms(1, c['height'], 0, 1, (c['pad'], 0), c['valid_norm'])(im)
+    cases = json.loads(str(z['cases']))
+    assert any(c.get('channels') == 3 for c in cases)              # the RGB path is pinned to the reference too (round 3)
+    for i, c in enumerate(cases):
+        ch = c.get('channels', 1)
+        im = Image.fromarray(z[f'im{i}'], 'L' if ch == 1 else 'RGB')
+        t = ImageInputTransforms(1, c['height'], 0, ch, (c['pad'], 0), c['valid_norm'])(im)
         assert tuple(t.shape) == z[f'out{i}'].shape
         np.testing.assert_allclose(t.numpy(), z[f'out{i}'], atol=1e-7)
 
