@@ -248,7 +248,7 @@ def _ref_transforms(batch, height, width, channels, pad, valid_norm):
             else:
                 im = F_t.pil_fixed_resize(im, scale=scale)
         if pad:
-            im = ImageOps.expand(im, border=(pad, 0), fill=255)
+            im = ImageOps.expand(im, border=(pad, 0), fill=255 if mode == 'L' else (255, 255, 255))   # v2.Pad(fill=255): every channel
         t = torch.from_numpy(np.array(im, dtype=np.uint8))
         t = t[None] if t.dim() == 2 else t.permute(2, 0, 1)
         t = t.to(torch.float32) / 255.0
