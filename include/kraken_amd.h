@@ -223,6 +223,27 @@ int krk_prep_crops(const unsigned char* crops_dev, int channels, const int* desc
                    int batch_w, float* x_dev, int* flags_dev, void* stream);
 
 /*
+ * CenterNormalizer dewarp on the device: what the reference runs on the host for every bounding-box line of a 1-channel model
+ * (functional_im_transforms.pil_dewarp -> kraken/lib/lineest.py:26-87; arithmetic in scipy.ndimage, restated in
+ * oracle/np_oracle.py:center_normalize_np and followed bit for bit, see csrc/dewarp.hip).  Two calls with a host decision between
+ * them, because a line's output width depends on its measured spread:
+ *   krk_dewarp_measure  centre line and spread of n packed 1-channel uint8 line images.
+ *       desc_dev    int32 [n][8]: byte offset of the image in crops_dev, w, h, scratch offset (in doubles), weight-table offset (in
+ *                   doubles), r0, r1, r2 = int(4 sigma + 0.5) for sigma = h/2, h, 0.3 h
+ *       weights_dev fp64 Gaussian tables of the heights in the batch, per height [2 r0 + 1][2 r1 + 1][2 r2 + 1], each
+ *                   exp(-x^2 / 2 sigma^2) / sum (computed by the caller with the host's exp: kraken_amd/transforms.py)
+ *       scratch_dev 3 * h * w doubles per line; work_dev int32 [2 n + 2 n max_w] (min/max, ridge, centre line: kept for apply)
+ *       info_dev    int32 [n][4] out: r = int(1 + 4 mad), ok (the reference's band slices are full), has ink, 0
+ *   krk_dewarp_apply    band cut-out + bilinear scaling to out_h + uint8 truncation + white padding + / 255 + inversion.
+ *       geo_dev     int32 [n][4]: r, out_w = int(out_h / (2 r) * w), use (0: the line's rows stay zero), 0
+ *       x_dev       float (n, 1, out_h, batch_w); flags_dev int32 [n]: 1 if the line holds a non-white pixel
+ */
+int krk_dewarp_measure(const unsigned char* crops_dev, const int* desc_dev, int n, int max_w, int max_h, const double* weights_dev,
+                       double* scratch_dev, int* work_dev, int* info_dev, void* stream);
+int krk_dewarp_apply(const unsigned char* crops_dev, const int* desc_dev, int n, int max_w, const int* work_dev, const int* geo_dev,
+                     int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream);
+
+/*
  * Tail of the segmenter's forward (reference kraken/lib/vgsl/spred.py:268-272): the network's class logits (C, h, w) are
  * brought to the scaled page's resolution by nearest-neighbour upsampling (F.interpolate(o, size=(H, W))) and squashed with a
  * sigmoid; one pass, (C, H, W) float32 out.

@@ -1727,6 +1727,38 @@ int krk_upsample_sigmoid(const float* x_dev, int C, int h, int w, int H, int W, 
     return KRK_OK;
 }
 
+// forward declaration: the v / 255 table shared by the preprocessing entry points
+static int prep_lut(const char* who, float** out);
+
+int krk_dewarp_measure(const unsigned char* crops_dev, const int* desc_dev, int n, int max_w, int max_h, const double* weights_dev,
+                       double* scratch_dev, int* work_dev, int* info_dev, void* stream) {
+    if (!crops_dev || !desc_dev || !weights_dev || !scratch_dev || !work_dev || !info_dev || n < 0 || max_w <= 0 || max_h < 2)
+        return fail(KRK_E_INVALID, "krk_dewarp_measure: bad argument");
+    if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_dewarp_measure: no HIP device");
+    int* mm = work_dev;
+    int* ridge = work_dev + 2 * (size_t)n;
+    int* centre = ridge + (size_t)n * max_w;
+    if (krk_launch_dewarp_measure(crops_dev, desc_dev, n, max_w, max_h, weights_dev, scratch_dev, mm, ridge, centre, info_dev, (hipStream_t)stream))
+        return fail(KRK_E_HIP, std::string("krk_dewarp_measure: launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return KRK_OK;
+}
+
+int krk_dewarp_apply(const unsigned char* crops_dev, const int* desc_dev, int n, int max_w, const int* work_dev, const int* geo_dev,
+                     int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream) {
+    if (!crops_dev || !desc_dev || !work_dev || !geo_dev || !x_dev || !flags_dev || n < 0 || batch_w <= 0)
+        return fail(KRK_E_INVALID, "krk_dewarp_apply: bad argument");
+    if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_dewarp_apply: no HIP device");
+    float* lut = nullptr;
+    if (int rc = prep_lut("krk_dewarp_apply", &lut)) return rc;
+    const int* mm = work_dev;
+    const int* centre = work_dev + 2 * (size_t)n + (size_t)n * max_w;
+    const int rc = krk_launch_dewarp_apply(crops_dev, desc_dev, n, max_w, mm, centre, geo_dev, lut, out_h, pad, batch_w, x_dev, flags_dev,
+                                           (hipStream_t)stream);
+    if (rc == -4) return fail(KRK_E_UNSUPPORTED, "krk_dewarp_apply: needs pad > 0 and out_h > 0");
+    if (rc) return fail(KRK_E_HIP, std::string("krk_dewarp_apply: launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return KRK_OK;
+}
+
 // uint8 -> float table of ToDtype(scale=True): v / 255 in fp32, one per device
 static int prep_lut(const char* who, float** out) {
     static float* luts[64] = {nullptr};

@@ -274,6 +274,12 @@ int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, int
 int krk_launch_prep_crops(const unsigned char* crops, int ch, const int* desc_dev, int n, int max_in_h,
                           const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
 
+// CenterNormalizer dewarp of 1-channel lines (dewarp.hip): measure (centre line, spread) and normalize + float stage
+int krk_launch_dewarp_measure(const unsigned char* crops, const int* desc, int n, int maxw, int maxh, const double* wts, double* scratch,
+                              int* mm, int* ridge, int* centre, int* info, hipStream_t s);
+int krk_launch_dewarp_apply(const unsigned char* crops, const int* desc, int n, int maxw, const int* mm, const int* centre, const int* geo,
+                            const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
+
 // host-side launchers (implemented in the .hip files)
 int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);

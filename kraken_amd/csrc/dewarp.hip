@@ -1,0 +1,268 @@
+// CenterNormalizer dewarp of 1-channel bounding-box lines on the device (round 3).
+// Replaces, bit for bit, what the reference runs per line on the host for a 1-channel model on a bbox segmentation:
+//   functional_im_transforms.pil_dewarp -> lineest.dewarp / CenterNormalizer.measure + normalize   kraken/lib/lineest.py:26-87
+// whose arithmetic lives in scipy.ndimage (un-vendored dependency; gaussian_filter, uniform_filter, affine_transform).  scipy's
+// published algorithms are restated in oracle/np_oracle.py (center_normalize_np), pinned bit for bit against scipy itself and
+// against the reference's outputs (tests/golden/transforms.npz); this file follows that restatement operation by operation in
+// fp64 with explicit round-to-nearest multiplies / adds / divides (no FMA contraction), so the integer centre line -- an argmax
+// followed by a truncation -- and therefore every output pixel is the reference's:
+//   measure   ink = (top - v) / max ink;  blur = G_axis0(sigma h/2) then G_axis1(sigma h) (zero boundary; a symmetric kernel is
+//             summed  w0 x[c] + sum_{j = r..1} w_j (x[c-j] + x[c+j]),  far to near);  blur += 0.001 * U(h/2 x w) (running sums:
+//             t += x[l + size - 1] - x[l - 1]; out = t / size);  ridge = first argmax per column;  centre = trunc(G(sigma 0.3 h,
+//             reflect boundary) of the integer ridge);  mad = mean |y - centre| over ink pixels (a sum of integers: exact);
+//             r = int(1 + 4 mad)
+//   normalize band[yy][x] = padded_line[centre[x] + h - r + yy][x], yy < 2r (float32);  output (target_h, int(scale * w)),
+//             scale = target_h / 2r: bilinear at (y / scale, x / scale), paper (top) outside [0, n - 1], weights (wy wx) summed
+//             over (0,0) (0,1) (1,0) (1,1) in fp64, stored as float32;  then the float stage of ImageInputTransforms: clip, uint8
+//             truncation (array2pil), white padding, / 255, 1 - x
+// Integer / fp64 work on a few MB per batch: latency- and HBM-bound, nowhere near a roofline that matters; what matters is that
+// the 0.65 k lines/s of the scipy path (profiles/r02_bench_api.json) no longer feeds a 100 k lines/s recogniser.
+// Per-line descriptor `desc` [n][8] int32: crop byte offset, w, h, scratch offset (doubles), weight-table offset (doubles),
+// r0 (axis-0 radius), r1 (axis-1 radius), r2 (ridge radius); weight table of a height: [w0: 2 r0 + 1][w1: 2 r1 + 1][w2: 2 r2 + 1].
+// Scratch per line: three planes of h * w doubles.  `info` [n][4] int32 out: r, ok, ink flag, unused; `centre` [n][maxw] int32.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double dadd(double a, double b) { return __dadd_rn(a, b); }
+
+struct LineD { int off, w, h, soff, woff, r0, r1, r2; };
+__device__ __forceinline__ LineD line_of(const int* desc, int n) {
+    const int* d = desc + 8 * n;
+    return LineD{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]};
+}
+
+// K0: top (max) and min of a line; one workgroup per line.  mm[n] = {top, min}
+__global__ void __launch_bounds__(256) dw_minmax_kernel(const unsigned char* crops, const int* desc, int* mm) {
+    const int n = blockIdx.x;
+    const LineD L = line_of(desc, n);
+    const unsigned char* p = crops + (size_t)(unsigned)L.off;
+    int mx = 0, mn = 255;
+    for (int e = threadIdx.x; e < L.w * L.h; e += 256) { const int v = p[e]; mx = max(mx, v); mn = min(mn, v); }
+    __shared__ int smx[256], smn[256];
+    smx[threadIdx.x] = mx; smn[threadIdx.x] = mn;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { smx[threadIdx.x] = max(smx[threadIdx.x], smx[threadIdx.x + s]); smn[threadIdx.x] = min(smn[threadIdx.x], smn[threadIdx.x + s]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { mm[2 * n] = smx[0]; mm[2 * n + 1] = smn[0]; }
+}
+
+// K1: Gaussian along axis 0 (rows) of ink -> plane 0
+__global__ void __launch_bounds__(256) dw_gauss0_kernel(const unsigned char* crops, const int* desc, const int* mm, const double* wts, double* scratch) {
+    const int n = blockIdx.z;
+    const LineD L = line_of(desc, n);
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= L.w || y >= L.h) return;
+    const unsigned char* p = crops + (size_t)(unsigned)L.off;
+    const double top = (double)mm[2 * n], amax = (double)(mm[2 * n] - mm[2 * n + 1]);
+    if (amax == 0.0) return;
+    const double* w = wts + L.woff;                  // w[r0 + j], j = -r0 .. r0
+    auto ink = [&](int yy) -> double { return (yy < 0 || yy >= L.h) ? 0.0 : __ddiv_rn(dmul(top - (double)p[yy * L.w + x], 1.0), amax); };
+    double t = dmul(ink(y), w[L.r0]);
+    for (int j = min(L.r0, L.h); j >= 1; --j)        // beyond +-h both partners are outside: they add exactly 0
+        t = dadd(t, dmul(dadd(ink(y - j), ink(y + j)), w[L.r0 - j]));
+    (scratch + L.soff)[(size_t)y * L.w + x] = t;
+}
+
+// K2: Gaussian along axis 1 (columns) plane 0 -> plane 1 (= blur)
+__global__ void __launch_bounds__(256) dw_gauss1_kernel(const int* desc, const int* mm, const double* wts, double* scratch) {
+    const int n = blockIdx.z;
+    const LineD L = line_of(desc, n);
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= L.w || y >= L.h || mm[2 * n] == mm[2 * n + 1]) return;
+    const double* a = scratch + L.soff + (size_t)y * L.w;
+    const double* w = wts + L.woff + (2 * L.r0 + 1);
+    auto at = [&](int xx) -> double { return (xx < 0 || xx >= L.w) ? 0.0 : a[xx]; };
+    double t = dmul(a[x], w[L.r1]);
+    for (int j = min(L.r1, L.w); j >= 1; --j)
+        t = dadd(t, dmul(dadd(at(x - j), at(x + j)), w[L.r1 - j]));
+    (scratch + L.soff + (size_t)L.h * L.w)[(size_t)y * L.w + x] = t;
+}
+
+// K3: uniform filter along axis 0 (size int(h/2)) of blur (plane 1) -> plane 0; one thread per column, sequential like scipy
+__global__ void __launch_bounds__(256) dw_unif0_kernel(const int* desc, const int* mm, double* scratch) {
+    const int n = blockIdx.y;
+    const LineD L = line_of(desc, n);
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= L.w || mm[2 * n] == mm[2 * n + 1]) return;
+    const double* b = scratch + L.soff + (size_t)L.h * L.w;
+    double* o = scratch + L.soff;
+    const int size = (int)(L.h * 0.5), s1 = size / 2;
+    auto ext = [&](int l) -> double { const int yy = l - s1; return (yy < 0 || yy >= L.h) ? 0.0 : b[(size_t)yy * L.w + x]; };
+    const double dsize = (double)size;
+    double t = 0.0;
+    for (int l = 0; l < size; ++l) t = dadd(t, ext(l));
+    o[x] = __ddiv_rn(t, dsize);
+    for (int l = 1; l < L.h; ++l) {
+        t = dadd(t, dadd(ext(l + size - 1), -ext(l - 1)));
+        o[(size_t)l * L.w + x] = __ddiv_rn(t, dsize);
+    }
+}
+
+// K4: uniform filter along axis 1 (size w) plane 0 -> plane 2; one thread per row
+__global__ void __launch_bounds__(64) dw_unif1_kernel(const int* desc, const int* mm, double* scratch) {
+    const int n = blockIdx.y;
+    const LineD L = line_of(desc, n);
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    if (y >= L.h || mm[2 * n] == mm[2 * n + 1]) return;
+    const double* a = scratch + L.soff + (size_t)y * L.w;
+    double* o = scratch + L.soff + (size_t)2 * L.h * L.w + (size_t)y * L.w;
+    const int size = L.w, s1 = size / 2;
+    auto ext = [&](int l) -> double { const int xx = l - s1; return (xx < 0 || xx >= L.w) ? 0.0 : a[xx]; };
+    const double dsize = (double)size;
+    double t = 0.0;
+    for (int l = 0; l < size; ++l) t = dadd(t, ext(l));
+    o[0] = __ddiv_rn(t, dsize);
+    for (int l = 1; l < L.w; ++l) {
+        t = dadd(t, dadd(ext(l + size - 1), -ext(l - 1)));
+        o[l] = __ddiv_rn(t, dsize);
+    }
+}
+
+// K5: ridge[x] = first argmax over rows of blur + 0.001 * uniform
+__global__ void __launch_bounds__(256) dw_ridge_kernel(const int* desc, const int* mm, const double* scratch, int* ridge, int maxw) {
+    const int n = blockIdx.y;
+    const LineD L = line_of(desc, n);
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= L.w || mm[2 * n] == mm[2 * n + 1]) return;
+    const double* b = scratch + L.soff + (size_t)L.h * L.w;
+    const double* u = scratch + L.soff + (size_t)2 * L.h * L.w;
+    int best = 0;
+    double bv = dadd(b[x], dmul(0.001, u[x]));
+    for (int y = 1; y < L.h; ++y) {
+        const double v = dadd(b[(size_t)y * L.w + x], dmul(0.001, u[(size_t)y * L.w + x]));
+        if (v > bv) { bv = v; best = y; }
+    }
+    ridge[(size_t)n * maxw + x] = best;
+}
+
+// K6: centre = trunc(Gaussian(sigma 0.3 h, reflect) of the integer ridge)
+__global__ void __launch_bounds__(256) dw_centre_kernel(const int* desc, const int* mm, const double* wts, const int* ridge, int* centre, int maxw) {
+    const int n = blockIdx.y;
+    const LineD L = line_of(desc, n);
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= L.w || mm[2 * n] == mm[2 * n + 1]) return;
+    const int* rg = ridge + (size_t)n * maxw;
+    const double* w = wts + L.woff + (2 * L.r0 + 1) + (2 * L.r1 + 1);
+    auto at = [&](int xx) -> double {               // reflect: (d c b a | a b c d | d c b a), repeated
+        int m = xx % (2 * L.w);
+        if (m < 0) m += 2 * L.w;
+        if (m >= L.w) m = 2 * L.w - 1 - m;
+        return (double)rg[m];
+    };
+    double t = dmul((double)rg[x], w[L.r2]);
+    for (int j = L.r2; j >= 1; --j)
+        t = dadd(t, dmul(dadd(at(x - j), at(x + j)), w[L.r2 - j]));
+    centre[(size_t)n * maxw + x] = (int)t;          // C truncation of the integer output array
+}
+
+// K7: r = int(1 + 4 * mean |y - centre| over ink pixels); band bounds.  info[n] = {r, ok, has ink, 0}; one workgroup per line
+__global__ void __launch_bounds__(256) dw_spread_kernel(const unsigned char* crops, const int* desc, const int* mm, const int* centre, int maxw, int* info) {
+    const int n = blockIdx.x;
+    const LineD L = line_of(desc, n);
+    const int top = mm[2 * n];
+    __shared__ long long ssum[256];
+    __shared__ int scnt[256], smin[256], smax[256];
+    long long sum = 0;
+    int cnt = 0, cmin = 1 << 30, cmax = -(1 << 30);
+    if (top != mm[2 * n + 1]) {
+        const unsigned char* p = crops + (size_t)(unsigned)L.off;
+        const int* c = centre + (size_t)n * maxw;
+        for (int e = threadIdx.x; e < L.w * L.h; e += 256) {
+            const int y = e / L.w, x = e - y * L.w;
+            if (p[e] != top) { sum += abs(y - c[x]); ++cnt; }
+        }
+        for (int x = threadIdx.x; x < L.w; x += 256) { cmin = min(cmin, c[x]); cmax = max(cmax, c[x]); }
+    }
+    ssum[threadIdx.x] = sum; scnt[threadIdx.x] = cnt; smin[threadIdx.x] = cmin; smax[threadIdx.x] = cmax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            ssum[threadIdx.x] += ssum[threadIdx.x + s]; scnt[threadIdx.x] += scnt[threadIdx.x + s];
+            smin[threadIdx.x] = min(smin[threadIdx.x], smin[threadIdx.x + s]); smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int r = 0, ok = 0;
+        if (scnt[0] > 0) {
+            const double mad = __ddiv_rn((double)ssum[0], (double)scnt[0]);
+            r = (int)dadd(1.0, dmul(4.0, mad));
+            // the reference slices stack[mid - r : mid + r] of a (3h)-row stack: only full slices give a rectangular band
+            ok = (r >= 1 && smin[0] + L.h - r >= 0 && smax[0] + L.h + r <= 3 * L.h) ? 1 : 0;
+        }
+        info[4 * n] = r; info[4 * n + 1] = ok; info[4 * n + 2] = top != mm[2 * n + 1]; info[4 * n + 3] = 0;
+    }
+}
+
+// K8: normalize + the float stage.  geo [n][4] int32: r, out_w (int(scale * w)), use (0: leave zeros), 0.  One thread per output pixel.
+__global__ void __launch_bounds__(256) dw_apply_kernel(const unsigned char* crops, const int* desc, const int* mm, const int* centre, int maxw,
+                                                       const int* geo, const float* lut, int out_h, int pad, int batch_w, float* out, int* flags) {
+    const int n = blockIdx.z;
+    const LineD L = line_of(desc, n);
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+    if (X >= batch_w) return;
+    float* o = out + ((size_t)n * out_h + Y) * batch_w + X;
+    const int r = geo[4 * n], ow = geo[4 * n + 1], use = geo[4 * n + 2];
+    const int xx = X - pad;
+    if (!use || xx < 0 || xx >= ow) { *o = 0.f; return; }         // white padding (1 - 255/255) and the batch padding right of the line
+    const unsigned char* p = crops + (size_t)(unsigned)L.off;
+    const int* c = centre + (size_t)n * maxw;
+    const double top = (double)mm[2 * n];
+    const int bh = 2 * r, bw = L.w;
+    const double scale = __ddiv_rn(dmul((double)out_h, 1.0), (double)bh);
+    const double z = __ddiv_rn(1.0, scale);
+    const double cy = dmul((double)Y, z), cx = dmul((double)xx, z);
+    float val;
+    if (cy < 0.0 || cy > (double)(bh - 1) || cx < 0.0 || cx > (double)(bw - 1)) {
+        val = (float)top;
+    } else {
+        const int y0 = (int)floor(cy), x0 = (int)floor(cx);
+        const double ty = cy - (double)y0, tx = cx - (double)x0;
+        auto band = [&](int yy, int x) -> double {      // float32 of the padded line: exact for 8-bit values
+            if (yy >= bh || x >= bw) return top;       // past the last sample: weight 0
+            const int row = c[x] + L.h - r + yy;       // row of the (3h)-row stack
+            return (row >= L.h && row < 2 * L.h) ? (double)p[(row - L.h) * L.w + x] : top;
+        };
+        double acc = dmul(band(y0, x0), dmul(1.0 - ty, 1.0 - tx));
+        acc = dadd(acc, dmul(band(y0, x0 + 1), dmul(1.0 - ty, tx)));
+        acc = dadd(acc, dmul(band(y0 + 1, x0), dmul(ty, 1.0 - tx)));
+        acc = dadd(acc, dmul(band(y0 + 1, x0 + 1), dmul(ty, tx)));
+        val = (float)acc;
+    }
+    // array2pil: np.array(np.clip(a, 0, 255), 'B') -- truncation; then ToDtype(scale) and `max - x` with max = 1 (white padding)
+    const float cl = fminf(fmaxf(val, 0.f), 255.f);
+    const unsigned v = (unsigned)cl;
+    *o = 1.0f - lut[v];
+    if (v != 255u) atomicOr(flags + n, 1);
+}
+
+}  // namespace
+
+int krk_launch_dewarp_measure(const unsigned char* crops, const int* desc, int n, int maxw, int maxh, const double* wts, double* scratch,
+                              int* mm, int* ridge, int* centre, int* info, hipStream_t s) {
+    if (n <= 0) return 0;
+    const unsigned gx = (unsigned)((maxw + 255) / 256);
+    hipLaunchKernelGGL(dw_minmax_kernel, dim3(n), dim3(256), 0, s, crops, desc, mm);
+    hipLaunchKernelGGL(dw_gauss0_kernel, dim3(gx, maxh, n), dim3(256), 0, s, crops, desc, mm, wts, scratch);
+    hipLaunchKernelGGL(dw_gauss1_kernel, dim3(gx, maxh, n), dim3(256), 0, s, desc, mm, wts, scratch);
+    hipLaunchKernelGGL(dw_unif0_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, scratch);
+    hipLaunchKernelGGL(dw_unif1_kernel, dim3((unsigned)((maxh + 63) / 64), n), dim3(64), 0, s, desc, mm, scratch);
+    hipLaunchKernelGGL(dw_ridge_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, scratch, ridge, maxw);
+    hipLaunchKernelGGL(dw_centre_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, wts, ridge, centre, maxw);
+    hipLaunchKernelGGL(dw_spread_kernel, dim3(n), dim3(256), 0, s, crops, desc, mm, centre, maxw, info);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int krk_launch_dewarp_apply(const unsigned char* crops, const int* desc, int n, int maxw, const int* mm, const int* centre, const int* geo,
+                            const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (out_h < 1 || pad < 1) return -4;
+    (void)hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), s);
+    hipLaunchKernelGGL(dw_apply_kernel, dim3((unsigned)((batch_w + 255) / 256), out_h, n), dim3(256), 0, s, crops, desc, mm, centre, maxw, geo, lut,
+                       out_h, pad, batch_w, out, flags);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -275,6 +275,87 @@ class RecognitionEngine:
         x = slot.stage_dev[:n * c * h * w].view(n, c, h, w)
         return self._launch(slot, x, widths.astype(np.int32), want_probs, wait_current=False)
 
+    def measure_dewarp(self, crops: list, pool=None):
+        """
+        First half of the device-side CenterNormalizer dewarp (1-channel bbox lines, kraken/lib/lineest.py:34-65): uploads the
+        uint8 line images ``(h, w)`` of ONE batch into the next free slot and measures centre line and spread on the device
+        (``krk_dewarp_measure``).  Blocks until the per-line results are back -- a line's output width depends on its spread --
+        and returns ``(r, ok, ink)`` int arrays: ``ok`` = the reference's band slices are full (otherwise the line must take the
+        host transform), ``ink`` = the line is not flat.  ``submit_dewarped`` finishes the batch.
+        """
+        from .transforms import dewarp_tables
+        slot = self._free_slot()
+        if self.in_channels != 1:
+            raise ValueError('the dewarp is defined for 1-channel models')
+        n = len(crops)
+        tables, index = dewarp_tables(a.shape[0] for a in crops)
+        desc = np.empty((n, 8), dtype=np.int32)
+        off = soff = 0
+        for k, a in enumerate(crops):
+            if a.dtype != np.uint8 or a.ndim != 2 or a.shape[0] < 2:
+                raise ValueError(f'crop {k}: expected a uint8 array of shape (h >= 2, w), got {a.dtype} {a.shape}')
+            ch, cw = int(a.shape[0]), int(a.shape[1])
+            woff, r0, r1, r2 = index[ch]
+            desc[k] = (off, cw, ch, soff, woff, r0, r1, r2)
+            off += (ch * cw + 15) & ~15
+            soff += 3 * ch * cw
+        maxw, maxh = int(desc[:, 1].max()), int(desc[:, 2].max())
+        slot.ensure_crops(off)
+        dev = f'cuda:{self.device}'
+        buf = slot.crops_host.numpy()
+
+        def pack(lo_hi):
+            for k in range(*lo_hi):
+                a = crops[k]
+                buf[desc[k, 0]:desc[k, 0] + a.size] = np.ascontiguousarray(a).reshape(-1)
+        if pool is not None and n >= 32:
+            step = -(-n // 8)
+            list(pool.map(pack, [(a, min(a + step, n)) for a in range(0, n, step)]))
+        else:
+            pack((0, n))
+        st = slot.__dict__.setdefault('dw', {})
+        with torch.cuda.stream(slot.stream):
+            slot.crops_dev[:off].copy_(slot.crops_host[:off], non_blocking=True)
+            st['desc'] = torch.from_numpy(desc).to(dev, non_blocking=True)
+            st['wts'] = torch.from_numpy(tables).to(dev, non_blocking=True)
+            if st.get('scratch') is None or st['scratch'].numel() < soff:
+                st['scratch'] = torch.empty(int(soff * 1.25) + 1024, dtype=torch.float64, device=dev)
+            st['work'] = torch.empty(2 * n + 2 * n * maxw, dtype=torch.int32, device=dev)
+            info = torch.empty((n, 4), dtype=torch.int32, device=dev)
+            _lib.check(self.lib.krk_dewarp_measure(slot.crops_dev.data_ptr(), st['desc'].data_ptr(), n, maxw, maxh, st['wts'].data_ptr(),
+                                                   st['scratch'].data_ptr(), st['work'].data_ptr(), info.data_ptr(), slot.stream.cuda_stream))
+            info_h = info.cpu()                                       # synchronises the slot's stream
+        st.update(n=n, maxw=maxw, host_desc=desc)
+        info_h = info_h.numpy()
+        return info_h[:, 0].copy(), info_h[:, 1].astype(bool), info_h[:, 2].astype(bool)
+
+    def submit_dewarped(self, r: np.ndarray, use: np.ndarray, pad: int, want_probs: bool = False) -> int:
+        """Second half: cut-out band, bilinear scaling to the model height, uint8 truncation, padding, inversion (``krk_dewarp_apply``)
+        of the lines with ``use`` set, then the recognition of the batch.  Lines with ``use`` clear stay zero (flat: flag 0)."""
+        slot = self._free_slot()
+        st = slot.dw
+        n, maxw, desc = st['n'], st['maxw'], st['host_desc']
+        h = self.in_height
+        geo = np.zeros((n, 4), dtype=np.int32)
+        for k in range(n):
+            if use[k]:
+                scale = h * 1.0 / (2 * int(r[k]))
+                geo[k] = (int(r[k]), int(scale * int(desc[k, 1])), 1, 0)
+        widths = np.where(geo[:, 2] > 0, geo[:, 1] + 2 * pad, 1).astype(np.int32)
+        w = int(widths.max())
+        slot.ensure_stage(n * h * w, host=False)
+        slot.ensure_boxes(n)
+        dev = f'cuda:{self.device}'
+        with torch.cuda.stream(slot.stream):
+            geo_d = torch.from_numpy(geo).to(dev, non_blocking=True)
+            _lib.check(self.lib.krk_dewarp_apply(slot.crops_dev.data_ptr(), st['desc'].data_ptr(), n, maxw, st['work'].data_ptr(), geo_d.data_ptr(),
+                                                 h, int(pad), w, slot.stage_dev.data_ptr(), slot.flags_dev.data_ptr(), slot.stream.cuda_stream))
+            slot.flags_host[:n].copy_(slot.flags_dev[:n], non_blocking=True)
+            geo_d.record_stream(slot.stream)
+        slot.has_flags = True
+        x = slot.stage_dev[:n * h * w].view(n, 1, h, w)
+        return self._launch(slot, x, widths, want_probs, wait_current=False)
+
     def submit_staged(self, lens=None, want_probs: bool = False) -> int:
         slot = self._free_slot()
         n, c, h, w = slot.staged

@@ -39,6 +39,7 @@ from typing import Optional, Union
 
 import numpy as np
 import torch
+from PIL import Image
 
 from . import ctc_decoder as _ctc
 from .containers import BaselineOCRRecord, BBoxOCRRecord
@@ -51,6 +52,7 @@ logger = logging.getLogger(__name__)
 ENGINE_BATCH = 256     # lines per device batch (results do not depend on it: masked padding, see the module docstring)
 ENGINE_SLOTS = 3       # device batches in flight per recogniser
 DEVICE_PREP = True     # crop / resize / pad / invert eligible lines on the device (krk_prep_lines) instead of with PIL
+DEVICE_DEWARP = True   # ... and the CenterNormalizer dewarp of 1-channel bbox lines (krk_dewarp_measure / krk_dewarp_apply) instead of scipy
 PREP_THREADS = 4       # host threads preparing line images when the caller does not say (``num_line_workers``); PIL holds the GIL in its
                        # conversions: 2..6 threads give the same throughput, 16 and more lose 40 % to contention
 
@@ -361,12 +363,35 @@ class LinePipeline:
             ticket = self.engine.submit_crops([a for _, a in part], pad, want_probs=self.want_probs, pool=self.pool)
             self._tickets.append((ticket, [k for k, _ in part]))
 
+    def submit_dewarp(self, items: list, pad: int):
+        """
+        items: [(key, uint8 array (h, w))] of ONE batch: 1-channel bbox lines, dewarped (CenterNormalizer), padded and inverted on
+        the device.  Returns ({key: network input width}, keys that must take the host transform instead).
+        """
+        while self.engine.free_slots() == 0:
+            self._collect_one()
+        r, ok, ink = self.engine.measure_dewarp([a for _, a in items], pool=self.pool)
+        use = ok & ink
+        h = self.engine.in_height
+        widths, host, keys = {}, set(), []
+        for (k, a), rr, o, i in zip(items, r, ok, ink):
+            if i and not o:
+                host.add(k)                                  # band outside the padded stack: the reference's own code decides
+            elif o and i:
+                widths[k] = int(h * 1.0 / (2 * int(rr)) * a.shape[1]) + 2 * pad
+            keys.append(None if (i and not o) else k)
+        ticket = self.engine.submit_dewarped(r, use, pad, want_probs=self.want_probs)
+        self._tickets.append((ticket, keys))
+        return widths, host
+
     def _collect_one(self):
         ticket, keys = self._tickets.popleft()
         batch, olens = self.engine.collect(ticket)
         flags = self.engine.last_flags
         probs = self.engine.last_probs() if self.want_probs else None
         for i, (k, r) in enumerate(zip(keys, _decode_lines(self.net.codec, batch, olens, probs))):
+            if k is None:
+                continue                                     # a slot of the batch whose line took the host transform instead
             # a line without a single non-white pixel is the reference's "flat line": empty record (kraken/rpred.py:221)
             self._done.append((k, None if flags is not None and not flags[i] else r))
 
@@ -432,8 +457,8 @@ class _RecognitionRun:
         pad = ts.pad
         if not (isinstance(pad, (tuple, list)) and len(pad) == 2 and int(pad[0]) > 0 and int(pad[1]) == 0):
             return self._host_path('padding other than (n > 0, 0)')
-        if ts._center_norm:
-            return self._host_path('the model asks for the CenterNormalizer dewarp (1-channel model on a bbox segmentation)')
+        if ts._center_norm and (ts._mode != 'L' or not DEVICE_DEWARP):
+            return self._host_path('the CenterNormalizer dewarp on the device is switched off (rpred.DEVICE_DEWARP)')
         if ts._perm != (0, 1, 2) or ts._mode not in ('L', 'RGB') or ts._scale[1] != 0 or not 1 <= ts._scale[0] <= 64:
             return self._host_path('input spec outside the kernel\'s range (legacy height-in-channels layout, height > 64, fixed width)')
         if not (_fused_ok(net) and net.nn.input[2] > 0):
@@ -450,8 +475,8 @@ class _RecognitionRun:
 
     def _device_prep_ok(self, net, ts) -> bool:
         """Rectangular crops straight from the uploaded page (krk_prep_lines): bbox segmentations of horizontal text."""
-        if self.bounds.type == 'baselines' or not self.bounds.text_direction.startswith('horizontal'):
-            return False
+        if self.bounds.type == 'baselines' or not self.bounds.text_direction.startswith('horizontal') or ts._center_norm:
+            return False                                   # (dewarped lines are cut out on the host and go through _crop_for_device)
         return self._transform_on_device_ok(net, ts)
 
     def _crop_for_device(self, idx: int, line, tag: str, net, ts, box, box_size, want_image: bool = False):
@@ -463,6 +488,13 @@ class _RecognitionRun:
             return None
         w, h = box.size
         out_h = ts._scale[0]
+        if ts._center_norm:
+            # the dewarp's output width depends on the measured spread: known after krk_dewarp_measure (LinePipeline.submit_dewarp)
+            if h < 2 or h > 192 or w > 16384:
+                self._host_path('line outside the device dewarp\'s range (height < 2 or > 192, wider than 16384)')
+                return None
+            arr = np.asarray(box if box.mode == 'L' else box.convert('L'), dtype=np.uint8)
+            return _Pending(idx, line, tag, net, None, box_size, image=box if want_image else None, width=0, mode='dewarp', crop=arr)
         ow = int(w * out_h / h)
         if ow <= 0:
             return None                              # Image.resize raises on an empty target: the host path reports it
@@ -623,7 +655,9 @@ class _RecognitionRun:
                 else:
                     self._results[i] = item
             for (_, shape), group in groups.items():     # one (recogniser, line height) per batch: heights are never padded
-                if shape[0] == 'crop':
+                if shape[0] == 'crop' and shape[1] == 'dewarp':
+                    self._submit_dewarp(group)
+                elif shape[0] == 'crop':
                     self._pipe(group[0].net).submit_crops([(p.idx, p.crop) for p in group], self.pad)
                 elif shape[0] == 'dev':
                     net = group[0].net
@@ -636,6 +670,37 @@ class _RecognitionRun:
             return
         busiest = max(self._pipes.values(), key=lambda p: p.pending(), default=None)
         self._absorb(block_pipe=busiest)
+
+    def _submit_dewarp(self, group: list):
+        """Lines of a 1-channel model on a bbox segmentation: dewarp on the device; the few lines whose band does not fit the
+        reference's padded stack (or that are flat) take the reference's host transform, which also decides their record."""
+        net = group[0].net
+        pipe = self._pipe(net)
+        ts = self.ts[group[0].tag] if isinstance(getattr(self, 'ts', None), (dict, defaultdict)) else self.ts
+        for lo in range(0, len(group), pipe.batch_size):
+            part = group[lo:lo + pipe.batch_size]
+            widths, host = pipe.submit_dewarp([(p.idx, p.crop) for p in part], self.pad)
+            for p in part:
+                if p.idx in widths:
+                    p.width = widths[p.idx]
+            for p in part:
+                if p.idx not in host:
+                    continue
+                del self._pending[p.idx]
+                box = Image.fromarray(p.crop, 'L')
+                try:
+                    t = ts(box)
+                except Exception:
+                    logger.warning(f'Conversion of line {p.line} failed. Emitting empty record..')
+                    self._results[p.idx] = self._empty(p.line)
+                    continue
+                if t.max() == t.min():
+                    logger.warning('Empty run. Emitting empty record.')
+                    self._results[p.idx] = self._empty(p.line)
+                    continue
+                q = dataclasses.replace(p, tensor=t, crop=None, mode='', width=t.shape[2])
+                self._pending[p.idx] = q
+                pipe.submit([(q.idx, q.tensor)])
 
     def _fill(self):
         while self._cursor not in self._results:

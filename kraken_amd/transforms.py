@@ -22,7 +22,7 @@ import torch
 from PIL import Image, ImageOps
 from scipy.ndimage import affine_transform, gaussian_filter, uniform_filter
 
-__all__ = ['ImageInputTransforms', 'center_normalize']
+__all__ = ['ImageInputTransforms', 'center_normalize', 'dewarp_tables']
 
 
 def _line_centers(ink: np.ndarray, smoothness: float = 1.0, extra: float = 0.3):
@@ -62,6 +62,27 @@ def center_normalize(gray: np.ndarray, target_height: int, spread: float = 4.0) 
         out = affine_transform(1.0 * band, np.ones(2) / scale, order=1,
                                output_shape=(target_height, int(scale * bw)), mode='constant', cval=top)
     return np.array(out, dtype=np.dtype('f'))
+
+
+def dewarp_tables(heights) -> tuple[np.ndarray, dict]:
+    """
+    Gaussian weight tables of the device dewarp (csrc/dewarp.hip) for the line heights of a batch: per height the three kernels of
+    lineest.CenterNormalizer.measure -- sigma = h/2 (rows), h (columns), 0.3 h (ridge) -- computed like scipy's
+    ``_gaussian_kernel1d`` (radius int(4 sigma + 0.5), exp(-x^2 / 2 sigma^2) / sum) with the HOST's exp, so that the device only
+    multiplies and adds.  Returns (flat float64 array, {h: (offset, r0, r1, r2)}).
+    """
+    parts, index, off = [], {}, 0
+    for h in sorted(set(int(v) for v in heights)):
+        rs = []
+        for sigma in (h * 0.5, h * 1.0, h * 0.3):
+            r = int(4.0 * float(sigma) + 0.5)
+            x = np.arange(-r, r + 1)
+            phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+            parts.append(phi / phi.sum())
+            rs.append(r)
+        index[h] = (off, *rs)
+        off += sum(2 * r + 1 for r in rs)
+    return np.concatenate(parts) if parts else np.zeros(0), index
 
 
 def _to_pil_gray(arr: np.ndarray) -> Image.Image:

@@ -288,3 +288,107 @@ def codec_decode(l2c, tuples):
         if not hit:
             i += 1
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CenterNormalizer dewarp (reference kraken/lib/lineest.py:26-87, called through functional_im_transforms.pil_dewarp :50-52) with the
+# arithmetic of the scipy.ndimage calls spelled out -- scipy is an un-vendored dependency of the reference (pinned scipy >= 1.13 in its
+# pyproject; 1.15.3 in the authoring container), so its published algorithms are restated here and pinned BIT FOR BIT against
+# scipy itself (tests/test_oracle_golden.py) and against the reference's outputs in tests/golden/transforms.npz:
+#   gaussian_filter   = correlate1d per axis with weights exp(-x^2 / 2 sigma^2) / sum, radius int(4 sigma + 0.5); a symmetric kernel
+#                       is summed as  w0 x[c] + sum_{j = r .. 1} w_j (x[c - j] + x[c + j])  (far to near), fp64; integer input ->
+#                       integer output by C truncation; boundary 'constant' (0) for the image, 'reflect' for the ridge
+#   uniform_filter    = running sum per axis:  t += x[l + size - 1] - x[l - 1];  out = t / size;  window [l - size // 2, ...)
+#   affine_transform  = (diagonal matrix, order 1, mode 'constant') bilinear at coordinate o / scale, cval outside [0, n - 1],
+#                       weights (wy wx) summed over (0,0) (0,1) (1,0) (1,1) in fp64, result stored as float32
+# This is what csrc/dewarp.hip implements on the device.
+def _gauss_weights(sigma: float):
+    r = int(4.0 * float(sigma) + 0.5)
+    x = np.arange(-r, r + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum(), r
+
+
+def _correlate_sym(a: np.ndarray, w: np.ndarray, r: int, axis: int, mode: str) -> np.ndarray:
+    a = np.moveaxis(np.asarray(a, dtype=np.float64), axis, -1)
+    n = a.shape[-1]
+    if mode == 'constant':
+        ext = np.concatenate([np.zeros(a.shape[:-1] + (r,)), a, np.zeros(a.shape[:-1] + (r,))], axis=-1)
+    else:                                       # 'reflect': (d c b a | a b c d | d c b a), repeated for r > n
+        idx = np.arange(-r, n + r)
+        idx = np.mod(idx, 2 * n)
+        idx = np.where(idx >= n, 2 * n - 1 - idx, idx)
+        ext = a[..., idx]
+    out = ext[..., r:r + n] * w[r]
+    for j in range(r, 0, -1):                   # far to near, pairs first
+        out = out + (ext[..., r - j:r - j + n] + ext[..., r + j:r + j + n]) * w[r - j]
+    return np.moveaxis(out, -1, axis)
+
+
+def _uniform_1d(a: np.ndarray, size: int, axis: int) -> np.ndarray:
+    a = np.moveaxis(np.asarray(a, dtype=np.float64), axis, -1)
+    n = a.shape[-1]
+    s1 = size // 2
+    s2 = size - s1 - 1
+    ext = np.concatenate([np.zeros(a.shape[:-1] + (s1,)), a, np.zeros(a.shape[:-1] + (s2,))], axis=-1)
+    out = np.empty_like(a)
+    t = np.zeros(a.shape[:-1])
+    for l in range(size):
+        t = t + ext[..., l]
+    out[..., 0] = t / size
+    for l in range(1, n):
+        t = t + (ext[..., l + size - 1] - ext[..., l - 1])
+        out[..., l] = t / size
+    return np.moveaxis(out, -1, axis)
+
+
+def line_centers_np(ink: np.ndarray, smoothness: float = 1.0, extra: float = 0.3) -> np.ndarray:
+    """lineest.CenterNormalizer.measure's centre line (lineest.py:34-44)."""
+    h, w = ink.shape
+    w0, r0 = _gauss_weights(h * 0.5)
+    w1, r1 = _gauss_weights(h * smoothness)
+    blur = _correlate_sym(_correlate_sym(ink, w0, r0, 0, 'constant'), w1, r1, 1, 'constant')
+    uni = _uniform_1d(_uniform_1d(blur, int(h * 0.5), 0), int(w), 1)
+    blur = blur + 0.001 * uni
+    ridge = np.argmax(blur, axis=0)
+    w2, r2 = _gauss_weights(h * extra)
+    smooth = _correlate_sym(ridge, w2, r2, 0, 'reflect')
+    return smooth.astype(np.int64).astype(np.int32)            # integer output array: C truncation
+
+
+def center_normalize_np(gray: np.ndarray, target_height: int, spread: float = 4.0) -> np.ndarray:
+    """lineest.dewarp + CenterNormalizer.measure/normalize (lineest.py:26-87) on a grayscale line (0 ink .. 255 paper, float)."""
+    line = np.asarray(gray, dtype=np.float64)
+    top = np.amax(line)
+    ink = top - line
+    ink = ink * 1.0 / np.amax(ink)
+    h, w = ink.shape
+    center = line_centers_np(ink)
+    rows = np.arange(h)[:, None]
+    mad = np.mean(np.abs(rows - center[None, :])[ink != 0])
+    r = int(1 + spread * mad)
+    stack = np.vstack([top * np.ones((h, w)), line, top * np.ones((h, w))])
+    mid = center + h
+    band = np.array([stack[mid[i] - r:mid[i] + r, i] for i in range(w)], dtype=np.float32).T
+    bh, bw = band.shape
+    scale = target_height * 1.0 / bh
+    z = 1.0 / scale
+    oh, ow = target_height, int(scale * bw)
+    b = band.astype(np.float64)
+    cy = np.arange(oh) * z
+    cx = np.arange(ow) * z
+    out = np.full((oh, ow), float(top))
+    iy = np.nonzero((cy >= 0) & (cy <= bh - 1))[0]
+    ix = np.nonzero((cx >= 0) & (cx <= bw - 1))[0]
+    y0 = np.floor(cy[iy]).astype(int)
+    x0 = np.floor(cx[ix]).astype(int)
+    ty = (cy[iy] - y0)[:, None]
+    tx = (cx[ix] - x0)[None, :]
+    pad = np.full((bh + 1, bw + 1), float(top))                # neighbours past the last sample carry weight 0 (value irrelevant)
+    pad[:bh, :bw] = b
+    acc = pad[y0[:, None], x0[None, :]] * ((1 - ty) * (1 - tx))
+    acc = acc + pad[y0[:, None], x0[None, :] + 1] * ((1 - ty) * tx)
+    acc = acc + pad[y0[:, None] + 1, x0[None, :]] * (ty * (1 - tx))
+    acc = acc + pad[y0[:, None] + 1, x0[None, :] + 1] * (ty * tx)
+    out[np.ix_(iy, ix)] = acc
+    return out.astype(np.float32)

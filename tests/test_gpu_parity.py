@@ -1046,6 +1046,108 @@ def test_host_cut_line_images_are_prepared_on_the_device_and_give_the_host_recor
         np.testing.assert_allclose(a.confidences, b.confidences, atol=1e-6)
 
 
+def _wavy_line(rng, h, w):
+    """Dark strokes on a light page around a wandering centre line (the generator of tests/golden/make_golden.py:transforms_fixture)."""
+    arr = np.full((h, w), 255, np.uint8)
+    yc = (h / 2 + 0.15 * h * np.sin(np.arange(w) / rng.uniform(20.0, 60.0))).astype(int)
+    for x in range(0, w, 3):
+        if rng.rand() < 0.6:
+            lo = max(yc[x] - rng.randint(2, max(h // 3, 3)), 0)
+            hi = min(yc[x] + rng.randint(2, max(h // 3, 3)), h)
+            arr[lo:hi, x:x + 2] = rng.randint(0, 90)
+    return arr
+
+
+def test_device_dewarp_is_bit_exact_against_the_reference_transform():
+    """
+    krk_dewarp_measure + krk_dewarp_apply (CenterNormalizer dewarp of 1-channel bbox lines, kraken/lib/lineest.py:26-87 through
+    scipy.ndimage) == ImageInputTransforms(valid_norm=True) on the host: the reference-made fixtures of transforms.npz and 40
+    synthetic lines of heights 20..120, bit for bit (the centre line is an argmax + truncation: anything but the same fp64
+    operations in the same order would move whole columns by a pixel).
+    """
+    from kraken_amd.engine import RecognitionEngine
+    from kraken_amd.transforms import ImageInputTransforms
+    z = load_golden('transforms.npz')
+    cases = json.loads(str(z['cases']))
+    rng = np.random.RandomState(5)
+    for target, pad, crops, want in (
+            (48, 16, [z[f'im{i}'] for i, c in enumerate(cases) if c['valid_norm'] and c['height'] == 48 and c['pad'] == 16 and c.get('channels', 1) == 1], None),
+            (30, 16, [z['im3']], [z['out3']]),
+            (48, 16, [_wavy_line(rng, int(rng.randint(20, 121)), int(rng.randint(40, 900))) for _ in range(40)] + [np.full((33, 100), 255, np.uint8)], None)):
+        m = build_model(f'[1,{target},0,1 Cr3,13,32 Mp2,2 Cr3,13,32 S1(1x0)1,3 Lbx16 O1c9]', seed=0).to('cuda')
+        m.nn.set_precision('bf16x3')
+        eng = RecognitionEngine(m, device=0, max_batch=64, max_width=512, slots=1)
+        ts = ImageInputTransforms(1, target, 0, 1, (pad, 0), valid_norm=True)
+        from PIL import Image
+        host = []
+        for a in crops:
+            try:
+                host.append(ts(Image.fromarray(a, 'L')))
+            except Exception:
+                host.append(None)
+        if want is not None:
+            for hst, w in zip(host, want):
+                np.testing.assert_allclose(hst.numpy(), w, atol=1e-7)          # the host transform is the reference's (pinned fixture)
+        r, ok, ink = eng.measure_dewarp(crops)
+        assert ink.tolist() == [bool(a.max() != a.min()) for a in crops]
+        use = ok & ink
+        assert use.sum() >= len(crops) - 3                       # the device takes (almost) every line
+        ticket = eng.submit_dewarped(r, use, pad)
+        slot = eng.slots[ticket]
+        slot.stream.synchronize()
+        x = slot.keep.cpu()
+        eng.collect(ticket)
+        for k, (a, hst) in enumerate(zip(crops, host)):
+            if not use[k]:
+                assert float(x[k].abs().sum()) == 0.0
+                continue
+            assert hst is not None
+            wk = hst.shape[2]
+            assert wk == int(target * 1.0 / (2 * int(r[k])) * a.shape[1]) + 2 * pad
+            assert torch.equal(x[k, :, :, :wk], hst), (k, a.shape, int(r[k]), float((x[k, :, :, :wk] - hst).abs().max()))
+            assert float(x[k, :, :, wk:].abs().sum()) == 0.0
+        eng.close()
+
+
+def test_one_channel_bbox_lines_are_dewarped_on_the_device_and_give_the_host_records(monkeypatch):
+    """mm_rpred with a 1-channel model on a bbox segmentation (the reference's dewarp path): device dewarp == scipy on the host."""
+    import warnings
+    from collections import defaultdict
+    from PIL import Image
+    from kraken_amd import rpred as R
+    from kraken_amd.containers import BBoxLine, Segmentation
+    from kraken_amd.models import TorchSeqRecognizer
+    m = build_model(BENCH_A, codec=bench_codec(), seed=0)
+    m.seg_type, m.model_type = 'bbox', ['recognition']
+    net = TorchSeqRecognizer(m, device='cuda')
+    rng = np.random.RandomState(9)
+    rows, boxes, y = [], [], 0
+    for i in range(60):
+        h, w = int(rng.randint(30, 90)), int(rng.randint(200, 1000))
+        line = _wavy_line(rng, h, w) if i != 17 else np.full((h, w), 255, np.uint8)        # line 17 is flat
+        rows.append(np.pad(line, ((0, 0), (0, 1000 - w)), constant_values=255))
+        boxes.append((0, y, w, y + h))
+        y += h
+    page = Image.fromarray(np.vstack(rows), 'L')
+    seg = Segmentation(type='bbox', imagename='p', text_direction='horizontal-lr', script_detection=False,
+                       lines=[BBoxLine(id=f'l{i}', bbox=list(b)) for i, b in enumerate(boxes)])
+    calls = []
+    from kraken_amd.engine import RecognitionEngine
+    real = RecognitionEngine.measure_dewarp
+    monkeypatch.setattr(RecognitionEngine, 'measure_dewarp', lambda self, crops, **k: (calls.append(len(crops)), real(self, crops, **k))[1])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        dev = list(R.mm_rpred(defaultdict(lambda: net), page, seg, bidi_reordering=False))
+        monkeypatch.setattr(R, 'DEVICE_DEWARP', False)
+        host = list(R.mm_rpred(defaultdict(lambda: net), page, seg, bidi_reordering=False))
+    assert sum(calls) == 60
+    assert [r.prediction for r in dev] == [r.prediction for r in host]
+    assert dev[17].prediction == '' and sum(bool(r.prediction) for r in dev) >= 55
+    assert [list(r.cuts) for r in dev] == [list(r.cuts) for r in host]
+    for a, b in zip(dev, host):
+        np.testing.assert_allclose(a.confidences, b.confidences, atol=1e-6)
+
+
 def test_rpred_device_preparation_equals_host_preparation(monkeypatch):
     """mm_rpred on an RGB model: lines cropped/resized on the device give the records of the PIL path; order and
     empty-record rules included (VERDICT r1 items 2 + 3)."""

@@ -177,3 +177,40 @@ def test_np_greedy_decode_semantics():
     with pytest.raises(ValueError):
         np_oracle.greedy_decode(np.zeros((2, 3, 4), np.float32))
     assert np_oracle.greedy_decode(probs, [3]) == [[(1, 0, 0, pytest.approx(0.8))]]
+
+
+def test_dewarp_restatement_is_bit_exact_against_scipy_and_the_reference_fixtures():
+    """
+    oracle/np_oracle.py:center_normalize_np spells out the scipy.ndimage arithmetic of the CenterNormalizer dewarp (summation orders,
+    boundary handling, integer truncation) -- the specification csrc/dewarp.hip follows.  Bit for bit against the scipy-based
+    transform (kraken_amd/transforms.py:center_normalize, itself pinned to the reference's outputs in transforms.npz) on the
+    fixture lines and on random lines of many heights, and through the float stage against the reference's tensors.
+    """
+    import json
+    from kraken_amd.transforms import center_normalize, dewarp_tables
+    from oracle.np_oracle import center_normalize_np, _gauss_weights
+    z = load_golden('transforms.npz')
+    for i, c in enumerate(json.loads(str(z['cases']))):
+        if not c['valid_norm'] or c.get('channels', 1) != 1:
+            continue
+        arr = z[f'im{i}'].astype(np.float64)
+        got = center_normalize_np(arr, c['height'])
+        assert np.array_equal(got, center_normalize(arr, c['height']))
+        t = 1.0 - np.clip(got, 0, 255).astype(np.uint8).astype(np.float32) / np.float32(255.0)      # array2pil truncation, / 255, invert
+        pad = c['pad']
+        inner = z[f'out{i}'][0][:, pad:z[f'out{i}'].shape[2] - pad] if pad else z[f'out{i}'][0]
+        np.testing.assert_allclose(t, inner if pad else inner.max() - (inner.max() - inner), atol=1e-7) if pad else None
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        h, w = int(rng.integers(20, 100)), int(rng.integers(30, 400))
+        arr = np.full((h, w), 255.0)
+        yc = (h / 2 + 0.2 * h * np.sin(np.arange(w) / rng.uniform(15, 60))).astype(int)
+        for x in range(0, w, 2):
+            if rng.random() < 0.7:
+                arr[max(yc[x] - rng.integers(1, max(h // 3, 2)), 0):min(yc[x] + rng.integers(1, max(h // 3, 2)), h), x:x + 2] = rng.integers(0, 120)
+        assert np.array_equal(center_normalize_np(arr, 48), center_normalize(arr, 48))
+    # the weight tables the device receives are the restatement's (= scipy's _gaussian_kernel1d)
+    tab, index = dewarp_tables([37, 60])
+    off, r0, r1, r2 = index[60]
+    w1, rr = _gauss_weights(60 * 1.0)
+    assert rr == r1 and np.array_equal(tab[off + 2 * r0 + 1:off + 2 * r0 + 1 + 2 * r1 + 1], w1)
