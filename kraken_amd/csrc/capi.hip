@@ -102,7 +102,6 @@ struct ConvGeom {
     bool c1x3 = false;        // one-channel first convolution on the bf16 cores (conv1_x3.hip); weights in d_wx3
     bool taps = false;        // wide-kernel convolution with taps as K (conv_taps_x3.hip); reads NHCW planes
     bool out_nhcw = false;    // conv1_x3 writes [N][H][C][pitch] planes for a following taps convolution
-    bool out_f32 = false;     // bf16x3 convolution writes plain fp32 NHWC: its consumer is a GroupNorm (norm_x3.hip)
 };
 
 // row pitch (elements) of the "NHCW" planes between conv1_x3 and conv_taps_x3: whole 16-byte pieces
@@ -401,7 +400,6 @@ struct Step {
     float* d_wrecsm = nullptr;  // recurrent weights for lstm_small.hip (Hp <= 32): register-resident A fragments
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
     bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
-    bool in_f32 = false;        // GN on split planes whose producer handed over fp32 NHWC (ConvGeom::out_f32)
     int img_axis = 0;           // LSTM over image rows (1) or columns (2): sequences = N*H (N*W), steps = W (H); 0 = plain sequence
     int yaxis = 0;              // IMG2ROWS / ROWS2IMG: 1 = columns are the sequences
     int last_only = 0;          // ROWS2IMG: keep the last step of every column (summarising LSTM): output height 1; LSTM step: time steps of the rows
@@ -807,8 +805,7 @@ int PlanBuilder::maxpool(const krk_layer& L, const std::string& where) {
 
 // GroupNorm (reference layers.py:967-984)
 int PlanBuilder::groupnorm(const krk_layer& L, const std::string& where) {
-    if (x3 && split_fmt && !seq && !krk_gn_x3_supported(C, L.cout)) leave_x3();
-    const bool x3 = this->x3 && split_fmt;
+    // (never on split planes: build() keeps every layer up to the network's last GroupNorm on the f32 kernels)
     if (seq) return fail(KRK_E_UNSUPPORTED, where + ": group norm after a sequence layer");
     if (L.cout <= 0 || C % L.cout) return fail(KRK_E_INVALID, where + ": groups must divide channels");
     if (!L.w[0] || !L.w[1]) return fail(KRK_E_INVALID, where + ": group norm weights missing");
@@ -817,13 +814,7 @@ int PlanBuilder::groupnorm(const krk_layer& L, const std::string& where) {
     s.C = C;
     s.H = H;
     s.groups = L.cout;
-    s.on_split = x3;
-    if (x3 && !p->steps.empty() && p->steps.back().kind == S_CONV && !p->steps.back().cg.out_seq &&
-        (p->steps.back().cg.x3 || p->steps.back().cg.c1x3 || p->steps.back().cg.taps)) {
-        // the convolution in front hands over exact fp32 values instead of (hi, lo): see gn_x3_kernel
-        p->steps.back().cg.out_f32 = true;
-        s.in_f32 = true;
-    }
+    s.on_split = false;
     std::vector<float> ga(L.w[0], L.w[0] + C), be(L.w[1], L.w[1] + C);
     if (upload(&s.d_gamma, ga) != KRK_OK || upload(&s.d_beta, be) != KRK_OK) return KRK_E_HIP;
     s.len_in = s.len_out = stage;
@@ -1182,7 +1173,7 @@ void fill_x3(const ConvGeom& g, X3Args& a, const void* xin, size_t x_plane, void
     a.IH = g.IH; a.IW = g.IW; a.PSTR = g.xPSTR; a.lds_plane = g.xplane; a.SR = g.SR;
     a.tiles_h = (g.Ho + g.TH - 1) / g.TH;
     a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
-    a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0; a.y_blkM = 0; a.y_cols = 0; a.y_f32 = g.out_f32;
+    a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0; a.y_blkM = 0; a.y_cols = 0; a.y_f32 = 0;
     a.dbg = dbg;
 }
 
@@ -1313,7 +1304,7 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
         a.act = g.act;
         a.tiles_h = (g.Ho + 3) / 4; a.tiles_w = (a.Wo + 127) / 128;
-        a.y_f32 = g.out_f32;
+        a.y_f32 = 0;
         a.dbg = probe.x3_dbg;
         split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
         s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
@@ -1345,7 +1336,7 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         a.tiles_h = (g.Ho + 7) / 8; a.tiles_w = (a.Wo + 127) / 128;
         split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
         a.y_pitch = g.out_nhcw ? nhcw_pitch(a.Wy) : 0;
-        a.y_f32 = g.out_f32;
+        a.y_f32 = 0;
         a.dbg = probe.x3_dbg;
         s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
         if (mark("conv1_x3", s.flops)) return kFailed;
@@ -1376,13 +1367,6 @@ int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int W
             if (mark("maxpool", 0)) return kFailed;
             return krk_launch_maxpool(cur, outp, lens_at(s.len_out), N, s.C, s.H, Win, s.kh, s.kw, s.sh, s.sw, s.Ho, Wout, stream);
         case S_GN: {
-            if (s.on_split) {
-                const int chunks = krk_gn_x3_chunks(N, s.H, Win);
-                if (s.aux.ensure((size_t)2 * N * (chunks + 1) * s.C * sizeof(float))) return nomem();
-                if (mark("groupnorm_x3", 0)) return kFailed;
-                return krk_launch_gn_x3(cur, s.in_f32, outp, out_elems, s.d_gamma, s.d_beta, lens_at(s.len_in), (float*)s.aux.p, N, s.C,
-                                        s.H, Win, s.groups, 1e-5f, stream);
-            }
             if (mark("groupnorm", 0)) return kFailed;
             const int chunks = krk_groupnorm_chunks(N, s.C, s.H, Win, s.groups);
             float* scratch = nullptr;

@@ -296,11 +296,7 @@ int krk_groupnorm_chunks(int N, int C, int H, int W, int G);
 int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const int* lens,
                          int N, int C, int H, int W, int G, float eps, float* scratch, hipStream_t s);
 int krk_launch_to_seq(const float* x, float* y, int N, int C, int H, int W, hipStream_t s);
-// split-bf16 NHWC planes (norm_x3.hip): GroupNorm (needs 2*N*chunks*C floats of scratch), MaxPool, height collapse
-bool krk_gn_x3_supported(int C, int G);
-int krk_gn_x3_chunks(int N, int H, int W);
-int krk_launch_gn_x3(const void* x, int x_f32, void* y, size_t plane, const float* gamma, const float* beta, const int* lens,
-                     float* part, int N, int C, int H, int W, int G, float eps, hipStream_t s);
+// split-bf16 NHWC planes (norm_x3.hip): MaxPool, height collapse
 int krk_launch_maxpool_x3(const void* x, size_t xplane, void* y, size_t yplane, const int* len_out, int N, int C, int H, int W,
                           int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);
 int krk_launch_toseq_x3(const void* x, void* y, size_t plane, int N, int C, int H, int W, hipStream_t s);

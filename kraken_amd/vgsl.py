@@ -25,6 +25,8 @@ import re
 from dataclasses import dataclass, field
 from typing import Any, Optional, Sequence
 
+import logging
+
 import numpy as np
 import torch
 from torch import nn
@@ -196,6 +198,8 @@ def parse_vgsl(spec: str):
 
 
 # ------------------------------------------------------------------ parameter containers
+logger = logging.getLogger(__name__)
+
 # Module/attribute names below are part of the on-disk format (state-dict keys).
 class _ConvHolder(nn.Module):
     def __init__(self, spec: LayerSpec):
@@ -438,7 +442,18 @@ class HipSequential(nn.Module):
                 self.invalidate()
             while len(self._plans) >= 4:                         # variable-height models: a few heights stay planned
                 self._plans.pop(next(iter(self._plans))).close()
-            plan = self._plans[key] = _Plan(self._specs, self, c, h, device_index, self.precision)
+            try:
+                plan = _Plan(self._specs, self, c, h, device_index, self.precision)
+            except _lib.KrakenAmdError as e:
+                # a network (or, for variable-height models, a height) the split-bf16 kernels do not cover keeps the exact-f32
+                # plan instead of failing at its first call -- said once, never silently
+                if self.precision == _lib.PREC_F32 or e.code != _lib.KRK_E_UNSUPPORTED:
+                    raise
+                logger.warning(f'the split-bf16 plan does not cover this network ({e}); using the exact-f32 plan')
+                self.precision = _lib.PREC_F32
+                self.invalidate()
+                return self.plan(device_index, height)
+            self._plans[key] = plan
         else:
             self._plans[key] = self._plans.pop(key)              # most recently used last
         return plan

@@ -19,6 +19,7 @@ cp gpurun_out/prof_$TAG/bench_default.json $O/${TAG}_bf16x3_bench_default.json
 bash tools/lstm_pmc.sh $O/lstm_pmc > $O/${TAG}_lstm_ws_pmc.txt 2>&1
 cd $R
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bf16x3_bench_steps20.json 2>/dev/null
+for sl in 2 4; do python bench.py --slots $sl --no-cpu-baseline > $O/${TAG}_bf16x3_bench_slots$sl.json 2>/dev/null; done
 python bench.py --host-input --no-cpu-baseline > $O/${TAG}_bf16x3_bench_host_input.json 2>/dev/null
 python bench.py --precision bf16 --no-cpu-baseline > $O/${TAG}_bf16_optin_bench_default.json 2>/dev/null
 python bench.py --precision f32 --no-cpu-baseline > $O/${TAG}_f32_bench_default.json 2>/dev/null
