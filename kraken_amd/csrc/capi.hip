@@ -379,6 +379,7 @@ struct Step {
     int C = 0, H = 1;
     // MAXPOOL
     int kh = 1, kw = 1, sh = 1, sw = 1, Ho = 1;
+    bool pooled = false;      // S_GN: the MaxPool that follows is part of the step (kh .. Ho describe it)
     // GROUPNORM
     int groups = 1;
     float* d_gamma = nullptr;
@@ -820,6 +821,22 @@ int PlanBuilder::groupnorm(const krk_layer& L, const std::string& where) {
     s.len_in = s.len_out = stage;
     s.outC = C;
     s.outH = H;
+    // a directly following MaxPool is taken in the apply pass: the normalised full-size tensor is never written
+    if (i + 1 < n_layers && layers[i + 1].op == KRK_OP_MAXPOOL && !getenv("KRK_NO_GN_POOL")) {
+        const krk_layer& P = layers[i + 1];
+        if (P.kh <= 0 || P.kw <= 0 || P.sh <= 0 || P.sw <= 0) return fail(KRK_E_INVALID, where + ": bad pool");
+        const int Ho = floordiv(H - (P.kh - 1) - 1, P.sh) + 1;
+        if (Ho <= 0) return fail(KRK_E_INVALID, where + ": pool output height <= 0");
+        s.pooled = true;
+        s.kh = P.kh; s.kw = P.kw; s.sh = P.sh; s.sw = P.sw;
+        s.Ho = Ho;
+        p->lenops.push_back({1, P.kw, P.sw, 1, 0});
+        ++stage;
+        ++i;
+        s.len_out = stage;
+        s.outH = Ho;
+        H = Ho;
+    }
     p->steps.push_back(std::move(s));
     return KRK_OK;
 }
@@ -1367,15 +1384,13 @@ int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int W
             if (mark("maxpool", 0)) return kFailed;
             return krk_launch_maxpool(cur, outp, lens_at(s.len_out), N, s.C, s.H, Win, s.kh, s.kw, s.sh, s.sw, s.Ho, Wout, stream);
         case S_GN: {
-            if (mark("groupnorm", 0)) return kFailed;
-            const int chunks = krk_groupnorm_chunks(N, s.C, s.H, Win, s.groups);
-            float* scratch = nullptr;
-            if (chunks > 1) {
-                if (s.aux.ensure((size_t)2 * N * s.groups * chunks * sizeof(float))) return nomem();
-                scratch = (float*)s.aux.p;
-            }
-            return krk_launch_groupnorm(cur, outp, s.d_gamma, s.d_beta, lens_at(s.len_in), N, s.C, s.H, Win, s.groups, 1e-5f,
-                                        scratch, stream);
+            const bool pool = s.pooled;
+            if (mark(pool ? "groupnorm_pool" : "groupnorm", 0)) return kFailed;
+            const int chunks = krk_groupnorm_chunks(N, s.C, s.H, Win, s.groups, pool ? s.Ho : 0);
+            if (s.aux.ensure((size_t)2 * N * s.groups * chunks * sizeof(double))) return nomem();
+            return krk_launch_groupnorm(cur, outp, s.d_gamma, s.d_beta, lens_at(s.len_in), pool ? lens_at(s.len_out) : nullptr, N, s.C,
+                                        s.H, Win, s.groups, 1e-5f, pool ? s.kh : 0, s.kw, s.sh, s.sw, s.Ho, Wout, (double*)s.aux.p,
+                                        stream);
         }
         case S_TOSEQ:
             if (s.on_split) {

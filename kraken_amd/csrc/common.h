@@ -291,10 +291,12 @@ int krk_launch_split_rows(const float* x, void* hi, int M, int K, hipStream_t s)
 int krk_x3_cb(int Cout);
 int krk_launch_maxpool(const float* x, float* y, const int* len_out, int N, int C, int H, int W,
                        int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);
-// `scratch`: 2 * N*G * krk_groupnorm_chunks(...) floats (or nullptr: always one workgroup per (line, group))
-int krk_groupnorm_chunks(int N, int C, int H, int W, int G);
-int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const int* lens,
-                         int N, int C, int H, int W, int G, float eps, float* scratch, hipStream_t s);
+// GroupNorm, optionally with the MaxPool that follows it (kh > 0: window kh x kw, stride sh x sw, output Ho x Wo, columns >=
+// len_out[n] zero; kh == 0: plain GroupNorm, Ho / Wo ignored).  `scratch`: 2 * N*G * krk_groupnorm_chunks(...) doubles.
+int krk_groupnorm_chunks(int N, int C, int H, int W, int G, int Ho);
+int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const int* lens, const int* len_out,
+                         int N, int C, int H, int W, int G, float eps, int kh, int kw, int sh, int sw, int Ho, int Wo,
+                         double* scratch, hipStream_t s);
 int krk_launch_to_seq(const float* x, float* y, int N, int C, int H, int W, hipStream_t s);
 // split-bf16 NHWC planes (norm_x3.hip): MaxPool, height collapse
 int krk_launch_maxpool_x3(const void* x, size_t xplane, void* y, size_t yplane, const int* len_out, int N, int C, int H, int W,

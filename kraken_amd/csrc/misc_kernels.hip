@@ -33,104 +33,208 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
 }
 
 // ----------------------------------------------------------------- GroupNorm
-// reference: GroupNorm.forward kraken/lib/vgsl/layers.py:967-984: fp32, eps 1e-5, affine,
-// statistics per (line, group) over (C/G, H, valid width only); positions past the valid
-// width are zero.  One workgroup per (line, group); mean, then centred variance, then apply.
-__device__ __forceinline__ float block_sum(float v, float* red) {
+// reference: GroupNorm.forward kraken/lib/vgsl/layers.py:967-984: fp32, eps 1e-5, affine, statistics per (line, group) over
+// (C/G, H, valid width only); positions past the valid width are zero.  HBM-bound: the activation in front of a GroupNorm is
+// the widest tensor of the network (BENCH-B: 1.9 GB per 256-line batch), so the layer is two streaming passes and nothing else:
+//   stats : ONE read; per (line, group) sum and sum of squares, accumulated in fp64 (full-rate on gfx950) so that
+//           var = E[x^2] - mean^2 needs no second, centred pass; a group is cut into `chunks` row ranges (one workgroup each) whose
+//           partial sums are combined in index order -- no atomics, results do not depend on scheduling
+//   apply : one read, (x - mean) * rstd * gamma + beta, masked; a directly following MaxPool (layers.py:381-388) is taken in the
+//           same pass, so the normalised full-size tensor is never written (BENCH-B: -1.9 GB write, -1.9 GB read per GroupNorm)
+// One wave per row (channel, image row): lanes run along the width with 16-byte loads; no per-element integer division.
+struct GnGeom {
+    int C, H, W, G, chunks;
+    float eps;
+    int kh, kw, sh, sw, Ho, Wo;   // the fused pool (kh == 0: none)
+};
+
+__device__ __forceinline__ void gn_block_sum2(double& s, double& q, double (*red)[4]) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
     __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
 }
 
-__global__ void __launch_bounds__(256) groupnorm_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                        const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta,
-                                                        const int* __restrict__ lens, int C, int H, int W, int G,
-                                                        float eps) {
-    __shared__ float red[4];
-    const int n = blockIdx.x, g = blockIdx.y;
-    const int Cg = C / G;
-    int L = lens ? lens[n] : W;
-    L = min(max(L, 1), W);   // the reference clamps to [1, W] (layers.py:982)
-    const size_t base = ((size_t)n * C + (size_t)g * Cg) * H * W;
-    const int rows = Cg * H;
-    const int cnt = rows * L;
-    float s = 0.f;
-    for (int e = threadIdx.x; e < cnt; e += 256) {
-        const int r = e / L, w = e - r * L;
-        s += x[base + (size_t)r * W + w];
-    }
-    const float mean = block_sum(s, red) / (float)cnt;
-    float q = 0.f;
-    for (int e = threadIdx.x; e < cnt; e += 256) {
-        const int r = e / L, w = e - r * L;
-        const float d = x[base + (size_t)r * W + w] - mean;
-        q += d * d;
-    }
-    const float var = block_sum(q, red) / (float)cnt;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    const int tot = rows * W;
-    for (int e = threadIdx.x; e < tot; e += 256) {
-        const int r = e / W, w = e - r * W;
-        const int c = g * Cg + r / H;
-        float v = 0.f;
-        if (w < L) v = (x[base + e] - mean) * rstd * gamma[c] + beta[c];
-        y[base + e] = v;
-    }
-}
-
-// Large images (the BLLA segmenter normalises 64..256 channels of a 900 x 675 map): one workgroup per (line, group)
-// would leave all but 32 CUs idle, so the same three passes are split over `chunks` workgroups per (line, group) with
-// the partial sums combined in a fixed order (no atomics: results do not depend on scheduling).
-//   pass 0: partial sums            -> part[ng][chunk]
-//   pass 1: mean, partial centred squares -> part[NG*chunks + ng*chunks + chunk]
-//   pass 2: mean, variance, apply
-__global__ void __launch_bounds__(256) groupnorm_split_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const int* __restrict__ lens, float* __restrict__ part,
-                                                              int C, int H, int W, int G, float eps, int chunks, int pass) {
-    __shared__ float red[4];
-    const int ng = blockIdx.y, n = ng / G, g = ng - n * G, ch = blockIdx.x;
-    const int NG = gridDim.y;
-    const int Cg = C / G;
-    int L = lens ? lens[n] : W;
-    L = min(max(L, 1), W);
-    const size_t base = ((size_t)n * C + (size_t)g * Cg) * H * W;
-    const int rows = Cg * H, tot = rows * W;
-    const float cnt = (float)rows * (float)L;
-    const int per = (tot + chunks - 1) / chunks;
-    const int e0 = ch * per, e1 = min(tot, e0 + per);
-    float mean = 0.f, rstd = 0.f;
-    if (pass >= 1) {
-        float sm = 0.f;
-        for (int i = 0; i < chunks; ++i) sm += part[(size_t)ng * chunks + i];
-        mean = sm / cnt;
-    }
-    if (pass == 2) {
-        float sq = 0.f;
-        for (int i = 0; i < chunks; ++i) sq += part[(size_t)(NG + ng) * chunks + i];
-        rstd = 1.0f / sqrtf(sq / cnt + eps);
-    }
-    if (pass < 2) {
-        float acc = 0.f;
-        for (int e = e0 + threadIdx.x; e < e1; e += 256) {
-            const int w = e % W;
-            if (w < L) {
-                const float d = x[base + e] - mean;      // pass 0: mean == 0 -> plain sum
-                acc += pass == 0 ? d : d * d;
+template <bool VEC>   // VEC: W % 4 == 0, rows are 16-byte aligned
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, const int* __restrict__ lens,
+                                                       double* __restrict__ part, const GnGeom p) {
+    __shared__ double red[2][4];
+    const int ng = blockIdx.y, n = ng / p.G, g = ng - n * p.G, ch = blockIdx.x;
+    const int Cg = p.C / p.G, rows = Cg * p.H;
+    int L = lens ? lens[n] : p.W;
+    L = min(max(L, 1), p.W);   // the reference clamps to [1, W] (layers.py:982)
+    const float* xg = x + ((size_t)n * p.C + (size_t)g * Cg) * p.H * p.W;
+    const int per = (rows + p.chunks - 1) / p.chunks, r0 = ch * per, r1 = min(rows, r0 + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0, q = 0.0;
+    auto acc = [&](float v) {
+        const double d = (double)v;
+        s += d;
+        q = fma(d, d, q);
+    };
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const float* row = xg + (size_t)r * p.W;
+        if (VEC) {
+            const int L4 = L >> 2;
+            // four 16-byte loads per lane in flight: clamped (not branched) indices, pinned by an empty asm (see gn_apply_kernel)
+            for (int ib = lane; ib < L4; ib += 256) {
+                float4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const float4*>(row)[min(ib + 64 * k, L4 - 1)];
+                asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z),
+                             "+v"(v[1].w), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y),
+                             "+v"(v[3].z), "+v"(v[3].w));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (ib + 64 * k < L4) { acc(v[k].x); acc(v[k].y); acc(v[k].z); acc(v[k].w); }
             }
+            const int w = (L4 << 2) + lane;
+            if (w < L) acc(row[w]);
+        } else {
+#pragma unroll 4
+            for (int w = lane; w < L; w += 64) acc(row[w]);
         }
-        const float tot_acc = block_sum(acc, red);
-        if (threadIdx.x == 0) part[(size_t)(pass * NG + ng) * chunks + ch] = tot_acc;
-    } else {
-        for (int e = e0 + threadIdx.x; e < e1; e += 256) {
-            const int r = e / W, w = e - r * W;
-            const int c = g * Cg + r / H;
-            y[base + e] = w < L ? (x[base + e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+    }
+    gn_block_sum2(s, q, red);
+    if (threadIdx.x == 0) {
+        part[((size_t)ng * p.chunks + ch) * 2] = s;
+        part[((size_t)ng * p.chunks + ch) * 2 + 1] = q;
+    }
+}
+
+// mean and 1/sqrt(var + eps) of group `ng` from the chunk partials (every thread of the workgroup computes the same values)
+__device__ __forceinline__ void gn_moments(const double* __restrict__ part, int ng, int chunks, double cnt, float eps, float& mean,
+                                           float& rstd) {
+    double S = 0.0, Q = 0.0;
+    for (int i = 0; i < chunks; ++i) {
+        S += part[((size_t)ng * chunks + i) * 2];
+        Q += part[((size_t)ng * chunks + i) * 2 + 1];
+    }
+    const double m = S / cnt;
+    const double var = fmax(Q / cnt - m * m, 0.0);
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const int* __restrict__ lens, const double* __restrict__ part, const GnGeom p) {
+    const int ng = blockIdx.y, n = ng / p.G, g = ng - n * p.G, ch = blockIdx.x;
+    const int Cg = p.C / p.G, rows = Cg * p.H;
+    int L = lens ? lens[n] : p.W;
+    L = min(max(L, 1), p.W);
+    float mean, rstd;
+    gn_moments(part, ng, p.chunks, (double)rows * (double)L, p.eps, mean, rstd);
+    const size_t base = ((size_t)n * p.C + (size_t)g * Cg) * p.H * p.W;
+    const int per = (rows + p.chunks - 1) / p.chunks, r0 = ch * per, r1 = min(rows, r0 + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const int c = g * Cg + r / p.H;
+        const float ga = gamma[c], be = beta[c];
+        const float* row = x + base + (size_t)r * p.W;
+        float* out = y + base + (size_t)r * p.W;
+        auto norm = [&](float v, int w) { return w < L ? (v - mean) * rstd * ga + be : 0.f; };
+        if (VEC) {
+            const int W4 = p.W >> 2;
+            auto put = [&](const float4& v, int i) {
+                const int w = i << 2;
+                reinterpret_cast<float4*>(out)[i] = make_float4(norm(v.x, w), norm(v.y, w + 1), norm(v.z, w + 2), norm(v.w, w + 3));
+            };
+            // four loads per lane at clamped (not branched) indices, pinned by an empty asm: with a conditional use hipcc sinks a
+            // load to its use and splits it per component -- one 4-byte load in flight instead of four 16-byte ones
+            for (int ib = lane; ib < W4; ib += 256) {
+                float4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const float4*>(row)[min(ib + 64 * k, W4 - 1)];
+                asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z),
+                             "+v"(v[1].w), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y),
+                             "+v"(v[3].z), "+v"(v[3].w));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (ib + 64 * k < W4) put(v[k], ib + 64 * k);
+            }
+        } else {
+#pragma unroll 4
+            for (int w = lane; w < p.W; w += 64) out[w] = norm(row[w], w);
+        }
+    }
+}
+
+// GroupNorm + MaxPool in one pass.  The pool sees what the stand-alone GroupNorm would have written: normalised values for
+// columns < len_in, zeros past it; pooled columns >= len_out are written as zeros (masked padding, as krk_launch_maxpool).
+// KH > 0: the fast case -- KH x 2 windows at stride (sh, 2) over rows of W % 4 == 0 floats: one 16-byte load per window row gives
+// two outputs; a lane takes two such pairs per whole trip, so 2 * KH loads are in flight per wave.  KH == 0: any window, scalar loads.
+template <int KH>
+__global__ void __launch_bounds__(256) gn_apply_pool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const int* __restrict__ lens, const int* __restrict__ len_out,
+                                                            const double* __restrict__ part, const GnGeom p) {
+    const int ng = blockIdx.y, n = ng / p.G, g = ng - n * p.G, ch = blockIdx.x;
+    const int Cg = p.C / p.G;
+    int L = lens ? lens[n] : p.W;
+    L = min(max(L, 1), p.W);
+    const int lo = len_out ? len_out[n] : p.Wo;
+    float mean, rstd;
+    gn_moments(part, ng, p.chunks, (double)(Cg * p.H) * (double)L, p.eps, mean, rstd);
+    const int orows = Cg * p.Ho;
+    const int per = (orows + p.chunks - 1) / p.chunks, r0 = ch * per, r1 = min(orows, r0 + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int ro = r0 + wave; ro < r1; ro += 4) {
+        const int cl = ro / p.Ho, ho = ro - cl * p.Ho;
+        const int c = g * Cg + cl;
+        const float ga = gamma[c], be = beta[c];
+        const float* xin = x + (((size_t)n * p.C + c) * p.H + (size_t)ho * p.sh) * p.W;
+        float* out = y + (((size_t)n * p.C + c) * p.Ho + ho) * p.Wo;
+        auto norm = [&](float v, int w) { return w < L ? (v - mean) * rstd * ga + be : 0.f; };
+        if constexpr (KH > 0) {
+            const int Wo2 = p.Wo >> 1;
+            auto pooled = [&](const float4 (&v)[KH], int j) {
+                const int w = j << 2;
+                float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+                for (int dy = 0; dy < KH; ++dy) {
+                    m0 = fmaxf(m0, fmaxf(norm(v[dy].x, w), norm(v[dy].y, w + 1)));
+                    m1 = fmaxf(m1, fmaxf(norm(v[dy].z, w + 2), norm(v[dy].w, w + 3)));
+                }
+                const int wo = j << 1;
+                reinterpret_cast<float2*>(out)[j] = make_float2(wo < lo ? m0 : 0.f, wo + 1 < lo ? m1 : 0.f);
+            };
+            // two output pairs per lane and trip at clamped (not branched) indices, the 2 * KH loads pinned by an empty asm
+            // (see gn_apply_kernel)
+            for (int jb = lane; jb < Wo2; jb += 128) {
+                float4 v[2][KH];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int dy = 0; dy < KH; ++dy)
+                        v[k][dy] = reinterpret_cast<const float4*>(xin + (size_t)dy * p.W)[min(jb + 64 * k, Wo2 - 1)];
+#pragma unroll
+                for (int dy = 0; dy < KH; ++dy)
+                    asm volatile("" : "+v"(v[0][dy].x), "+v"(v[0][dy].y), "+v"(v[0][dy].z), "+v"(v[0][dy].w), "+v"(v[1][dy].x),
+                                 "+v"(v[1][dy].y), "+v"(v[1][dy].z), "+v"(v[1][dy].w));
+                pooled(v[0], jb);
+                if (jb + 64 < Wo2) pooled(v[1], jb + 64);
+            }
+        } else {
+            for (int wo = lane; wo < p.Wo; wo += 64) {
+                float m = 0.f;
+                if (wo < lo) {
+                    m = -INFINITY;
+                    for (int dy = 0; dy < p.kh; ++dy)
+                        for (int dx = 0; dx < p.kw; ++dx) {
+                            const int w = wo * p.sw + dx;
+                            m = fmaxf(m, norm(w < L ? xin[(size_t)dy * p.W + w] : 0.f, w));
+                        }
+                }
+                out[wo] = m;
+            }
         }
     }
 }
@@ -411,24 +515,41 @@ int krk_launch_maxpool(const float* x, float* y, const int* len_out, int N, int 
     return last_ok();
 }
 
-int krk_groupnorm_chunks(int N, int C, int H, int W, int G) {
+int krk_groupnorm_chunks(int N, int C, int H, int W, int G, int Ho) {
     const long per_group = (long)(C / G) * H * W;
     if (per_group < (1L << 17) || (long)N * G >= 512) return 1;     // text lines: one workgroup per (line, group)
     long chunks = (per_group + (1L << 15) - 1) >> 15;                // ~32k elements per workgroup
     const long cap = (2048 + (long)N * G - 1) / ((long)N * G);      // ~2k workgroups per pass are plenty
-    return (int)(chunks < cap ? chunks : (cap < 1 ? 1 : cap));
+    chunks = chunks < cap ? chunks : (cap < 1 ? 1 : cap);
+    const long rows = (long)(C / G) * (Ho > 0 ? Ho : H);             // a chunk is a range of (output) rows
+    return (int)(chunks < rows ? chunks : rows);
 }
 
-int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const int* lens,
-                         int N, int C, int H, int W, int G, float eps, float* scratch, hipStream_t s) {
-    const int chunks = scratch ? krk_groupnorm_chunks(N, C, H, W, G) : 1;
-    if (chunks > 1) {
-        for (int pass = 0; pass < 3; ++pass)
-            hipLaunchKernelGGL(groupnorm_split_kernel, dim3(chunks, N * G), dim3(256), 0, s, x, y, gamma, beta, lens, scratch,
-                               C, H, W, G, eps, chunks, pass);
-        return last_ok();
+int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const int* lens, const int* len_out,
+                         int N, int C, int H, int W, int G, float eps, int kh, int kw, int sh, int sw, int Ho, int Wo,
+                         double* scratch, hipStream_t s) {
+    if (!scratch || (size_t)N * C * H * W == 0) return scratch ? 0 : -4;
+    GnGeom p;
+    p.C = C; p.H = H; p.W = W; p.G = G;
+    p.eps = eps;
+    p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.Ho = Ho; p.Wo = Wo;
+    p.chunks = krk_groupnorm_chunks(N, C, H, W, G, kh ? Ho : 0);
+    const dim3 grid(p.chunks, N * G);
+    const bool vec = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
+    if (vec) hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(256), 0, s, x, lens, scratch, p);
+    else hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(256), 0, s, x, lens, scratch, p);
+    if (!kh) {
+        if (vec) hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, scratch, p);
+        else hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, scratch, p);
+    } else {
+        const int fast = (vec && kw == 2 && sw == 2 && Wo * 2 == W && kh <= 3) ? kh : 0;
+        switch (fast) {
+            case 1: hipLaunchKernelGGL(gn_apply_pool_kernel<1>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, len_out, scratch, p); break;
+            case 2: hipLaunchKernelGGL(gn_apply_pool_kernel<2>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, len_out, scratch, p); break;
+            case 3: hipLaunchKernelGGL(gn_apply_pool_kernel<3>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, len_out, scratch, p); break;
+            default: hipLaunchKernelGGL(gn_apply_pool_kernel<0>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, len_out, scratch, p);
+        }
     }
-    hipLaunchKernelGGL(groupnorm_kernel, dim3(N, G), dim3(256), 0, s, x, y, gamma, beta, lens, C, H, W, G, eps);
     return last_ok();
 }
 

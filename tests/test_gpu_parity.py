@@ -565,8 +565,8 @@ def test_x3_plan_keeps_everything_up_to_the_last_groupnorm_on_the_f32_cores():
     assert n1[:3] == ['conv', 'groupnorm', 'to_seq'] and 'lstm_xproj_x3' in n1 and 'linear_x3' in n1, n1
     # convolutions behind the last GroupNorm: the first of them computes in f32 and hands over split planes, the next is split
     n2 = kernels('[1,16,0,1 Cr3,3,16 Gn4 Mp2,2 Cr3,5,32 Cr3,3,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx16 O1c9]', 16)
-    assert n2[:2] == ['conv', 'groupnorm'] and n2[n2.index('groupnorm') + 1] in ('maxpool', 'conv') and 'conv_x3' in n2, n2
-    assert 'gn_x3' not in n2 and 'groupnorm' not in n2[n2.index('conv_x3'):], n2
+    assert n2[:3] == ['conv', 'groupnorm_pool', 'conv'] and 'conv_x3' in n2, n2          # the pool behind the GroupNorm is part of its apply pass
+    assert 'gn_x3' not in n2 and not any(k.startswith('groupnorm') for k in n2[n2.index('conv_x3'):]), n2
 
 
 def test_x3_bench_b_groupnorm_network_against_reference_golden():
@@ -598,7 +598,7 @@ def test_x3_bench_b_groupnorm_network_against_reference_golden():
     eng.collect()
     names = [n_ for n_, _, _ in eng.layer_times()[0]]
     eng.close()
-    assert names[:7] == ['conv', 'groupnorm', 'maxpool', 'conv', 'groupnorm', 'maxpool', 'to_seq'], names
+    assert names[:5] == ['conv', 'groupnorm_pool', 'conv', 'groupnorm_pool', 'to_seq'], names
     assert 'lstm_xproj_x3' in names and 'lstm_rec_x3' in names and 'linear_x3' in names, names
 
 
@@ -805,6 +805,38 @@ def test_groupnorm_large_image_split_path(lens):
     got, _ = m.nn(x.cuda(), None if lens is None else torch.tensor(lens))
     for i in range(2):
         L = lens[i] if lens else 400
+        assert (got.cpu()[i, ..., :L] - want[i, ..., :L]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('spec,shape,lens', [
+    ('[1,24,0,1 Cr3,3,8 Gn4 Mp2,2 Cr3,3,4]', (3, 1, 24, 96), [96, 57, 1]),            # 2 x 2 / 2: one 16-byte load per window row
+    ('[1,24,0,1 Cr3,3,8 Gn8 Mp1,2,1,2 Cr3,3,4]', (2, 1, 24, 600), None),              # 1 x 2, rows longer than one trip of the wave
+    ('[1,24,0,1 Cr3,3,8 Gn2 Mp3,2,3,2 Cr3,3,4]', (2, 1, 24, 100), [100, 31]),         # 3 x 2 / (3, 2)
+    ('[1,24,0,1 Cr3,3,8 Gn2 Mp3,3,2,2 Cr3,3,4]', (2, 1, 24, 100), [77, 100]),         # overlapping windows: the scalar kernel
+    ('[1,24,0,1 Cr3,3,8 Gn1 Mp2,2 Cr3,3,4]', (2, 1, 24, 97), [97, 50]),               # odd width: rows are not 16-byte aligned
+    ('[1,24,0,1 Cr3,3,8 Gn8 Mp2,2 Cr3,3,4]', (2, 1, 24, 98), None),                   # W % 4 == 2
+    ('[1,96,0,8 Gn2 Mp2,2 Cr3,3,4]', (2, 8, 96, 400), [400, 333]),                    # >= 128k elements per group: several workgroups per group
+    ('[1,96,0,8 Gn2 Mp4,2,4,2 Cr3,3,4]', (2, 8, 96, 400), None),
+])
+def test_groupnorm_takes_the_following_pool_in_its_apply_pass(spec, shape, lens, monkeypatch):
+    """GroupNorm + MaxPool (reference layers.py:967-984 + :381-388) as ONE apply pass: equal to the oracle, and bit-equal to
+    the stand-alone GroupNorm followed by the stand-alone pool (KRK_NO_GN_POOL) -- the pool sees exactly what GroupNorm would
+    have written, zeros past the valid width included."""
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(5)) * 3 + 1
+    if lens:
+        for i, L in enumerate(lens):
+            x[i, ..., L:] = 0
+    tl = None if lens is None else torch.tensor(lens)
+    m = build_model(spec, seed=12)
+    want, wl = CpuRecognizer(m.layer_specs, m.state_dict()).forward(x, lens)
+    m.to('cuda')
+    got, ol = m.nn(x.cuda(), tl)
+    monkeypatch.setenv('KRK_NO_GN_POOL', '1')
+    m2 = build_model(spec, seed=12).to('cuda')
+    sep, _ = m2.nn(x.cuda(), tl)
+    assert torch.equal(got, sep)
+    for i in range(shape[0]):
+        L = int(ol[i]) if ol is not None else want.shape[-1]
         assert (got.cpu()[i, ..., :L] - want[i, ..., :L]).abs().max().item() < 2e-5
 
 

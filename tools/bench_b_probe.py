@@ -21,3 +21,11 @@ for prec in ('f32', 'bf16x3'):
     for n_, ms, _ in eng.layer_times()[0]: names[n_] = names.get(n_, 0) + ms
     print(prec, '%.0f lines/s, %.2f ms/step' % (256 * 40 / dt, 1e3 * dt / 40), {k: round(v, 2) for k, v in names.items()}, flush=True)
     eng.close()
+    # the same steps with ONE batch in flight (each kernel has the chip to itself), in schedule order
+    solo = RecognitionEngine(m, device=0, max_batch=256, max_width=1200, slots=1)
+    solo.set_profiling(True)
+    for _ in range(3):
+        solo.submit(x)
+        solo.collect()
+    print(prec, 'alone:', ' '.join('%s=%.3f' % (n_, ms) for n_, ms, _ in solo.layer_times()[0]), flush=True)
+    solo.close()
