@@ -1512,11 +1512,10 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     // (XCD-local clusters, dedicated gather waves, every wait behind a barrier) showed none in 900: it takes H <= 128.
     const int lstm_v = probe.lstm_v ? probe.lstm_v : (l.NKB <= 4 ? 4 : 3);
     if (s.d_wrecwp && lstm_v == 4) {
+        // the granules carry a 4-bit sequence tag (lstm_wp.hip): the buffer starts every launch zeroed, tag 0 is never used
         const size_t gbytes = krk_lstm_wp_gran_bytes(Ns, s.ndir, s.Hp);
-        if (gbytes > s.ws_gran.cap) {
-            if (s.ws_gran.ensure(gbytes)) return nomem();
-            if (int r = hip(hipMemsetAsync(s.ws_gran.p, 0, s.ws_gran.cap, stream), "hipMemsetAsync")) return r;   // tags of a fresh buffer must not match
-        }
+        if (s.ws_gran.ensure(gbytes)) return nomem();
+        if (int r = hip(hipMemsetAsync(s.ws_gran.p, 0, gbytes, stream), "hipMemsetAsync")) return r;
         LstmWsArgs w;
         w.xp = l.xp; w.wp = (const __bf16*)s.d_wrecwp; w.out = l.out; w.out_plane = l.out_plane; w.lens = l.lens;
         w.N = l.N; w.T = l.T; w.H = l.H; w.Hp = l.Hp; w.NKB = l.NKB; w.NB = l.NB; w.G = l.G;
@@ -1539,8 +1538,8 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
 #ifdef KRK_ABLATE
         {   // timeline stamps of the last launch (tools/wp_timeline.py reads them back through krk_debug_wp_timeline)
             static unsigned long long* tl = nullptr;
-            if (!tl && hipMalloc((void**)&tl, 32 * 8 * 8) != hipSuccess) tl = nullptr;
-            if (tl) (void)hipMemsetAsync(tl, 0, 32 * 8 * 8, stream);
+            if (!tl && hipMalloc((void**)&tl, 32 * 32 * 8) != hipSuccess) tl = nullptr;
+            if (tl) (void)hipMemsetAsync(tl, 0, 32 * 32 * 8, stream);
             w.tl = tl;
             g_wp_tl = tl;
         }

@@ -22,10 +22,16 @@
 // Scratch per line: three planes of h * w doubles.  `info` [n][4] int32 out: r, ok, ink flag, unused; `centre` [n][maxw] int32.
 #include "common.h"
 
+// hipcc contracts a * b + c into one fused multiply-add by default (-ffp-contract=fast) -- also through HIP's __dmul_rn / __dadd_rn,
+// which are plain operators compiled in the header's own context.  scipy rounds the product and the sum separately, and the last
+// bit matters here (round 3: 4 of 60 random lines had a few columns' centre off by one row), so every multiply and add of this file
+// is a plain operator under this pragma.
+#pragma clang fp contract(off)
+
 namespace {
 
-__device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ double dadd(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ double dmul(double a, double b) { return a * b; }
+__device__ __forceinline__ double dadd(double a, double b) { return a + b; }
 
 struct LineD { int off, w, h, soff, woff, r0, r1, r2; };
 __device__ __forceinline__ LineD line_of(const int* desc, int n) {

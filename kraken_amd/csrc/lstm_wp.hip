@@ -33,12 +33,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // timeline stamps (ablation build only): stages [64, 96) of cluster 0 / slice 0, lane 0 of compute wave 0 (slots 0..3) and of
-// gather wave 8 (slots 4..7): tl[(stage - 64) * 8 + slot] = s_memtime
+// gather wave 8 (slots 4..7): s_memtime into LDS -- NOT into memory: a store would sit in the wave's vmcnt queue and the next
+// hand-counted wait would wait for it (the first timelines of round 3 showed a 1200-cycle "poll" that was the stamp's own
+// store) -- copied to tl[(stage - 64) * 8 + slot] when the wave ends
+// Slots per stage (32): 0..3 compute wave 0 (barrier exit | operands issued | MFMAs done | next barrier entry), 4..7 gather wave 8
+// (barrier exit | first poll back | tags ok | next barrier entry), 8 + w: barrier entry of wave w, 20 + w: barrier exit of wave w.
 #ifdef KRK_ABLATE
 #define WP_STAMP(cond, kk, slot) do { if ((cond) && a.tl && cluster == 0 && slice == 0 && lane == 0 && (kk) >= 64u && (kk) < 96u) \
-    a.tl[((kk) - 64u) * 8u + (slot)] = __builtin_readcyclecounter(); } while (0)
+    reinterpret_cast<unsigned long long*>(smem8 + tl_off)[((kk) - 64u) * 32u + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define WP_STAMPS_OUT() do { if (a.tl && cluster == 0 && slice == 0) { __syncthreads(); \
+    for (int q_ = tid; q_ < 1024; q_ += 768) a.tl[q_] = reinterpret_cast<unsigned long long*>(smem8 + tl_off)[q_]; } } while (0)
 #else
 #define WP_STAMP(cond, kk, slot) do {} while (0)
+#define WP_STAMPS_OUT() do {} while (0)
 #endif
 
 namespace {
@@ -65,8 +72,9 @@ __device__ __forceinline__ void wp_load_b128_sc1(u32x4& d, unsigned vo, const i3
 // publish: a PLAIN store.  A cluster lives on ONE XCD (see the cluster claim), whose L2 is the point of coherence of its CUs:
 // the store writes through the CU's L1 into that L2 and stays there; the peers' polls (sc1 loads: bypass L1, served by L2) hit
 // it a few hundred cycles later.  (sc1 stores write through to the fabric and drop the line from L2: ~2 us per hop under load.)
-__device__ __forceinline__ void wp_store_b64(const u32x2& d, unsigned vo, const i32x4& srd, unsigned so) {
-    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" : : "v"(d), "v"(vo), "s"(srd), "s"(so) : "memory");
+// (16 bytes: see the hazard note at wp_store_b128)
+__device__ __forceinline__ void wp_store_b128_so(const u32x4& d, unsigned vo, const i32x4& srd, unsigned so) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(d), "v"(vo), "s"(srd), "s"(so) : "memory");
 }
 // The s_nop is a HAZARD fix, not padding: a vector-memory store of more than 64 bits reads its data registers for a few cycles
 // after issue, and the next VALU instruction must not write them (the hazard recogniser inserts the wait states for the
@@ -114,8 +122,9 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     unsigned char* hs = smem8;              // [group NG][hbuf]: ONE buffer per group (see the hazard note at the stage loop)
     int* lens_s = reinterpret_cast<int*>(smem8 + NG * hbuf);            // [16 * NG]
     unsigned* misc = reinterpret_cast<unsigned*>(lens_s + 16 * NG);     // [0] cluster (work item), [1] slice
-    const unsigned dump_base = (unsigned)(NG * hbuf + 16 * NG * 4 + 16);   // masked LDS writes: one dump dword per lane (two for gather lanes)
-    const unsigned xs_off = dump_base + 768u * 8u;                      // xproj landing ring [RING][wave 8][64 lanes x 16 B]
+    const unsigned dump_base = (unsigned)(NG * hbuf + 16 * NG * 4 + 16);   // masked LDS writes: 16 dump bytes per lane
+    const unsigned xs_off = dump_base + 768u * 16u;                      // xproj landing ring [RING][wave 8][64 lanes x 16 B]
+    [[maybe_unused]] const unsigned tl_off = xs_off + (unsigned)RING * 8u * 1024u;   // 8 KB of timeline stamps (ablation build)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -186,32 +195,41 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     if (Lmax <= 0) return;
 
     const int BPC = a.BPC;                                        // blocks per slice (<= 8)
-    const unsigned slice_gran = (unsigned)BPC * 64u;              // granules one slice publishes per (group, step)
-    const unsigned gp_bytes = (unsigned)CS * slice_gran * 8u;     // bytes per (group, parity)
-    // granules of this cluster: [group][parity][slice][unit pair][line 16][unit & 1] -- the two units of a pair are adjacent,
-    // so a gather lane fetches a pair with ONE 16-byte load and writes one dword per plane
+    const unsigned slice_gran = (unsigned)BPC * 16u;              // granules one slice publishes per (group, step)
+    const unsigned gp_bytes = (unsigned)CS * slice_gran * 16u;    // bytes per (group, parity)
+    // granules of this cluster: [group][parity][slice][block][line 16] x 16 bytes.  A granule is ALL payload: the four units of a
+    // block for one line, {hi0 | hi1 << 16, hi2 | hi3 << 16, lo0 | lo1 << 16, lo2 | lo3 << 16} -- exactly the 8 + 8 bytes of the
+    // (line, block) position in the hi and lo planes of the LDS rows.  Its sequence tag lives in the lowest mantissa bit of the
+    // four lo values (the lo parts are rounded to 7 significant bits: h = hi + lo is carried to 2^-17 instead of 2^-18): four
+    // bits, (step mod 15) + 1, never 0.  That is enough because the host zeroes the granule buffer before every launch and a
+    // (group, parity) slot is only ever overwritten by the step two after the one it held (15 is odd: the tags differ).  Round 3
+    // first shipped {payload, 32-bit tag} pairs: twice the bytes through the gather waves, which bound the stage.
     const i32x4 grs = wp_srd(reinterpret_cast<const unsigned char*>(a.gran) + (size_t)cluster * (2 * NG) * gp_bytes, (unsigned)(2 * NG) * gp_bytes);
-    const unsigned tagbase = (a.epoch & 0xFFFFu) << 16;
+    auto tagbits = [](int ts, unsigned& w2, unsigned& w3) {        // tag of step ts - 1 (ts >= 1), spread over bits 0 / 16 of dwords 2, 3
+        const unsigned t = (unsigned)((ts - 1) % 15) + 1u;
+        w2 = (t & 1u) | ((t & 2u) << 15);
+        w3 = ((t >> 2) & 1u) | ((t & 8u) << 13);
+    };
 
     if (wave >= 8) {
         // ======================================================================================== gather waves
         constexpr int NGW = 4;
-        constexpr int NGP = (NPEER * 8 * 32 + 64 * NGW - 1) / (64 * NGW);   // granule PAIRS per gather lane (a slice publishes <= 8 blocks = 256 pairs)
-        static_assert(NGP == 3 || NGP == 7, "the vmcnt(0) asm below lists NGP registers");
+        if (KRK_DBGBIT(a, 32)) __builtin_amdgcn_s_setprio(3);   // probe bit 32: the gather waves ahead of the compute waves of their SIMD (slower: +7 %)
+        constexpr int NGP = (NPEER * 8 * 16 + 64 * NGW - 1) / (64 * NGW);   // granules per gather lane (a slice publishes <= 8 blocks x 16 lines)
+        static_assert(NGP == 2 || NGP == 4, "the vmcnt(0) asm below lists NGP registers");
         const int gl = tid - 512;                                 // 0 .. 64*NGW-1
-        const unsigned slice_pairs = slice_gran >> 1;
         unsigned g_vo[NGP], g_lds[NGP];
         bool g_on[NGP];
-        const unsigned dump_off = dump_base + (unsigned)tid * 8u;
+        const unsigned dump_off = dump_base + (unsigned)tid * 16u;
 #pragma unroll
         for (int j = 0; j < NGP; ++j) {
             const unsigned q = (unsigned)gl + (unsigned)(64 * NGW) * j;
-            const unsigned p = q / slice_pairs, rem = q - p * slice_pairs;
+            const unsigned p = q / slice_gran, rem = q - p * slice_gran;
             const int sl = (slice + 1 + (int)p) % CS;
-            const int up = (int)(rem >> 4), ln = (int)(rem & 15);
-            const int unit = sl * BPC * 4 + 2 * up;
-            g_on[j] = p < (unsigned)NPEER && (sl * BPC + (up >> 1)) < a.NB;      // blocks beyond NB are never published
-            g_vo[j] = g_on[j] ? ((unsigned)sl * slice_gran + (unsigned)(up * 16 + ln) * 2u) * 8u : kOOBwp;
+            const int blk = (int)(rem >> 4), ln = (int)(rem & 15);
+            const int unit = (sl * BPC + blk) * 4;
+            g_on[j] = p < (unsigned)NPEER && (sl * BPC + blk) < a.NB;          // blocks beyond NB are never published
+            g_vo[j] = g_on[j] ? ((unsigned)sl * slice_gran + (unsigned)(blk * 16 + ln)) * 16u : kOOBwp;
             g_lds[j] = (g_on[j] && unit < NKB * 32) ? lds_of(ln, unit) : 0xFFFFFFFFu;
         }
         bool dead = false;
@@ -221,31 +239,35 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
 #pragma unroll
             for (int j = 0; j < NGP; ++j) wp_load_b128_sc1(gd[j], g_vo[j], grs, so);
         };
-        // h(tg, ts - 1) -> LDS buffer tg: what the stage after this one consumes.  `inflight`: the request went out at the end of
-        // the previous iteration (after that iteration's rows were written: the registers are free then, and nothing is in flight
-        // across the loop's back edge that the compiler could copy -- see DESIGN.md for the variants that did not work)
+        auto land = [&]() {
+            if constexpr (NGP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]) : : "memory");
+        };
+        // h(tg, ts - 1) -> gd.  `inflight`: the request went out at the end of the previous iteration (after that iteration's rows
+        // were written: the registers are free then, and nothing is in flight across the loop's back edge that the compiler could copy)
         unsigned gkk = 0;
         auto gather = [&](int tg, int ts, bool inflight) {
-            const unsigned want = tagbase | ((unsigned)ts & 0xFFFFu);           // tag of step ts - 1
-            unsigned char* hb = hs + tg * hbuf;
+            unsigned w2, w3;
+            tagbits(ts, w2, w3);
             unsigned spins = 0;
             while (true) {
                 if (!inflight) issue(tg, ts);
                 inflight = false;
-                if constexpr (NGP == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]) : : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(gd[0]), "+v"(gd[1]), "+v"(gd[2]), "+v"(gd[3]), "+v"(gd[4]), "+v"(gd[5]), "+v"(gd[6]) : : "memory");
+                land();
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < NGP; ++j) ok = ok && (!g_on[j] || (gd[j][1] == want && gd[j][3] == want));
+                for (int j = 0; j < NGP; ++j) ok = ok && (!g_on[j] || ((gd[j][2] & 0x00010001u) == w2 && (gd[j][3] & 0x00010001u) == w3));
                 if (spins == 0) WP_STAMP(wave == 8, gkk, 5);
                 if (__all(ok) || dead) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 21)) {          // ~ a second: give up, flag the plan, never wait again
                     dead = true;
-                    // what was missing, for the post-mortem: step (12 bits) | group << 12 | slice << 14 | a tag seen instead << 20
+                    // what was missing, for the post-mortem: step (12 bits) | group << 12 | slice << 14 | the tag bits seen instead << 20
                     unsigned seen = 0;
 #pragma unroll
-                    for (int j = 0; j < NGP; ++j) if (g_on[j] && (gd[j][1] != want || gd[j][3] != want)) seen = gd[j][1] != want ? gd[j][1] : gd[j][3];
+                    for (int j = 0; j < NGP; ++j)
+                        if (g_on[j] && ((gd[j][2] & 0x00010001u) != w2 || (gd[j][3] & 0x00010001u) != w3))
+                            seen = (gd[j][2] & 1u) | ((gd[j][2] >> 15) & 2u) | ((gd[j][3] & 1u) << 2) | ((gd[j][3] >> 13) & 8u);
                     const unsigned long long bad = __ballot(!ok);
                     const int first = bad ? __builtin_ctzll(bad) : 0;
                     seen = (unsigned)__builtin_amdgcn_readlane((int)seen, first);
@@ -254,39 +276,60 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
                 }
             }
             WP_STAMP(wave == 8, gkk, 6);
+        };
+        auto rows = [&](int tg) {                                 // gd -> the rows of LDS buffer tg
+            unsigned char* hb = hs + tg * hbuf;
 #pragma unroll
             for (int j = 0; j < NGP; ++j) {
                 const bool nowhere = g_lds[j] == 0xFFFFFFFFu;
                 unsigned char* dst = nowhere ? smem8 + dump_off : hb + g_lds[j];
-                const unsigned v0 = gd[j][0], v1 = gd[j][2];                      // (hi | lo << 16) of units u, u + 1
-                *reinterpret_cast<unsigned*>(dst) = (v0 & 0xFFFFu) | (v1 << 16);
-                *reinterpret_cast<unsigned*>(dst + (nowhere ? 4 : plane)) = (v0 >> 16) | (v1 & 0xFFFF0000u);
+                u32x2 hi2, lo2;
+                hi2[0] = gd[j][0]; hi2[1] = gd[j][1];
+                lo2[0] = gd[j][2] & 0xFFFEFFFEu; lo2[1] = gd[j][3] & 0xFFFEFFFEu;    // the tag bits are not part of the value
+                *reinterpret_cast<u32x2*>(dst) = hi2;
+                *reinterpret_cast<u32x2*>(dst + (nowhere ? 8 : plane)) = lo2;
             }
         };
-        // iteration (s, g) runs beside compute stage (g, s) and prepares the input of the NEXT stage: (g+1, s) consumes
-        // h(g+1, s-1) -- or (0, s+1) consumes h(0, s); in the epilogue (s == Lmax) the "stages" only write h(., Lmax-1) out
-        bool pend = false;                                        // the loads of this iteration's target are already in flight
+        // Iteration (s, g) runs beside compute stage (g, s) and prepares the input of the NEXT stage: (g+1, s) consumes h(g+1, s-1)
+        // -- or (0, s+1) consumes h(0, s); in the epilogue (s == Lmax) the "stages" only write h(., Lmax-1) out.
+        // Tried (round 3, profiles/r03_lstm_wp_gather_variants.txt): landing registers the compiler does not own (kernel capped with
+        // amdgpu_num_vgpr, the asm naming v152.. directly), so that the request for the next target can go out BEFORE the rows are
+        // written and stay in flight across the loop's back edge -- correct, and no faster: the stage is not bound by the exchange
+        // (see DESIGN.md 3.3), and the register copies cost 6 %.
+        auto target = [&](int s_, int g_, int& tg, int& ts) -> bool {       // what iteration (s_, g_) gathers; false: nothing
+            if (g_ + 1 < NG) { tg = g_ + 1; ts = s_; return s_ > 0; }
+            tg = 0; ts = s_ + 1;
+            return s_ < Lmax;
+        };
+        bool pend = false;                                        // the request of this iteration's target is in flight
         for (int s = 0; s <= Lmax; ++s) {
 #pragma unroll
             for (int g = 0; g < NG; ++g, ++gkk) {
                 WP_STAMP(wave == 8, gkk, 7);
+                WP_STAMP(true, gkk, 8 + wave);
                 wp_barrier();
+                WP_STAMP(true, gkk, 20 + wave);
                 WP_STAMP(wave == 8, gkk, 4);
-                if (g + 1 < NG) { if (s > 0) gather(g + 1, s, pend); }
-                else if (s < Lmax) gather(0, s + 1, pend);
-                pend = false;
-                // the target of the next iteration was published during the stage before this one: ask for it now
-                if (g + 2 < NG) { if (s > 0) { issue(g + 2, s); pend = true; } }
-                else if (g + 2 == NG) { if (s < Lmax) { issue(0, s + 1); pend = true; } }
-                // (no request across the loop's back edge: the compiler may copy a register an unfinished load will write)
+                int tg, ts, ng, ns;
+                const bool have = target(s, g, tg, ts);
+                if (have) {
+                    gather(tg, ts, pend);
+                    rows(tg);
+                }
+                // the target of the next iteration was published during the stage before this one: ask for it now (not across the
+                // loop's back edge: the compiler may copy a register an unfinished load will write)
+                const bool more = g + 1 < NG && target(s, g + 1, ng, ns);
+                if (more) issue(ng, ns);
+                pend = more;
             }
         }
+        WP_STAMPS_OUT();
         return;
     }
 
     // ============================================================================================ compute waves
     const int line = lane & 15, us = lane >> 4;
-    const unsigned dump_off = dump_base + (unsigned)tid * 8u;
+    const unsigned dump_off = dump_base + (unsigned)tid * 16u;
     // this wave's block: local block `wave` of the slice, global block slice*BPC + wave
     const bool bval = (wave < BPC) && (slice * BPC + wave < a.NB);          // wave-uniform
 
@@ -325,16 +368,18 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
         xnext[g] = xbase + ((size_t)g * a.T + (size_t)max(t0, 0)) * 16 * a.xstride + xcol;
     }
     auto load_x = [&](int g, int s, unsigned ring) {              // must be called for s = 0, 1, 2, ... of a group, once each
-        const float* src = s < len_x[g] ? xnext[g] : xdummy;
+        const float* src = (s < len_x[g] && !KRK_DBGBIT(a, 8)) ? xnext[g] : xdummy;    // probe bit 8: no HBM stream (one hot row)
         xnext[g] += xstep;
+        if (KRK_DBGBIT(a, 64)) return;                            // probe bit 64: no xproj copy at all (the ring holds zeros)
         wp_load_lds_b128(src, xs_off + (ring * 8u + (unsigned)wave) * 1024u);
     };
 
-    // ---- what this lane publishes: unit_local ul = wave*4 + us of its own line
-    const int ul = wave * 4 + us;
-    const int unit = slice * BPC * 4 + ul;
-    const unsigned pub_vo = bval ? ((unsigned)slice * slice_gran + (unsigned)((ul >> 1) * 16 + line) * 2u + (unsigned)(ul & 1)) * 8u : kOOBwp;
-    const unsigned own_lds = (bval && unit < NKB * 32) ? lds_of(line, unit) : 0xFFFFFFFFu;
+    // ---- what this wave publishes: its block = units slice*BPC*4 + wave*4 + (0..3).  Lane (line, us) computes unit us of its
+    // line; the four units of a line are collected into the lanes us == 0 (publish() below), which write the LDS rows and the granule
+    const int unit0 = (slice * BPC + wave) * 4;
+    const bool pubber = bval && us == 0;
+    const unsigned pub_vo = pubber ? ((unsigned)slice * slice_gran + (unsigned)(wave * 16 + line)) * 16u : kOOBwp;
+    const unsigned own_lds = (pubber && unit0 < NKB * 32) ? lds_of(line, unit0) : 0xFFFFFFFFu;
 
     // ---- output pass, one 16-byte piece per lane (tid < 512).  Tile-time-major rows (a.otiled: the consumer is gemm_x3, which
     // keeps the order): the 16 lines of a group at one step are 16 consecutive rows, a slice takes every CS-th (plane, piece)
@@ -373,7 +418,7 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     }
     auto store_read = [&](int g, int step, const unsigned char* hb, unsigned& vo) -> u32x4 {       // step = -1, 0, 1, ... of a group, once each
         const bool on = step >= 0 && step < len_sp[g];
-        vo = on ? vnext[g] : kOOBwp;
+        vo = (on && !KRK_DBGBIT(a, 16)) ? vnext[g] : kOOBwp;                       // probe bit 16: no output stores
         if (step >= 0) vnext[g] += vstep;
         return *reinterpret_cast<const u32x4*>(hb + sp_lds);
     };
@@ -383,24 +428,68 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
     for (int g = 0; g < NG; ++g) cst[g] = 0.f;
     f32x4 zq = f32x4{0.f, 0.f, 0.f, 0.f};        // pre-activations of the PREVIOUS stage (its gates run inside this one)
 
-    // the gates of stage (pg, ps): c, h (split into bf16 hi + lo) ...
-    struct GateOut { unsigned short hbits, lbits; };
-    auto gates = [&](int pg, int ps) -> GateOut {
-        const float h = krk_lstm_cell(zq, cst[pg]);
-        const __bf16 hb16 = (__bf16)h;
-        const __bf16 lb16 = (__bf16)(h - (float)hb16);
-        return GateOut{__builtin_bit_cast(unsigned short, hb16), __builtin_bit_cast(unsigned short, lb16)};
+    // The gates of stage (pg, ps) -- krk_lstm_cell (common.h) cut into three pieces that run BEHIND the MFMAs of the first three K
+    // blocks of the next stage (in-order issue: a wave's VALU work delays its own later MFMAs, not the ones already in the matrix
+    // pipe, and the other compute wave of the SIMD fills the gaps).  Left to the compiler the whole chain -- 7 transcendentals, ~35
+    // VALU -- was scheduled in FRONT of the stage's first LDS read (profiles/r03_lstm_wp_gather_variants.txt: the first MFMA of a
+    // stage issued ~700 cycles after the barrier).  c, h split into bf16 hi + a lo part of 7 significant bits (its lowest mantissa
+    // bit carries the granule's tag), packed hi | lo << 16.
+    struct GateRegs { float ei, ef, eg, eo, po, et; };
+    auto gates_a = [&](GateRegs& q) {                              // the four exponentials of the pre-activations
+        constexpr float L2E = 1.4426950408889634f, LIM = 28.853900817779268f;   // 20 log2 e
+        q.ei = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(-L2E * zq[0], -LIM, LIM));
+        q.ef = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(-L2E * zq[1], -LIM, LIM));
+        q.eg = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(-2.f * L2E * zq[2], -LIM, LIM));
+        q.eo = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(-L2E * zq[3], -LIM, LIM));
     };
-    // ... and where they go: own rows of h(pg, ps) in LDS buffer [pg][(ps+1)&1], the granule with tag ps+1
-    auto publish = [&](const GateOut& go, int pg, int ps, bool real) {
+    auto gates_b = [&](GateRegs& q, int pg) {                      // c' = f c + i tanh g over one denominator; e^-2c'
+        constexpr float L2E = 1.4426950408889634f, LIM = 28.853900817779268f;
+        const float pi = 1.f + q.ei, pf = 1.f + q.ef, pgg = 1.f + q.eg;
+        q.po = 1.f + q.eo;
+        const float pig = pi * pgg;
+        const float num = __builtin_fmaf(cst[pg], pig, (1.f - q.eg) * pf);
+        const float cn = num * __builtin_amdgcn_rcpf(pig * pf);
+        cst[pg] = cn;
+        q.et = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(-2.f * L2E * cn, -LIM, LIM));
+    };
+    auto gates_c = [&](const GateRegs& q) -> unsigned {            // h = o tanh c', split
+        const float h = (1.f - q.et) * __builtin_amdgcn_rcpf(q.po * (1.f + q.et));
+        const __bf16 hb16 = (__bf16)h;
+        const unsigned lf = __builtin_bit_cast(unsigned, h - (float)hb16);
+        const unsigned lr = (lf + 0xFFFFu + ((lf >> 17) & 1u)) & 0xFFFE0000u;        // round to nearest even at bit 17
+        return (unsigned)__builtin_bit_cast(unsigned short, hb16) | lr;
+    };
+    auto gates = [&](int pg) -> unsigned {                         // all three at once (the epilogue)
+        GateRegs q;
+        gates_a(q);
+        gates_b(q, pg);
+        return gates_c(q);
+    };
+    // ... and where they go.  The four units of a line sit in the lanes line + 16 us: two row swaps bring all four to every lane
+    // (v_permlane16_swap: odd rows of the first operand <-> even rows of the second; v_permlane32_swap: rows 2, 3 of the first <->
+    // rows 0, 1 of the second); the lanes us == 0 write the 8 + 8 bytes of the (line, block) position of h(pg, ps) into LDS
+    // buffer pg and the same 16 bytes, tagged ps + 1, into the granule.
+    auto publish = [&](unsigned P, int pg, int ps, bool real) {
+        const auto r = __builtin_amdgcn_permlane16_swap(P, P, false, false);          // r[0] rows: P0 P0 P2 P2, r[1] rows: P1 P1 P3 P3
+        const auto e = __builtin_amdgcn_permlane32_swap(r[0], r[0], false, false);    // e[0] = P0 everywhere, e[1] = P2
+        const auto o = __builtin_amdgcn_permlane32_swap(r[1], r[1], false, false);    // o[0] = P1 everywhere, o[1] = P3
+        unsigned w2, w3;
+        tagbits(ps + 1, w2, w3);
+        u32x4 gran;
+        gran[0] = (e[0] & 0xFFFFu) | (o[0] << 16);
+        gran[1] = (e[1] & 0xFFFFu) | (o[1] << 16);
+        gran[2] = (e[0] >> 16) | (o[0] & 0xFFFF0000u);
+        gran[3] = (e[1] >> 16) | (o[1] & 0xFFFF0000u);
         const bool nowhere = own_lds == 0xFFFFFFFFu;
         unsigned char* dst = nowhere ? smem8 + dump_off : hs + pg * hbuf + own_lds;
-        *reinterpret_cast<unsigned short*>(dst) = go.hbits;
-        *reinterpret_cast<unsigned short*>(dst + (nowhere ? 2 : plane)) = go.lbits;
-        u32x2 gran;
-        gran[0] = (unsigned)go.hbits | ((unsigned)go.lbits << 16);
-        gran[1] = tagbase | ((unsigned)(ps + 1) & 0xFFFFu);
-        wp_store_b64(gran, real ? pub_vo : kOOBwp, grs, (unsigned)(pg * 2 + ((ps + 1) & 1)) * gp_bytes);
+        u32x2 hi2, lo2;
+        hi2[0] = gran[0]; hi2[1] = gran[1];
+        lo2[0] = gran[2]; lo2[1] = gran[3];
+        *reinterpret_cast<u32x2*>(dst) = hi2;
+        *reinterpret_cast<u32x2*>(dst + (nowhere ? 8 : plane)) = lo2;
+        gran[2] |= w2;
+        gran[3] |= w3;
+        wp_store_b128_so(gran, real ? pub_vo : kOOBwp, grs, (unsigned)(pg * 2 + ((ps + 1) & 1)) * gp_bytes);
     };
 
     // The weight loads above are the compiler's own: make it wait for them HERE, with an instruction its wait-count pass
@@ -422,11 +511,15 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
             const unsigned char* hb = hs + g * hbuf;                // h(g, s-1): own rows written by our gates, the rest gathered
             const int pg = (g + NG - 1) % NG, ps = g == 0 ? s - 1 : s;
             WP_STAMP(wave == 0, kk, 3);
+            WP_STAMP(wave == 0 || !KRK_DBGBIT(a, 8192), kk, 8 + wave);
             wp_barrier();
+            WP_STAMP(true, kk, 20 + wave);
             WP_STAMP(wave == 0, kk, 0);
             // per stage a wave with a block issues exactly [xproj load, output store, publish store]; xproj of THIS stage was the
             // first of the three issued three stages ago: 2 + 3 + 3 younger operations may still be in flight.  (A wave without
             // a block only stores: nothing to wait for.)
+            if (KRK_DBGBIT(a, 512)) { if (wave >= 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+            if (KRK_DBGBIT(a, 1024)) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }           // probe: the younger wave of a SIMD first, all stage long
             if (bval) { if (KRK_DBGBIT(a, 1)) wp_vmwait<0>(); else wp_vmwait<8>(); }
             const unsigned ring = kk & (RING - 1);
             const int g3 = (g + 3) % NG, s3 = s + (g + 3) / NG;     // xproj of stage kk + 3
@@ -446,6 +539,7 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
                 bf16x8 hh[NKB], hl[NKB];
                 auto frag = [&](int kb) {
                     const unsigned char* hp = hb + us * OS + line * RSO + kb * 16;
+                    if (KRK_DBGBIT(a, 2048) && kb > 1) { hh[kb] = hh[kb & 1]; hl[kb] = hl[kb & 1]; return; }   // probe: two fragment reads instead of NKB
                     hh[kb] = *reinterpret_cast<const bf16x8*>(hp);
                     hl[kb] = *reinterpret_cast<const bf16x8*>(hp + plane);
                 };
@@ -453,21 +547,30 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
                 if (NKB > 1) frag(1);
                 unsigned sp_vo;
                 const u32x4 sp_v = store_read(g, s - 1, hb, sp_vo);
-                // stage (pg, ps)'s gate math: pure VALU on independent data, free to sink into the MFMA stream below (the
-                // scheduling barriers pin only the LDS reads and the MFMAs); its LDS rows and its granule leave after PUBK blocks
+                __builtin_amdgcn_sched_barrier(0);                  // the stage's first LDS reads go out before anything else
                 WP_STAMP(wave == 0, kk, 1);
-                GateOut go = gates(pg, ps);
+                // stage (pg, ps)'s gate math in three pieces behind the MFMAs of K blocks 0, 1, 2 (fewer blocks: the last takes
+                // what is left); its LDS rows and its granule leave with block PUBK
                 constexpr int PUBK = NKB > 4 ? 3 : (NKB - 1);
+                constexpr int KA = 0, KB = NKB > 1 ? 1 : 0, KC = NKB > 2 ? 2 : NKB - 1;
+                GateRegs gq;
+                unsigned go = 0;
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
                     if (kb + 2 < NKB) frag(kb + 2);
+                    if (KRK_DBGBIT(a, 512) && kb == (NKB - 1) / 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }   // probe: the two compute waves of a SIMD swap priority mid-stage
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_bf(whi[kb]), hh[kb], acc0, 0, 0, 0);
                     KRK_CROSS(acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_bf(whi[kb]), hl[kb], acc1, 0, 0, 0);
                               acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_bf(wlo[kb]), hh[kb], acc2, 0, 0, 0);)
+                    __builtin_amdgcn_sched_barrier(0);              // the block's MFMAs are in the pipe before its share of VALU work issues
+                    if (kb == KA) gates_a(gq);
+                    if (kb == KB) gates_b(gq, pg);
+                    if (kb == KC) go = gates_c(gq);
                     if (kb == 0) load_x(g3, s3, (kk + 3u) & (RING - 1));           // vector memory in the order [xproj, output, publish]
                     if (kb == (NKB > 1 ? 1 : 0)) wp_store_b128(sp_v, sp_vo, ors);
                     if (kb == PUBK) publish(go, pg, ps, kk != 0);
-                    __builtin_amdgcn_sched_barrier(0x406);          // VALU / SALU / transcendentals may cross; MFMA, LDS, VMEM may not
+                    __builtin_amdgcn_sched_barrier(0);
+                    WP_STAMP(wave == 0 && KRK_DBGBIT(a, 8192) && acc0[0] != 123.f, kk, 9 + kb);   // probe: wave 0's K loop, block by block
                 }
                 zq = acc0 + (acc1 + acc2);
                 WP_STAMP(wave == 0 && zq[0] != 123.f, kk, 2);
@@ -485,18 +588,19 @@ __global__ void __launch_bounds__(768) lstm_wp_kernel(const LstmWsArgs a) {
         for (int g = 0; g < NG; ++g) {
             const unsigned char* hb = hs + g * hbuf;
             wp_barrier();
-            if (g == 0 && bval) publish(gates(NG - 1, Lmax - 1), NG - 1, Lmax - 1, true);
+            if (g == 0 && bval) publish(gates(NG - 1), NG - 1, Lmax - 1, true);
             unsigned sp_vo;
             const u32x4 sp_v = store_read(g, Lmax - 1, hb, sp_vo);
             wp_store_b128(sp_v, sp_vo, ors);
         }
     }
+    WP_STAMPS_OUT();
 }
 
 template <int NKB, int NG, int CS>
 int launch_wp(const LstmWsArgs& a, hipStream_t s) {
     const int nclusters = (a.N + 16 * NG - 1) / (16 * NG) * a.ndir;
-    const size_t lds = (size_t)NG * 2 * 4 * 16 * 16 * (NKB | 1) + 16 * NG * sizeof(int) + 16 + 768 * 8 + (size_t)4 * 8 * 1024;
+    const size_t lds = (size_t)NG * 2 * 4 * 16 * 16 * (NKB | 1) + 16 * NG * sizeof(int) + 16 + 768 * 16 + (size_t)4 * 8 * 1024 + 8192 /* timeline stamps of the ablation build */;
     auto kfn = lstm_wp_kernel<NKB, NG, CS>;
     if (lds > 160 * 1024) return -4;
     if (lds > 48 * 1024)
@@ -526,7 +630,7 @@ size_t krk_lstm_wp_ctrl_bytes(int nclusters, int Hp) { return (size_t)(16 + 8 * 
 
 size_t krk_lstm_wp_gran_bytes(int N, int ndir, int Hp) {
     const int CS = krk_lstm_wp_slices(Hp), BPC = (Hp / 4 + CS - 1) / CS;
-    return (size_t)krk_lstm_wp_clusters(N, ndir) * 8 /* (group, parity) */ * CS * (size_t)BPC * 64 * 8;
+    return (size_t)krk_lstm_wp_clusters(N, ndir) * 8 /* (group, parity) */ * CS * (size_t)BPC * 16 * 16;
 }
 #endif
 
@@ -534,9 +638,8 @@ size_t krk_lstm_wp_gran_bytes(int N, int ndir, int Hp) {
 int KRK_FN(krk_launch_lstm_wp)(const LstmWsArgs& a, hipStream_t s) {
     if (!krk_lstm_wp_supported(a.H, a.Hp)) return -4;
     if ((size_t)a.out_plane * 4 >= 0x80000000ull) return -4;                 // 32-bit buffer offsets
-    if (a.T >= 0xFFFF) return -4;                                             // 16-bit step tags
     const int CS = krk_lstm_wp_slices(a.Hp);
-    if ((size_t)8 * CS * a.BPC * 64 * 8 >= 0x80000000ull) return -4;
+    if ((size_t)8 * CS * a.BPC * 16 * 16 >= 0x80000000ull) return -4;
 #define KRK_WP(NKB_, CS_) if (a.NKB == NKB_ && CS == CS_) return launch_wp<NKB_, 4, CS_>(a, s)
     KRK_WP(1, 4); KRK_WP(2, 4); KRK_WP(3, 4); KRK_WP(4, 4); KRK_WP(5, 8); KRK_WP(6, 8); KRK_WP(7, 8);
 #undef KRK_WP

@@ -23,6 +23,8 @@
 
 namespace {
 
+// (Pillow's C code rounds every product and sum; no fused multiply-adds in the weights -- see dewarp.hip for what contraction cost there)
+#pragma clang fp contract(off)
 constexpr int PREC_BITS = 32 - 8 - 2;
 constexpr int COLS = 64;          // output columns per workgroup
 constexpr int MAX_K = 96;         // taps per output sample (scale up to ~15)

@@ -1173,15 +1173,14 @@ def test_one_channel_bbox_lines_are_dewarped_on_the_device_and_give_the_host_rec
         monkeypatch.setattr(R, 'DEVICE_DEWARP', False)
         host = list(R.mm_rpred(defaultdict(lambda: net), page, seg, bidi_reordering=False))
     assert sum(calls) == 60
-    # The network inputs are bit-identical (test above); the two runs batch the lines differently (input order vs width-sorted), and
-    # the f32 recurrent kernel picks its line-tile shape by batch size, so logits agree to ~1e-6, not bitwise: on this random-weight
-    # network a tie-sensitive step may flip in one or two lines.  Everything else must be equal.
-    # (a flipped frame inside a run of one label keeps the string and moves a cut: cuts count as part of the record)
-    same = [i for i, (a, b) in enumerate(zip(dev, host)) if a.prediction == b.prediction and list(a.cuts) == list(b.cuts)]
-    assert len(same) >= 56, [(i, a.prediction, b.prediction) for i, (a, b) in enumerate(zip(dev, host)) if a.prediction != b.prediction]
+    # The network inputs are bit-identical (test above) and a line's logits do not depend on the batch it travels in
+    # (tools/batch_invariance.py: 0.0 on every plan), so the records are the host path's, all of them.  (Round 3 shipped this test
+    # with "58 of 60": hipcc had contracted dewarp.hip's multiply-adds into FMAs, which moved a few columns' centre by a row.)
     assert dev[17].prediction == '' and host[17].prediction == '' and sum(bool(r.prediction) for r in dev) >= 55
-    for i in same:
-        np.testing.assert_allclose(dev[i].confidences, host[i].confidences, atol=1e-4)
+    for i, (a, b) in enumerate(zip(dev, host)):
+        assert a.prediction == b.prediction, i
+        assert list(a.cuts) == list(b.cuts), i
+        np.testing.assert_allclose(a.confidences, b.confidences, atol=1e-6)
 
 
 def test_rpred_device_preparation_equals_host_preparation(monkeypatch):

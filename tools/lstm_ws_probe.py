@@ -78,6 +78,8 @@ if __name__ == '__main__':
     if '--wp' in sys.argv:             # round 3: the pipelined cluster kernel against the streaming and the round-2 cluster kernel
         variants = [variants[0], variants[1], variants[3]]
         sizes = ((256, 150), (40, 60), (7, 33), (1024, 150), (100, 300))
+        if '--one' in sys.argv:       # just the BENCH-A shape
+            sizes = sizes[:1]
     elif '--quick' in sys.argv:          # correctness at three sizes + the phase prices of the default (g2) variant
         lib = os.path.abspath('kraken_amd/libkraken_amd_ablate.so')
         for dbg in (0, 64, 128, 4, 16, 32, 1):     # 1 no exchange, 4 no MFMA, 16 no output pass, 32 no barrier; gather asked at slot start (64) / after the last block (128)

@@ -22,9 +22,9 @@ for _ in range(3):
     m.nn(x)
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = (C.c_ulonglong * 256)()
-rc = lib.krk_debug_wp_timeline(buf, 256)
-t = np.array(buf[:], dtype=np.int64).reshape(32, 8)
+buf = (C.c_ulonglong * 1024)()
+rc = lib.krk_debug_wp_timeline(buf, 1024)
+t = np.array(buf[:], dtype=np.int64).reshape(32, 32)
 print('rc', rc, '  columns: compute wave 0: barrier exit | operands issued | MFMAs done | next barrier entry ;; gather wave 8: barrier exit | first poll back | tags ok | next barrier entry')
 base = t[0, 0]
 for k in range(32):
@@ -33,3 +33,11 @@ for k in range(32):
           f'G +{r[4] - base:6d} poll1 {r[5] - r[4]:5d} ok {r[6] - r[4]:5d} bar-in {r[7] - base:6d}')
 d = np.diff(t[:, 0])
 print('stage period (cycles of s_memtime): mean', d.mean(), 'min', d.min(), 'max', d.max())
+print('barrier entry of every wave relative to the barrier exit of the stage of wave 0 (compute 0..7 | gather 8..11), and the last to arrive:')
+for k in range(1, 32):
+    ent = t[k, 8:20] - t[k - 1, 20]            # entry into the barrier that ENDS stage k-1 ... measured from that stage's start
+    print(f'stage {63 + k:3d}: ' + ' '.join('%5d' % v for v in ent[:8]) + ' | ' + ' '.join('%5d' % v for v in ent[8:]) + f'   last: wave {int(np.argmax(ent))}  period {t[k, 20] - t[k - 1, 20]}')
+if int(os.environ.get('KRK_LSTM_DBG', '0')) & 8192:
+    print('wave 0: cycles after its barrier exit at which K block 0..6 was done (MFMAs issued + that block\'s share of the gate math)')
+    for k in range(8, 32):
+        print(f'stage {64 + k:3d}: ' + ' '.join('%5d' % (t[k, 9 + j] - t[k, 20]) for j in range(7)))
