@@ -1094,18 +1094,21 @@ def test_device_dewarp_is_bit_exact_against_the_reference_transform():
     """
     krk_dewarp_measure + krk_dewarp_apply (CenterNormalizer dewarp of 1-channel bbox lines, kraken/lib/lineest.py:26-87 through
     scipy.ndimage) == ImageInputTransforms(valid_norm=True) on the host: the reference-made fixtures of transforms.npz and 40
-    synthetic lines of heights 20..120, bit for bit (the centre line is an argmax + truncation: anything but the same fp64
+    synthetic lines of heights 20..120 plus 120 more of heights 16..140, bit for bit (the centre line is an argmax + truncation: anything but the same fp64
     operations in the same order would move whole columns by a pixel).
     """
     from kraken_amd.engine import RecognitionEngine
     from kraken_amd.transforms import ImageInputTransforms
     z = load_golden('transforms.npz')
     cases = json.loads(str(z['cases']))
-    rng = np.random.RandomState(5)
+    rng, rng9 = np.random.RandomState(5), np.random.RandomState(9)
     for target, pad, crops, want in (
             (48, 16, [z[f'im{i}'] for i, c in enumerate(cases) if c['valid_norm'] and c['height'] == 48 and c['pad'] == 16 and c.get('channels', 1) == 1], None),
             (30, 16, [z['im3']], [z['out3']]),
-            (48, 16, [_wavy_line(rng, int(rng.randint(20, 121)), int(rng.randint(40, 900))) for _ in range(40)] + [np.full((33, 100), 255, np.uint8)], None)):
+            (48, 16, [_wavy_line(rng, int(rng.randint(20, 121)), int(rng.randint(40, 900))) for _ in range(40)] + [np.full((33, 100), 255, np.uint8)], None),
+            # round 3: fused multiply-adds (hipcc's default contraction) moved a few columns' centre on lines 3, 22, 50, 53 of this set
+            (48, 16, [_wavy_line(rng9, int(rng9.randint(30, 90)), int(rng9.randint(200, 1000))) for _ in range(60)], None),
+            (36, 8, [_wavy_line(rng9, int(rng9.randint(16, 140)), int(rng9.randint(60, 1400))) for _ in range(60)], None)):
         m = build_model(f'[1,{target},0,1 Cr3,13,32 Mp2,2 Cr3,13,32 S1(1x0)1,3 Lbx16 O1c9]', seed=0).to('cuda')
         m.nn.set_precision('bf16x3')
         eng = RecognitionEngine(m, device=0, max_batch=64, max_width=512, slots=1)
@@ -1123,7 +1126,7 @@ def test_device_dewarp_is_bit_exact_against_the_reference_transform():
         r, ok, ink = eng.measure_dewarp(crops)
         assert ink.tolist() == [bool(a.max() != a.min()) for a in crops]
         use = ok & ink
-        assert use.sum() >= len(crops) - 3                       # the device takes (almost) every line
+        assert use.sum() >= len(crops) - max(3, len(crops) // 10)       # the device takes (almost) every line
         ticket = eng.submit_dewarped(r, use, pad)
         slot = eng.slots[ticket]
         slot.stream.synchronize()
