@@ -65,7 +65,7 @@ template <bool VEC>   // VEC: W % 4 == 0, rows are 16-byte aligned
 __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, const int* __restrict__ lens,
                                                        double* __restrict__ part, const GnGeom p) {
     __shared__ double red[2][4];
-    const int ng = blockIdx.y, n = ng / p.G, g = ng - n * p.G, ch = blockIdx.x;
+    const int ng = blockIdx.x, n = ng / p.G, g = ng - n * p.G, ch = blockIdx.y;   // (line, group) in x: N * G may exceed the 65535 of y
     const int Cg = p.C / p.G, rows = Cg * p.H;
     int L = lens ? lens[n] : p.W;
     L = min(max(L, 1), p.W);   // the reference clamps to [1, W] (layers.py:982)
@@ -126,7 +126,7 @@ template <bool VEC>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const int* __restrict__ lens, const double* __restrict__ part, const GnGeom p) {
-    const int ng = blockIdx.y, n = ng / p.G, g = ng - n * p.G, ch = blockIdx.x;
+    const int ng = blockIdx.x, n = ng / p.G, g = ng - n * p.G, ch = blockIdx.y;   // (line, group) in x: N * G may exceed the 65535 of y
     const int Cg = p.C / p.G, rows = Cg * p.H;
     int L = lens ? lens[n] : p.W;
     L = min(max(L, 1), p.W);
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) gn_apply_pool_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const int* __restrict__ lens, const int* __restrict__ len_out,
                                                             const double* __restrict__ part, const GnGeom p) {
-    const int ng = blockIdx.y, n = ng / p.G, g = ng - n * p.G, ch = blockIdx.x;
+    const int ng = blockIdx.x, n = ng / p.G, g = ng - n * p.G, ch = blockIdx.y;   // (line, group) in x: N * G may exceed the 65535 of y
     const int Cg = p.C / p.G;
     int L = lens ? lens[n] : p.W;
     L = min(max(L, 1), p.W);
@@ -534,7 +534,7 @@ int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const flo
     p.eps = eps;
     p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.Ho = Ho; p.Wo = Wo;
     p.chunks = krk_groupnorm_chunks(N, C, H, W, G, kh ? Ho : 0);
-    const dim3 grid(p.chunks, N * G);
+    const dim3 grid((unsigned)N * G, p.chunks);
     const bool vec = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
     if (vec) hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(256), 0, s, x, lens, scratch, p);
     else hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(256), 0, s, x, lens, scratch, p);

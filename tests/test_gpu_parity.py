@@ -840,6 +840,16 @@ def test_groupnorm_takes_the_following_pool_in_its_apply_pass(spec, shape, lens,
         assert (got.cpu()[i, ..., :L] - want[i, ..., :L]).abs().max().item() < 2e-5
 
 
+def test_groupnorm_with_more_than_65535_line_groups():
+    """2100 lines x 32 groups = 67 200 (line, group) pairs: they index the grid's x dimension (y and z end at 65 535)."""
+    m = build_model('[1,8,0,1 Cr3,3,32 Gn32 Mp2,2 S1(1x0)1,3 Lbx8 O1c5]', seed=3)
+    x = synth_input(2100, 24, h=8, seed=8)
+    want, _ = CpuRecognizer(m.layer_specs, m.state_dict()).forward(x[-3:])
+    m.to('cuda')
+    got, _ = m.nn(x.cuda())
+    assert (got.cpu()[-3:] - want).abs().max().item() < LOGIT_TOL
+
+
 def test_blla_segmenter_forward_matches_oracle():
     """BASELINE.json config 5 at reduced size: the reference's default BLLA spec (+ 4-class heatmap head) on a
     (1, 3, 360, 270) page; the full 1800 x 1350 page is timed and checked by tools/blla_forward.py."""

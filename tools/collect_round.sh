@@ -30,5 +30,7 @@ python bench.py --mode api --no-cpu-baseline > $O/${TAG}_bench_api.json 2>/dev/n
 (timeout 200 python tools/lstm_ws_probe.py --wp 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lstm_probe.txt)
 (timeout 150 python tools/ws_flake.py 100 2>&1 | grep -v amdgpu.ids > $O/${TAG}_exchange_timeouts_default.txt)
 (KRK_LSTM_V=3 timeout 150 python tools/ws_flake.py 60 2 2>&1 | grep -v amdgpu.ids > $O/${TAG}_exchange_timeouts_lstm_ws_forced.txt)
-(timeout 200 python tools/fuzz_plans.py ${FUZZ:-120} --time-seed 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz.txt)
+(timeout 60 python tools/batch_invariance.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_batch_invariance.txt)
+(KRK_LSTM_V=4 timeout 60 python tools/wp_timeline.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lstm_wp_timeline.txt)
+(timeout 200 python tools/fuzz_plans.py ${FUZZ:-100} --time-seed 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz.txt)
 for f in $O/${TAG}_*bench*.json; do echo $(basename $f) $(tail -1 $f | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['unit'], d.get('steps'))" 2>&1 | tail -1); done
