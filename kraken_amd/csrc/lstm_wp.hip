@@ -12,7 +12,7 @@
 //     are issued INSIDE the MFMA stream of stage k+1 (another group: independent data), one MFMA : ~2 VALU, so the VALU work
 //     runs in the shadow of the matrix pipe instead of after it.  NG = 4 groups per cluster: h(g, s) leaves in the first half
 //     of stage k+1 and is needed by stage k+4;
-//   * THE EXCHANGE HAS ITS OWN WAVES.  vmcnt retires in order: a wave that publishes (sc1 store, ~1 us to be acknowledged)
+//   * THE EXCHANGE HAS ITS OWN WAVES.  vmcnt retires in order: a wave that publishes (a store, ~1 us to be acknowledged)
 //     and streams xproj from HBM cannot also wait for gather loads without waiting for those.  Waves 8..11 do nothing but
 //     gather: poll the peers' granules of the group the NEXT stage consumes until every tag matches, drop the payloads into
 //     the LDS rows, arrive at the stage barrier.  No optimistic path, no flags, no slow path in the compute waves; a late
@@ -20,12 +20,14 @@
 //     LDS (global_load_lds) THREE stages ahead and is waited for with a fixed count (every stage issues exactly
 //     xproj load, output store, publish store);
 //   * CS = 8 SLICES, ONE BLOCK PER WAVE.  A wave owns one block of 16 gate columns (all four gates of four units): 56 weight
-//     registers, 21 MFMAs per stage, so a stage is ~0.45 us instead of 1.5 and a time step of a cluster's four groups ~1.8 us
-//     instead of 3.1 on the same number of CUs (N = 256: 8 clusters x 8 CUs).  (H <= 128: CS = 4.)
-// Everything else follows lstm_ws.hip: cluster membership claimed at run time (ticket = atomicAdd, so a partially resident
-// grid cannot deadlock), bounded spins that raise the plan's status word, h in LDS as [plane][K octet][line][K block]
-// (conflict-free fragment reads), granules {(hi, lo) bf16, tag = launch epoch | step + 1} written with one sc1 store, two
-// parity buffers per group, the output pass from the gathered rows (tile-time-major or line-major).
+//     registers, 21 MFMAs per stage (N = 256: 8 clusters x 8 CUs; H <= 128: CS = 4).  The plan was a stage of ~0.45 us against
+//     the 1.5 of lstm_ws.hip's two-block slot; measured: 0.78 us -- half the work in half the time, the same chip time.
+// Cluster membership is claimed at run time, per XCD (see the claim below: a partially resident grid cannot deadlock), spins are
+// bounded and raise the plan's status word, h lives in LDS as [plane][K octet][line][K block] (conflict-free fragment reads), ONE
+// buffer per group; granules are 16 bytes of payload with a 4-bit step tag in the lo parts' lowest mantissa bits, written with one
+// plain store into a buffer the host zeroes before every launch, two parity slots per group; the output pass (tile-time-major or
+// line-major rows) reads the gathered rows.  What the round-3 measurements say about this design -- it equals lstm_ws.hip, it does
+// not beat it -- is in DESIGN.md 3.3 and profiles/r03_lstm_wp_gather_variants.txt.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
