@@ -54,3 +54,15 @@ def build_model(spec, sd=None, codec=None, seed=None):
         missing, unexpected = m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()}, strict=False)
         assert not missing and not unexpected, (missing, unexpected)
     return m
+
+
+def wavy_line(rng, h, w):
+    """Dark strokes on a light page around a wandering centre line (the generator of tests/golden/make_golden.py:transforms_fixture)."""
+    arr = np.full((h, w), 255, np.uint8)
+    yc = (h / 2 + 0.15 * h * np.sin(np.arange(w) / rng.uniform(20.0, 60.0))).astype(int)
+    for x in range(0, w, 3):
+        if rng.rand() < 0.6:
+            lo = max(yc[x] - rng.randint(2, max(h // 3, 3)), 0)
+            hi = min(yc[x] + rng.randint(2, max(h // 3, 3)), h)
+            arr[lo:hi, x:x + 2] = rng.randint(0, 90)
+    return arr

@@ -15,7 +15,7 @@ import torch
 
 from oracle import np_oracle
 from oracle.torch_port import CpuRecognizer
-from tests.helpers import arr_to_tuples, build_model, layer_cases, load_golden, synth_input
+from tests.helpers import arr_to_tuples, build_model, layer_cases, load_golden, synth_input, wavy_line as _wavy_line
 from tests.specs import BENCH_A, BENCH_B, bench_codec
 
 pytestmark = pytest.mark.gpu
@@ -1086,18 +1086,6 @@ def test_host_cut_line_images_are_prepared_on_the_device_and_give_the_host_recor
     assert [list(r.cuts) for r in dev_recs] == [list(r.cuts) for r in host_recs]
     for a, b in zip(dev_recs, host_recs):
         np.testing.assert_allclose(a.confidences, b.confidences, atol=1e-6)
-
-
-def _wavy_line(rng, h, w):
-    """Dark strokes on a light page around a wandering centre line (the generator of tests/golden/make_golden.py:transforms_fixture)."""
-    arr = np.full((h, w), 255, np.uint8)
-    yc = (h / 2 + 0.15 * h * np.sin(np.arange(w) / rng.uniform(20.0, 60.0))).astype(int)
-    for x in range(0, w, 3):
-        if rng.rand() < 0.6:
-            lo = max(yc[x] - rng.randint(2, max(h // 3, 3)), 0)
-            hi = min(yc[x] + rng.randint(2, max(h // 3, 3)), h)
-            arr[lo:hi, x:x + 2] = rng.randint(0, 90)
-    return arr
 
 
 def test_device_dewarp_is_bit_exact_against_the_reference_transform():

@@ -209,6 +209,14 @@ def test_dewarp_restatement_is_bit_exact_against_scipy_and_the_reference_fixture
             if rng.random() < 0.7:
                 arr[max(yc[x] - rng.integers(1, max(h // 3, 2)), 0):min(yc[x] + rng.integers(1, max(h // 3, 2)), h), x:x + 2] = rng.integers(0, 120)
         assert np.array_equal(center_normalize_np(arr, 48), center_normalize(arr, 48))
+    # the 60 lines of the GPU record test (tests/test_gpu_parity.py): lines 3, 22, 50, 53 of this set are the ones on which a device
+    # build with fused multiply-adds moved a few columns' centre by a row -- the restatement itself is scipy's on all of them
+    from tests.helpers import wavy_line as _wavy_line
+    rs = np.random.RandomState(9)
+    for i in range(60):
+        h, w = int(rs.randint(30, 90)), int(rs.randint(200, 1000))
+        arr = _wavy_line(rs, h, w).astype(np.float64)
+        assert np.array_equal(center_normalize_np(arr, 48), center_normalize(arr, 48)), i
     # the weight tables the device receives are the restatement's (= scipy's _gaussian_kernel1d)
     tab, index = dewarp_tables([37, 60])
     off, r0, r1, r2 = index[60]

@@ -11,7 +11,7 @@ from PIL import Image  # noqa: E402
 from kraken_amd.transforms import ImageInputTransforms  # noqa: E402
 from tests.helpers import build_model  # noqa: E402
 from tests.specs import BENCH_A, bench_codec  # noqa: E402
-from tests.test_gpu_parity import _wavy_line  # noqa: E402
+from tests.helpers import wavy_line as _wavy_line  # noqa: E402
 
 rng = np.random.RandomState(9)
 ts = ImageInputTransforms(1, 48, 0, 1, (16, 0), valid_norm=True)

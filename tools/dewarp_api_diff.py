@@ -9,7 +9,7 @@ from kraken_amd.containers import BBoxLine, Segmentation
 from kraken_amd.models import TorchSeqRecognizer
 from tests.helpers import build_model
 from tests.specs import BENCH_A, bench_codec
-from tests.test_gpu_parity import _wavy_line
+from tests.helpers import wavy_line as _wavy_line
 
 m = build_model(BENCH_A, codec=bench_codec(), seed=0)
 m.seg_type, m.model_type = 'bbox', ['recognition']

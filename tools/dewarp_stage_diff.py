@@ -6,7 +6,7 @@ from kraken_amd.engine import RecognitionEngine
 from oracle import np_oracle as O
 from tests.helpers import build_model
 from tests.specs import BENCH_A, bench_codec
-from tests.test_gpu_parity import _wavy_line
+from tests.helpers import wavy_line as _wavy_line
 
 rng = np.random.RandomState(9)
 crops = []
