@@ -67,6 +67,10 @@ def parse():
     ap.add_argument('--stub-engine', action='store_true',
                     help='TEST ONLY (tests/test_dist_cpu.py): replace the device engine by a host stub and RCCL by gloo, to run the '
                          'launcher / sharding / gather plumbing on a box without GPUs; the JSON line says so and its value is meaningless')
+    ap.add_argument('--share-device', action='store_true',
+                    help='PLUMBING ONLY: all --gpus N ranks run on HIP device 0 (gloo collective: RCCL refuses two ranks per device). Two real '
+                         'processes, two real engines, ShardedRecognizer.stream + gather, recognize_lines in input order -- on a one-GPU box. '
+                         'The line is labelled as such and is NEVER a scaling number')
     ap.add_argument('--api-lines', type=int, default=2048, help='--mode api: bbox lines on the synthetic page')
     ap.add_argument('--api-workers', type=int, default=6, help='--mode api: host threads preparing lines (PIL conversions hold the GIL: more than ~6 threads only contend, 16 cost 40 %)')
     return ap.parse_args()
@@ -451,6 +455,32 @@ def mode_config4(args, model, local_rank):
                                        f'padding / scaling / inversion on the device, {R.ENGINE_SLOTS} batches in flight)'}}
 
 
+def share_device_product_check(model, rank, world):
+    """
+    --share-device: the product call on the same box.  `ShardedRecognizer.recognize_lines` over a ragged set of lines (every rank
+    holds the same list) must return one result per line in INPUT order on every rank, identical to what a single unsharded
+    engine returns for the same lines.
+    """
+    from kraken_amd import dist as kdist
+    g = torch.Generator().manual_seed(99)
+    widths = torch.randint(200, 1201, (97,), generator=g).tolist()
+    lines = [torch.rand(1, 48, w, generator=g) for w in widths]
+    sr = kdist.ShardedRecognizer(model, device=0, batch=32, slots=2, max_width=1200)
+    got = sr.recognize_lines(lines)
+    sr.close()
+    # the unsharded answer: the same call in a one-rank group (every rank computes it for itself)
+    groups = [torch.distributed.new_group([r]) for r in range(world)]       # collective: every rank creates every group
+    solo = kdist.ShardedRecognizer(model, device=0, batch=32, slots=2, max_width=1200, group=groups[rank])
+    want = solo.recognize_lines(lines)
+    solo.close()
+    same = [a.text == b.text and list(a.starts) == list(b.starts) and list(a.ends) == list(b.ends) and a.out_width == b.out_width
+            for a, b in zip(got, want)]
+    ok = torch.tensor([int(all(same) and len(got) == len(lines))])
+    torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+    return {'lines': len(lines), 'ranks': world, 'results_in_input_order_and_identical_to_one_rank': bool(ok.item()),
+            'nonempty': sum(bool(r.text) for r in got)}
+
+
 def launch_ranks(args) -> int:
     """
     `python bench.py --gpus N` without a launcher: become the launcher.  Spawns N copies of this command, one rank per GPU
@@ -463,7 +493,8 @@ def launch_ranks(args) -> int:
     if not args.stub_engine:
         from kraken_amd import _lib
         have = _lib.device_count()
-        if have < n:
+        need = 1 if args.share_device else n
+        if have < need:
             print(f'bench.py: --gpus {n} but only {have} HIP device(s) visible; refusing to run', file=sys.stderr)
             return 3
     with socket.socket() as sk:
@@ -488,6 +519,23 @@ def launch_ranks(args) -> int:
     return rc
 
 
+def pin_rank_to_cpus(local_rank: int, local_world: int) -> int:
+    """
+    One rank per GPU must not mean N ranks x (intra-op threads + worker pools) on every core: rank r keeps the r-th contiguous
+    block of the CPUs this process may run on (`os.sched_setaffinity`) and caps torch's intra-op threads to it.  Returns the
+    number of CPUs the rank keeps.
+    """
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // max(1, local_world))
+        mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+        os.sched_setaffinity(0, mine)
+    except (AttributeError, OSError):
+        mine = list(range(os.cpu_count() or 1))
+    torch.set_num_threads(max(1, min(8, len(mine))))
+    return len(mine)
+
+
 def main():
     args = parse()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -497,6 +545,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.share_device and (args.mode != 'engine' or args.stub_engine):
+        raise SystemExit('--share-device is a plumbing run of the default mode on a real device')
+    cpus_kept = pin_rank_to_cpus(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1 else (os.cpu_count() or 1)
+    if args.share_device:
+        local_rank = 0                      # every rank on HIP device 0
     import kraken_amd
     from kraken_amd import _lib, dist as kdist
     from kraken_amd.specs import BENCH_A, bench_codec
@@ -511,7 +564,7 @@ def main():
         torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        kdist.init(backend='gloo' if stub else 'nccl')
+        kdist.init(backend='gloo' if (stub or args.share_device) else 'nccl')
 
     torch.manual_seed(0)
     model = kraken_amd.TorchVGSLModel(vgsl=BENCH_A, codec=bench_codec())
@@ -526,6 +579,16 @@ def main():
         out = mode_engine(args, model, rank, world, local_rank, use_dist, kdist)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'engine' and not stub:
         out['cpu_baseline'] = cpu_baseline(model, args.width, args.cpu_lines)
+    if world > 1:
+        out['host_cpus_per_rank'] = cpus_kept
+    if args.share_device:
+        out['recognize_lines_check'] = share_device_product_check(model, rank, world)
+        out['n_gpus'] = 1
+        out['ranks_on_one_device'] = world
+        out['metric'] = 'PLUMBING RUN, NOT A SCALING NUMBER -- ' + out['metric']
+        out['data'] += f'; {world} ranks (processes) share HIP device 0, gloo collective: what this line shows is that two real engines, ' \
+                       'ShardedRecognizer.stream + gather and recognize_lines work across processes on hardware; its value says nothing about scaling'
+        out['scaling'] = 'none (one device)'
     if use_dist:
         torch.distributed.destroy_process_group()
     if rank == 0:

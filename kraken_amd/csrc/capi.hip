@@ -15,6 +15,16 @@
 #include <string>
 #include <vector>
 
+// phase cycle counters of the instrumented kernels (common.h KRK_PHASES): which = 0 conv_x3p, 1 gemm_x3w; returns the count
+int krk_phase_stats_x3p(unsigned long long* out, int reset);
+int krk_phase_stats_x3w(unsigned long long* out, int reset);
+#ifdef KRK_ABLATE
+extern "C" int krk_debug_phase_stats(int which, unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return which == 0 ? krk_phase_stats_x3p(out, reset) : krk_phase_stats_x3w(out, reset);
+}
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -97,8 +107,11 @@ struct ConvGeom {
     bool x3 = false;          // run on the bf16 matrix cores with split operands
     bool split_out = false;   // write the output as split channels-last bf16 planes
     int xchunk = 16, xnchunks = 1, xKB = 1, xKB_last = 1, xPSTR = 48, xplane = 0;
+    int xtps = 0;             // > 0: the pipelined kernel (conv_x3p.hip) covers this geometry: tile copies per weight-stage boundary
     void* d_wx3 = nullptr;
     void* d_wx5 = nullptr;    // conv_taps_x3.hip, five-group packing (kw <= 13)
+    void* d_wx3w = nullptr;   // gemm_x3w.hip: the same weights in column groups of wtn (256 | 320) for the wide-tile kernel
+    int wtn = 0;
     bool c1x3 = false;        // one-channel first convolution on the bf16 cores (conv1_x3.hip); weights in d_wx3
     bool taps = false;        // wide-kernel convolution with taps as K (conv_taps_x3.hip); reads NHCW planes
     bool out_nhcw = false;    // conv1_x3 writes [N][H][C][pitch] planes for a following taps convolution
@@ -231,6 +244,19 @@ int plan_x3_geom(ConvGeom& g) {
     g.xKB_last = (g.Cin - (g.xnchunks - 1) * g.xchunk) / 16;
     g.xPSTR = g.xchunk * 2 + 16;
     g.xplane = npix * g.xPSTR;
+    // conv_x3p.hip (asynchronous double-buffered staging) works on 16-channel chunks: where it covers the geometry the chunking
+    // is its own -- conv_x3.hip runs the same plan (same weights) when the probe switch KRK_CONV_X3P=0 asks for it
+    if (!getenv("KRK_NO_CONV_X3P")) {
+        const int tps = krk_conv_x3p_tps(16, 1, 1, npix, g.IW, g.kh * g.kw, g.Cout, 0);
+        if (tps > 0) {
+            g.xtps = tps;
+            g.xchunk = 16;
+            g.xnchunks = g.Cin / 16;
+            g.xKB = g.xKB_last = 1;
+            g.xPSTR = 48;
+            g.xplane = npix * g.xPSTR;
+        }
+    }
     return KRK_OK;
 }
 
@@ -343,15 +369,15 @@ int upload_conv_taps_weights(ConvGeom& g, const float* w) {
     return KRK_OK;
 }
 
-// gemm_x3.hip weight order: [column group of 128][K/16][plane][k-half][column][8] (bf16); `w` is (rows, K) f32.
-int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
-    if (g.Cin % 16) return fail(KRK_E_UNSUPPORTED, "bf16x3: input features must be a multiple of 16");
-    const int ncg = (g.Cout + 127) / 128, nkb = g.Cin / 16;
-    std::vector<uint16_t> pack((size_t)ncg * nkb * 4096, 0);
+// gemm_x3.hip / gemm_x3w.hip weight order: [column group of tn][K/16][plane][k-half][column][8] (bf16); `w` is (rows, K) f32.
+int pack_gemm_x3_weights(const ConvGeom& g, const float* w, const std::vector<int>* rowmap, int tn, void** dst) {
+    const int ncg = (g.Cout + tn - 1) / tn, nkb = g.Cin / 16;
+    const size_t rec = (size_t)32 * tn;            // elements per (column group, K step): 2 planes x 2 k-halves x tn x 8
+    std::vector<uint16_t> pack((size_t)ncg * nkb * rec, 0);
     for (int cg = 0; cg < ncg; ++cg)
         for (int kb = 0; kb < nkb; ++kb)
-            for (int col = 0; col < 128; ++col) {
-                const int co = cg * 128 + col;
+            for (int col = 0; col < tn; ++col) {
+                const int co = cg * tn + col;
                 if (co >= g.Cout) continue;
                 int src = co;
                 if (rowmap) {
@@ -362,13 +388,25 @@ int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* 
                     for (int e = 0; e < 8; ++e) {
                         const float v = w[(size_t)src * g.Cin + kb * 16 + h * 8 + e];
                         const uint16_t hi = f2bf(v);
-                        const size_t base = ((size_t)cg * nkb + kb) * 4096 + ((size_t)h * 128 + col) * 8 + e;
+                        const size_t base = ((size_t)cg * nkb + kb) * rec + ((size_t)h * tn + col) * 8 + e;
                         pack[base] = hi;
-                        pack[base + 2048] = f2bf(v - bf2f(hi));
+                        pack[base + rec / 2] = f2bf(v - bf2f(hi));
                     }
             }
-    HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
-    HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(dst, pack.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(*dst, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
+int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
+    if (g.Cin % 16) return fail(KRK_E_UNSUPPORTED, "bf16x3: input features must be a multiple of 16");
+    if (int rc = pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3)) return rc;
+    // wide outputs (the LSTM input projections) also get the wide-tile kernel's order; which kernel runs is decided per call
+    // by the number of rows (Pass::projection)
+    if (g.Cout >= 512 && !getenv("KRK_NO_GEMM_W")) {
+        g.wtn = krk_gemm_x3w_tn(g.Cout);
+        if (int rc = pack_gemm_x3_weights(g, w, rowmap, g.wtn, &g.d_wx3w)) return rc;
+    }
     return KRK_OK;
 }
 
@@ -571,6 +609,7 @@ void free_step(Step& s) {
     if (s.cg.d_b) (void)hipFree(s.cg.d_b);
     if (s.cg.d_wx3) (void)hipFree(s.cg.d_wx3);
     if (s.cg.d_wx5) (void)hipFree(s.cg.d_wx5);
+    if (s.cg.d_wx3w) (void)hipFree(s.cg.d_wx3w);
     if (s.d_wrecsm) (void)hipFree(s.d_wrecsm);
     if (s.d_gamma) (void)hipFree(s.d_gamma);
     if (s.d_beta) (void)hipFree(s.d_beta);
@@ -1192,6 +1231,7 @@ void fill_x3(const ConvGeom& g, X3Args& a, const void* xin, size_t x_plane, void
     a.tiles_w = (a.Wo + g.TW - 1) / g.TW;
     a.y_plane = 0; a.y_sn = a.y_sr = a.y_sc = 0; a.y_blkM = 0; a.y_cols = 0; a.y_f32 = 0;
     a.dbg = dbg;
+    a.tps = 0;
 }
 
 void fill_gemm(const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane, float* yout, int rows, int dbg) {
@@ -1203,6 +1243,8 @@ void fill_gemm(const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane
     a.tileT = 0;
     a.nlines = 0;
     a.dbg = dbg;
+    a.stagger = 0;
+    a.nbuf = 3;
 }
 
 // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
@@ -1219,6 +1261,10 @@ struct Probes {
     int lstm_v = env_int("KRK_LSTM_V", 0);       // 0: by hidden size (see recurrence_x3); 3: cluster kernel lstm_ws.hip; 4: pipelined XCD-local kernel lstm_wp.hip; 1: streaming kernel
     int lstm_g = env_int("KRK_LSTM_G", 2);       // 4: four 16-line groups per cluster
     int lstm_m = env_int("KRK_LSTM_M");          // f32 plan: force 16- or 32-line tiles
+    int gemm_w = env_int("KRK_GEMM_W", -1);      // wide-tile projection kernel: 0 never, 1 always (where packed), -1 by size
+    int gemm_nbuf = env_int("KRK_GEMM_NBUF", 3); // wide-tile projection kernel: LDS buffers (3 | 4)
+    int gemm_stag = env_int("KRK_GEMM_STAG", 0); // wide-tile projection kernel: start delay (cycles) per workgroup phase
+    int conv_x3p = env_int("KRK_CONV_X3P", 1);   // 0: conv_x3.hip also where the pipelined kernel (conv_x3p.hip) covers the geometry
 };
 
 constexpr int kFailed = -100;     // a step hit a hard error: the KRK_E_* code is in Pass::err, the message in g_err
@@ -1258,6 +1304,7 @@ struct Pass {
     int conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win);
     int layout(Step& s, const float* cur, float* outp, size_t out_elems, int Win, int Wout);
     int split_input(Step& s, const float* cur, size_t in_elems, const void** xin);
+    int projection(const ConvGeom& g, GemmX3Args& a);
     int linear(Step& s, const float* cur, float* outp, int Win);
     int lstm(Step& s, const float* cur, float* outp, size_t out_elems, int Win);
     int recurrence_x3(Step& s, float* outp, size_t out_elems, int N, int T, int G);
@@ -1339,6 +1386,10 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         }
         s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
         if (mark("conv_x3", s.flops)) return kFailed;
+        if (g.xtps > 0 && probe.conv_x3p && (size_t)g.H * Win * g.Cin * 2 < 0x7fffffffull) {
+            a.tps = g.xtps;
+            return one ? krk_launch_conv_x3p_b1(a, g.pool, stream) : krk_launch_conv_x3p(a, g.pool, stream);
+        }
         return one ? krk_launch_conv_x3_b1(a, false, g.pool, stream) : krk_launch_conv_x3(a, false, g.pool, stream);
     }
     if (g.c1x3) {
@@ -1424,6 +1475,22 @@ int Pass::split_input(Step& s, const float* cur, size_t in_elems, const void** x
     return 0;
 }
 
+// split-bf16 row projection: the wide-tile kernel (gemm_x3w.hip) when its 256 x wtn tiles fill the chip, else gemm_x3.hip
+int Pass::projection(const ConvGeom& g, GemmX3Args& a) {
+    const int gw = probe.gemm_w;                 // KRK_GEMM_W: 0 never, 1 whenever the weights are packed for it, -1 (default) by size
+    if (g.d_wx3w && gw != 0) {
+        const int ncg = (g.Cout + g.wtn - 1) / g.wtn;
+        if (gw > 0 || (long)a.ntiles * ncg >= 256) {
+            a.w = (const __bf16*)g.d_wx3w;
+            a.ncg = ncg;
+            a.stagger = probe.gemm_stag;
+            a.nbuf = probe.gemm_nbuf;
+            return one ? krk_launch_gemm_x3w_b1(a, g.wtn, stream) : krk_launch_gemm_x3w(a, g.wtn, stream);
+        }
+    }
+    return one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
+}
+
 // LinSoftmax's projection (logits; the softmax belongs to the decode)
 int Pass::linear(Step& s, const float* cur, float* outp, int Win) {
     s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
@@ -1436,7 +1503,7 @@ int Pass::linear(Step& s, const float* cur, float* outp, int Win) {
         fill_gemm(s.cg, a, xin, in_elems, outp, Nr * Win, probe.x3_dbg);
         if (s.in_tiled) { a.tileT = -Win; a.nlines = N; }          // back to line-major rows for the decode
         if (mark("linear_x3", s.flops)) return kFailed;
-        return one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
+        return projection(s.cg, a);
     }
     ConvArgs a;
     fill_conv(s.cg, a, cur, outp, 1, N * Win, nullptr, nullptr);
@@ -1470,7 +1537,7 @@ int Pass::lstm(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         a.tileT = s.rec_x3 ? (s.in_tiled ? 0 : T) : (s.in_tiled ? -T : 0);
         a.nlines = Ns;
         if (mark("lstm_xproj_x3", xflops)) return kFailed;
-        rc = one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
+        rc = projection(s.cg, a);
     } else {
         ConvArgs a;
         fill_conv(s.cg, a, cur, (float*)s.aux.p, 1, Ns * T, nullptr, nullptr);

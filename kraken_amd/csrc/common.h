@@ -25,6 +25,21 @@
 #define KRK_FN(name) name
 #endif
 
+// Cycle accounting of a kernel's phases (dev tool, -DKRK_ABLATE builds with probe bit 64 only): every wave sums, per phase, the
+// shader cycles between two stamps (s_memtime) and adds its totals to a per-kernel array of device counters at its end;
+// tools/phase_stats.py reads them through krk_debug_phase_stats.  Compiled out of the release library.
+#ifdef KRK_ABLATE
+#define KRK_PHASES(n) unsigned long long ph_acc_[n] = {}; unsigned long long ph_t_ = 0
+#define KRK_PH_START(a) do { if (KRK_DBGBIT(a, 64)) ph_t_ = __builtin_readcyclecounter(); } while (0)
+#define KRK_PH(a, i) do { if (KRK_DBGBIT(a, 64)) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc_[i] += n_ - ph_t_; ph_t_ = n_; } } while (0)
+#define KRK_PH_FLUSH(a, arr, n) do { if (KRK_DBGBIT(a, 64) && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < (n); ++i_) atomicAdd(&(arr)[i_], ph_acc_[i_]); atomicAdd(&(arr)[n], 1ull); } } while (0)
+#else
+#define KRK_PHASES(n)
+#define KRK_PH_START(a)
+#define KRK_PH(a, i)
+#define KRK_PH_FLUSH(a, arr, n)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -126,6 +141,7 @@ struct X3Args {
     int IH, IW, PSTR, lds_plane;        // LDS tile: pixels, bytes per pixel (padded), bytes per plane
     int y_f32;                   // 1: write fp32 NHWC (same element index as the hi plane) for a GroupNorm consumer
     int y_blkM, y_cols;          // > 0: sequence output in K-blocked order, y_blkM rows of y_cols per line (see gemm_x3.hip)
+    int tps;                     // conv_x3p.hip: tile copies per weight-stage boundary (0: not eligible)
     int SR, tiles_h, tiles_w;    int dbg;                            // probe bits (env KRK_X3_DBG): 1 skip K loop, 2 skip staging loads, 4 skip stores
 };
 
@@ -185,9 +201,15 @@ struct GemmX3Args {
     int nlines;           // tileT < 0: lines that exist (rows of the padding lines of the last 16-line tile are dropped)
     int act;
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no MFMA, 2 no copies, 4 no stores, 8 no LDS reads
+    int stagger;          // gemm_x3w.hip probe (KRK_GEMM_STAG): start delay in cycles per phase ((workgroup / 8) % 4)
+    int nbuf;             // gemm_x3w.hip: LDS buffers (3 | 4), copies nbuf - 1 steps ahead
 };
 int krk_launch_gemm_x3(const GemmX3Args& a, hipStream_t s);
 int krk_launch_gemm_x3_b1(const GemmX3Args& a, hipStream_t s);
+// wide-tile variant (gemm_x3w.hip): a.w packed in column groups of tn = krk_gemm_x3w_tn(Cout), a.ncg = groups of tn
+int krk_gemm_x3w_tn(int cout);
+int krk_launch_gemm_x3w(const GemmX3Args& a, int tn, hipStream_t s);
+int krk_launch_gemm_x3w_b1(const GemmX3Args& a, int tn, hipStream_t s);
 
 // ----------------------------------------------------------------------- LSTM
 struct LstmArgs {
@@ -285,6 +307,10 @@ int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hip
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);
 int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
 int krk_launch_conv_x3_b1(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
+// pipelined variant (conv_x3p.hip): asynchronous double-buffered tile staging; split outputs only
+int krk_conv_x3p_tps(int cchunk, int kb, int kb_last, int npix, int iw, int ntaps, int cout, size_t line_bytes);
+int krk_launch_conv_x3p(const X3Args& a, bool pool, hipStream_t s);
+int krk_launch_conv_x3p_b1(const X3Args& a, bool pool, hipStream_t s);
 int krk_launch_split(const float* x, void* hi, size_t plane_elems, size_t n, hipStream_t s);
 // fp32 rows [M][K] -> K-blocked split planes [K/8][M][8] (hi, lo at + M*K elements)
 int krk_launch_split_rows(const float* x, void* hi, int M, int K, hipStream_t s);

@@ -189,6 +189,8 @@ def test_bench_launches_its_own_ranks_and_refuses_missing_devices():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out['n_gpus'] == 2 and out['ranks_in_collective'] == 2 and out['gathered_lines'] == 2 * 5 * 8
     assert out['config']['parallelism'] == 'dp2' and 'STUB' in out['data'] and out['gather_ms'] > 0
+    # every rank keeps its own block of the host's CPUs (no 8 ranks x all cores)
+    assert 1 <= out['host_cpus_per_rank'] <= max(1, len(os.sched_getaffinity(0)) // 2)
     # without the stub there is no device here: the launcher refuses instead of running one rank labelled as two
     import torch
     if not torch.cuda.is_available():

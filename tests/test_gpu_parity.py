@@ -1367,3 +1367,26 @@ print('RCCL-OK')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-c', code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert 'RCCL-OK' in r.stdout, r.stderr[-2000:]
+
+
+# --------------------------------------------------------------------- two ranks on the one device of a gpurun box
+@pytest.mark.timeout(600)
+def test_two_ranks_share_one_device_plumbing():
+    """
+    VERDICT r3 item 3: two real processes, two real engines, ShardedRecognizer.stream + gather and recognize_lines (input order) on
+    hardware.  RCCL refuses two ranks per device, so the collective is gloo and the line says it is NOT a scaling number.
+    """
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--share-device', '--steps', '6', '--warmup', '3',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['ranks_in_collective'] == 2 and out['ranks_on_one_device'] == 2 and out['n_gpus'] == 1
+    assert out['gathered_lines'] == 2 * 6 * 256 and out['collective_backend'] == 'gloo'
+    assert out['metric'].startswith('PLUMBING RUN, NOT A SCALING NUMBER')
+    chk = out['recognize_lines_check']
+    assert chk['lines'] == 97 and chk['ranks'] == 2 and chk['results_in_input_order_and_identical_to_one_rank'] and chk['nonempty'] > 80
