@@ -403,7 +403,7 @@ int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* 
     if (int rc = pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3)) return rc;
     // wide outputs (the LSTM input projections) also get the wide-tile kernel's order; which kernel runs is decided per call
     // by the number of rows (Pass::projection)
-    if (g.Cout >= 512 && !getenv("KRK_NO_GEMM_W")) {
+    if (g.Cout >= 512 && env_int("KRK_GEMM_W", 0) != 0) {
         g.wtn = krk_gemm_x3w_tn(g.Cout);
         if (int rc = pack_gemm_x3_weights(g, w, rowmap, g.wtn, &g.d_wx3w)) return rc;
     }
@@ -1261,7 +1261,9 @@ struct Probes {
     int lstm_v = env_int("KRK_LSTM_V", 0);       // 0: by hidden size (see recurrence_x3); 3: cluster kernel lstm_ws.hip; 4: pipelined XCD-local kernel lstm_wp.hip; 1: streaming kernel
     int lstm_g = env_int("KRK_LSTM_G", 2);       // 4: four 16-line groups per cluster
     int lstm_m = env_int("KRK_LSTM_M");          // f32 plan: force 16- or 32-line tiles
-    int gemm_w = env_int("KRK_GEMM_W", -1);      // wide-tile projection kernel: 0 never, 1 always (where packed), -1 by size
+    int gemm_w = env_int("KRK_GEMM_W", 0);       // wide-tile projection kernel (gemm_x3w.hip): 0 never (default: alone it is 6-10 % faster than
+                                                 // gemm_x3, but one 110 KB workgroup per CU shuts the other batches' kernels out: 111.2 k vs 113.1 k
+                                                 // lines/s on the pipelined bench, profiles/r04_kernel_matrix.txt), 1 where packed, -1 by size
     int gemm_nbuf = env_int("KRK_GEMM_NBUF", 3); // wide-tile projection kernel: LDS buffers (3 | 4)
     int gemm_stag = env_int("KRK_GEMM_STAG", 0); // wide-tile projection kernel: start delay (cycles) per workgroup phase
     int conv_x3p = env_int("KRK_CONV_X3P", 1);   // 0: conv_x3.hip also where the pipelined kernel (conv_x3p.hip) covers the geometry

@@ -155,17 +155,16 @@ __global__ void __launch_bounds__(512, 2) gemm_x3w_kernel(const GemmX3Args a) {
 
     // Slots 0 .. 2 nkb, one barrier each (2 nkb + 1 for every wave).  Group 0 reads step j in slot 2j and multiplies in slot 2j + 1;
     // group 1 reads step j in slot 2j + 1 and multiplies in slot 2j + 2.  Step j's buffer (j % NBUF) is therefore read in slots 2j
-    // and 2j + 1 and refilled (with step j + NBUF) behind the barrier that opens slot 2j + 2; its copies were issued behind the
-    // barrier of slot 2 (j - NBUF + 1) and are waited for in front of the barrier of slot 2j.
+    // and 2j + 1 and refilled (with step j + NBUF) in slots 2j + 2 (group 0's waves) and 2j + 3 (group 1's); all of a step's
+    // copies are waited for in front of the barrier of the even slot that reads it first.
     if (!no_copy) {
 #pragma unroll
         for (int k = 0; k < NBUF - 1; ++k)
             if (k < nkb) issue(k, k);
     }
     KRK_PH(a, 0);
-    // opens an even slot 2j: my copies of step j have landed, everyone's after the barrier; then the refill of the buffer step
-    // j - 1 occupied.  Two straight-line loops, one per group (a single loop with the group as a run-time condition makes
-    // the compiler carry the accumulators through phi copies and spill them).
+    // Two straight-line loops, one per group (a single loop with the group as a run-time condition makes the compiler carry the
+    // accumulators through phi copies and spill them).
     // a slot boundary: the MFMAs are register-only, so without the scheduling fences the compiler moves them across the barrier
     // (it sank 29 of a slot's 30 behind the NEXT barrier: both waves of a SIMD multiplying in the same slot)
     auto slot_barrier = [&]() {
@@ -174,42 +173,46 @@ __global__ void __launch_bounds__(512, 2) gemm_x3w_kernel(const GemmX3Args a) {
         __builtin_amdgcn_sched_barrier(0);
         KRK_PH(a, 2);
     };
-    auto open_even = [&](int j) {
-        wait_older(min(NBUF - 2, nkb - 1 - j));
-        KRK_PH(a, 1);
-        slot_barrier();
-        if (j + NBUF - 1 < nkb && !no_copy) issue(j + NBUF - 1, (j + NBUF - 1) % NBUF);
-        KRK_PH(a, 3);
-    };
     // the reads are complete before this wave arrives at the next barrier: the buffer may be refilled behind it.  Through the
     // builtin (vmcnt 63, expcnt 7, lgkmcnt 0) so that the compiler's own wait-count pass knows the fragments arrived
     auto reads_done = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); KRK_PH(a, 4); };
+    // A group issues ITS waves' copies of step j + NBUF - 1 at the start of its own READ slot of step j (behind the barrier that
+    // follows the last read of the buffer's previous tenant, step j - 1) -- never in front of its MFMAs: a copy instruction costs
+    // the issuing wave ~20 cycles of the CU's address path per KB, and with all eight waves issuing in one slot the multiplying
+    // group stood ~800 cycles behind its partner's copies (phase accounting, profiles/r04_phase_stats.txt).  A group waits for
+    // its own copies of the step the NEXT even slot reads, in front of the barrier that opens it.
+    auto refill = [&](int j) {
+        if (j + NBUF - 1 < nkb && !no_copy) issue(j + NBUF - 1, (j + NBUF - 1) % NBUF);
+        KRK_PH(a, 3);
+    };
     if (grp == 0) {
         for (int j = 0; j < nkb; ++j) {
-            open_even(j);
+            wait_older(min(NBUF - 2, nkb - 1 - j));      // my copies of step j
+            KRK_PH(a, 1);
+            slot_barrier();                              // slot 2j
+            refill(j);
             read(j % NBUF);
             reads_done();
-            slot_barrier();
+            slot_barrier();                              // slot 2j + 1
             mma();
             KRK_PH(a, 5);
         }
-        slot_barrier();
+        slot_barrier();                                  // slot 2 nkb: the other group's last MFMAs
     } else {
-        open_even(0);
-        slot_barrier();
-        read(0);
-        reads_done();
-        for (int j = 1; j < nkb; ++j) {
-            open_even(j);
-            mma();
-            KRK_PH(a, 5);
-            slot_barrier();
+        wait_older(min(NBUF - 2, nkb - 1));              // my copies of step 0
+        KRK_PH(a, 1);
+        slot_barrier();                                  // slot 0: nothing to do yet
+        for (int j = 0; j < nkb; ++j) {
+            slot_barrier();                              // slot 2j + 1
+            refill(j);
             read(j % NBUF);
             reads_done();
+            if (j + 1 < nkb) wait_older(min(NBUF - 2, nkb - 2 - j));   // my copies of step j + 1
+            KRK_PH(a, 1);
+            slot_barrier();                              // slot 2j + 2
+            mma();
+            KRK_PH(a, 5);
         }
-        slot_barrier();
-        mma();
-        KRK_PH(a, 5);
     }
 
     // ---- epilogue: D[column][row] (weights are the MFMA's A operand): lane = row px of its segment, registers 4j..4j+3 = columns

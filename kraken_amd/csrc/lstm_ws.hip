@@ -180,6 +180,15 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         pub_vo[i] = ok ? ((unsigned)slice * slice_gran + (unsigned)ul * 16u + (unsigned)line) * 8u : kOOBws;
         own_lds[i] = (ok && unit < NKB * 32) ? lds_of(line, unit) : dump_off;
     }
+    // HEARTBEAT (round 4: the cause of the exchange timeouts on narrow layers).  The two parity buffers are safe only because a
+    // producer cannot publish step s+2 before it has gathered step s+1 from every peer -- which that peer publishes after ALL its
+    // waves consumed step s.  A slice WITHOUT a gate-column block (slice * BPC >= NB: NB in {1, 2, 3, 5, 6, 9}, i.e. hidden sizes
+    // below 40) published nothing, so nobody ever waited for it: its peers ran ahead, overwrote h(g, s) with h(g, s+2) before it had
+    // read it, and it spun on a tag that was gone (5..50 timeouts in 100 forwards of an H = 8 net; never at H >= 40, where every
+    // slice owns a block).  An empty slice now publishes one pair of payload-free granules per (group, step) -- units 0 and 1,
+    // line 0 of its own, otherwise unused region -- and every peer gathers that pair (to nowhere): the same flow control for all.
+    const bool empty_slice = slice * BPC >= a.NB;
+    if (empty_slice && wave == 0 && line == 0 && us < 2) pub_vo[0] = ((unsigned)slice * slice_gran + (unsigned)us * 16u) * 8u;
     // what this lane gathers: pair q = tid + 512 k over [peer 3][BPC*2 unit pairs][16 lines]; packed into one register: bit 31 =
     // wanted, bits 16..30 = LDS offset / 4 of the pair's dword (0x7FFF = nowhere: padding units), bits 0..15 = index of the
     // first granule (the second one is 16 granules = one unit further)
@@ -192,8 +201,9 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         const int sl = (slice + 1 + (int)p) & 3;
         const int ul = 2 * (int)(rem >> 4), ln = (int)(rem & 15);
         const int unit = sl * BPC * 4 + ul;
-        const bool ok = p < 3 && (sl * BPC + (ul >> 2)) < a.NB;      // blocks beyond NB are never published
-        const unsigned lo = (ok && unit < NKB * 32) ? (lds_of(ln, unit) >> 2) : 0x7FFFu;
+        const bool beat = p < 3 && sl * BPC >= a.NB && rem == 0;     // the heartbeat pair of a slice without blocks (see above)
+        const bool ok = (p < 3 && (sl * BPC + (ul >> 2)) < a.NB) || beat;      // blocks beyond NB are never published
+        const unsigned lo = (ok && !beat && unit < NKB * 32) ? (lds_of(ln, unit) >> 2) : 0x7FFFu;
         g_item[k] = (ok ? 0x80000000u : 0u) | (lo << 16) | (((unsigned)sl * slice_gran + (unsigned)ul * 16u + (unsigned)ln) & 0xFFFFu);
     }
     auto g_vo = [&](int k) -> unsigned { return (g_item[k >> 1] >> 31) ? ((g_item[k >> 1] & 0xFFFFu) + 16u * (k & 1)) * 8u : kOOBws; };

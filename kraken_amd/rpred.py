@@ -375,11 +375,15 @@ class LinePipeline:
         h = self.engine.in_height
         widths, host, keys = {}, set(), []
         for (k, a), rr, o, i in zip(items, r, ok, ink):
-            if i and not o:
-                host.add(k)                                  # band outside the padded stack: the reference's own code decides
+            # a UNIFORM crop (ink False: max == min) is the reference's flat line only when it is white: any other value becomes a
+            # non-flat tensor once the white padding is added (kraken/rpred.py:221 tests the PADDED tensor) and is recognised --
+            # solid black crops do occur on binarised pages.  Those take the reference's own transform on the host.
+            to_host = (i and not o) or (not i and a.size > 0 and int(a.flat[0]) != 255)
+            if to_host:
+                host.add(k)                                  # (band outside the padded stack: the reference's own code decides)
             elif o and i:
                 widths[k] = int(h * 1.0 / (2 * int(rr)) * a.shape[1]) + 2 * pad
-            keys.append(None if (i and not o) else k)
+            keys.append(None if to_host else k)
         ticket = self.engine.submit_dewarped(r, use, pad, want_probs=self.want_probs)
         self._tickets.append((ticket, keys))
         return widths, host

@@ -162,8 +162,10 @@ def parse_vgsl(spec: str):
             # the reference derives this shape from a dummy tensor with variable dims set to 1
             oshape = (n or 1, c * h, 1, w or 1)
         elif kind == 'rnn':
-            if g['legacy'] or g['cell'] != 'L' or (g['sum'] and g['axis'] != 'y'):
-                raise NotImplementedError(f'RNN variant "{block}" (x-axis summarising / legacy / GRU) is not supported '
+            # 'G' parses as a GRU but the reference builds the same torch.nn.LSTM for it (layers.py:504-511, model.py:579-593):
+            # an alias, layer name G_<idx>
+            if g['legacy'] or (g['sum'] and g['axis'] != 'y'):
+                raise NotImplementedError(f'RNN variant "{block}" (x-axis summarising / legacy) is not supported '
                                           'by the HIP executor')
             hidden = int(g['out'])
             if hidden > 256:

@@ -152,6 +152,14 @@ X3_NETWORK_CASES = {
 }
 
 
+BREADTH_CASES = {
+    # round 4: VGSL forms the executor learned after the first fixtures were made
+    # 'G' cell: the reference parses it and builds the same torch.nn.LSTM (layers.py:504-511); layer name G_<idx>
+    'g_alias':       ('[1,1,0,12 Gbx10]', 3, 17, [17, 9, 4]),
+    'g_stack':       ('[1,4,0,2 Cr3,3,4 S1(1x0)1,3 Gfx8 Lbx6 O1c5]', 3, 23, [23, 15, 8]),
+}
+
+
 @torch.inference_mode()
 def layer_fixture(path, cases=None):
     cases = cases or {
@@ -403,7 +411,7 @@ def transforms_fixture(path):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'codec', 'transforms']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'codec', 'transforms']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -419,6 +427,8 @@ if __name__ == '__main__':
         layer_fixture(os.path.join(HERE, 'image_lstm.npz'), IMAGE_LSTM_CASES)
     if 'x3_networks' in which:
         layer_fixture(os.path.join(HERE, 'x3_networks.npz'), X3_NETWORK_CASES)
+    if 'breadth' in which:
+        layer_fixture(os.path.join(HERE, 'breadth.npz'), BREADTH_CASES)
     if 'codec' in which:
         codec_fixture(os.path.join(HERE, 'codec.npz'))
     if 'transforms' in which:

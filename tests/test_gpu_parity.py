@@ -24,6 +24,7 @@ LOGIT_TOL = 1e-3
 CONF_TOL = 1e-4
 CASES = layer_cases()
 CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, scaled-down BLLA segmenter
+CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes above 256, ...
 
 
 def _keys(tuples):
@@ -1158,6 +1159,8 @@ def test_one_channel_bbox_lines_are_dewarped_on_the_device_and_give_the_host_rec
     for i in range(60):
         h, w = int(rng.randint(30, 90)), int(rng.randint(200, 1000))
         line = _wavy_line(rng, h, w) if i != 17 else np.full((h, w), 255, np.uint8)        # line 17 is flat
+        if i in (23, 41):                                   # uniform but NOT white: the reference's rule tests the padded
+            line = np.full((h, w), 0 if i == 23 else 100, np.uint8)   # tensor, which is not flat -> these lines are recognised
         rows.append(np.pad(line, ((0, 0), (0, 1000 - w)), constant_values=255))
         boxes.append((0, y, w, y + h))
         y += h
@@ -1178,6 +1181,13 @@ def test_one_channel_bbox_lines_are_dewarped_on_the_device_and_give_the_host_rec
     # (tools/batch_invariance.py: 0.0 on every plan), so the records are the host path's, all of them.  (Round 3 shipped this test
     # with "58 of 60": hipcc had contracted dewarp.hip's multiply-adds into FMAs, which moved a few columns' centre by a row.)
     assert dev[17].prediction == '' and host[17].prediction == '' and sum(bool(r.prediction) for r in dev) >= 55
+    # the uniform black / gray lines take the reference's transform (not the "flat line" shortcut): same record as the host path,
+    # and the host path is the reference's rule (max == min on the PADDED tensor: false for them)
+    from kraken_amd.transforms import ImageInputTransforms
+    ts = ImageInputTransforms(1, 48, 0, 1, (16, 0), valid_norm=True)
+    for i in (23, 41):
+        t = ts(page.crop(boxes[i]))
+        assert float(t.max()) != float(t.min())
     for i, (a, b) in enumerate(zip(dev, host)):
         assert a.prediction == b.prediction, i
         assert list(a.cuts) == list(b.cuts), i

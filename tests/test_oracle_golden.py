@@ -17,6 +17,7 @@ from tests.specs import BENCH_A, BENCH_B
 LAYER_TOL = 2e-5
 CASES = layer_cases()
 CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, scaled-down BLLA segmenter
+CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes above 256, ...
 
 
 def _zero_pad_x(x, lens):
