@@ -119,8 +119,8 @@ def cpu_baseline(model, width, n_lines):
 
 # kernels behind the launch groups (rocprofv3 kernel names)
 KERNEL_OF = {'conv': 'conv_f32_kernel', 'lstm_xproj': 'conv_f32_kernel<1,1,0,4>', 'linear': 'conv_f32_kernel<1,1,0,4>',
-             'lstm_rec': 'lstm_f32_kernel', 'conv_x3': 'conv_x3_kernel', 'conv1_x3': 'conv1_x3_kernel',
-             'conv_taps_x3': 'conv_taps_kernel', 'lstm_xproj_x3': 'gemm_x3_kernel', 'linear_x3': 'gemm_x3_kernel',
+             'lstm_rec': 'lstm_f32_kernel', 'conv_x3': 'conv_x3', 'conv1_x3': 'conv1_x3_kernel',
+             'conv_taps_x3': 'conv_taps_kernel', 'lstm_xproj_x3': 'gemm_x3_kernel', 'linear_x3': 'gemm_x3_kernel',   # (conv_x3 matches conv_x3p_kernel too)
              'lstm_rec_x3': 'lstm_ws_kernel'}
 
 
@@ -153,9 +153,12 @@ def roofline_of(engine, precision):
                 'note': ('algorithmic FLOPs of the launch group / its HIP-event time with the other batches in flight; the '
                          'split-operand kernels issue 3 bf16 MFMAs per algorithmic product'
                          if dom_name.endswith('_x3') else 'exact f32 MFMA')}
-    # HBM traffic of the dominant kernel from the committed PMC summary of this same command (separate rocprofv3 --pmc passes at
-    # the benchmark's slot count, tools/profile_round.sh + tools/summarize_pmc.py); the NEWEST summary of this precision under
-    # profiles/ is used and named in `source`; null when there is none
+    # rocprofv3 quantities of the SAME command from the committed PMC summary (separate --pmc passes at the benchmark's slot count,
+    # tools/profile_round.sh + tools/summarize_pmc.py): the NEWEST summary of this precision under profiles/ is used and named in
+    # `source`; everything below stays null / absent when there is none.  Per launch group: the kernel's rocprofv3 average duration,
+    # MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles): of the chip, and of the CUs the kernel occupies),
+    # HBM bytes per launch (FETCH_SIZE doubled where the guide's gfx950 half-count applies) and the HBM rate they imply.
+    pmc_groups, step_traffic = {}, None
     try:
         import glob
         pat = 'r*_bf16x3_pmc_summary*.json' if precision != 'f32' else 'r*_f32_pmc_summary*.json'
@@ -165,17 +168,51 @@ def roofline_of(engine, precision):
         summary = cands[-1]
         tag = os.path.basename(summary)
         pmc = json.load(open(summary))['kernels']
-        kname = roofline['kernel'].split('<')[0]
-        hit = [v for k, v in pmc.items() if k.startswith(kname) and 'hbm_write_MB_per_launch' in v]
-        if hit:
-            v = max(hit, key=lambda e: e.get('total_ms', 0))
+        steps_profiled = max(1, max((v.get('calls', 0) for k, v in pmc.items() if k.startswith('rowmax_rows_kernel')), default=1))
+
+        def entry(kname):
+            hit = [v for k, v in pmc.items() if k.startswith(kname.split('<')[0]) and 'hbm_write_MB_per_launch' in v]
+            return max(hit, key=lambda e: e.get('total_ms', 0)) if hit else None
+
+        def cus_of(kname, v):          # CUs a launch occupies: the recurrent cluster kernels hold 4 CUs per 32 lines and direction
+            return 64.0 if kname.startswith(('lstm_ws', 'lstm_wp')) else 256.0
+
+        for gname in groups:
+            kname = KERNEL_OF.get(gname, gname)
+            v = entry(kname)
+            if not v:
+                continue
             rd = v.get('hbm_read_MB_x2', v.get('hbm_read_MB_per_launch', 0.0))
-            roofline['traffic'] = {'read_MB': rd, 'write_MB': v['hbm_write_MB_per_launch'], 'per': 'launch',
+            wr = v['hbm_write_MB_per_launch']
+            e = {'kernel': kname, 'rocprof_avg_launch_ms': round(v['avg_us'] / 1e3, 4), 'hbm_read_MB': rd, 'hbm_write_MB': wr,
+                 'hbm_GBps': round((rd + wr) / v['avg_us'] * 1e3, 1) if v.get('avg_us') else None}
+            if v.get('mfma_util_chip') is not None:
+                e['mfma_busy_chip'] = v['mfma_util_chip']
+                e['mfma_busy_on_its_CUs'] = round(v['mfma_util_chip'] * 256.0 / cus_of(kname, v), 4)
+            pmc_groups[gname] = e
+        # HBM bytes of one step = sum over all profiled kernels of calls x bytes / profiled steps (one rowmax launch per step)
+        tot = sum(v.get('calls', 0) * (v.get('hbm_read_MB_x2', v.get('hbm_read_MB_per_launch', 0.0)) + v.get('hbm_write_MB_per_launch', 0.0))
+                  for v in pmc.values())
+        step_traffic = {'GB': round(tot / steps_profiled / 1e3, 3), 'steps_profiled': steps_profiled, 'source': f'profiles/{tag}'}
+        d = pmc_groups.get(dom_name)
+        if d:
+            roofline['traffic'] = {'read_MB': d['hbm_read_MB'], 'write_MB': d['hbm_write_MB'], 'per': 'launch', 'hbm_GBps': d['hbm_GBps'],
                                    'source': f'profiles/{tag} (FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the guide for the wide streaming reads)'}
+            # the same fraction on the profiler's clock: rocprofv3's average duration of the kernel in the committed run
+            roofline['frac_hip_events'] = roofline['frac']
+            roofline['frac_rocprof'] = round(dom['gflop'] / dom['n'] / d['rocprof_avg_launch_ms'] / peak_of(dom_name), 4)
+            roofline['rocprof_avg_launch_ms'] = d['rocprof_avg_launch_ms']
+            if 'mfma_busy_chip' in d:
+                roofline['mfma_busy_chip'] = d['mfma_busy_chip']
+                roofline['mfma_busy_on_its_CUs'] = d['mfma_busy_on_its_CUs']
     except Exception:
         pass
+    roofline['step_traffic'] = step_traffic
+    for k, v in groups.items():
+        v['pmc'] = pmc_groups.get(k)
     return roofline, launches, {k: {'ms': round(v['ms'], 3), 'tflops': round(v['gflop'] / v['ms'], 1) if v['ms'] > 0 else 0,
-                                    'frac_of_peak': round(v['gflop'] / v['ms'] / peak_of(k), 4) if v['ms'] > 0 else 0}
+                                    'frac_of_peak': round(v['gflop'] / v['ms'] / peak_of(k), 4) if v['ms'] > 0 else 0,
+                                    'rocprof': v.get('pmc')}
                                 for k, v in groups.items()}
 
 
@@ -308,6 +345,9 @@ def mode_api(args, rank, local_rank):
     from kraken_amd.specs import BENCH_A, BENCH_A_RGB, bench_codec
     out = {}
     n, W = args.api_lines, args.width
+    if os.environ.get('KRK_API_NOGC'):               # probe: how much of the host time is the cyclic collector?
+        import gc
+        gc.disable()
     for name, spec, mode in (('bbox_L_dewarped_on_device', BENCH_A, 'L'), ('bbox_RGB_prepared_on_device', BENCH_A_RGB, 'RGB')):
         torch.manual_seed(0)
         m = kraken_amd.TorchVGSLModel(vgsl=spec, codec=bench_codec())

@@ -49,6 +49,26 @@ class KrakenAmdError(RuntimeError):
         self.code = code
 
 
+def is_exchange_timeout(e: Exception) -> bool:
+    """The status word of a plan (krk_plan_status): a recurrent cluster kernel gave up waiting for its peers."""
+    return isinstance(e, KrakenAmdError) and 'timed out waiting for its peers' in str(e)
+
+
+class streaming_recurrence:
+    """Context: forward calls made inside use the streaming recurrent kernel (lstm_x3.hip, no inter-workgroup exchange) instead of
+    the cluster kernels -- the one retry after an exchange timeout.  The switch is the library's per-call probe KRK_LSTM_V."""
+
+    def __enter__(self):
+        self._old = os.environ.get('KRK_LSTM_V')
+        os.environ['KRK_LSTM_V'] = '1'
+
+    def __exit__(self, *exc):
+        if self._old is None:
+            os.environ.pop('KRK_LSTM_V', None)
+        else:
+            os.environ['KRK_LSTM_V'] = self._old
+
+
 _lib = None
 _lock = threading.Lock()
 

@@ -182,6 +182,7 @@ struct ConvTapArgs {
     int act, tiles_h, tiles_w;
     int y_f32;            // 1: write fp32 NHWC instead of split planes (GroupNorm consumer)
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no K loop, 2 no weight refresh (FIVE), 4 no staging loads, 16 no stores
+    int dma;              // 1: stage the input tile with raw-buffer -> LDS copies (both planes of a line within one 4 GB descriptor)
 };
 bool krk_conv_taps_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
 int krk_launch_conv_taps(const ConvTapArgs& a, bool pool, hipStream_t s);
@@ -305,6 +306,7 @@ int krk_launch_dewarp_apply(const unsigned char* crops, const int* desc, int n, 
 // host-side launchers (implemented in the .hip files)
 int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);
+int krk_launch_lstm_big(const LstmArgs& a, hipStream_t s);   // 256 < Hp <= 768 (lstm_rec.hip)
 int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
 int krk_launch_conv_x3_b1(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
 // pipelined variant (conv_x3p.hip): asynchronous double-buffered tile staging; split outputs only
@@ -323,6 +325,25 @@ int krk_groupnorm_chunks(int N, int C, int H, int W, int G, int Ho);
 int krk_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const int* lens, const int* len_out,
                          int N, int C, int H, int W, int G, float eps, int kh, int kw, int sh, int sw, int Ho, int Wo,
                          double* scratch, hipStream_t s);
+// first convolution of a one-channel image fused into the GroupNorm (+ 2x2 MaxPool) behind it (c1gn.hip)
+struct C1GnArgs {
+    const float* x;        // (N, 1, H, W)
+    const float* w;        // [C][9] filter taps (ky, kx), [C] bias
+    const float* bias;
+    const float* gamma;    // [C]
+    const float* beta;
+    const int* lens;       // [N] valid input (= convolution output) width, or null
+    const int* len_out;    // [N] valid pooled width, or null
+    double* part;          // [N * G][chunks][2]
+    float* y;              // (N, C, Ho, Wo) pooled, or (N, C, H, W) without a pool
+    int N, C, H, W, G, chunks, act, pool;
+    int Ho, Wo;
+    float eps;
+};
+bool krk_c1gn_supported(int Cin, int C, int kh, int kw, int sh, int sw, int dh, int dw, int G, int pool_kh, int pool_kw, int pool_sh,
+                        int pool_sw);
+int krk_c1gn_chunks(int N, int H);
+int krk_launch_c1gn(const C1GnArgs& a, hipStream_t s);
 int krk_launch_to_seq(const float* x, float* y, int N, int C, int H, int W, hipStream_t s);
 // split-bf16 NHWC planes (norm_x3.hip): MaxPool, height collapse
 int krk_launch_maxpool_x3(const void* x, size_t xplane, void* y, size_t yplane, const int* len_out, int N, int C, int H, int W,

@@ -38,6 +38,25 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// LDS-DMA by hand (the lstm_ws.hip idiom).  Through the builtins the compiler books every copy as a store to "some" LDS address and
+// waits for it in front of the next ds_read that might alias -- the fragment reads of the CURRENT chunk: progressive vmcnt(3..0)
+// waits a third of the way into a chunk's MFMAs for copies that only the NEXT chunk reads.  In asm it neither sees nor counts them;
+// its own counted waits stay safe (vmcnt retires in order: a wait that covers one of its loads covers every older copy too), and the
+// chunk boundary waits explicitly (vmcnt(0) + barrier).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+__device__ __forceinline__ void dma_global_b128(const void* gptr, unsigned lds_off) {     // 64 lanes x 16 B -> LDS [lds_off, + 1 KB)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gptr), "s"(lds_off) : "memory");
+}
+__device__ __forceinline__ void dma_buffer_b128(unsigned voff, const i32x4_t& srd, unsigned soff, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_off) : "memory");
+}
+
 constexpr int LW6 = 152;  // LDS row of the six-group kernel: 8 (aligned left margin) + 128 + 15, rounded to 16-byte pieces
 constexpr int LW5 = 144;  // five-group kernel: 8 + 128 + 8 (its windows end at column 143)
 constexpr int WPAIR = 3 * 4 * 64 * 16;   // bytes of the weight fragments of one channel pair (five-group kernel)
@@ -74,7 +93,7 @@ __device__ __forceinline__ unsigned px1(const unsigned (&W)[NW]) {             /
     else return W[J / 2] >> 16;
 }
 
-template <int KH, int PW, bool POOL, bool FIVE>
+template <int KH, int PW, bool POOL, bool FIVE, bool DMA>
 __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) {
     constexpr int IH = TH + KH - 1;
     constexpr int SHIFT = 8 - PW;                    // LDS column 0 is image column w0 - 8
@@ -116,15 +135,50 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
         s_src[i] = (long)plane * (long)a.x_plane + (((long)n * a.H + gh) * a.Cin + ch) * a.pitch + gw;
         s_dst[i] = e * 8;
     }
-    f32x4 st[NST];
-    auto gload = [&](int ch0) {
+    // ---- round 4: the same pieces as raw-buffer -> LDS copies (buffer_load_dwordx4 ... lds): piece e of the chunk lands at LDS
+    // byte 16 e of the tile buffer (= wave-uniform base + 16 * lane), out-of-range pieces (image border, pitch) deliver zeros, lanes
+    // past the tile are masked off by EXEC.  No staging registers, no ds_write pass, no exec-masked global loads whose count the
+    // compiler cannot track; the chunk's channel offset travels in soffset.  One descriptor spans both planes of the line.
+    constexpr bool dma = DMA;   // compile-time: with both staging forms behind a run-time flag the compiler merged their control flow
+                                // and waited vmcnt(0) for the copies right where they are issued
+    unsigned d_vo[NST];
+    const size_t line_elems = (size_t)a.H * a.Cin * a.pitch;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = tid + 256 * i;
+        const int row = e / (LW / 8), q = e - row * (LW / 8);
+        const int plane = row / (CC * IH), r2 = row - plane * (CC * IH);
+        const int ch = r2 / IH, ih = r2 - ch * IH;
+        const int gh = h0 - a.ph + ih, gw = w0 - 8 + 8 * q;
+        const bool ok = e < PIECES && gh >= 0 && gh < a.H && gw >= 0 && gw < a.pitch && !KRK_DBGBIT(a, 4);
+        d_vo[i] = ok ? (unsigned)(((size_t)plane * a.x_plane + ((size_t)gh * a.Cin + ch) * a.pitch + gw) * 2) : 0xFFFFFFF0u;
+    }
+    i32x4_t xrs;
+    {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(a.x + (size_t)n * line_elems);
+        xrs[0] = (int)__builtin_amdgcn_readfirstlane((unsigned)u);
+        xrs[1] = (int)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32) & 0xFFFFu);
+        xrs[2] = (int)__builtin_amdgcn_readfirstlane((unsigned)((a.x_plane + line_elems) * 2));
+        xrs[3] = 0x00020000;
+    }
+    const unsigned tile_lds = lds_offset_of(&tile[0][0][0][0][0]);
+    constexpr unsigned TILE_BYTES = sizeof(__bf16) * 2 * CC * IH * LW;
+    [[maybe_unused]] auto dma_stage = [&](int ch0, int buf) {
+        const unsigned t = tile_lds + (unsigned)buf * TILE_BYTES + (unsigned)wave * 1024u;
+        const unsigned so = (unsigned)(ch0 * a.pitch * 2);
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (tid + 256 * i < PIECES) dma_buffer_b128(d_vo[i], xrs, so, t + i * 4096);
+    };
+    [[maybe_unused]] f32x4 st[NST];
+    [[maybe_unused]] auto gload = [&](int ch0) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (s_ok[i] && !KRK_DBGBIT(a, 4)) st[i] = *reinterpret_cast<const f32x4*>(a.x + s_src[i] + (long)ch0 * a.pitch);
         }
     };
-    auto lstore = [&](int buf) {
+    [[maybe_unused]] auto lstore = [&](int buf) {
         __bf16* t = &tile[buf][0][0][0][0];
 #pragma unroll
         for (int i = 0; i < NST; ++i)
@@ -152,8 +206,13 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
     const bool live = (w0 + 64 * chalf) < wlim;      // this wave's columns are inside the line
     const int nchunks = a.Cin / CC;
 
-    gload(0);
-    lstore(0);
+    if constexpr (dma) {
+        dma_stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        gload(0);
+        lstore(0);
+    }
     if constexpr (!FIVE) {
     bf16x8 wha[KH], wla[KH], whb[KH], wlb[KH];
     wload(0, wha, wla);
@@ -189,7 +248,10 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
 
     for (int k = 0; k < nchunks; ++k) {
         const int buf = k & 1;
-        if (k + 1 < nchunks) gload((k + 1) * CC);
+        if (k + 1 < nchunks) {
+            if constexpr (dma) dma_stage((k + 1) * CC, buf ^ 1);
+            else gload((k + 1) * CC);
+        }
         if (live && !KRK_DBGBIT(a, 1)) {
             static_assert(CC == 4, "channel loop is unrolled for 4-channel chunks");
             const int cg = k * CC;
@@ -202,7 +264,8 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
             wload(min(cg + 4, a.Cin - 1), wha, wla);
             channel(buf, 3, whb, wlb);
         }
-        if (k + 1 < nchunks) lstore(buf ^ 1);
+        if constexpr (!dma) { if (k + 1 < nchunks) lstore(buf ^ 1); }
+        if constexpr (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     } else {
@@ -214,14 +277,13 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
     // global -> LDS copies, one chunk ahead (per-wave loads of 24 KB per chunk ran the CU's 64 B/clk vector-memory path
     // at ~80 %, in order with the tile staging loads: 0.59 ms without the weight traffic against 0.75 ms with it)
     const int npairs = a.Cin >> 1;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const unsigned wts_lds = lds_offset_of(wts);
     auto wdma = [&](int chunk, int wb) {       // this wave's quarter of the chunk's (two channel pairs) fragments -> weight buffer wb
         if (KRK_DBGBIT(a, 2)) return;
         const unsigned char* src = reinterpret_cast<const unsigned char*>(a.wpack5) + (size_t)chunk * (2 * WPAIR) + wave * (WPAIR / 2) + lane * 16;
-        unsigned char* dst = wts + wb * (2 * WPAIR) + wave * (WPAIR / 2);
+        const unsigned dst = wts_lds + (unsigned)(wb * (2 * WPAIR) + wave * (WPAIR / 2));
 #pragma unroll
-        for (int j = 0; j < WPAIR / 2 / 1024; ++j)
-            __builtin_amdgcn_global_load_lds((const void*)(src + j * 1024), (lds_ptr)(dst + j * 1024), 16, 0, 0);
+        for (int j = 0; j < WPAIR / 2 / 1024; ++j) dma_global_b128(src + j * 1024, dst + j * 1024);
     };
     auto landed = [&]() {                       // my copies are in LDS; after the barrier: everyone's, and the other buffers are free
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -284,13 +346,14 @@ __global__ void __launch_bounds__(256, 2) conv_taps_kernel(const ConvTapArgs a) 
         // (~3.5 us) covers the HBM latency of the tile loads and the copies of the weight fragments alike
         if (k + 1 < nchunks) {
             wdma(k + 1, buf ^ 1);
-            gload((k + 1) * CC);
+            if constexpr (dma) dma_stage((k + 1) * CC, buf ^ 1);
+            else gload((k + 1) * CC);
         }
         if (work) {
             pair_rows(buf, 0, 2 * buf);
             pair_rows(buf, 1, 2 * buf + 1);
         }
-        if (k + 1 < nchunks) lstore(buf ^ 1);
+        if constexpr (!dma) { if (k + 1 < nchunks) lstore(buf ^ 1); }
         landed();
     }
 #endif
@@ -388,18 +451,30 @@ int launch_pw(const ConvTapArgs& a, bool pool, hipStream_t s) {
             int dev = 0;
             (void)hipGetDevice(&dev);
             if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taps_kernel<3, PW, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taps_kernel<3, PW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taps_kernel<3, PW, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taps_kernel<3, PW, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taps_kernel<3, PW, true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taps_kernel<3, PW, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
                 if (dev >= 0 && dev < 64) attr_set[dev] = true;
             }
-            if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, true>), grid, dim3(256), lds5, s, a);
-            else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, true>), grid, dim3(256), lds5, s, a);
+            if (a.dma) {
+                if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, true, true>), grid, dim3(256), lds5, s, a);
+                else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, true, true>), grid, dim3(256), lds5, s, a);
+            } else {
+                if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, true, false>), grid, dim3(256), lds5, s, a);
+                else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, true, false>), grid, dim3(256), lds5, s, a);
+            }
             return hipGetLastError() == hipSuccess ? 0 : -2;
         }
     }
 #endif
-    if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, false>), grid, dim3(256), tile6, s, a);
-    else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, false>), grid, dim3(256), tile6, s, a);
+    if (a.dma) {
+        if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, false, true>), grid, dim3(256), tile6, s, a);
+        else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, false, true>), grid, dim3(256), tile6, s, a);
+    } else {
+        if (pool) hipLaunchKernelGGL((conv_taps_kernel<3, PW, true, false, false>), grid, dim3(256), tile6, s, a);
+        else hipLaunchKernelGGL((conv_taps_kernel<3, PW, false, false, false>), grid, dim3(256), tile6, s, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

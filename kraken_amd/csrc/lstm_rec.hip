@@ -246,6 +246,95 @@ __global__ void __launch_bounds__(256, 1) lstm_f32_kernel(const LstmArgs a) {
     }
 }
 
+// Hidden sizes above 256 (round 4; the reference builds nn.LSTM for any width, kraken/lib/vgsl/model.py:579-593,
+// layers.py:504-511): the same arithmetic as lstm_time_loop on 16-line tiles (v_mfma_f32_16x16x4_f32, weights in the M = 16 /
+// KG = 4 fragment order), but the gate-column blocks of a wave are a RUN-TIME loop -- each block runs its whole K loop, then its
+// gate math -- and the cell state lives in LDS, so nothing is sized by the hidden width except LDS (h twice + c: 12 bytes x 17 per
+// unit: Hp <= 768).  A correctness path: W_hh streams from L2 every step (4 Hp^2 floats per workgroup), no prefetch pipelining.
+__global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
+    constexpr int M = 16, KG = 4, KPI = 4, LS = M + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int hrows = a.NG * KG * KPI;                 // K rows incl. the zero padding of the last group
+    float* hs = smem;                                  // [2][hrows][LS]
+    float* cs = smem + 2 * hrows * LS;                 // [Hp][LS] cell state of (unit, line)
+    int* lens_s = reinterpret_cast<int*>(cs + a.Hp * LS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const bool rev = (a.dirmode == 1) || (a.dirmode == 2 && dir == 1);
+    const int n0 = blockIdx.x * M;
+    if (tid < M) {
+        const int n = n0 + tid;
+        int l = 0;
+        if (n < a.N) l = a.lens ? min(max(a.lens[n], 0), a.T) : a.T;
+        lens_s[tid] = l;
+    }
+    for (int e = tid; e < 2 * hrows * LS + a.Hp * LS; e += 256) smem[e] = 0.f;
+    __syncthreads();
+    int Lmax = 0;
+    for (int i = 0; i < M; ++i) Lmax = max(Lmax, lens_s[i]);
+
+    const int cl = lane & 15, gate = cl & 3, ul = cl >> 2, khalf = lane >> 4, arow = lane & 15;
+    int irow[4], ilen[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        irow[r] = 4 * (lane >> 4) + r;
+        ilen[r] = lens_s[irow[r]];
+    }
+    const float* wbase = a.wp + ((size_t)dir * a.NG * a.NB * 64 + lane) * KG;
+    const size_t gstride = (size_t)a.NB * 64 * KG;
+    const float gscale = (gate == 2) ? 2.f : 1.f;
+    int cur = 0;
+    for (int s = 0; s < Lmax; ++s) {
+        const float* hcur = hs + cur * hrows * LS;
+        float* hnext = hs + (cur ^ 1) * hrows * LS;
+        for (int b = wave; b < a.NB; b += 4) {
+            f32x4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool on = s < ilen[r];
+                const int t = rev ? (ilen[r] - 1 - s) : s;
+                const float* xr = a.xp + ((size_t)(n0 + irow[r]) * a.T + (on ? t : 0)) * a.xstride + (size_t)dir * a.G + cl;
+                acc[r] = on ? xr[(size_t)b * M] : 0.f;
+            }
+            for (int g = 0; g < a.NG; ++g) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wbase + (size_t)g * gstride + (size_t)b * 64 * KG);
+#pragma unroll
+                for (int e = 0; e < KG; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hcur[(KPI * (g * KG + e) + khalf) * LS + arow], w[e], acc, 0, 0, 0);
+            }
+            const int unit = b * 4 + ul;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * acc[r]));
+                gv = (gate == 2) ? (2.f * gv - 1.f) : gv;
+                const float gi = quad_bcast<0x00>(gv);
+                const float gf = quad_bcast<0x55>(gv);
+                const float gg = quad_bcast<0xAA>(gv);
+                const float go = quad_bcast<0xFF>(gv);
+                const float c = gf * cs[unit * LS + irow[r]] + gi * gg;
+                const float h = go * krk_tanh(c);
+                if (gate == 0) {
+                    cs[unit * LS + irow[r]] = c;
+                    hnext[unit * LS + irow[r]] = h;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = wave; i < M; i += 4) {
+            const int li = lens_s[i];
+            if (s < li) {
+                const int t = rev ? (li - 1 - s) : s;
+                float* o = a.out + ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H;
+                for (int k = lane; k < a.H; k += 64) o[k] = hnext[k * LS + i];
+            }
+        }
+        cur ^= 1;
+    }
+}
+
 template <int M, int MAXB, int KG, bool XPRE>
 int launch_one(const LstmArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.N + M - 1) / M), (unsigned)a.ndir);
@@ -267,6 +356,16 @@ int launch_one(const LstmArgs& a, hipStream_t s) {
 int krk_lstm_kg(int M, int per_wave) {
     if (M == 32) return 4;
     return per_wave <= 13 ? 8 : 4;
+}
+
+// hidden sizes 256 < Hp <= 768: a.NB = Hp / 4 blocks of 16 gate columns, a.NG = K groups of 4 steps (weights: the M = 16 pack)
+int krk_launch_lstm_big(const LstmArgs& a, hipStream_t s) {
+    if (a.Hp > 768 || a.N <= 0) return a.N <= 0 ? 0 : -4;
+    dim3 grid((unsigned)((a.N + 15) / 16), (unsigned)a.ndir);
+    const size_t lds = ((size_t)2 * a.NG * 16 * 17 + (size_t)a.Hp * 17 + 16) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(lstm_big_kernel, grid, dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // M in {16, 32}; a.NB = 4*Hp / M column blocks; a.NG = K-groups of krk_lstm_kg() steps.

@@ -33,7 +33,7 @@ from .vgsl import DecodedBatch, TorchVGSLModel, _Plan
 
 class _Slot:
     def __init__(self, model: TorchVGSLModel, dev: int):
-        self.plan = _Plan(model.nn._specs, model.nn, model.input[1], model.input[2], dev, model.nn.precision)
+        self.plan = model.nn.new_plan(dev)        # same f32 fallback (and warning) as a direct nn(x) call
         self.dev = dev
         self.stream = torch.cuda.Stream(device=dev)
         self.event = torch.cuda.Event()
@@ -283,8 +283,20 @@ class RecognitionEngine:
         and returns ``(r, ok, ink)`` int arrays: ``ok`` = the reference's band slices are full (otherwise the line must take the
         host transform), ``ink`` = the line is not flat.  ``submit_dewarped`` finishes the batch.
         """
+        return self.measure_dewarp_begin(crops, pool).result()
+
+    def measure_dewarp_begin(self, crops: list, pool=None, ahead: int = 0):
+        """
+        The same without the wait: enqueues upload + ``krk_dewarp_measure`` on the slot ``ahead`` places behind the next free one
+        and returns a handle whose ``result()`` blocks for ``(r, ok, ink)``.  With ``ahead=1`` the measurement of batch k+1 is
+        in flight while the host finishes batch k (``submit_dewarped`` of the slot in front) -- the device -> host read-back of a
+        batch then costs the host nothing (round 4: it was 15 % of the API path's wall time).  Between a ``begin`` and the
+        ``submit_dewarped`` of its slot nothing else may be submitted.
+        """
         from .transforms import dewarp_tables
-        slot = self._free_slot()
+        slot = self.slots[(self._next + ahead) % len(self.slots)]
+        if slot.busy:
+            raise RuntimeError('all slots busy: collect() a ticket before submitting more')
         if self.in_channels != 1:
             raise ValueError('the dewarp is defined for 1-channel models')
         n = len(crops)
@@ -324,10 +336,20 @@ class RecognitionEngine:
             info = torch.empty((n, 4), dtype=torch.int32, device=dev)
             _lib.check(self.lib.krk_dewarp_measure(slot.crops_dev.data_ptr(), st['desc'].data_ptr(), n, maxw, maxh, st['wts'].data_ptr(),
                                                    st['scratch'].data_ptr(), st['work'].data_ptr(), info.data_ptr(), slot.stream.cuda_stream))
-            info_h = info.cpu()                                       # synchronises the slot's stream
+            info_h = torch.empty((n, 4), dtype=torch.int32).pin_memory() if st.get('info_h') is None or st['info_h'].shape[0] < n \
+                else st['info_h']
+            st['info_h'] = info_h
+            info_h[:n].copy_(info, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(slot.stream)
         st.update(n=n, maxw=maxw, host_desc=desc)
-        info_h = info_h.numpy()
-        return info_h[:, 0].copy(), info_h[:, 1].astype(bool), info_h[:, 2].astype(bool)
+
+        class _Measured:
+            def result(_self):
+                done.synchronize()
+                a = info_h[:n].numpy()
+                return a[:, 0].copy(), a[:, 1].astype(bool), a[:, 2].astype(bool)
+        return _Measured()
 
     def submit_dewarped(self, r: np.ndarray, use: np.ndarray, pad: int, want_probs: bool = False) -> int:
         """Second half: cut-out band, bilinear scaling to the model height, uint8 truncation, padding, inversion (``krk_dewarp_apply``)
@@ -417,6 +439,7 @@ class RecognitionEngine:
             slot.host_buf.copy_(slot.dev_buf, non_blocking=True)
             slot.event.record(slot.stream)
         slot.busy, slot.n, slot.t, slot.keep = True, N, T, x
+        slot.keep_lens = lens_arr
         self._next = (slot_id + 1) % len(self.slots)
         self._inflight.append(slot_id)
         return slot_id
@@ -429,8 +452,24 @@ class RecognitionEngine:
         self._inflight.remove(ticket)
         slot = self.slots[ticket]
         slot.event.synchronize()
-        slot.busy, slot.keep = False, None                         # the slot is free again whatever the status below says
-        _lib.check(self.lib.krk_plan_status(slot.plan.handle))     # a kernel that gave up waiting raises here, never hangs
+        x, lens = slot.keep, getattr(slot, 'keep_lens', None)
+        slot.busy, slot.keep, slot.keep_lens = False, None, None    # the slot is free again whatever the status below says
+        try:
+            _lib.check(self.lib.krk_plan_status(slot.plan.handle))  # a kernel that gave up waiting raises here, never hangs
+        except _lib.KrakenAmdError as e:
+            # one retry of THIS batch on the streaming recurrent kernel (no inter-workgroup exchange) before the page is lost
+            if not _lib.is_exchange_timeout(e) or x is None:
+                raise
+            import logging
+            logging.getLogger(__name__).warning(f'{e}; running the batch again on the streaming recurrent kernel')
+            keep_next, inflight = self._next, list(self._inflight)
+            self._next = ticket
+            with _lib.streaming_recurrence():
+                self._launch(slot, x, lens, slot.want_probs, False)
+            self._inflight, self._next = deque(inflight), keep_next
+            slot.event.synchronize()
+            slot.busy, slot.keep, slot.keep_lens = False, None, None
+            _lib.check(self.lib.krk_plan_status(slot.plan.handle))
         nt = slot.cap_n * slot.cap_t
         h = slot.host_buf.numpy()
         n, t = slot.n, slot.cap_t

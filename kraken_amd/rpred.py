@@ -53,6 +53,7 @@ ENGINE_BATCH = 256     # lines per device batch (results do not depend on it: ma
 ENGINE_SLOTS = 3       # device batches in flight per recogniser
 DEVICE_PREP = True     # crop / resize / pad / invert eligible lines on the device (krk_prep_lines) instead of with PIL
 DEVICE_DEWARP = True   # ... and the CenterNormalizer dewarp of 1-channel bbox lines (krk_dewarp_measure / krk_dewarp_apply) instead of scipy
+DEWARP_BATCH_PIXELS = 32 * 1024 * 1024   # pixels per device dewarp batch (krk_dewarp_measure: 24 bytes of fp64 scratch per pixel, 32-bit offsets)
 PREP_THREADS = 4       # host threads preparing line images when the caller does not say (``num_line_workers``); PIL holds the GIL in its
                        # conversions: 2..6 threads give the same throughput, 16 and more lose 40 % to contention
 
@@ -215,8 +216,8 @@ def _engine_for(net, temperature: float):
     dev = p.device.index if p.device.index is not None else torch.cuda.current_device()
     key = (dev, hs.precision, hs._weights_version())
     cache = hs.__dict__.setdefault('_engines', {})
-    for k in [k for k in cache if k != key]:          # weights updated in place / other arithmetic: those plans are stale
-        for old in cache.pop(k):
+    for k in [k for k in cache if k[1:] != key[1:]]:  # weights updated in place / other arithmetic: those plans are stale;
+        for old in cache.pop(k):                      # engines of ANOTHER device stay (one model used on two devices in turn)
             if old.in_use:
                 old.stale = True                      # closed by the pipeline that still holds it
             else:
@@ -225,9 +226,17 @@ def _engine_for(net, temperature: float):
     eng = next((e for e in pool if not e.in_use and not e.closed), None)
     if eng is None:
         eng = RecognitionEngine(vgsl, device=dev, max_batch=32, max_width=256, slots=ENGINE_SLOTS, temperature=temperature)
+        if hs.precision != key[1]:                    # the engine's plans fell back to exact f32 (new_plan): file it under what it is
+            key = (dev, hs.precision, hs._weights_version())
+            pool = hs.__dict__.setdefault('_engines', {}).setdefault(key, [])
         eng.stale = False
         pool.append(eng)
-        del pool[:-4]                                 # engines still held elsewhere stay alive through their holders
+        for old in pool[:-4]:                         # evicted: an idle engine is closed now, a held one by its holder
+            if old.in_use:
+                old.stale = True
+            else:
+                old.close()
+        del pool[:-4]
     else:
         eng.reset()
     eng.temperature = float(temperature)
@@ -368,9 +377,17 @@ class LinePipeline:
         items: [(key, uint8 array (h, w))] of ONE batch: 1-channel bbox lines, dewarped (CenterNormalizer), padded and inverted on
         the device.  Returns ({key: network input width}, keys that must take the host transform instead).
         """
-        while self.engine.free_slots() == 0:
+        return self.dewarp_finish(items, self.dewarp_begin(items), pad)
+
+    def dewarp_begin(self, items: list, ahead: int = 0):
+        """Upload + measurement of one dewarp batch, not waited for (engine.measure_dewarp_begin); ``ahead=1``: a batch that was
+        begun before is still to be finished (``dewarp_finish``) -- nothing else may be submitted in between."""
+        while self.engine.free_slots() < 1 + ahead:
             self._collect_one()
-        r, ok, ink = self.engine.measure_dewarp([a for _, a in items], pool=self.pool)
+        return self.engine.measure_dewarp_begin([a for _, a in items], pool=self.pool, ahead=ahead)
+
+    def dewarp_finish(self, items: list, measured, pad: int):
+        r, ok, ink = measured.result()
         use = ok & ink
         h = self.engine.in_height
         widths, host, keys = {}, set(), []
@@ -452,6 +469,8 @@ class _RecognitionRun:
         self._batch = int(min(b, max(32, math.ceil(self.len / (2 * ENGINE_SLOTS)))))
         self._chunk = self._batch * ENGINE_SLOTS
         self._pages: dict = {}     # PIL mode -> the page as a device tensor (device-side line preparation)
+        self._gray = None          # the page as one uint8 'L' array, converted band by band (bbox lines of a dewarping model)
+        self._gray_done: set = set()
 
     # -- device-side preparation (krk_prep_lines): rectangular crops of a fixed-height model, no dewarp ------------
     def _transform_on_device_ok(self, net, ts) -> bool:
@@ -482,6 +501,65 @@ class _RecognitionRun:
         if self.bounds.type == 'baselines' or not self.bounds.text_direction.startswith('horizontal') or ts._center_norm:
             return False                                   # (dewarped lines are cut out on the host and go through _crop_for_device)
         return self._transform_on_device_ok(net, ts)
+
+    # -- bbox lines of a dewarping (1-channel) model: cut out of ONE grayscale copy of the page ----------------------------
+    GRAY_ROWS = 256            # rows converted per work item
+
+    def _gray_wanted(self) -> bool:
+        """bbox segmentation of horizontal text, the reference's own extractor, device dewarp on: the per-line `im.crop(box)` +
+        `convert('L')` + array copy of the reference (~50 us of interpreter time per line, under the GIL) becomes a numpy view."""
+        if self.bounds.type == 'baselines' or not self.bounds.text_direction.startswith('horizontal'):
+            return False
+        if extract_polygons is not _EXTRACT_POLYGONS or not (DEVICE_PREP and DEVICE_DEWARP):
+            return False
+        ts = getattr(self, 'ts', None)
+        tss = list(ts.values()) if isinstance(ts, dict) else [ts]
+        return any(getattr(t, '_center_norm', False) and getattr(t, '_mode', '') == 'L' for t in tss)
+
+    def _ensure_gray(self, idxs):
+        """Main thread, before a chunk is prepared: converts the page rows the chunk's boxes touch (pool: 256-row pieces)."""
+        W, H = self.im.size
+        rows = [ln.bbox for ln in (self.bounds.lines[i] for i in idxs) if getattr(ln, 'bbox', None) is not None]
+        rows = [(b[1], b[3]) for b in rows if 0 <= b[1] < b[3] <= H]
+        if not rows:
+            return
+        if self._gray is None:
+            self._gray = np.empty((H, W), dtype=np.uint8)
+        step = self.GRAY_ROWS
+        need = sorted({k for y0, y1 in rows for k in range(y0 // step, (y1 - 1) // step + 1)} - self._gray_done)
+
+        def part(k):
+            ya, yb = k * step, min((k + 1) * step, H)
+            sub = self.im.crop((0, ya, W, yb))
+            self._gray[ya:yb] = np.asarray(sub if sub.mode == 'L' else sub.convert('L'))
+        if self._pool and len(need) > 1:
+            list(self._pool.map(part, need))
+        else:
+            for k in need:
+                part(k)
+        self._gray_done.update(need)
+
+    def _dewarp_crop_from_page(self, idx: int, line, tag: str, net, ts, want_image: bool = False):
+        """
+        The common case of a dewarped bbox line -- box inside the page, 2 <= height <= 192 -- as a view of the grayscale page
+        (pixel for pixel `im.crop(box).convert('L')`: the conversion is point-wise).  None: the general path decides (boxes
+        touching the page border are padded by PIL, invalid ones give the reference's empty records).
+        """
+        if self._gray is None or not ts._center_norm or not self._transform_on_device_ok(net, ts):
+            return None
+        box = line.bbox
+        if box is None or len(box) != 4:
+            return None
+        x0, y0, x1, y1 = (int(v) for v in box)
+        W, H = self.im.size
+        if not (0 <= x0 < x1 <= W and 0 <= y0 < y1 <= H) or list(box) != [x0, y0, x1, y1]:
+            return None
+        w, h = x1 - x0, y1 - y0
+        step = self.GRAY_ROWS
+        if h < 2 or h > 192 or w > 16384 or any(k not in self._gray_done for k in range(y0 // step, (y1 - 1) // step + 1)):
+            return None
+        return _Pending(idx, line, tag, net, None, (w, h), image=self.im.crop((x0, y0, x1, y1)) if want_image else None, width=0,
+                        mode='dewarp', crop=self._gray[y0:y1, x0:x1])
 
     def _crop_for_device(self, idx: int, line, tag: str, net, ts, box, box_size, want_image: bool = False):
         """
@@ -641,6 +719,8 @@ class _RecognitionRun:
         """Prepares + submits the next chunk (the device keeps working on earlier ones meanwhile), or waits for results."""
         if self._prepared < self.len:
             idxs = range(self._prepared, min(self._prepared + self._chunk, self.len))
+            if self._gray_wanted():
+                self._ensure_gray(idxs)
             if self._pool and len(idxs) > 1:
                 # a future per line costs more than a crop descriptor does: hand the pool a few slices per worker instead
                 k = max(1, len(idxs) // (4 * self._workers))
@@ -681,30 +761,55 @@ class _RecognitionRun:
         net = group[0].net
         pipe = self._pipe(net)
         ts = self.ts[group[0].tag] if isinstance(getattr(self, 'ts', None), (dict, defaultdict)) else self.ts
-        for lo in range(0, len(group), pipe.batch_size):
-            part = group[lo:lo + pipe.batch_size]
-            widths, host = pipe.submit_dewarp([(p.idx, p.crop) for p in part], self.pad)
-            for p in part:
-                if p.idx in widths:
-                    p.width = widths[p.idx]
-            for p in part:
-                if p.idx not in host:
-                    continue
-                del self._pending[p.idx]
-                box = Image.fromarray(p.crop, 'L')
-                try:
-                    t = ts(box)
-                except Exception:
-                    logger.warning(f'Conversion of line {p.line} failed. Emitting empty record..')
-                    self._results[p.idx] = self._empty(p.line)
-                    continue
-                if t.max() == t.min():
-                    logger.warning('Empty run. Emitting empty record.')
-                    self._results[p.idx] = self._empty(p.line)
-                    continue
-                q = dataclasses.replace(p, tensor=t, crop=None, mode='', width=t.shape[2])
-                self._pending[p.idx] = q
-                pipe.submit([(q.idx, q.tensor)])
+        # a dewarp batch is bounded by lines AND by pixels: krk_dewarp_measure keeps 3 fp64 planes per pixel of scratch behind
+        # 32-bit offsets (a batch of 256 lines at the per-line maximum of 192 x 16384 would ask for 19 GB)
+        parts, cur, px = [], [], 0
+        for p in group:
+            n = int(p.crop.shape[0]) * int(p.crop.shape[1])
+            if cur and (len(cur) >= pipe.batch_size or px + n > DEWARP_BATCH_PIXELS):
+                parts.append(cur)
+                cur, px = [], 0
+            cur.append(p)
+            px += n
+        if cur:
+            parts.append(cur)
+        # software pipeline over the batches: the measurement of batch k + 1 is enqueued (next slot but one) before the host
+        # waits for batch k's -- the read-back between krk_dewarp_measure and krk_dewarp_apply costs the host no idle time.
+        # Lines that take the host transform are submitted after the last batch (no other submission may come between a
+        # batch's two halves).
+        to_host, begun = [], None
+        two = len(pipe.engine.slots) >= 2
+        for part in parts + [None]:
+            nxt = None
+            if part is not None and not two and begun is None:       # a one-slot engine: both halves of a batch back to back
+                begun = (part, pipe.dewarp_begin([(p.idx, p.crop) for p in part]))
+                part = None
+            if part is not None:
+                nxt = (part, pipe.dewarp_begin([(p.idx, p.crop) for p in part], ahead=1 if begun else 0))
+            if begun is not None:
+                bpart, handle = begun
+                widths, host = pipe.dewarp_finish([(p.idx, p.crop) for p in bpart], handle, self.pad)
+                for p in bpart:
+                    if p.idx in widths:
+                        p.width = widths[p.idx]
+                to_host += [p for p in bpart if p.idx in host]
+            begun = nxt
+        for p in to_host:
+            del self._pending[p.idx]
+            box = Image.fromarray(np.ascontiguousarray(p.crop), 'L')
+            try:
+                t = ts(box)
+            except Exception:
+                logger.warning(f'Conversion of line {p.line} failed. Emitting empty record..')
+                self._results[p.idx] = self._empty(p.line)
+                continue
+            if t.max() == t.min():
+                logger.warning('Empty run. Emitting empty record.')
+                self._results[p.idx] = self._empty(p.line)
+                continue
+            q = dataclasses.replace(p, tensor=t, crop=None, mode='', width=t.shape[2])
+            self._pending[p.idx] = q
+            pipe.submit([(q.idx, q.tensor)])
 
     def _fill(self):
         while self._cursor not in self._results:
@@ -816,6 +921,9 @@ class mm_rpred(_RecognitionRun):
             item = self._prepare_on_device(idx, line, tag, net, self.ts[tag])
             if item is not None:
                 return item
+        item = self._dewarp_crop_from_page(idx, line, tag, net, self.ts[tag])
+        if item is not None:
+            return item
         legacy = self._use_legacy_extractor(net)
         seg = dataclasses.replace(self.bounds, lines=[line])
         try:
@@ -914,6 +1022,9 @@ class _PredRun(_RecognitionRun):
                 if not isinstance(item, _Pending):           # this API's empty records carry list cuts (lib/vgsl/rpred.py:105-116)
                     return self._record_cls('', [], [], line)
                 return item
+        item = self._dewarp_crop_from_page(idx, line, 'default', self.net, self.ts, want_image=self._return_image)
+        if item is not None:
+            return item
         seg = dataclasses.replace(self.bounds, lines=[line])
         try:
             box, _ = next(extract_polygons(self.im, seg, legacy=self.legacy))

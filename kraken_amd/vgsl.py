@@ -168,8 +168,8 @@ def parse_vgsl(spec: str):
                 raise NotImplementedError(f'RNN variant "{block}" (x-axis summarising / legacy) is not supported '
                                           'by the HIP executor')
             hidden = int(g['out'])
-            if hidden > 256:
-                raise NotImplementedError(f'recurrent layer "{block}": hidden sizes above 256 are not supported by the HIP recurrent kernels')
+            if hidden > 768:
+                raise NotImplementedError(f'recurrent layer "{block}": hidden sizes above 768 are not supported by the HIP recurrent kernels')
             # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523);
             # 's' keeps only the last step of every column (:537-539): (N, C, H, W) -> (N, O, 1, W)
             p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'], summarize=bool(g['sum']))
@@ -440,25 +440,40 @@ class HipSequential(nn.Module):
         key = (device_index, self.precision, self._weights_version(), h)
         plan = self._plans.get(key)
         if plan is None:
-            if any(k[:3] != key[:3] for k in self._plans):       # in-place weight update, other device: everything is stale
+            # in-place weight update or another arithmetic: everything is stale.  Another DEVICE or input height only adds a
+            # plan (plans and engines of several devices live side by side)
+            if any(k[1:3] != key[1:3] for k in self._plans):
                 self.invalidate()
-            while len(self._plans) >= 4:                         # variable-height models: a few heights stay planned
+            while len(self._plans) >= 4:                         # variable-height models / devices: a few stay planned
                 self._plans.pop(next(iter(self._plans))).close()
-            try:
-                plan = _Plan(self._specs, self, c, h, device_index, self.precision)
-            except _lib.KrakenAmdError as e:
-                # a network (or, for variable-height models, a height) the split-bf16 kernels do not cover keeps the exact-f32
-                # plan instead of failing at its first call -- said once, never silently
-                if self.precision == _lib.PREC_F32 or e.code != _lib.KRK_E_UNSUPPORTED:
-                    raise
-                logger.warning(f'the split-bf16 plan does not cover this network ({e}); using the exact-f32 plan')
-                self.precision = _lib.PREC_F32
-                self.invalidate()
-                return self.plan(device_index, height)
+            precision = self.precision
+            plan = self.new_plan(device_index, h)
+            if self.precision != precision:                      # fell back to the exact-f32 plan: the key changes with it
+                key = (device_index, self.precision, self._weights_version(), h)
             self._plans[key] = plan
         else:
             self._plans[key] = self._plans.pop(key)              # most recently used last
         return plan
+
+    def new_plan(self, device_index: int, height: Optional[int] = None) -> _Plan:
+        """
+        A plan of its own for the caller (the engine's slots, `plan()`'s cache), with ONE rule for networks the split-bf16
+        kernels do not cover: such a network (or, for variable-height models, such a height) keeps the exact-f32 plan instead
+        of failing -- said once, never silently -- whether it is reached through `nn(x)`, `rpred`, `mm_rpred` or a
+        `ShardedRecognizer`.
+        """
+        _, c, h, _ = self._input
+        if height is not None:
+            h = height
+        try:
+            return _Plan(self._specs, self, c, h, device_index, self.precision)
+        except _lib.KrakenAmdError as e:
+            if self.precision == _lib.PREC_F32 or e.code != _lib.KRK_E_UNSUPPORTED:
+                raise
+            logger.warning(f'the split-bf16 plan does not cover this network ({e}); using the exact-f32 plan')
+            self.precision = _lib.PREC_F32
+            self.invalidate()
+            return _Plan(self._specs, self, c, h, device_index, self.precision)
 
     def _specs_for_height(self, height: int):
         """
@@ -523,9 +538,20 @@ class HipSequential(nn.Module):
                                              N, W, stream, out.data_ptr()))
             if plan.has_status:
                 # the recurrent cluster kernel reports a timed-out exchange through the plan's status word only: callers of
-                # nn(x) (custom decoders, the segmenter) must not receive such logits silently
+                # nn(x) (custom decoders, the segmenter) must not receive such logits silently.  One retry on the streaming
+                # kernel (no exchange) before giving up
                 torch.cuda.current_stream().synchronize()
-                _lib.check(plan._lib.krk_plan_status(plan.handle))
+                try:
+                    _lib.check(plan._lib.krk_plan_status(plan.handle))
+                except _lib.KrakenAmdError as e:
+                    if not _lib.is_exchange_timeout(e):
+                        raise
+                    logger.warning(f'{e}; running this batch again on the streaming recurrent kernel')
+                    with _lib.streaming_recurrence():
+                        _lib.check(plan._lib.krk_forward(plan.handle, xd.data_ptr(), lens.ctypes.data if lens is not None else None,
+                                                         N, W, stream, out.data_ptr()))
+                    torch.cuda.current_stream().synchronize()
+                    _lib.check(plan._lib.krk_plan_status(plan.handle))
         olens = None
         if lens is not None:
             olens = torch.from_numpy(plan.olens(lens))

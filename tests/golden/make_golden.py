@@ -157,6 +157,10 @@ BREADTH_CASES = {
     # 'G' cell: the reference parses it and builds the same torch.nn.LSTM (layers.py:504-511); layer name G_<idx>
     'g_alias':       ('[1,1,0,12 Gbx10]', 3, 17, [17, 9, 4]),
     'g_stack':       ('[1,4,0,2 Cr3,3,4 S1(1x0)1,3 Gfx8 Lbx6 O1c5]', 3, 23, [23, 15, 8]),
+    # hidden sizes above 256: the generic-width recurrent kernel (lstm_big_kernel), also between split-bf16 layers
+    'lstm_b_h300':   ('[1,1,0,24 Lbx300]', 3, 19, [19, 11, 5]),
+    'lstm_f_h520':   ('[1,1,0,16 Lfx520 O1c9]', 2, 13, None),
+    'big_stack':     ('[1,8,0,1 Cr3,3,8 Cr3,3,16 S1(1x0)1,3 Lbx264 Lbx24 O1c12]', 3, 40, [40, 27, 9]),
 }
 
 

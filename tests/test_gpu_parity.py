@@ -563,10 +563,11 @@ def test_x3_plan_keeps_everything_up_to_the_last_groupnorm_on_the_f32_cores():
 
     # GroupNorm right in front of the sequence layers: the whole image part is f32, the rows are split for the projection
     n1 = kernels('[1,8,0,1 Cr3,3,24 Gn4 S1(1x0)1,3 Lbx8 O1c5]', 8)
-    assert n1[:3] == ['conv', 'groupnorm', 'to_seq'] and 'lstm_xproj_x3' in n1 and 'linear_x3' in n1, n1
+    # (round 4: the one-channel first convolution is recomputed inside the GroupNorm's two passes, c1gn.hip: one launch group)
+    assert n1[:2] == ['conv1_groupnorm', 'to_seq'] and 'lstm_xproj_x3' in n1 and 'linear_x3' in n1, n1
     # convolutions behind the last GroupNorm: the first of them computes in f32 and hands over split planes, the next is split
     n2 = kernels('[1,16,0,1 Cr3,3,16 Gn4 Mp2,2 Cr3,5,32 Cr3,3,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx16 O1c9]', 16)
-    assert n2[:3] == ['conv', 'groupnorm_pool', 'conv'] and 'conv_x3' in n2, n2          # the pool behind the GroupNorm is part of its apply pass
+    assert n2[:2] == ['conv1_groupnorm_pool', 'conv'] and 'conv_x3' in n2, n2   # the pool behind the GroupNorm is part of its apply pass
     assert 'gn_x3' not in n2 and not any(k.startswith('groupnorm') for k in n2[n2.index('conv_x3'):]), n2
 
 
@@ -599,7 +600,8 @@ def test_x3_bench_b_groupnorm_network_against_reference_golden():
     eng.collect()
     names = [n_ for n_, _, _ in eng.layer_times()[0]]
     eng.close()
-    assert names[:5] == ['conv', 'groupnorm_pool', 'conv', 'groupnorm_pool', 'to_seq'], names
+    # (round 4: the one-channel first convolution is recomputed inside its GroupNorm's two passes, c1gn.hip)
+    assert names[:4] == ['conv1_groupnorm_pool', 'conv', 'groupnorm_pool', 'to_seq'], names
     assert 'lstm_xproj_x3' in names and 'lstm_rec_x3' in names and 'linear_x3' in names, names
 
 
@@ -1169,8 +1171,8 @@ def test_one_channel_bbox_lines_are_dewarped_on_the_device_and_give_the_host_rec
                        lines=[BBoxLine(id=f'l{i}', bbox=list(b)) for i, b in enumerate(boxes)])
     calls = []
     from kraken_amd.engine import RecognitionEngine
-    real = RecognitionEngine.measure_dewarp
-    monkeypatch.setattr(RecognitionEngine, 'measure_dewarp', lambda self, crops, **k: (calls.append(len(crops)), real(self, crops, **k))[1])
+    real = RecognitionEngine.measure_dewarp_begin
+    monkeypatch.setattr(RecognitionEngine, 'measure_dewarp_begin', lambda self, crops, *a, **k: (calls.append(len(crops)), real(self, crops, *a, **k))[1])
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         dev = list(R.mm_rpred(defaultdict(lambda: net), page, seg, bidi_reordering=False))
@@ -1400,3 +1402,38 @@ def test_two_ranks_share_one_device_plumbing():
     assert out['metric'].startswith('PLUMBING RUN, NOT A SCALING NUMBER')
     chk = out['recognize_lines_check']
     assert chk['lines'] == 97 and chk['ranks'] == 2 and chk['results_in_input_order_and_identical_to_one_rank'] and chk['nonempty'] > 80
+
+
+def test_exchange_timeout_is_retried_once_on_the_streaming_kernel(bench_a, monkeypatch):
+    """
+    ADVICE r3: a timed-out exchange of the recurrent cluster kernel must not cost the page.  The status word is faked once (the
+    real cause is fixed: lstm_ws.hip heartbeat granules); the engine and nn(x) run the batch again on the streaming recurrent kernel
+    and return the results of an undisturbed run; a second failure in a row still raises.
+    """
+    from kraken_amd import _lib, engine as E
+    x = synth_input(6, 400, seed=31).cuda()
+    lens = np.array([400, 380, 333, 200, 120, 64], dtype=np.int32)
+    eng = E.RecognitionEngine(bench_a, device=0, max_batch=8, max_width=400, slots=2)
+    eng.submit(x, lens)
+    want, wol = eng.collect()
+    real = _lib.check
+    armed = {'n': 0}
+
+    def flaky(rc):
+        if armed['n'] > 0 and rc == 0:
+            armed['n'] -= 1
+            raise _lib.KrakenAmdError(_lib.KRK_E_HIP, 'a recurrent cluster kernel timed out waiting for its peers (injected)')
+        return real(rc)
+
+    eng.submit(x, lens)
+    eng.slots[eng._inflight[0]].event.synchronize()
+    monkeypatch.setattr(_lib, 'check', flaky)
+    armed['n'] = 1
+    got, gol = eng.collect()
+    assert armed['n'] == 0
+    monkeypatch.setattr(_lib, 'check', real)
+    assert np.array_equal(gol, wol) and np.array_equal(got.counts, want.counts)
+    k = np.arange(got.labels.shape[1])[None, :] < got.counts[:, None]
+    assert np.array_equal(got.labels[k], want.labels[k]) and np.array_equal(got.starts[k], want.starts[k])
+    np.testing.assert_allclose(got.confs[k], want.confs[k], atol=1e-4)
+    eng.close()

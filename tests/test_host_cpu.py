@@ -82,7 +82,7 @@ UNSUPPORTED_FORMS = [
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxs20 O1c10]', 'Lbxs20', 'model.py:579 (x-axis summarising)'),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxc20 O1c10]', 'Lbxc20', 'layers.py:498 (legacy 1-augmented LSTM)'),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxo20 O1c10]', 'Lbxo20', 'layers.py:146 (peephole LSTM)'),
-    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbx300 O1c10]', 'Lbx300', 'hidden size above 256'),
+    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbx800 O1c10]', 'Lbx800', 'hidden size above 768'),
     ('[1,48,0,1 Cr3,3,32 S3(4x8)1,3 O1c10]', 'S3(4x8)1,3', 'model.py:748 (general reshape)'),
     ('[1,48,0,1 Cr3,3,32 O2s4]', 'softmax heatmap', 'model.py:806 (softmax heatmap head)'),
     ('[1,48,0,1 Cr3,3,32 O2la4]', 'O2la4', 'model.py:788 (1-augmented heatmap head)'),
