@@ -445,6 +445,7 @@ struct Step {
     float* d_wrecsm = nullptr;  // recurrent weights for lstm_small.hip (Hp <= 32): register-resident A fragments
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
     bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
+    bool split_rows = false;    // TOSEQ: fp32 NCHW in, K-blocked split sequence rows out (toseq_split_f32)
     int img_axis = 0;           // LSTM over image rows (1) or columns (2): sequences = N*H (N*W), steps = W (H); 0 = plain sequence
     int yaxis = 0;              // IMG2ROWS / ROWS2IMG: 1 = columns are the sequences
     int last_only = 0;          // ROWS2IMG: keep the last step of every column (summarising LSTM): output height 1; LSTM step: time steps of the rows
@@ -917,6 +918,13 @@ int PlanBuilder::reshape(const krk_layer& L, const std::string& where) {
     if (seq) return fail(KRK_E_UNSUPPORTED, where + ": reshape after a sequence layer");
     push_toseq();
     p->steps.back().on_split = x3;   // writes the K-blocked split sequence rows gemm_x3.hip reads
+    // An exact-f32 image part (GroupNorm networks) in front of split-bf16 sequence layers: collapse AND split in one pass
+    // (norm_x3.hip toseq_split_f32) instead of to_seq + split_rows -- one read and one write of the tensor instead of two each
+    if (this->x3 && !split_fmt && C % 16 == 0 && i + 1 < n_layers &&
+        (layers[i + 1].op == KRK_OP_LSTM || layers[i + 1].op == KRK_OP_LINEAR) && !getenv("KRK_NO_TOSEQ_SPLIT")) {
+        p->steps.back().split_rows = true;
+        split_fmt = true;
+    }
     return KRK_OK;
 }
 
@@ -1497,6 +1505,10 @@ int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int W
             if (s.on_split) {
                 if (mark("to_seq_x3", 0)) return kFailed;
                 return krk_launch_toseq_x3(cur, outp, out_elems, N, s.C, s.H, Win, stream);
+            }
+            if (s.split_rows) {
+                if (mark("to_seq_split", 0)) return kFailed;
+                return krk_launch_toseq_split_f32(cur, outp, out_elems, N, s.C, s.H, Win, stream);
             }
             if (mark("to_seq", 0)) return kFailed;
             return krk_launch_to_seq(cur, outp, N, s.C, s.H, Win, stream);

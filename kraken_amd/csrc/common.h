@@ -349,6 +349,8 @@ int krk_launch_to_seq(const float* x, float* y, int N, int C, int H, int W, hipS
 int krk_launch_maxpool_x3(const void* x, size_t xplane, void* y, size_t yplane, const int* len_out, int N, int C, int H, int W,
                           int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);
 int krk_launch_toseq_x3(const void* x, void* y, size_t plane, int N, int C, int H, int W, hipStream_t s);
+// fp32 (N,C,H,W) -> K-blocked split sequence rows in one pass (height collapse + split; norm_x3.hip)
+int krk_launch_toseq_split_f32(const float* x, void* y, size_t plane, int N, int C, int H, int W, hipStream_t s);
 // split NHWC planes (hi, lo at + plane elements) -> fp32 (N,C,H,W): where a bf16x3 plan continues with f32-only layers
 int krk_launch_unsplit(const void* x, size_t plane, float* y, int N, int C, int H, int W, hipStream_t s);
 // (N,C,H,W) <-> sequence rows [(n,h)][w][C] (yaxis = 0) or [(n,w)][h][C] (yaxis = 1) for LSTMs over image rows/columns

@@ -66,7 +66,44 @@ __global__ void __launch_bounds__(256) toseq_x3_kernel(const __bf16* __restrict_
     }
 }
 
+// fp32 NCHW -> K-blocked split sequence rows (round 4): the height collapse S1(1x0)1,3 (feature = h*C + c, reference layers.py:313-335)
+// and the split of the rows for the bf16x3 projection in ONE pass, where a plan's exact-f32 image part (GroupNorm networks) meets
+// its split-bf16 sequence part.  Before: to_seq (fp32 rows) + split_rows = two reads and two writes of the tensor.
+// A thread makes one 16-byte piece per plane: 8 channels of one (line, row, column), read as 8 dwords that are each coalesced
+// along the columns of the wave's lanes.
+__global__ void __launch_bounds__(256) toseq_split_f32_kernel(const float* __restrict__ x, __bf16* __restrict__ y, size_t plane,
+                                                              int N, int C, int H, int W, size_t total) {
+    const int Q = C >> 3;
+    const size_t rows = (size_t)N * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i % rows, piece = i / rows;          // piece = h*Q + q
+        const int h = (int)(piece / Q), q = (int)(piece % Q);
+        const int n = (int)(row / W), w = (int)(row % W);
+        const float* src = x + (((size_t)n * C + q * 8) * H + h) * W + w;
+        bf16x8 hv, lv;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = src[(size_t)k * H * W];
+            const __bf16 hi = (__bf16)v;
+            hv[k] = hi;
+            lv[k] = (__bf16)(v - (float)hi);
+        }
+        const size_t dst = (piece * rows + row) * 8;
+        *reinterpret_cast<bf16x8*>(y + dst) = hv;
+        *reinterpret_cast<bf16x8*>(y + plane + dst) = lv;
+    }
+}
+
 }  // namespace
+
+int krk_launch_toseq_split_f32(const float* x, void* y, size_t plane, int N, int C, int H, int W, hipStream_t s) {
+    if (C % 8) return -4;
+    const size_t total = (size_t)N * H * W * (C / 8);
+    if (!total) return 0;
+    const unsigned blocks = (unsigned)min((size_t)16384, (total + 255) / 256);
+    hipLaunchKernelGGL(toseq_split_f32_kernel, dim3(blocks), dim3(256), 0, s, x, (__bf16*)y, plane, N, C, H, W, total);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int krk_launch_maxpool_x3(const void* x, size_t xplane, void* y, size_t yplane, const int* len_out, int N, int C, int H, int W,
                           int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s) {

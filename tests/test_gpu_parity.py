@@ -564,7 +564,8 @@ def test_x3_plan_keeps_everything_up_to_the_last_groupnorm_on_the_f32_cores():
     # GroupNorm right in front of the sequence layers: the whole image part is f32, the rows are split for the projection
     n1 = kernels('[1,8,0,1 Cr3,3,24 Gn4 S1(1x0)1,3 Lbx8 O1c5]', 8)
     # (round 4: the one-channel first convolution is recomputed inside the GroupNorm's two passes, c1gn.hip: one launch group)
-    assert n1[:2] == ['conv1_groupnorm', 'to_seq'] and 'lstm_xproj_x3' in n1 and 'linear_x3' in n1, n1
+    # (... and the height collapse hands the rows over split: to_seq_split, no separate split pass)
+    assert n1[:2] == ['conv1_groupnorm', 'to_seq_split'] and 'split' not in n1 and 'lstm_xproj_x3' in n1 and 'linear_x3' in n1, n1
     # convolutions behind the last GroupNorm: the first of them computes in f32 and hands over split planes, the next is split
     n2 = kernels('[1,16,0,1 Cr3,3,16 Gn4 Mp2,2 Cr3,5,32 Cr3,3,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx16 O1c9]', 16)
     assert n2[:2] == ['conv1_groupnorm_pool', 'conv'] and 'conv_x3' in n2, n2   # the pool behind the GroupNorm is part of its apply pass
@@ -601,7 +602,7 @@ def test_x3_bench_b_groupnorm_network_against_reference_golden():
     names = [n_ for n_, _, _ in eng.layer_times()[0]]
     eng.close()
     # (round 4: the one-channel first convolution is recomputed inside its GroupNorm's two passes, c1gn.hip)
-    assert names[:4] == ['conv1_groupnorm_pool', 'conv', 'groupnorm_pool', 'to_seq'], names
+    assert names[:4] == ['conv1_groupnorm_pool', 'conv', 'groupnorm_pool', 'to_seq_split'] and 'split' not in names, names
     assert 'lstm_xproj_x3' in names and 'lstm_rec_x3' in names and 'linear_x3' in names, names
 
 
