@@ -108,6 +108,9 @@ struct ConvGeom {
     bool split_out = false;   // write the output as split channels-last bf16 planes
     int xchunk = 16, xnchunks = 1, xKB = 1, xKB_last = 1, xPSTR = 48, xplane = 0;
     int xtps = 0;             // > 0: the pipelined kernel (conv_x3p.hip) covers this geometry: tile copies per weight-stage boundary
+    bool x6 = false;          // three-plane ("bf16x6") convolution in front of a GroupNorm (conv_x6.hip): fp32 NCHW in and out
+    void* d_wx6 = nullptr;    // its weights [chunk][tap][block][plane 3][lane][8]
+    int x6CBpad = 1;
     void* d_wx3 = nullptr;
     void* d_wx5 = nullptr;    // conv_taps_x3.hip, five-group packing (kw <= 13)
     void* d_wx3w = nullptr;   // gemm_x3w.hip: the same weights in column groups of wtn (256 | 320) for the wide-tile kernel
@@ -296,6 +299,51 @@ int upload_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowma
     }
     HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
+// conv_x6.hip: 16-channel chunks, tile = 3 planes x npix x 48 bytes, ring 3 x (cb x 3 KB): two workgroups per CU
+int plan_x6_geom(ConvGeom& g) {
+    if (g.Cin % 16) return -1;
+    const int npix = g.IH * g.IW;
+    const int cb = krk_x6_cb(g.Cout);
+    if ((size_t)3 * npix * 48 + (size_t)9 * cb * 1024 > 80 * 1024) return -1;
+    g.xchunk = 16;
+    g.xnchunks = g.Cin / 16;
+    g.xKB = g.xKB_last = 1;
+    g.xPSTR = 48;
+    g.xplane = npix * 48;
+    const int CBt = (g.Cout + 31) / 32;
+    g.x6CBpad = (CBt + cb - 1) / cb * cb;
+    return 0;
+}
+
+// wx6[chunk][tap][cb][plane 3][lane][8] (bf16): lane l of block cb holds filter cb*32 + (l&31), channels chunk*16 + 8*(l>>5) + 0..7 of
+// tap (dy,dx); planes h = bf16(w), m = bf16(w - h), l = bf16(w - h - m).  `w` is (Cout, Cin, kh, kw) f32.
+int upload_x6_weights(ConvGeom& g, const float* w) {
+    const int kk = g.kh * g.kw;
+    const int CBt = (g.Cout + 31) / 32, CBpad = g.x6CBpad;
+    std::vector<uint16_t> pack(((size_t)g.xnchunks * kk + 4) * CBpad * 1536, 0);     // + slack records (the ring looks two stages ahead)
+    for (int ci = 0; ci < g.xnchunks; ++ci)
+        for (int t = 0; t < kk; ++t)
+            for (int b = 0; b < CBt; ++b)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int co = b * 32 + (lane & 31);
+                        const int c = ci * 16 + 8 * (lane >> 5) + e;
+                        if (co >= g.Cout || c >= g.Cin) continue;
+                        const float v = w[((size_t)co * g.Cin + c) * kk + t];
+                        const uint16_t h = f2bf(v);
+                        const float r1 = v - bf2f(h);
+                        const uint16_t m = f2bf(r1);
+                        const uint16_t l = f2bf(r1 - bf2f(m));
+                        const size_t base = ((((size_t)ci * kk + t) * CBpad + b) * 3) * 512 + lane * 8 + e;
+                        pack[base] = h;
+                        pack[base + 512] = m;
+                        pack[base + 1024] = l;
+                    }
+    HIPCHK(hipMalloc(&g.d_wx6, pack.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(g.d_wx6, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return KRK_OK;
 }
 
@@ -617,6 +665,7 @@ void free_step(Step& s) {
     if (s.cg.d_wx3) (void)hipFree(s.cg.d_wx3);
     if (s.cg.d_wx5) (void)hipFree(s.cg.d_wx5);
     if (s.cg.d_wx3w) (void)hipFree(s.cg.d_wx3w);
+    if (s.cg.d_wx6) (void)hipFree(s.cg.d_wx6);
     if (s.d_c1w) (void)hipFree(s.d_c1w);
     if (s.d_c1b) (void)hipFree(s.d_c1b);
     if (s.d_wrecsm) (void)hipFree(s.d_wrecsm);
@@ -785,6 +834,13 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
     }
     plan_conv_geom(g);
     if (upload_conv_weights(g, L.w[0], L.w[1], nullptr, nullptr) != KRK_OK) return KRK_E_HIP;
+    // A convolution of a split-bf16 plan that must keep fp32-class operands (it feeds a GroupNorm, directly or through later
+    // layers: i <= last_gn) takes the three-plane kernel (conv_x6.hip) when its geometry fits: fp32 NCHW in and out like the f32
+    // kernel it replaces, 6/16 of its matrix time.  KRK_NO_CONV_X6 keeps the exact-f32 kernel.
+    if (want_x3 && !left_x3 && !x3 && !g.out_seq && g.Cin % 16 == 0 && !getenv("KRK_NO_CONV_X6") && plan_x6_geom(g) == 0) {
+        if (upload_x6_weights(g, L.w[0]) != KRK_OK) return KRK_E_HIP;
+        g.x6 = true;
+    }
     if (x3) {
         // the first convolution reads the caller's fp32 NCHW image on the f32 cores and hands
         // over split channels-last planes; every later one runs on the bf16 cores
@@ -1284,7 +1340,7 @@ void fill_gemm(const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane
     a.nlines = 0;
     a.dbg = dbg;
     a.stagger = 0;
-    a.nbuf = 3;
+    a.nbuf = env_int("KRK_GEMM_SPREAD", 1) ? 3 : 2;   // gemm_x3.hip reads nbuf == 2 as "copies in front of the MFMAs" (A/B probe)
 }
 
 // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
@@ -1304,6 +1360,7 @@ struct Probes {
     int gemm_w = env_int("KRK_GEMM_W", 0);       // wide-tile projection kernel (gemm_x3w.hip): 0 never (default: alone it is 6-10 % faster than
                                                  // gemm_x3, but one 110 KB workgroup per CU shuts the other batches' kernels out: 111.2 k vs 113.1 k
                                                  // lines/s on the pipelined bench, profiles/r04_kernel_matrix.txt), 1 where packed, -1 by size
+    int conv_x6 = env_int("KRK_CONV_X6", 1);     // 0: the exact-f32 kernel also where the three-plane kernel (conv_x6.hip) is planned
     int taps_dma = env_int("KRK_TAPS_DMA", 1);   // conv_taps_x3.hip: input tile through raw-buffer -> LDS copies (0: register staging)
     int gemm_nbuf = env_int("KRK_GEMM_NBUF", 3); // wide-tile projection kernel: LDS buffers (3 | 4)
     int gemm_stag = env_int("KRK_GEMM_STAG", 0); // wide-tile projection kernel: start delay (cycles) per workgroup phase
@@ -1453,6 +1510,20 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
         if (mark("conv1_x3", s.flops)) return kFailed;
         return one ? krk_launch_conv1_x3_b1(a, g.pool, stream) : krk_launch_conv1_x3(a, g.pool, stream);
+    }
+    if (g.x6 && probe.conv_x6) {
+        // fp32 NCHW -> three bf16 planes NHWC (h + m + l = x to 2^-24), then the six-term convolution; fp32 NCHW out
+        const size_t in_elems = (size_t)N * s.C * s.H * Win;
+        if (s.aux2.ensure(in_elems * 3 * sizeof(uint16_t))) return nomem();
+        if (mark("split3", 0)) return kFailed;
+        if (int rc = krk_launch_split3_nhwc(cur, s.aux2.p, in_elems, N, s.C, s.H, Win, stream)) return rc;
+        X3Args a;
+        fill_x3(g, a, s.aux2.p, in_elems, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out), probe.x3_dbg);
+        a.wpack = (const __bf16*)g.d_wx6;
+        a.CBpad = g.x6CBpad;
+        s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
+        if (mark("conv_x6", s.flops)) return kFailed;
+        return krk_launch_conv_x6(a, g.pool, stream);
     }
     ConvArgs a;
     fill_conv(g, a, cur, outp, N, Win, lens_at(s.len_in), lens_at(s.len_out));

@@ -309,6 +309,11 @@ int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);
 int krk_launch_lstm_big(const LstmArgs& a, hipStream_t s);   // 256 < Hp <= 768 (lstm_rec.hip)
 int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
 int krk_launch_conv_x3_b1(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
+// three-plane ("bf16x6") convolution in front of a GroupNorm (conv_x6.hip): fp32-class products on the bf16 cores, fp32 NCHW out
+int krk_x6_cb(int Cout);
+int krk_launch_conv_x6(const X3Args& a, bool pool, hipStream_t s);
+// fp32 (N,C,H,W) -> three bf16 planes (h, m, l: x = h + m + l exactly to 2^-24) in NHWC order (norm_x3.hip)
+int krk_launch_split3_nhwc(const float* x, void* y, size_t plane, int N, int C, int H, int W, hipStream_t s);
 // pipelined variant (conv_x3p.hip): asynchronous double-buffered tile staging; split outputs only
 int krk_conv_x3p_tps(int cchunk, int kb, int kb_last, int npix, int iw, int ntaps, int cout, size_t line_bytes);
 int krk_launch_conv_x3p(const X3Args& a, bool pool, hipStream_t s);

@@ -57,16 +57,20 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     // asynchronous global -> LDS copies (global_load_lds_dwordx4): the destination is wave-uniform
     // base + lane*16, which is exactly the [piece][row] order of the tile
-    auto issue = [&](int kb, int buf) {
+    // copy c (0..5) of K step kb into buffer buf: 0..3 = X pieces (plane, k-half), 4..5 = the two halves of the W tile
+    auto issue_one = [&](int kb, int buf, int c) {
         f32x4* dst = lds + buf * (A_Q + B_Q) + wave * 64;
+        if (c < 4) {
+            const int p = c >> 1, h = c & 1;
+            __builtin_amdgcn_global_load_lds((const void*)(xa + p * a.x_plane + (size_t)(kb * 2 + h) * a.M * 8),
+                                             (lds_ptr)(dst + (p * 2 + h) * TM), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((const void*)(wb + (size_t)kb * B_Q + (c - 4) * 256), (lds_ptr)(dst + A_Q + (c - 4) * 256), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int kb, int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                __builtin_amdgcn_global_load_lds((const void*)(xa + p * a.x_plane + (size_t)(kb * 2 + h) * a.M * 8),
-                                                 (lds_ptr)(dst + (p * 2 + h) * TM), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void*)(wb + (size_t)kb * B_Q), (lds_ptr)(dst + A_Q), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void*)(wb + (size_t)kb * B_Q + 256), (lds_ptr)(dst + A_Q + 256), 16, 0, 0);
+        for (int c = 0; c < 6; ++c) issue_one(kb, buf, c);
     };
 
     f32x16 acc[4][2];
@@ -83,6 +87,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
     // of 768 cycles of MFMAs, hidden only as far as the CU's second workgroup happened to be out of phase
     // (0.106 ms for the bare loop against 0.056 ms of MFMA time).
     const bool no_mma = KRK_DBGBIT(a, 1), no_copy = KRK_DBGBIT(a, 2), no_lds = KRK_DBGBIT(a, 8);
+    const bool spread = a.nbuf != 2;          // probe (KRK_GEMM_SPREAD=0 -> nbuf 2): all six copies in front of the MFMAs, as before
     if (!no_copy) { issue(0, 0);
     if (nkb > 1) issue(1, 1); }
 
@@ -102,16 +107,28 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
             f.wl[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (2 + half) * TN + cb * 32 + px]);
         }
     };
-    auto mma = [&](const Frag& f) {
-        if (no_mma) return;
+    // `refill_kb` >= 0: the six copies of that K step are issued BETWEEN the MFMAs (round 4): a copy instruction stands ~200-300
+    // cycles in the CU's address path when all eight waves of the CU issue theirs (phase accounting of gemm_x3w.hip,
+    // profiles/r04_phase_stats.txt); in front of the MFMAs that is dead time for the wave, behind a group of six MFMAs most of it
+    // is covered by the matrix pipe working them off
+    auto mma = [&](const Frag& f, int refill_kb, int refill_buf) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < 4; ++cb) {
+            if (!no_mma) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[cb], f.xh[s], acc[cb][s], 0, 0, 0);
-                KRK_CROSS(acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[cb], f.xl[s], acc[cb][s], 0, 0, 0);
-                          acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wl[cb], f.xh[s], acc[cb][s], 0, 0, 0);)
+                for (int s = 0; s < 2; ++s) {
+                    acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[cb], f.xh[s], acc[cb][s], 0, 0, 0);
+                    KRK_CROSS(acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[cb], f.xl[s], acc[cb][s], 0, 0, 0);
+                              acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wl[cb], f.xh[s], acc[cb][s], 0, 0, 0);)
+                }
             }
+            if (refill_kb >= 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (cb < 2) { issue_one(refill_kb, refill_buf, 2 * cb); issue_one(refill_kb, refill_buf, 2 * cb + 1); }
+                else issue_one(refill_kb, refill_buf, 2 + cb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     };
     // one K step: publish step kb+1 (its copies landed, everyone is done reading step kb-1 ... kb), start its fragment reads,
     // refill the buffer step kb used, then the MFMAs of step kb on the fragments read one step ago
@@ -124,9 +141,10 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
             read((kb + 1) % 3, nxt);
-            if (kb + 3 < nkb && !no_copy) issue(kb + 3, kb % 3);
+            if (kb + 3 < nkb && !no_copy && !spread) issue(kb + 3, kb % 3);
         }
-        mma(cur);
+        // ONE call site for the MFMAs (two, with the accumulators flowing through both, made the compiler spill them)
+        mma(cur, (spread && !no_copy && kb + 3 < nkb) ? kb + 3 : -1, kb % 3);
     };
     Frag fa = {}, fb = {};
     if (nkb > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");

@@ -94,7 +94,47 @@ __global__ void __launch_bounds__(256) toseq_split_f32_kernel(const float* __res
     }
 }
 
+// fp32 NCHW -> three bf16 planes NHWC, x = h + m + l (conv_x6.hip's input).  Thread = (pixel, 8-channel piece), pieces of a pixel in
+// adjacent lanes: the three 16-byte stores of a wave are contiguous; the 8 reads of a thread are each coalesced along the columns.
+__global__ void __launch_bounds__(256) split3_nhwc_kernel(const float* __restrict__ x, __bf16* __restrict__ y, size_t plane,
+                                                          int C, int H, int W, size_t total) {
+    const int Q = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % Q);
+        const size_t pix = i / Q;                                  // (n*H + h)*W + w
+        const int w = (int)(pix % W);
+        const size_t nh = pix / W;
+        const int h = (int)(nh % H);
+        const size_t n = nh / H;
+        const float* src = x + ((n * C + (size_t)q * 8) * H + h) * W + w;
+        bf16x8 hv, mv, lv;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = src[(size_t)k * H * W];
+            const __bf16 hi = (__bf16)v;
+            const float r1 = v - (float)hi;
+            const __bf16 mi = (__bf16)r1;
+            hv[k] = hi;
+            mv[k] = mi;
+            lv[k] = (__bf16)(r1 - (float)mi);
+        }
+        const size_t dst = pix * C + (size_t)q * 8;
+        *reinterpret_cast<bf16x8*>(y + dst) = hv;
+        *reinterpret_cast<bf16x8*>(y + plane + dst) = mv;
+        *reinterpret_cast<bf16x8*>(y + 2 * plane + dst) = lv;
+    }
+}
+
 }  // namespace
+
+int krk_launch_split3_nhwc(const float* x, void* y, size_t plane, int N, int C, int H, int W, hipStream_t s) {
+    if (C % 8) return -4;
+    const size_t total = (size_t)N * H * W * (C / 8);
+    if (!total) return 0;
+    const unsigned blocks = (unsigned)min((size_t)16384, (total + 255) / 256);
+    hipLaunchKernelGGL(split3_nhwc_kernel, dim3(blocks), dim3(256), 0, s, x, (__bf16*)y, plane, C, H, W, total);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int krk_launch_toseq_split_f32(const float* x, void* y, size_t plane, int N, int C, int H, int W, hipStream_t s) {
     if (C % 8) return -4;

@@ -569,6 +569,7 @@ def test_x3_plan_keeps_everything_up_to_the_last_groupnorm_on_the_f32_cores():
     # convolutions behind the last GroupNorm: the first of them computes in f32 and hands over split planes, the next is split
     n2 = kernels('[1,16,0,1 Cr3,3,16 Gn4 Mp2,2 Cr3,5,32 Cr3,3,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx16 O1c9]', 16)
     assert n2[:2] == ['conv1_groupnorm_pool', 'conv'] and 'conv_x3' in n2, n2   # the pool behind the GroupNorm is part of its apply pass
+    assert 'conv_x6' not in n2, n2          # three-plane operands only IN FRONT of a GroupNorm: behind the last one bf16x3 suffices
     assert 'gn_x3' not in n2 and not any(k.startswith('groupnorm') for k in n2[n2.index('conv_x3'):]), n2
 
 
@@ -602,7 +603,8 @@ def test_x3_bench_b_groupnorm_network_against_reference_golden():
     names = [n_ for n_, _, _ in eng.layer_times()[0]]
     eng.close()
     # (round 4: the one-channel first convolution is recomputed inside its GroupNorm's two passes, c1gn.hip)
-    assert names[:4] == ['conv1_groupnorm_pool', 'conv', 'groupnorm_pool', 'to_seq_split'] and 'split' not in names, names
+    # (... and the convolution between the two GroupNorms runs as six bf16 MFMAs per product on three-plane operands, conv_x6.hip)
+    assert names[:5] == ['conv1_groupnorm_pool', 'split3', 'conv_x6', 'groupnorm_pool', 'to_seq_split'] and 'split' not in names, names
     assert 'lstm_xproj_x3' in names and 'lstm_rec_x3' in names and 'linear_x3' in names, names
 
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything the round's profiles/ directory holds, from ONE build, in one gpurun call:
-#   bash tools/collect_round.sh r03      ->  gpurun_out/final_<tag>/   (copy what should be judged into profiles/)
+#   bash tools/collect_round.sh r04      ->  gpurun_out/final_<tag>/   (copy what should be judged into profiles/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/final_$TAG
 rm -rf $O
@@ -26,11 +26,21 @@ python bench.py --precision f32 --no-cpu-baseline > $O/${TAG}_f32_bench_default.
 python bench.py --mode config4 --no-cpu-baseline > $O/${TAG}_bench_config4.json 2>/dev/null
 python bench.py --force-dist --no-cpu-baseline > $O/${TAG}_bench_force_dist.json 2> $O/force_dist.err
 python bench.py --mode api --no-cpu-baseline > $O/${TAG}_bench_api.json 2>/dev/null
-(timeout 100 python tools/bench_b_probe.py > $O/${TAG}_bench_b.txt 2>&1)
+(timeout 200 python tools/bench_b_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bench_b.txt)
+(KRK_NO_C1GN=1 KRK_NO_CONV_X6=1 KRK_NO_TOSEQ_SPLIT=1 timeout 200 python tools/bench_b_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bench_b_round3_kernels.txt)
+python bench.py --gpus 2 --share-device --no-cpu-baseline > $O/${TAG}_two_ranks_one_device.json 2> $O/two_ranks.err
+(timeout 300 python tools/kernel_ab.py "KRK_GEMM_W=0,KRK_CONV_X3P=0,KRK_TAPS_DMA=0" "KRK_GEMM_W=0,KRK_CONV_X3P=1,KRK_TAPS_DMA=1" "KRK_GEMM_W=1,KRK_CONV_X3P=1,KRK_TAPS_DMA=1" 2>&1 | grep -v amdgpu.ids > $O/${TAG}_kernel_ab_alone.txt)
+for rep in 1 2; do for cfg in "0 0 0" "0 1 0" "0 1 1" "1 1 1"; do set -- $cfg
+  echo "KRK_GEMM_W=$1 KRK_CONV_X3P=$2 KRK_TAPS_DMA=$3 rep $rep:" $(KRK_GEMM_W=$1 KRK_CONV_X3P=$2 KRK_TAPS_DMA=$3 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'lines/s', d['ms_per_step'], 'ms/step')") >> $O/${TAG}_kernel_matrix.txt
+done; done
+python -m kraken_amd.build --ablate > /dev/null 2>&1
+(timeout 200 python tools/phase_stats.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_stats.txt)
+(timeout 200 python tools/phase_stats.py KRK_GEMM_W=1 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_phase_stats.txt)
+for i in 0 1 2; do (KRK_LSTM_V=3 timeout 300 python tools/ws_flake.py 350 $i 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_exchange_timeouts_lstm_ws_forced_narrow.txt); done
+(KRK_CONV_X6=0 timeout 200 python tools/fuzz_plans.py 60 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz_f32_convs_same_seed.txt)
+(timeout 200 python tools/fuzz_plans.py 60 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz_x6_convs_same_seed.txt)
 (timeout 200 python tools/lstm_ws_probe.py --wp 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lstm_probe.txt)
 (timeout 150 python tools/ws_flake.py 100 2>&1 | grep -v amdgpu.ids > $O/${TAG}_exchange_timeouts_default.txt)
-(KRK_LSTM_V=3 timeout 150 python tools/ws_flake.py 60 2 2>&1 | grep -v amdgpu.ids > $O/${TAG}_exchange_timeouts_lstm_ws_forced.txt)
 (timeout 60 python tools/batch_invariance.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_batch_invariance.txt)
-(KRK_LSTM_V=4 timeout 60 python tools/wp_timeline.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lstm_wp_timeline.txt)
 (timeout 200 python tools/fuzz_plans.py ${FUZZ:-100} --time-seed 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz.txt)
 for f in $O/${TAG}_*bench*.json; do echo $(basename $f) $(tail -1 $f | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['unit'], d.get('steps'))" 2>&1 | tail -1); done
