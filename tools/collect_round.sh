@@ -33,7 +33,7 @@ python bench.py --gpus 2 --share-device --no-cpu-baseline > $O/${TAG}_two_ranks_
 for rep in 1 2; do for cfg in "0 0 0" "0 1 0" "0 1 1" "1 1 1"; do set -- $cfg
   echo "KRK_GEMM_W=$1 KRK_CONV_X3P=$2 KRK_TAPS_DMA=$3 rep $rep:" $(KRK_GEMM_W=$1 KRK_CONV_X3P=$2 KRK_TAPS_DMA=$3 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'lines/s', d['ms_per_step'], 'ms/step')") >> $O/${TAG}_kernel_matrix.txt
 done; done
-python -m kraken_amd.build --ablate > /dev/null 2>&1
+[ -f kraken_amd/libkraken_amd_ablate.so ] || python -m kraken_amd.build --ablate > /dev/null 2>&1
 (timeout 200 python tools/phase_stats.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_stats.txt)
 (timeout 200 python tools/phase_stats.py KRK_GEMM_W=1 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_phase_stats.txt)
 for i in 0 1 2; do (KRK_LSTM_V=3 timeout 300 python tools/ws_flake.py 350 $i 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_exchange_timeouts_lstm_ws_forced_narrow.txt); done
