@@ -61,6 +61,14 @@ extern "C" {
 #define KRK_OP_RESHAPE_HC 4   /* Reshape S1(1x0)1,3: fold height into channels, layers.py:285 */
 #define KRK_OP_LSTM       5   /* TransposedSummarizingRNN (L{f,r,b}x) layers.py:462 */
 #define KRK_OP_LINEAR     6   /* LinSoftmax (logits, no softmax) layers.py:679 */
+/* A parallel group `( a b ... )` (MultiParamParallel, layers.py:56-71; model.py:876-905) is written into the layer list as
+ * PAR_BEGIN, the layers of member a, PAR_NEXT, the layers of member b, ..., PAR_END: every member reads the tensor in front of
+ * PAR_BEGIN, PAR_END concatenates the members' outputs on the channel axis.  Groups nest; a serial group `[ ... ]` needs no
+ * marker (it IS its layers). */
+#define KRK_OP_PAR_BEGIN  7
+#define KRK_OP_PAR_NEXT   8
+#define KRK_OP_PAR_END    9
+#define KRK_OP_ADD        10  /* Addition layers.py:188-223: cout = chunk size, kh = 0 channels / 1 height */
 
 /* activations of ActConv2D (layers.py:808-825).  'sigmoid' is skipped in the
  * reference's forward (layers.py:850-852) and is therefore identical to LINEAR. */
@@ -100,13 +108,19 @@ typedef struct krk_plan krk_plan;
  *            w[4d+0]=weight_ih (4H,In)  w[4d+1]=weight_hh (4H,H)  w[4d+2]=bias_ih (4H)  w[4d+3]=bias_hh (4H)
  *            gate row order i,f,g,o (torch.nn.LSTM)
  *            kw = 0: time runs along W (Lxx); kw = 1: along H (Lxy, the reference's `transpose`, layers.py:521-523).
- *            kh = 1 (with kw = 1 only): summarising LSTM (Lxys): only the last step of every column is kept, the output
- *            has height 1 (layers.py:537-539).
+ *            kh = 1: summarising LSTM: only the last step of every sequence is kept (layers.py:537-539) -- with kw = 1 (L?ys) the
+ *            output has height 1, with kw = 0 (L?xs) width 1 (valid widths become 1; the reference refuses seq_lens > 1
+ *            there, layers.py:543-545, and so does the host side).
  *            After the height collapse (height 1, kw = 0) the layer is a plain sequence layer; on an image
  *            (height > 1, or kw = 1) every row / column is one sequence and the output is an image again
  *            (TransposedSummarizingRNN.forward on a 4-D input, layers.py:519-547) -- f32 plan only; seq_lens only with
  *            kw = 1 (columns run their full height, padding columns are zeroed afterwards), like the reference.
  *  LINEAR    cout=out features; w[0]=lin.weight (cout,In), w[1]=lin.bias (cout)
+ *  PAR_BEGIN / PAR_NEXT / PAR_END  no parameters (see above).  The members' output heights and sequence/image form must
+ *            agree (KRK_E_INVALID otherwise); their widths must agree for the width of the call (checked in krk_forward, as
+ *            torch.cat would); valid widths behind the group are those of its LAST member (layers.py:64-66).  Exact-f32
+ *            arithmetic up to the group's end (the split-bf16 kernels may take over behind it).
+ *  ADD       cout = chunk, kh = axis (0 channels, 1 height): out[j] = sum_k in[k*chunk + j], k < floor(size / chunk)
  */
 typedef struct krk_layer {
     int op;

@@ -49,8 +49,8 @@ int fail(int code, const std::string& msg) {
             return fail(KRK_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
-enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG, S_UNSPLIT };
-const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img", "unsplit"};
+enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG, S_UNSPLIT, S_ALIAS, S_CONCAT, S_ADD };
+const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img", "unsplit", "alias", "concat", "add"};
 
 
 
@@ -496,6 +496,13 @@ struct Step {
     bool split_rows = false;    // TOSEQ: fp32 NCHW in, K-blocked split sequence rows out (toseq_split_f32)
     int img_axis = 0;           // LSTM over image rows (1) or columns (2): sequences = N*H (N*W), steps = W (H); 0 = plain sequence
     int yaxis = 0;              // IMG2ROWS / ROWS2IMG: 1 = columns are the sequences
+    // parallel groups (MultiParamParallel): S_ALIAS makes the output of step `src` (-1: the plan's input) the current tensor
+    // again (a group member's input; no kernel); S_CONCAT joins the members' outputs `srcs` = (step, channels, length stage)
+    // on the channel axis; S_ADD sums the `nk` pieces of `chunk` entries of the channel (add_axis 0) or height (1) axis
+    int src = -1;
+    struct Member { int step, C, stage; };
+    std::vector<Member> srcs;
+    int add_axis = 0, chunk = 0, nk = 0;
     int last_only = 0;          // ROWS2IMG: keep the last step of every column (summarising LSTM): output height 1; LSTM step: time steps of the rows
     // output description
     bool out_is_seq = false;
@@ -519,8 +526,9 @@ struct krk_plan {
     std::vector<Step> steps;
     int nstages = 1;  // length-table rows: 0 = input widths
     // how lengths evolve: stage s+1 = f(stage s) for the steps that change the width
-    struct LenOp { int kind; int k, s, d, p; };  // kind 0: conv (clamp min 1), 1: pool
-    std::vector<LenOp> lenops;                     // lenops[i] produces stage i+1 from stage i
+    struct LenOp { int kind; int k, s, d, p; int from; };  // kind 0: conv (clamp min 1), 1: pool, 2: one column (L?xs)
+    std::vector<LenOp> lenops;                     // lenops[i] produces stage i+1 from stage `from` <= i (a tree: parallel groups)
+    int out_stage = 0;                             // the stage of the plan's output
     DevBuf d_lens;
     int* h_lens_pinned = nullptr;
     size_t h_lens_cap = 0;
@@ -544,13 +552,24 @@ struct krk_plan {
 namespace {
 
 int width_after(const krk_plan::LenOp& op, int L) {
+    if (op.kind == 2) return std::min(L, 1);
     if (op.kind == 0) return std::max(conv_out(L, op.k, op.s, op.d, op.p), 1);
     return floordiv(L - (op.k - 1) - 1, op.s) + 1;
 }
 // tensor width (not clamped: shapes follow torch's conv/pool arithmetic)
 int shape_after(const krk_plan::LenOp& op, int W) {
+    if (op.kind == 2) return std::min(W, 1);
     if (op.kind == 0) return conv_out(W, op.k, op.s, op.d, op.p);
     return floordiv(W - (op.k - 1) - 1, op.s) + 1;
+}
+
+// value of length stage `stage` for an input width/length v0 (stage s+1 derives from stage lenops[s].from <= s)
+template <typename F>
+int stage_value(const krk_plan& p, int v0, int stage, F step, std::vector<int>& v) {
+    v.resize(p.lenops.size() + 1);
+    v[0] = v0;
+    for (int s = 0; s < stage; ++s) v[s + 1] = step(p.lenops[s], v[p.lenops[s].from]);
+    return v[stage];
 }
 
 void pack_lstm_recurrent(const Step& st, const float* const* whh, int M, std::vector<float>& pack) {
@@ -743,6 +762,39 @@ struct PlanBuilder {
     bool left_x3 = false;     // a layer that exists in the f32 plan only was met: the rest of the network stays there
     int last_gn = -1;         // index of the network's last GroupNorm layer
 
+    // a layer that changes the width: a new row of the length table, derived from the current one
+    void new_stage(int kind, int k, int s_, int d, int pd) {
+        p->lenops.push_back({kind, k, s_, d, pd, stage});
+        stage = (int)p->lenops.size();
+    }
+
+    // parallel groups being compiled, innermost last
+    struct Fork {
+        int src, C, H, stage;
+        bool seq;
+        std::vector<Step::Member> members;
+        int outH = 0;
+        bool outseq = false;
+    };
+    std::vector<Fork> forks;
+    int last_f32_only = -1;   // index of the last layer that exists in the exact-f32 arithmetic only (GroupNorm, group markers, A)
+
+    int par_begin(const std::string& where);
+    int par_member_done(const std::string& where);
+    int par_next(const std::string& where);
+    int par_end(const std::string& where);
+    int addition(const krk_layer& L, const std::string& where);
+    void push_alias(int src) {
+        Step a;
+        a.kind = S_ALIAS;
+        a.src = src;
+        a.C = C; a.H = H;
+        a.out_is_seq = seq;
+        a.outC = C; a.outH = H;
+        a.len_in = a.len_out = stage;
+        p->steps.push_back(std::move(a));
+    }
+
     void push_toseq() {
         Step s;
         s.kind = S_TOSEQ;
@@ -811,8 +863,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
     g.pw = (L.dw * (L.kw - 1)) / 2;
     g.act = map_act(L.act);
     s.len_in = stage;
-    p->lenops.push_back({0, L.kw, L.sw, L.dw, g.pw});
-    ++stage;
+    new_stage(0, L.kw, L.sw, L.dw, g.pw);
     const int Ho = conv_out(H, L.kh, L.sh, L.dh, g.ph);
     if (Ho <= 0) return fail(KRK_E_INVALID, where + ": conv output height <= 0");
     // fuse a directly following 2x2/2 max-pool, or the height->channel reshape
@@ -820,8 +871,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
         layers[i + 1].kw == 2 && layers[i + 1].sh == 2 && layers[i + 1].sw == 2 && Ho >= 2 &&
         monotone_act(L.act)) {
         g.pool = true;
-        p->lenops.push_back({1, 2, 2, 1, 0});
-        ++stage;
+        new_stage(1, 2, 2, 1, 0);
         ++i;
         // bf16x3: conv_x3.hip can pool AND write the collapsed sequence rows in one epilogue
         if (x3 && split_fmt && i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
@@ -898,8 +948,7 @@ int PlanBuilder::maxpool(const krk_layer& L, const std::string& where) {
     s.Ho = floordiv(H - (L.kh - 1) - 1, L.sh) + 1;
     if (s.Ho <= 0) return fail(KRK_E_INVALID, where + ": pool output height <= 0");
     s.len_in = stage;
-    p->lenops.push_back({1, L.kw, L.sw, 1, 0});
-    ++stage;
+    new_stage(1, L.kw, L.sw, 1, 0);
     s.len_out = stage;
     s.outC = C;
     s.outH = s.Ho;
@@ -935,8 +984,7 @@ int PlanBuilder::groupnorm(const krk_layer& L, const std::string& where) {
         s.pooled = true;
         s.kh = P.kh; s.kw = P.kw; s.sh = P.sh; s.sw = P.sw;
         s.Ho = Ho;
-        p->lenops.push_back({1, P.kw, P.sw, 1, 0});
-        ++stage;
+        new_stage(1, P.kw, P.sw, 1, 0);
         ++i;
         s.len_out = stage;
         s.outH = Ho;
@@ -972,11 +1020,13 @@ int PlanBuilder::reshape(const krk_layer& L, const std::string& where) {
     if (x3 && split_fmt && !seq && C % 8) leave_x3();
     const bool x3 = this->x3 && split_fmt;
     if (seq) return fail(KRK_E_UNSUPPORTED, where + ": reshape after a sequence layer");
+    const int Cimg = C;
     push_toseq();
     p->steps.back().on_split = x3;   // writes the K-blocked split sequence rows gemm_x3.hip reads
     // An exact-f32 image part (GroupNorm networks) in front of split-bf16 sequence layers: collapse AND split in one pass
     // (norm_x3.hip toseq_split_f32) instead of to_seq + split_rows -- one read and one write of the tensor instead of two each
-    if (this->x3 && !split_fmt && C % 16 == 0 && i + 1 < n_layers &&
+    // (the kernel moves 8 channels per lane; the rows' K blocks want 16 features)
+    if (this->x3 && !split_fmt && Cimg % 8 == 0 && C % 16 == 0 && i + 1 < n_layers &&
         (layers[i + 1].op == KRK_OP_LSTM || layers[i + 1].op == KRK_OP_LINEAR) && !getenv("KRK_NO_TOSEQ_SPLIT")) {
         p->steps.back().split_rows = true;
         split_fmt = true;
@@ -1063,9 +1113,11 @@ int PlanBuilder::recurrent_or_linear(const krk_layer& L, const std::string& wher
     // LSTM over the rows (kw = 0) or columns (kw = 1) of an image: reference TransposedSummarizingRNN on a
     // 4-D input (layers.py:519-547; the BLLA segmenter's Lbx/Lby pairs).  img2rows -> LSTM -> rows2img.
     const bool img_lstm = L.op == KRK_OP_LSTM && !seq && (H != 1 || L.kw == 1);
+    // summarising: only the last step of every sequence is kept (layers.py:537-539).  Along the height (L?ys) the image loses
+    // its rows, along the width (L?xs) its columns: the tensor is one column wide from there on
     const bool summarize = L.op == KRK_OP_LSTM && L.kh == 1;
-    if (summarize && !(img_lstm && L.kw == 1))
-        return fail(KRK_E_UNSUPPORTED, where + ": only column (y-axis) LSTMs can summarise");
+    const bool sum_x = summarize && L.kw == 0;
+    if (sum_x && (x3 || split_fmt)) return fail(KRK_E_UNSUPPORTED, where + ": x-axis summarising LSTM on split-bf16 planes");
     const int Himg = H;   // image height in front of the layer
     if (img_lstm) {
         if (x3) leave_x3();   // LSTMs over image rows/columns exist in the f32 plan only
@@ -1104,16 +1156,94 @@ int PlanBuilder::recurrent_or_linear(const krk_layer& L, const std::string& wher
     }
     if (int rc = (L.op == KRK_OP_LINEAR) ? linear(L, where, s) : lstm(L, where, s)) return rc;
     p->steps.push_back(std::move(s));
-    if (img_lstm) {
+    if (img_lstm || sum_x) {
+        // sum_x on a plain sequence: rows (N, W, C) -> (N, 1, C), the same pick with one row per line
         Step b;
         b.kind = S_ROWS2IMG;
         b.C = C; b.H = Himg; b.yaxis = L.kw == 1;
         b.last_only = summarize;
-        b.outC = C; b.outH = summarize ? 1 : Himg;
-        b.len_in = b.len_out = stage;
+        b.out_is_seq = !img_lstm;
+        b.outC = C; b.outH = (summarize && !sum_x) ? 1 : Himg;
+        b.len_in = stage;
+        if (sum_x) new_stage(2, 1, 1, 1, 0);
+        b.len_out = stage;
         p->steps.push_back(std::move(b));
-        if (summarize) H = 1;
+        if (summarize && !sum_x) H = 1;
     }
+    return KRK_OK;
+}
+
+// MultiParamParallel (reference layers.py:56-71, model.py:876-905).  Every member starts from the tensor in front of the group
+// (an S_ALIAS step: no kernel, no copy -- every step owns its output buffer, nothing computes in place) and S_CONCAT gathers the
+// members' outputs on the channel axis.
+int PlanBuilder::par_begin(const std::string& where) {
+    if (split_fmt) return fail(KRK_E_UNSUPPORTED, where + ": parallel group behind split-bf16 layers");
+    Fork f;
+    f.src = (int)p->steps.size() - 1;
+    f.C = C; f.H = H; f.seq = seq; f.stage = stage;
+    forks.push_back(f);
+    push_alias(f.src);
+    return KRK_OK;
+}
+
+int PlanBuilder::par_member_done(const std::string& where) {
+    if (forks.empty()) return fail(KRK_E_INVALID, where + ": group marker outside a parallel group");
+    Fork& f = forks.back();
+    if (split_fmt) return fail(KRK_E_UNSUPPORTED, where + ": parallel member ends in split-bf16 planes");
+    if (!f.members.empty() && (f.outH != H || f.outseq != seq))
+        return fail(KRK_E_INVALID, where + ": Output shape in parallel block not equal!");
+    f.outH = H;
+    f.outseq = seq;
+    f.members.push_back({(int)p->steps.size() - 1, C, stage});
+    return KRK_OK;
+}
+
+int PlanBuilder::par_next(const std::string& where) {
+    if (int rc = par_member_done(where)) return rc;
+    const Fork& f = forks.back();
+    C = f.C; H = f.H; seq = f.seq; stage = f.stage;
+    push_alias(f.src);
+    return KRK_OK;
+}
+
+int PlanBuilder::par_end(const std::string& where) {
+    if (int rc = par_member_done(where)) return rc;
+    Fork f = std::move(forks.back());
+    forks.pop_back();
+    Step c;
+    c.kind = S_CONCAT;
+    c.srcs = f.members;
+    c.C = 0;
+    for (const auto& m : f.members) c.C += m.C;
+    c.H = f.outH;
+    c.out_is_seq = f.outseq;
+    c.outC = c.C; c.outH = f.outH;
+    // valid widths behind the group: those of its LAST member (the reference keeps the seq_lens the last module returned)
+    c.len_in = c.len_out = stage;
+    p->steps.push_back(std::move(c));
+    C = p->steps.back().C;
+    H = f.outH;
+    seq = f.outseq;
+    return KRK_OK;
+}
+
+// Addition (reference layers.py:188-223): unfold(dim, chunk, chunk).sum(dim) -- out[j] = sum_k in[k*chunk + j]
+int PlanBuilder::addition(const krk_layer& L, const std::string& where) {
+    if (split_fmt) return fail(KRK_E_UNSUPPORTED, where + ": addition on split-bf16 planes");
+    const int size = L.kh == 0 ? C : H;
+    if (L.kh < 0 || L.kh > 1 || L.cout < 1 || L.cout > size)
+        return fail(KRK_E_INVALID, where + ": addition with chunk " + std::to_string(L.cout) + " on an axis of " + std::to_string(size));
+    if (L.kh == 1 && seq) return fail(KRK_E_UNSUPPORTED, where + ": addition over the height of a sequence");
+    Step a;
+    a.kind = S_ADD;
+    a.C = C; a.H = H;
+    a.add_axis = L.kh; a.chunk = L.cout; a.nk = size / L.cout;
+    a.out_is_seq = seq;
+    a.outC = L.kh == 0 ? L.cout : C;
+    a.outH = L.kh == 1 ? L.cout : H;
+    a.len_in = a.len_out = stage;
+    C = a.outC; H = a.outH;
+    p->steps.push_back(std::move(a));
     return KRK_OK;
 }
 
@@ -1125,12 +1255,18 @@ int PlanBuilder::build() {
     // matrix cores; the split-bf16 kernels take over behind it (the next convolution computes in f32 and hands over split planes;
     // sequence layers split their fp32 rows on the way in), where the error is the ~1e-5 of a GroupNorm-free network.
     want_x3 = x3;
-    for (int k = 0; k < n_layers; ++k)
+    for (int k = 0; k < n_layers; ++k) {
         if (layers[k].op == KRK_OP_GROUPNORM) last_gn = k;
+        // parallel groups and additions work on fp32 tensors: like the GroupNorm part, everything up to the last of them runs on
+        // the exact-f32 kernels and the split-bf16 ones take over behind it
+        if (layers[k].op == KRK_OP_GROUPNORM || (layers[k].op >= KRK_OP_PAR_BEGIN && layers[k].op <= KRK_OP_ADD) ||
+            (layers[k].op == KRK_OP_LSTM && layers[k].kh == 1 && layers[k].kw == 0))
+            last_f32_only = k;
+    }
     for (i = 0; i < n_layers; ++i) {
         const krk_layer& L = layers[i];
         const std::string where = "layer " + std::to_string(i);
-        x3 = want_x3 && !left_x3 && i > last_gn;
+        x3 = want_x3 && !left_x3 && i > last_f32_only;
         // a convolution that would be the first split-bf16 layer AND carry the height collapse has no split-plane hand-over
         // (the f32 kernel writes split NHWC planes, not sequence rows): it stays f32, the sequence layers behind it split their rows
         if (x3 && !split_fmt && !seq && L.op == KRK_OP_CONV) {
@@ -1146,11 +1282,19 @@ int PlanBuilder::build() {
             case KRK_OP_RESHAPE_HC: rc = reshape(L, where); break;
             case KRK_OP_LSTM:
             case KRK_OP_LINEAR: rc = recurrent_or_linear(L, where); break;
+            case KRK_OP_PAR_BEGIN: rc = par_begin(where); break;
+            case KRK_OP_PAR_NEXT: rc = par_next(where); break;
+            case KRK_OP_PAR_END: rc = par_end(where); break;
+            case KRK_OP_ADD: rc = addition(L, where); break;
             default: rc = fail(KRK_E_UNSUPPORTED, where + ": unknown op " + std::to_string(L.op));
         }
         if (rc) return rc;
     }
-    p->nstages = stage + 1;
+    if (!forks.empty()) return fail(KRK_E_INVALID, "parallel group not closed");
+    // a network that ENDS in a split-bf16 convolution (no sequence part): the caller gets fp32 NCHW like from every other plan
+    if (split_fmt && !seq) leave_x3();
+    p->nstages = (int)p->lenops.size() + 1;
+    p->out_stage = stage;
     return KRK_OK;
 }
 
@@ -1199,8 +1343,8 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
 
 int krk_plan_out_shape(const krk_plan* plan, int W, int* C, int* H, int* Wout) {
     if (!plan || plan->steps.empty()) return fail(KRK_E_INVALID, "krk_plan_out_shape: null plan");
-    int w = W;
-    for (const auto& op : plan->lenops) w = shape_after(op, w);
+    std::vector<int> tmp;
+    const int w = stage_value(*plan, W, plan->out_stage, shape_after, tmp);
     const Step& last = plan->steps.back();
     if (C) *C = last.outC;
     if (H) *H = last.outH;
@@ -1210,10 +1354,9 @@ int krk_plan_out_shape(const krk_plan* plan, int W, int* C, int* H, int* Wout) {
 
 int krk_plan_olens(const krk_plan* plan, const int* lens_host, int N, int* olens_host) {
     if (!plan || !lens_host || !olens_host || N < 0) return fail(KRK_E_INVALID, "krk_plan_olens: bad argument");
+    std::vector<int> tmp;
     for (int n = 0; n < N; ++n) {
-        int l = lens_host[n];
-        for (const auto& op : plan->lenops) l = width_after(op, l);
-        olens_host[n] = l;
+        olens_host[n] = stage_value(*plan, lens_host[n], plan->out_stage, width_after, tmp);
     }
     return KRK_OK;
 }
@@ -1403,6 +1546,7 @@ struct Pass {
     int upload_lens(int W);
     int conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win);
     int layout(Step& s, const float* cur, float* outp, size_t out_elems, int Win, int Wout);
+    int concat(Step& s, const std::vector<const float*>& outs, float* outp, int Wout);
     int split_input(Step& s, const float* cur, size_t in_elems, const void** xin);
     int projection(const ConvGeom& g, GemmX3Args& a);
     int linear(Step& s, const float* cur, float* outp, int Win);
@@ -1416,7 +1560,7 @@ int Pass::widths(int W) {
     Ws.assign(p->nstages, 0);
     Ws[0] = W;
     for (int s = 0; s + 1 < p->nstages; ++s) {
-        Ws[s + 1] = shape_after(p->lenops[s], Ws[s]);
+        Ws[s + 1] = shape_after(p->lenops[s], Ws[p->lenops[s].from]);
         if (Ws[s + 1] <= 0) return hard(KRK_E_INVALID, "forward: input width " + std::to_string(W) + " too small for this network");
     }
     return 0;
@@ -1437,13 +1581,14 @@ int Pass::upload_lens(int W) {
     // the pinned staging buffer may still be in flight from the previous call
     if (p->lens_ev_pending) { if (int r = hip(hipEventSynchronize(p->lens_ev), "hipEventSynchronize")) return r; p->lens_ev_pending = false; }
     int* hl = p->h_lens_pinned;
+    std::vector<int> raw(p->nstages);      // a line's lengths per stage before the clamp to the tensor width
     for (int n = 0; n < N; ++n) {
-        int l = lens_host[n];
+        const int l = lens_host[n];
         if (l < 1 || l > W) return hard(KRK_E_INVALID, "forward: lens[" + std::to_string(n) + "] outside [1, W]");
-        hl[n] = l;
+        hl[n] = raw[0] = l;
         for (int s = 0; s + 1 < p->nstages; ++s) {
-            l = width_after(p->lenops[s], l);
-            hl[(size_t)(s + 1) * N + n] = std::max(0, std::min(l, Ws[s + 1]));
+            raw[s + 1] = width_after(p->lenops[s], raw[p->lenops[s].from]);
+            hl[(size_t)(s + 1) * N + n] = std::max(0, std::min(raw[s + 1], Ws[s + 1]));
         }
     }
     if (int r = hip(hipMemcpyAsync(p->d_lens.p, hl, cnt * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync")) return r;
@@ -1592,9 +1737,38 @@ int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int W
         case S_ROWS2IMG:
             if (mark("rows2img", 0)) return kFailed;
             return krk_launch_rows2img(cur, outp, N, s.C, s.H, Win, s.yaxis, s.yaxis ? lens_at(s.len_in) : nullptr, s.last_only, stream);
+        case S_ADD: {
+            if (mark("add", 0)) return kFailed;
+            // channels of an image: N blocks of C*H*W, pieces of chunk*H*W; channels of sequence rows: N*T rows of C, pieces of
+            // chunk; height: N*C planes of H*W, pieces of chunk*W
+            if (s.add_axis == 1)
+                return krk_launch_chunk_sum(cur, outp, (size_t)N * s.C, (size_t)s.chunk * Win, s.nk, (size_t)s.H * Win, stream);
+            if (s.out_is_seq)
+                return krk_launch_chunk_sum(cur, outp, (size_t)N * Win, (size_t)s.chunk, s.nk, (size_t)s.C, stream);
+            return krk_launch_chunk_sum(cur, outp, (size_t)N, (size_t)s.chunk * s.H * Win, s.nk, (size_t)s.C * s.H * Win, stream);
+        }
         default:
             return -4;
     }
+}
+
+// MultiParamParallel: torch.cat(outputs, dim=1) of the members' fp32 outputs (reference layers.py:70)
+int Pass::concat(Step& s, const std::vector<const float*>& outs, float* outp, int Wout) {
+    if (mark("concat", 0)) return kFailed;
+    size_t coff = 0;
+    for (const auto& m : s.srcs) {
+        if (Ws[m.stage] != Wout)       // torch.cat would refuse: the members' widths differ for this input width
+            return hard(KRK_E_INVALID, "forward: parallel group members produce different widths (" + std::to_string(Ws[m.stage]) +
+                                           " and " + std::to_string(Wout) + ")");
+        const float* src = m.step < 0 ? nullptr : outs[m.step];
+        if (!src) return hard(KRK_E_INVALID, "forward: parallel group member without an output");
+        // image: N blocks of C_k*H*W floats into blocks of C*H*W; sequence rows (N, T, C): N*T blocks of C_k into rows of C
+        const size_t unit = s.out_is_seq ? 1 : (size_t)s.H * Wout;
+        const size_t outer = s.out_is_seq ? (size_t)N * Wout : (size_t)N;
+        if (int rc = krk_launch_concat(src, outp, outer, m.C * unit, s.C * unit, coff * unit, stream)) return rc;
+        coff += m.C;
+    }
+    return 0;
 }
 
 // fp32 rows (from an f32 producer) -> the split planes the bf16x3 projection reads; a no-op when they arrive split
@@ -1832,6 +2006,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
 
     const float* cur = x_dev;
     const size_t nsteps = p->steps.size();
+    std::vector<const float*> outs(nsteps, nullptr);      // where every step's output lives (parallel groups read them again)
     p->prof_n = 0;
     if (p->profiling) {
         p->prof_names.assign(p->events.size(), nullptr);
@@ -1844,18 +2019,24 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         size_t out_elems = (size_t)N * s.outC * s.outH * Wout;
         if (s.kind == S_CONV && s.cg.out_nhcw) out_elems = (size_t)N * s.outC * s.outH * nhcw_pitch(Wout);
         if (s.kind == S_LSTM && s.out_tiled) out_elems = (size_t)((N + 15) / 16 * 16) * s.outC * s.outH * Wout;
+        if (s.kind == S_ALIAS) {      // a parallel member starts from the tensor in front of its group
+            cur = s.src < 0 ? x_dev : outs[s.src];
+            outs[si] = cur;
+            continue;
+        }
         float* outp;
         if (is_last && final_out) outp = final_out;
         else {
             if (s.out.ensure(out_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
             outp = (float*)s.out.p;
         }
-        if (s.skip) continue;       // recomputed inside the next step (c1gn.hip): `cur` stays the step's input
+        if (s.skip) { outs[si] = cur; continue; }   // recomputed inside the next step (c1gn.hip): `cur` stays the step's input
         int rc;
         switch (s.kind) {
             case S_CONV: rc = pass.conv(s, cur, outp, out_elems, Win); break;
             case S_LINEAR: rc = pass.linear(s, cur, outp, Win); break;
             case S_LSTM: rc = pass.lstm(s, cur, outp, out_elems, Win); break;
+            case S_CONCAT: rc = pass.concat(s, outs, outp, Wout); break;
             default: rc = pass.layout(s, cur, outp, out_elems, Win, Wout); break;
         }
         if (rc == kFailed) return pass.err;
@@ -1863,12 +2044,13 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         if (rc) return fail(KRK_E_HIP, std::string("forward: launch of ") + kStepNames[s.kind] + " failed: " +
                                            hipGetErrorString(hipGetLastError()));
         cur = outp;
+        outs[si] = outp;
     }
     if (!pass.front_done) HIPCHK(hipEventRecord(p->front_ev, stream));
     if (p->profiling) HIPCHK(hipEventRecord(p->events[p->prof_n], stream));
     if (final_ptr) *final_ptr = cur;
-    if (d_olens) *d_olens = pass.lens_at(p->nstages - 1);
-    if (T_out) *T_out = pass.Ws[p->nstages - 1];
+    if (d_olens) *d_olens = pass.lens_at(p->out_stage);
+    if (T_out) *T_out = pass.Ws[p->out_stage];
     return KRK_OK;
 }
 

@@ -361,6 +361,9 @@ int krk_launch_unsplit(const void* x, size_t plane, float* y, int N, int C, int 
 // (N,C,H,W) <-> sequence rows [(n,h)][w][C] (yaxis = 0) or [(n,w)][h][C] (yaxis = 1) for LSTMs over image rows/columns
 int krk_launch_img2rows(const float* x, float* y, int N, int C, int H, int W, int yaxis, hipStream_t s);
 int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, int yaxis, const int* lens, int last, hipStream_t s);
+// torch.cat on the channel axis, one source at a time, and Addition's sum over pieces of an axis (parallel groups, `A` layers)
+int krk_launch_concat(const float* x, float* y, size_t outer, size_t inner, size_t stride, size_t off, hipStream_t s);
+int krk_launch_chunk_sum(const float* x, float* y, size_t outer, size_t inner, int nk, size_t in_stride, hipStream_t s);
 // nearest upsampling + sigmoid of the segmenter's heatmaps: (C, h, w) -> (C, H, W)
 int krk_launch_upsample_sigmoid(const float* x, float* y, int C, int h, int w, int H, int W, hipStream_t s);
 int krk_launch_rowmax(const float* scores, long sn, long sc, long st, int N, int C, int T,

@@ -297,14 +297,17 @@ __global__ void __launch_bounds__(256) img2rows_kernel(const float* __restrict__
 //         the destination image has height 1.
 __global__ void __launch_bounds__(256) rows2img_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        int C, int H, int W, int yaxis, const int* __restrict__ lens, int last) {
-    if (last) {   // (N*W, H, C) rows -> (N, C, 1, W): one thread per (n, c, w), reads strided by H*C (small tensors)
+    if (last) {
+        // summarising LSTM: keep the last step of every sequence.  Columns as sequences: (N*W, H, C) rows -> (N, C, 1, W);
+        // rows as sequences: (N*H, W, C) rows -> (N, C, H, 1).  One thread per (n, c, sequence), strided reads (small tensors)
         const int n = blockIdx.z;
-        const size_t total = (size_t)C * W;
+        const int K = yaxis ? W : H, S = yaxis ? H : W;     // sequences per line, steps per sequence
+        const size_t total = (size_t)C * K;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-            const int c = (int)(i / W), w = (int)(i - (size_t)c * W);
-            float v = x[(((size_t)n * W + w) * H + (H - 1)) * C + c];
-            if (lens && w >= lens[n]) v = 0.f;
-            y[((size_t)n * C + c) * W + w] = v;
+            const int c = (int)(i / K), j = (int)(i - (size_t)c * K);
+            float v = x[(((size_t)n * K + j) * S + (S - 1)) * C + c];
+            if (lens && yaxis && j >= lens[n]) v = 0.f;
+            y[((size_t)n * C + c) * K + j] = v;
         }
         return;
     }
@@ -568,7 +571,7 @@ int krk_launch_img2rows(const float* x, float* y, int N, int C, int H, int W, in
 int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, int yaxis, const int* lens, int last,
                         hipStream_t s) {
     dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
-    if (last) grid = dim3((unsigned)std::min<size_t>(1024, ((size_t)C * W + 255) / 256), 1, N);
+    if (last) grid = dim3((unsigned)std::min<size_t>(1024, ((size_t)C * (yaxis ? W : H) + 255) / 256), 1, N);
     hipLaunchKernelGGL(rows2img_kernel, grid, dim3(256), 0, s, x, y, C, H, W, yaxis, lens, last);
     return last_ok();
 }
@@ -576,6 +579,48 @@ int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, in
 int krk_launch_unsplit(const void* x, size_t plane, float* y, int N, int C, int H, int W, hipStream_t s) {
     dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
     hipLaunchKernelGGL(unsplit_kernel, grid, dim3(256), 0, s, (const __bf16*)x, plane, y, C, H * W);
+    return last_ok();
+}
+
+namespace {
+// MultiParamParallel's torch.cat(outputs, dim=1) (reference layers.py:70), one member at a time: `outer` blocks of `inner`
+// contiguous floats go to offset `off` of blocks `stride` apart (NCHW: outer = N, inner = C_k*H*W; sequence rows: outer = rows,
+// inner = C_k).  HBM-bound copy.
+__global__ void __launch_bounds__(256) concat_kernel(const float* __restrict__ x, float* __restrict__ y, size_t inner, size_t stride,
+                                                     size_t off, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t o = e / inner, j = e - o * inner;
+        y[o * stride + off + j] = x[e];
+    }
+}
+
+// Addition (reference layers.py:205-210): y[o][j] = sum_k x[o][k*inner + j], k = 0..nk-1 in ascending order; a block of the
+// input is `in_stride` floats (>= nk*inner: what is left behind the last whole piece is dropped)
+__global__ void __launch_bounds__(256) chunk_sum_kernel(const float* __restrict__ x, float* __restrict__ y, size_t inner, int nk,
+                                                        size_t in_stride, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t o = e / inner, j = e - o * inner;
+        const float* src = x + o * in_stride + j;
+        float acc = src[0];
+        for (int k = 1; k < nk; ++k) acc += src[(size_t)k * inner];
+        y[e] = acc;
+    }
+}
+}  // namespace
+
+int krk_launch_concat(const float* x, float* y, size_t outer, size_t inner, size_t stride, size_t off, hipStream_t s) {
+    const size_t total = outer * inner;
+    if (!total) return 0;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(concat_kernel, dim3(blocks), dim3(256), 0, s, x, y, inner, stride, off, total);
+    return last_ok();
+}
+
+int krk_launch_chunk_sum(const float* x, float* y, size_t outer, size_t inner, int nk, size_t in_stride, hipStream_t s) {
+    const size_t total = outer * inner;
+    if (!total) return 0;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(blocks), dim3(256), 0, s, x, y, inner, nk, in_stride, total);
     return last_ok();
 }
 

@@ -40,12 +40,25 @@ __all__ = ['TorchVGSLModel', 'parse_vgsl', 'LayerSpec', 'HipSequential']
 # --------------------------------------------------------------------------- spec parsing
 @dataclass
 class LayerSpec:
-    kind: str                      # conv | maxpool | groupnorm | dropout | reshape | rnn | linear
-    name: str                      # state-dict name, e.g. 'C_0'
-    text: str                      # spec block with the {name} inserted (named_spec entry)
+    kind: str                      # conv | maxpool | groupnorm | dropout | reshape | rnn | linear | add | par_begin | par_next | par_end
+    name: str                      # state-dict name, e.g. 'C_0' ('' for the par_* markers)
+    text: str                      # spec block with the {name} inserted (named_spec entry; '' for the par_* markers)
     params: dict = field(default_factory=dict)
     in_shape: tuple = ()           # (batch, channels, height, width); 0 = variable
     out_shape: tuple = ()
+    # containers around the layer, outermost first: (module name, 'series' | 'parallel').  The reference registers a nested
+    # `[ ... ]` / `( ... )` block under the space-joined names of the layers inside it (model.py:236), which makes the
+    # state-dict key of a nested layer 'nn.<names of the block>.<...>.<name>.co.weight'
+    path: tuple = ()
+
+    @property
+    def key(self) -> str:
+        """State-dict prefix below 'nn.': container names and the layer's own name, dot-joined."""
+        return '.'.join([c for c, _ in self.path] + [self.name])
+
+    @property
+    def structural(self) -> bool:
+        return self.kind in ('par_begin', 'par_next', 'par_end')
 
 
 _RE_INPUT = re.compile(r'^(\d+),(\d+),(\d+),(\d+)$')
@@ -61,8 +74,10 @@ _GRAMMAR = [
                        r'(?P<out>\d+)$')),
     ('output', re.compile(r'^O' + _RE_NAME + r'(?P<dim>[012])(?P<type>l|s|c)(?P<aug>a)?(?P<out>\d+)$')),
     ('identity', re.compile(r'^I' + _RE_NAME + r'$')),
+    ('add', re.compile(r'^A' + _RE_NAME + r'(?P<dim>\d+),(?P<chunk>\d+)$')),
 ]
-_TYPE_TAG = {'conv': 'C', 'maxpool': 'Mp', 'groupnorm': 'Gn', 'dropout': 'Do', 'reshape': 'S', 'output': 'O', 'identity': 'I'}
+_TYPE_TAG = {'conv': 'C', 'maxpool': 'Mp', 'groupnorm': 'Gn', 'dropout': 'Do', 'reshape': 'S', 'output': 'O', 'identity': 'I',
+             'add': 'A'}
 
 
 def _floor_out(size: int, k: int, s: int, d: int = 1, p: int = 0) -> int:
@@ -80,13 +95,222 @@ def _named_block(block: str, name: str) -> str:
     return f'{head}{{{name}}}{block[len(head):]}'
 
 
+def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
+    """One VGSL layer block -> LayerSpec (reference model.py:570-817, one build_* method per kind)."""
+    if not block:
+        raise ValueError(' invalid layer definition')
+    hit = None
+    for kind, rx in _GRAMMAR:
+        mm = rx.match(block)
+        if mm:
+            hit = (kind, mm)
+            break
+    if hit is None:
+        if re.match(r'^W', block):
+            raise NotImplementedError(f'VGSL block "{block}" is not supported by the HIP executor')
+        raise ValueError(f'{block} invalid layer definition')
+    kind, mm = hit
+    g = mm.groupdict()
+    tag = g['cell'] if kind == 'rnn' else _TYPE_TAG[kind]
+    if kind == 'output' and g['dim'] == '2':
+        tag = g['type']   # heatmap heads are named after their type letter: 'l_8' (reference model.py:811)
+    name = g.get('name') or f'{tag}_{idx}'
+    n, c, h, w = shape
+    p: dict[str, Any] = {}
+    if kind == 'conv':
+        if g['trans']:
+            raise NotImplementedError('transposed convolutions are not supported by the HIP executor')
+        if g['nl'] == 'm':
+            raise NotImplementedError('softmax-activated convolutions are not supported by the HIP executor')
+        ky, kx, out = int(g['ky']), int(g['kx']), int(g['out'])
+        sy, sx = (int(g['sy']), int(g['sx'])) if g['sx'] else (1, 1)
+        dy, dx = (int(g['dy']), int(g['dx'])) if g['dx'] else (1, 1)
+        p = dict(kernel=(ky, kx), out=out, stride=(sy, sx), dilation=(dy, dx), nl=g['nl'],
+                 padding=((dy * (ky - 1)) // 2, (dx * (kx - 1)) // 2))
+        oshape = (n, out, _floor_out(h, ky, sy, dy, p['padding'][0]), _floor_out(w, kx, sx, dx, p['padding'][1]))
+    elif kind == 'maxpool':
+        ky, kx = int(g['ky']), int(g['kx'])
+        sy, sx = (int(g['sy']), int(g['sx'])) if g['sx'] else (ky, kx)
+        p = dict(kernel=(ky, kx), stride=(sy, sx))
+        oshape = (n, c, _floor_out(h, ky, sy), _floor_out(w, kx, sx))
+    elif kind == 'groupnorm':
+        p = dict(groups=int(g['groups']))
+        oshape = shape
+    elif kind == 'dropout':
+        p = dict(p=float(g['p']) if g['p'] else 0.5, dim=int(g['dim']) if g['dim'] else 1)
+        oshape = shape
+    elif kind == 'add':
+        # layers.Addition (layers.py:188-223, model.py:616-635): the axis is cut into pieces of `chunk` entries which are summed,
+        # out[j] = sum_k in[k * chunk + j] (what is left over behind the last whole piece is dropped: Tensor.unfold)
+        dim, chunk = int(g['dim']), int(g['chunk'])
+        if dim > 3:
+            raise ValueError(f'Invalid dimension {dim} in addition block')
+        axis = {0: 0, 1: 2, 2: 3, 3: 1}[dim]
+        if axis in (0, 3):
+            raise NotImplementedError(f'addition "{block}" over the {"batch" if axis == 0 else "width"} axis is not supported '
+                                      'by the HIP executor (channels and height are)')
+        if chunk < 1 or (shape[axis] and chunk > shape[axis]):
+            raise ValueError(f'addition "{block}": chunk size {chunk} does not fit an axis of {shape[axis]} entries')
+        p = dict(axis=axis, chunk=chunk)
+        oshape = tuple(chunk if a == axis else v for a, v in enumerate(shape))
+    elif kind == 'identity':     # layers.Identity (model.py:637-650): elided like dropout
+        kind, p, oshape = 'dropout', dict(identity=True), shape
+    elif kind == 'reshape':
+        src, a, b, high, low = int(g['dim']), int(g['a']), int(g['b']), int(g['high']), int(g['low'])
+        if src != high and src != low:
+            raise ValueError(f'Either high ({high}) or low ({low}) must be source dimension ({src})')
+        if a == 0 and b == 0:
+            raise ValueError('Only one size may be -1')
+        # the only form on the recognition path: fold height into channels, S1(1x0)1,3
+        # (feature index h*C + c)
+        if not (src == 1 and high == 1 and low == 3 and b == 0 and a == 1) or h == 0:
+            raise NotImplementedError(f'reshape "{block}" is not supported by the HIP executor '
+                                      '(only the height->channel collapse S1(1x0)1,3)')
+        p = dict(src=src, a=a, b=b, high=high, low=low)
+        # the reference derives this shape from a dummy tensor with variable dims set to 1
+        oshape = (n or 1, c * h, 1, w or 1)
+    elif kind == 'rnn':
+        # 'G' parses as a GRU but the reference builds the same torch.nn.LSTM for it (layers.py:504-511, model.py:579-593):
+        # an alias, layer name G_<idx>
+        if g['legacy']:
+            raise NotImplementedError(f'RNN variant "{block}" (legacy clstm / ocropy cell) is not supported '
+                                      'by the HIP executor')
+        hidden = int(g['out'])
+        if hidden > 768:
+            raise NotImplementedError(f'recurrent layer "{block}": hidden sizes above 768 are not supported by the HIP recurrent kernels')
+        # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523);
+        # 's' keeps only the last step of every column (:537-539): (N, C, H, W) -> (N, O, 1, W)
+        # on the x axis 's' keeps the last COLUMN: (N, C, H, W) -> (N, O, H, 1) (get_shape, :549-561)
+        p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'], summarize=bool(g['sum']))
+        oc = hidden * (2 if g['dir'] == 'b' else 1)
+        oshape = (n, oc, h, w) if not g['sum'] else ((n, oc, 1, w) if g['axis'] == 'y' else (n, oc, h, 1))
+    else:  # output
+        dim, typ, out = int(g['dim']), g['type'], int(g['out'])
+        if dim == 0:
+            raise ValueError('categorical output not supported, yet.')
+        if typ == 'c' and dim == 2:
+            raise ValueError('CTC not supported for heatmap output')
+        if g['aug'] and dim == 2:
+            raise NotImplementedError(f'1-augmented heatmap output "{block}" is not supported by the HIP executor')
+        if dim == 2:
+            if typ != 'l':
+                raise NotImplementedError('softmax heatmap outputs are not supported by the HIP executor')
+            kind = 'conv'   # 1x1 ActConv2D with (skipped) sigmoid, reference model.py:806-811
+            p = dict(kernel=(1, 1), out=out, stride=(1, 1), dilation=(1, 1), nl='s', padding=(0, 0),
+                     output_type=typ)
+        else:
+            kind = 'linear'
+            # 'a': LinSoftmax(augmentation=True) prepends a constant 1 to every input vector (layers.py:703-719); the extra
+            # weight column is folded into the bias when the plan is compiled
+            p = dict(out=out, output_type=typ, aug=bool(g['aug']))
+        oshape = (n, out, h, w)
+    return LayerSpec(kind, name, _named_block(block, name), p, shape, oshape)
+
+
+def _depth_change(block: str, opening: str, closing: str, other_open: str, other_close: str) -> int:
+    """
+    The reference's `_bracket_count` / `_parenthesis_count` (model.py:819-845): leading `opening` characters (runs of the
+    other kind of opening bracket are looked through) minus trailing `closing` characters of one block.
+    """
+    n = 0
+    for c in block:
+        if c == opening:
+            n += 1
+        elif c != other_open:
+            break
+    for c in reversed(block):
+        if c == closing:
+            n -= 1
+        elif c != other_close:
+            break
+    return n
+
+
+class _SpecParser:
+    """
+    Recursive descent over the space-separated blocks of a spec, following the reference's `_parse` / `build_series` /
+    `build_parallel` (model.py:202-241, 847-905): a block starting with '[' opens a serial group, one starting with '('
+    a parallel group whose members all see the group's input and whose outputs are concatenated on the channel axis
+    (layers.py:56-71); layer indices run globally over the leaf layers, groups take none.  The result is a FLAT list:
+    leaf LayerSpecs with their container path, and par_begin / par_next / par_end markers around the members of a
+    parallel group -- the order krk_plan_create consumes.
+    """
+
+    def __init__(self):
+        self.idx = -1
+
+    def parse(self, shape: tuple, blocks: Sequence[str], parallel: bool = False):
+        specs: list[LayerSpec] = []
+        names: list[str] = []
+        i = 0
+        first_out = None
+        channels = 0
+        oshape = shape
+        while i < len(blocks):
+            block = blocks[i]
+            if block and block[0] in '[(':
+                series = block[0] == '['
+                o, c = ('[', ']') if series else ('(', ')')
+                oo, oc = ('(', ')') if series else ('[', ']')
+                if block[-1] == c:          # single block in brackets
+                    inner, used = [block[1:-1]], 1
+                else:
+                    depth, used = 0, 0
+                    for used, b in enumerate(blocks[i:]):
+                        depth += _depth_change(b, o, c, oo, oc)
+                        if depth == 0:
+                            break
+                    if depth:
+                        raise ValueError('Unbalanced parentheses in VGSL spec')
+                    inner = [block[1:]] + list(blocks[i + 1:i + used]) + [blocks[i + used][:-1]]
+                    used += 1
+                sub, sub_names, oshape = self.parse(shape, inner, parallel=not series)
+                if not sub_names:
+                    raise ValueError(f'{block} invalid layer definition')
+                cname = (' '.join(sub_names), 'series' if series else 'parallel')
+                leaves = [sp for sp in sub if not sp.structural]
+                for sp in sub:
+                    sp.path = (cname,) + sp.path
+                leaves[0].text = o + leaves[0].text
+                leaves[-1].text = leaves[-1].text + c
+                if not series:
+                    sub = ([LayerSpec('par_begin', '', '', {}, shape, shape, (cname,))] + sub +
+                           [LayerSpec('par_end', '', '', {}, shape, oshape, (cname,))])
+                if len(sub_names) != used:
+                    # the reference advances by the number of LAYERS a group returned (model.py:235), which equals the blocks
+                    # it spans for every spec it accepts
+                    raise ValueError(f'{block} invalid layer definition')
+            else:
+                self.idx += 1
+                try:
+                    sp = _parse_layer(block, shape, self.idx)
+                except Exception:
+                    self.idx -= 1
+                    raise
+                sub, sub_names, oshape, used = [sp], [sp.name], sp.out_shape, 1
+            if parallel:
+                if first_out is not None and first_out[2:] != oshape[2:]:
+                    raise ValueError('Output shape in parallel block not equal!')
+                if first_out is not None:
+                    specs.append(LayerSpec('par_next', '', '', {}, shape, shape))
+                first_out = first_out or oshape
+                channels += oshape[1]
+            else:
+                shape = oshape
+            specs += sub
+            names += sub_names
+            i += used
+        if parallel and first_out is not None:
+            oshape = (first_out[0], channels) + tuple(first_out[2:])
+        return specs, names, oshape
+
+
 def parse_vgsl(spec: str):
     """
-    Parses a sequential VGSL spec into the input 4-tuple (batch, channels, height, width)
-    and a list of LayerSpec.  Grammar: SURVEY.md Appendix A (reference model.py:579-817).
-    Raises ValueError for malformed specs and NotImplementedError for valid VGSL the
-    HIP executor does not cover (parallel blocks, transposed conv, summarising/legacy
-    RNNs, addition, wav2vec masking).
+    Parses a VGSL spec into the input 4-tuple (batch, channels, height, width) and a flat list of LayerSpec (see
+    _SpecParser for nested `[ ... ]` / `( ... )` groups).  Grammar: SURVEY.md Appendix A (reference model.py:570-905).
+    Raises ValueError for malformed specs and NotImplementedError for valid VGSL the HIP executor does not cover
+    (transposed / softmax convolutions, legacy RNN cells, addition over batch or width, wav2vec masking, general reshapes).
     """
     spec = spec.strip()
     if not spec or spec[0] != '[' or spec[-1] != ']':
@@ -96,106 +320,7 @@ def parse_vgsl(spec: str):
     if not m:
         raise ValueError('Invalid input spec.')
     batch, height, width, channels = (int(v) for v in m.groups())
-    shape = (batch, channels, height, width)
-    layers: list[LayerSpec] = []
-    idx = -1
-    for block in blocks[1:]:
-        if not block:
-            raise ValueError(' invalid layer definition')
-        if block[0] in '[(' or block[-1] in '])':
-            raise NotImplementedError(f'nested/parallel VGSL block "{block}" is not supported by the HIP executor')
-        hit = None
-        for kind, rx in _GRAMMAR:
-            mm = rx.match(block)
-            if mm:
-                hit = (kind, mm)
-                break
-        if hit is None:
-            if re.match(r'^(A|W)', block):
-                raise NotImplementedError(f'VGSL block "{block}" is not supported by the HIP executor')
-            raise ValueError(f'{block} invalid layer definition')
-        kind, mm = hit
-        idx += 1
-        g = mm.groupdict()
-        tag = g['cell'] if kind == 'rnn' else _TYPE_TAG[kind]
-        if kind == 'output' and g['dim'] == '2':
-            tag = g['type']   # heatmap heads are named after their type letter: 'l_8' (reference model.py:811)
-        name = g.get('name') or f'{tag}_{idx}'
-        n, c, h, w = shape
-        p: dict[str, Any] = {}
-        if kind == 'conv':
-            if g['trans']:
-                raise NotImplementedError('transposed convolutions are not supported by the HIP executor')
-            if g['nl'] == 'm':
-                raise NotImplementedError('softmax-activated convolutions are not supported by the HIP executor')
-            ky, kx, out = int(g['ky']), int(g['kx']), int(g['out'])
-            sy, sx = (int(g['sy']), int(g['sx'])) if g['sx'] else (1, 1)
-            dy, dx = (int(g['dy']), int(g['dx'])) if g['dx'] else (1, 1)
-            p = dict(kernel=(ky, kx), out=out, stride=(sy, sx), dilation=(dy, dx), nl=g['nl'],
-                     padding=((dy * (ky - 1)) // 2, (dx * (kx - 1)) // 2))
-            oshape = (n, out, _floor_out(h, ky, sy, dy, p['padding'][0]), _floor_out(w, kx, sx, dx, p['padding'][1]))
-        elif kind == 'maxpool':
-            ky, kx = int(g['ky']), int(g['kx'])
-            sy, sx = (int(g['sy']), int(g['sx'])) if g['sx'] else (ky, kx)
-            p = dict(kernel=(ky, kx), stride=(sy, sx))
-            oshape = (n, c, _floor_out(h, ky, sy), _floor_out(w, kx, sx))
-        elif kind == 'groupnorm':
-            p = dict(groups=int(g['groups']))
-            oshape = shape
-        elif kind == 'dropout':
-            p = dict(p=float(g['p']) if g['p'] else 0.5, dim=int(g['dim']) if g['dim'] else 1)
-            oshape = shape
-        elif kind == 'identity':     # layers.Identity (model.py:637-650): elided like dropout
-            kind, p, oshape = 'dropout', dict(identity=True), shape
-        elif kind == 'reshape':
-            src, a, b, high, low = int(g['dim']), int(g['a']), int(g['b']), int(g['high']), int(g['low'])
-            if src != high and src != low:
-                raise ValueError(f'Either high ({high}) or low ({low}) must be source dimension ({src})')
-            if a == 0 and b == 0:
-                raise ValueError('Only one size may be -1')
-            # the only form on the recognition path: fold height into channels, S1(1x0)1,3
-            # (feature index h*C + c)
-            if not (src == 1 and high == 1 and low == 3 and b == 0 and a == 1) or h == 0:
-                raise NotImplementedError(f'reshape "{block}" is not supported by the HIP executor '
-                                          '(only the height->channel collapse S1(1x0)1,3)')
-            p = dict(src=src, a=a, b=b, high=high, low=low)
-            # the reference derives this shape from a dummy tensor with variable dims set to 1
-            oshape = (n or 1, c * h, 1, w or 1)
-        elif kind == 'rnn':
-            # 'G' parses as a GRU but the reference builds the same torch.nn.LSTM for it (layers.py:504-511, model.py:579-593):
-            # an alias, layer name G_<idx>
-            if g['legacy'] or (g['sum'] and g['axis'] != 'y'):
-                raise NotImplementedError(f'RNN variant "{block}" (x-axis summarising / legacy) is not supported '
-                                          'by the HIP executor')
-            hidden = int(g['out'])
-            if hidden > 768:
-                raise NotImplementedError(f'recurrent layer "{block}": hidden sizes above 768 are not supported by the HIP recurrent kernels')
-            # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523);
-            # 's' keeps only the last step of every column (:537-539): (N, C, H, W) -> (N, O, 1, W)
-            p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'], summarize=bool(g['sum']))
-            oshape = (n, hidden * (2 if g['dir'] == 'b' else 1), 1 if g['sum'] else h, w)
-        else:  # output
-            dim, typ, out = int(g['dim']), g['type'], int(g['out'])
-            if dim == 0:
-                raise ValueError('categorical output not supported, yet.')
-            if typ == 'c' and dim == 2:
-                raise ValueError('CTC not supported for heatmap output')
-            if g['aug'] and dim == 2:
-                raise NotImplementedError(f'1-augmented heatmap output "{block}" is not supported by the HIP executor')
-            if dim == 2:
-                if typ != 'l':
-                    raise NotImplementedError('softmax heatmap outputs are not supported by the HIP executor')
-                kind = 'conv'   # 1x1 ActConv2D with (skipped) sigmoid, reference model.py:806-811
-                p = dict(kernel=(1, 1), out=out, stride=(1, 1), dilation=(1, 1), nl='s', padding=(0, 0),
-                         output_type=typ)
-            else:
-                kind = 'linear'
-                # 'a': LinSoftmax(augmentation=True) prepends a constant 1 to every input vector (layers.py:703-719); the extra
-                # weight column is folded into the bias when the plan is compiled
-                p = dict(out=out, output_type=typ, aug=bool(g['aug']))
-            oshape = (n, out, h, w)
-        layers.append(LayerSpec(kind, name, _named_block(block, name), p, shape, oshape))
-        shape = oshape
+    layers, _, _ = _SpecParser().parse((batch, channels, height, width), blocks[1:])
     return (batch, channels, height, width), layers
 
 
@@ -234,6 +359,21 @@ class _NoParams(nn.Module):
     pass
 
 
+class _Group(nn.Module):
+    """A nested `[ ... ]` (MultiParamSequential) or `( ... )` (MultiParamParallel, layers.py:39-71) block: a parameter-free
+    container whose children carry the reference's module names, so that the state-dict keys agree."""
+
+    def __init__(self, kind: str):
+        super().__init__()
+        self.kind = kind
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __getitem__(self, i: int):
+        return list(self._modules.values())[i]
+
+
 _HOLDERS = {'conv': _ConvHolder, 'groupnorm': _GroupNormHolder, 'rnn': _RnnHolder, 'linear': _LinearHolder}
 _ACTS = {'l': _lib.ACT_LINEAR, 'r': _lib.ACT_RELU, 't': _lib.ACT_TANH, 'lr': _lib.ACT_LEAKY, 's': _lib.ACT_SIGMOID}
 # The reference builds nn.LSTM(bidirectional = direction == 'b') and never flips the sequence, so an
@@ -257,7 +397,11 @@ class _Plan:
             if spec.kind == 'dropout':
                 continue   # identity in eval mode (reference layers.py:433-437)
             d = _lib.KrkLayer()
-            mod = getattr(modules, spec.name)
+            if spec.structural:
+                d.op = {'par_begin': _lib.OP_PAR_BEGIN, 'par_next': _lib.OP_PAR_NEXT, 'par_end': _lib.OP_PAR_END}[spec.kind]
+                descs.append(d)
+                continue
+            mod = modules.holder(spec)
             arrays: list[np.ndarray] = []
             p = spec.params
             if spec.kind == 'conv':
@@ -278,12 +422,16 @@ class _Plan:
                 arrays = [_f32(mod.layer.weight), _f32(mod.layer.bias)]
             elif spec.kind == 'reshape':
                 d.op = _lib.OP_RESHAPE_HC
+            elif spec.kind == 'add':
+                d.op = _lib.OP_ADD
+                d.kh = 1 if p['axis'] == 2 else 0              # include/kraken_amd.h: 0 = channels, 1 = height
+                d.cout = p['chunk']
             elif spec.kind == 'rnn':
                 d.op = _lib.OP_LSTM
                 d.cout = p['hidden']
                 d.direction = _DIRS[p['direction']]
                 d.kw = 1 if p.get('axis', 'x') == 'y' else 0   # include/kraken_amd.h: time axis of an LSTM layer
-                d.kh = 1 if p.get('summarize') else 0          # include/kraken_amd.h: keep only the last step (Lxys)
+                d.kh = 1 if p.get('summarize') else 0          # include/kraken_amd.h: keep only the last step (L?ys / L?xs)
                 sfx = [''] + (['_reverse'] if p['direction'] == 'b' else [])
                 for s in sfx:
                     arrays += [_f32(getattr(mod.layer, f'weight_ih_l0{s}')), _f32(getattr(mod.layer, f'weight_hh_l0{s}')),
@@ -366,8 +514,16 @@ class HipSequential(nn.Module):
         self._specs = list(specs)
         self._input = tuple(input_shape)
         for spec in specs:
-            self.add_module(spec.name, _HOLDERS[spec.kind](spec) if spec.kind in _HOLDERS else _NoParams())
+            if spec.structural:
+                continue
+            parent = self
+            for cname, ckind in spec.path:
+                if cname not in parent._modules:
+                    parent.add_module(cname, _Group(ckind))
+                parent = parent._modules[cname]
+            parent.add_module(spec.name, _HOLDERS[spec.kind](spec) if spec.kind in _HOLDERS else _NoParams())
         self._plans: dict = {}          # (device, precision, weights version, height) -> _Plan, a few heights at most
+        self._sum_x = any(s.kind == 'rnn' and s.params.get('summarize') and s.params.get('axis') == 'x' for s in specs)
         self.precision = _lib.PREC_F32
 
     # -- plan management -------------------------------------------------------------
@@ -482,7 +638,7 @@ class HipSequential(nn.Module):
         channel count; a height-collapsing reshape does not, and the reference would fail in the next layer too.
         """
         n, c, _, w = self._input
-        text = f'[{n},{height},{w},{c} ' + ' '.join(s.text for s in self._specs) + ']'
+        text = f'[{n},{height},{w},{c} ' + ' '.join(s.text for s in self._specs if s.text) + ']'
         _, specs = parse_vgsl(text)
         for a, b in zip(self._specs, specs):
             if a.kind in ('conv', 'groupnorm', 'rnn', 'linear') and a.in_shape[1] != b.in_shape[1]:
@@ -496,7 +652,17 @@ class HipSequential(nn.Module):
         return r
 
     def __len__(self):
-        return len(self._specs)
+        return len(self._modules)
+
+    def __getitem__(self, i: int):
+        return list(self._modules.values())[i]
+
+    def holder(self, spec: LayerSpec) -> nn.Module:
+        """The parameter container of a layer (inside its nested groups)."""
+        mod = self
+        for cname, _ in spec.path:
+            mod = mod._modules[cname]
+        return mod._modules[spec.name]
 
     # -- execution ---------------------------------------------------------------------
     @staticmethod
@@ -527,6 +693,7 @@ class HipSequential(nn.Module):
         logits tensor (a permuted view of the time-major buffer the kernels write) on the GPU.
         """
         dev, xd, lens = self._prep(x, seq_lens)
+        self._check_lens(lens)
         plan = self.plan(dev, xd.shape[2])
         N, _, _, W = xd.shape
         c, h, w = plan.out_shape(W)
@@ -562,10 +729,17 @@ class HipSequential(nn.Module):
     def _specs_out_is_seq(self) -> bool:
         """True when the network ends in the time-major sequence layout (after the height collapse)."""
         seq = False
+        forks = []
         for spec in self._specs:
-            if spec.kind == 'dropout':
+            if spec.kind in ('dropout', 'add', 'par_end'):
+                if spec.kind == 'par_end':
+                    forks.pop()                    # the members agree (the plan refuses a mix)
                 continue
-            if spec.kind in ('reshape', 'linear'):
+            if spec.kind == 'par_begin':
+                forks.append(seq)
+            elif spec.kind == 'par_next':
+                seq = forks[-1]
+            elif spec.kind in ('reshape', 'linear'):
                 seq = True
             elif spec.kind == 'rnn':
                 # an LSTM over the rows/columns of an image (height > 1 or y axis) returns an image again
@@ -573,6 +747,11 @@ class HipSequential(nn.Module):
             else:
                 seq = False
         return seq
+
+    def _check_lens(self, lens) -> None:
+        """The reference's run-time refusals that depend on seq_lens (TransposedSummarizingRNN.forward, layers.py:540-545)."""
+        if lens is not None and self._sum_x and int(lens.max()) > 1:
+            raise Exception('Do not use summarizing layer in x-axis with batching/sequences')
 
     @torch.no_grad()
     def recognize(self, x: torch.Tensor, seq_lens=None, temperature: float = 1.0, want_logits: bool = False,
@@ -583,6 +762,7 @@ class HipSequential(nn.Module):
         (N, C, T) permuted views on the GPU.
         """
         dev, xd, lens = self._prep(x, seq_lens)
+        self._check_lens(lens)
         plan = self.plan(dev, xd.shape[2])
         N, _, _, W = xd.shape
         c, h, T = plan.out_shape(W)
@@ -635,7 +815,7 @@ class TorchVGSLModel(nn.Module):
         self.layer_specs = specs
         self.nn = HipSequential(specs, self.input)
         self.output = specs[-1].out_shape if specs else self.input
-        self.named_spec = [vgsl.strip()[1:-1].split(' ')[0]] + [s.text for s in specs]
+        self.named_spec = [vgsl.strip()[1:-1].split(' ')[0]] + [s.text for s in specs if s.text]
         self.user_metadata['vgsl'] = '[' + ' '.join(self.named_spec) + ']'
         self.criterion = None
         if specs and specs[-1].params.get('output_type') == 'c':

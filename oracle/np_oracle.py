@@ -196,10 +196,32 @@ def forward(specs, sd, x, lens=None):
     x = np.asarray(x, F32)
     cur = None if lens is None else [int(v) for v in lens]
     x = mask_width(x, cur)
+    forks = []                                            # parallel groups being evaluated: [input, input lens, member outputs]
     for sp in specs:
-        k, p, nm = sp.kind, sp.params, sp.name
+        k, p, nm = sp.kind, sp.params, getattr(sp, 'key', sp.name)
         if k == 'dropout':
             continue                                      # identity in eval, layers.py:433-437
+        # MultiParamParallel.forward, layers.py:60-71: every member gets the group's input, the outputs are concatenated on the
+        # channel axis, the seq_lens are those the LAST member returned
+        if k == 'par_begin':
+            forks.append([x, cur, []])
+            continue
+        if k in ('par_next', 'par_end'):
+            forks[-1][2].append(x)
+            if k == 'par_next':
+                x, cur = forks[-1][0], forks[-1][1]
+            else:
+                x = np.concatenate(forks.pop()[2], axis=1)
+            continue
+        if k == 'add':                                    # Addition.forward, layers.py:205-210
+            ax, ch = p['axis'], p['chunk']
+            nk = x.shape[ax] // ch
+            pieces = [np.take(x, range(i * ch, (i + 1) * ch), axis=ax) for i in range(nk)]
+            acc = pieces[0].astype(F32)
+            for piece in pieces[1:]:
+                acc = (acc + piece).astype(F32)
+            x = acc
+            continue
         if k == 'conv':
             x = conv2d(x, sd[f'nn.{nm}.co.weight'], sd[f'nn.{nm}.co.bias'], p['stride'], p['dilation'], p['nl'])
             if cur is not None:
@@ -221,10 +243,14 @@ def forward(specs, sd, x, lens=None):
                 # through untouched (every column runs its full height) and the width mask below zeroes the padding columns
                 assert cur is None or p.get('axis', 'x') == 'y', 'seq_lens with an LSTM over image rows (the reference raises)'
                 x = lstm_image(x, ws, p['hidden'], p['direction'], p.get('axis', 'x'))
-                if p.get('summarize'):
-                    x = x[:, :, -1:, :]                     # o[:, :, -1, :].unsqueeze(2), layers.py:537-539
+                if p.get('summarize'):                      # o[:, :, -1, :].unsqueeze(2), layers.py:537-539
+                    x = x[:, :, -1:, :] if p.get('axis', 'x') == 'y' else x[:, :, :, -1:]
             else:
                 x = lstm(x, ws, p['hidden'], p['direction'], cur)
+                if p.get('summarize'):
+                    # the reference raises when a seq_len exceeds the one column that is left (layers.py:543-545)
+                    assert cur is None or max(cur) <= 1, 'Do not use summarizing layer in x-axis with batching/sequences'
+                    x = x[:, :, :, -1:]
         elif k == 'linear':
             x = linear(x, sd[f'nn.{nm}.lin.weight'], sd[f'nn.{nm}.lin.bias'])
         else:

@@ -49,9 +49,9 @@ class CpuRecognizer:
                 m = torch.nn.LSTM(s.in_shape[1], s.params['hidden'], bidirectional=s.params['direction'] == 'b',
                                   batch_first=True)
                 m.load_state_dict({k.split('.layer.')[1]: v for k, v in self.sd.items()
-                                   if k.startswith(f'nn.{s.name}.layer.')})
+                                   if k.startswith(f'nn.{getattr(s, "key", s.name)}.layer.')})
                 m.eval()
-                self.rnn[s.name] = m
+                self.rnn[getattr(s, 'key', s.name)] = m
 
     @torch.inference_mode()
     def forward(self, x, lens=None, reference_batched=False):
@@ -60,8 +60,25 @@ class CpuRecognizer:
         masked = cur is not None and not reference_batched
         if masked:
             x = _mask(x, cur)
+        forks = []
         for s in self.specs:
-            p, nm = s.params, s.name
+            p, nm = s.params, getattr(s, 'key', s.name)
+            # MultiParamParallel.forward (layers.py:60-71): members share the input, outputs are concatenated on C, the seq_lens
+            # are the last member's; Addition.forward (layers.py:205-210)
+            if s.kind == 'par_begin':
+                forks.append([x, cur, []])
+                continue
+            if s.kind in ('par_next', 'par_end'):
+                forks[-1][2].append(x)
+                if s.kind == 'par_next':
+                    x, cur = forks[-1][0], forks[-1][1]
+                else:
+                    x = torch.cat(forks.pop()[2], dim=1)
+                continue
+            if s.kind == 'add':
+                o = x.unfold(p['axis'], p['chunk'], p['chunk']).sum(p['axis'], keepdim=True)
+                x = o.transpose(-1, p['axis']).squeeze(-1)
+                continue
             if s.kind == 'conv':        # layers.py:842-860
                 x = _ACT[p['nl']](F.conv2d(x, self.sd[f'nn.{nm}.co.weight'], self.sd[f'nn.{nm}.co.bias'],
                                            p['stride'], p['padding'], p['dilation']))
@@ -105,6 +122,10 @@ class CpuRecognizer:
                 else:
                     o, _ = self.rnn[nm](seq)
                 x = o.reshape(h, n, w, -1).permute(1, 3, 0, 2)
+                if s.params.get('summarize'):               # the last column of every row (:537-539, :543-545)
+                    if cur is not None and int(cur.max()) > 1:
+                        raise Exception('Do not use summarizing layer in x-axis with batching/sequences')
+                    x = x[..., -1:]
             elif s.kind == 'linear':    # layers.py:710-722
                 xt = x.transpose(1, 3)
                 if s.params.get('aug'):     # 1-augmentation, layers.py:718-719

@@ -164,6 +164,25 @@ BREADTH_CASES = {
 }
 
 
+GROUP_CASES = {
+    # round 4: nested serial `[ ... ]` and parallel `( ... )` groups (model.py:847-905, layers.py:56-71), Addition (layers.py:188-223),
+    # x-axis summarising LSTMs (layers.py:537-545).  The first spec is the reference's own (tests/test_vgsl.py:71)
+    'par_nested':   ('[1,48,0,1 Cr4,2,1,4,2 ([Cr4,2,1,1,1 Do Cr3,3,2,1,1] [Cr4,2,1,1,1 Cr3,3,2,1,1 Do]) S1(1x0)1,3 Lbx2 Do0.5 Lbx2]',
+                     2, 40, [40, 25]),
+    'par_bare':     ('[1,12,0,1 (Cr3,3,4 Cr5,5,6 Ct1,1,2) Mp2,2 S1(1x0)1,3 Lbx8 O1c5]', 3, 30, [30, 21, 8]),
+    'par_residual': ('[1,10,0,2 Cr3,3,8 (I [Cr3,3,8 Cl3,3,8]) A3,8 Cr3,3,4]', 2, 19, None),
+    'par_seq':      ('[1,1,0,12 (Lfx6 Lbx5) O1c7]', 3, 17, [17, 9, 4]),
+    'par_in_par':   ('[1,8,0,1 ([Cr3,3,4 (Cr3,3,2 Cr1,1,3)] Cr3,3,4) Gn3 S1(1x0)1,3 Lbx6]', 2, 21, None),
+    'par_then_x3':  ('[1,16,0,1 (Cr3,3,8 Cr5,5,8) Cr3,3,16 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx16 Lbx8 O1c10]', 3, 44, [44, 30, 21]),
+    'par_pooled':   ('[1,12,0,1 ([Cr3,3,4 Mp2,2] [Mp2,2 Cr3,3,4]) S1(1x0)1,3 Lfx6]', 3, 33, [33, 20, 9]),
+    'add_h':        ('[1,12,0,2 Cr3,3,4 A1,4 S1(1x0)1,3 Lfx5]', 2, 15, None),
+    'add_c_rem':    ('[1,6,0,7 A3,3 Cr3,3,2]', 2, 11, None),
+    'add_seq':      ('[1,1,0,12 Lbx6 A3,6 O1c4]', 3, 17, [17, 9, 4]),
+    'sum_x_img':    ('[1,6,0,2 Lfxs4]', 2, 13, None),
+    'sum_x_seq':    ('[1,1,0,9 Lbxs5 O1c3]', 3, 11, None),
+}
+
+
 @torch.inference_mode()
 def layer_fixture(path, cases=None):
     cases = cases or {
@@ -203,6 +222,7 @@ def layer_fixture(path, cases=None):
         x = torch.randn(n, c, h or 24, w)      # variable-height specs ([1,0,0,1 ...]) get 24 rows
         for k, v in net.state_dict().items():
             out[f'{name}/sd/{k}'] = v.numpy()
+        out[f'{name}/vgsl'] = np.array(net.user_metadata['vgsl'])     # the named spec the reference stores with a model
         out[f'{name}/x'] = x.numpy()
         if lens is None:
             y, _ = net.nn(x, None)
@@ -415,7 +435,7 @@ def transforms_fixture(path):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'codec', 'transforms']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'codec', 'transforms']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -433,6 +453,8 @@ if __name__ == '__main__':
         layer_fixture(os.path.join(HERE, 'x3_networks.npz'), X3_NETWORK_CASES)
     if 'breadth' in which:
         layer_fixture(os.path.join(HERE, 'breadth.npz'), BREADTH_CASES)
+    if 'groups' in which:
+        layer_fixture(os.path.join(HERE, 'groups.npz'), GROUP_CASES)
     if 'codec' in which:
         codec_fixture(os.path.join(HERE, 'codec.npz'))
     if 'transforms' in which:

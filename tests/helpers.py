@@ -36,6 +36,8 @@ def layer_cases(fname='layers.npz'):
         entry = dict(meta)
         entry['sd'] = sd
         entry['x'] = z[f'{name}/x']
+        if f'{name}/vgsl' in z.files:
+            entry['vgsl'] = str(z[f'{name}/vgsl'])      # the reference's named spec (user_metadata['vgsl'])
         if meta['lens'] is None:
             entry['y'] = z[f'{name}/y']
         else:

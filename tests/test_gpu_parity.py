@@ -25,6 +25,7 @@ CONF_TOL = 1e-4
 CASES = layer_cases()
 CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, scaled-down BLLA segmenter
 CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes above 256, ...
+CASES.update(layer_cases('groups.npz'))       # round 4: nested [ ] / ( ) groups, Addition, x-axis summarising LSTMs
 
 
 def _keys(tuples):
@@ -97,6 +98,95 @@ def test_x3_kernels_against_reference_golden(name, prec):
         for i, want in enumerate(c['ys']):
             w = want.shape[3]
             assert float((y[i:i + 1, ..., :w] - torch.from_numpy(want)).abs().max()) < tol, (name, prec, i)
+
+
+GROUP_NETS = layer_cases('groups.npz')
+
+
+@pytest.mark.parametrize('name', sorted(GROUP_NETS))
+def test_groups_in_the_split_bf16_plan_against_reference_golden(name):
+    """
+    Nested / parallel groups, Addition and x-axis summarising LSTMs (reference model.py:847-905, layers.py:56-71, 188-223, 537-545)
+    in a bf16x3 plan: they work on fp32 tensors, so -- like a GroupNorm part -- everything up to the last of them runs on the
+    exact-f32 kernels and the split-bf16 ones take over behind it.  Against the reference's own outputs (ragged batches: its
+    per-line results); the f32 plan of the same cases is covered by test_layers_against_reference_golden.
+    """
+    c = GROUP_NETS[name]
+    m = build_model(c['spec'], c['sd']).to('cuda')
+    m.nn.set_precision('bf16x3')
+    tol = 1e-3 if 'Gn' in c['spec'] else 2e-4
+    x = torch.from_numpy(c['x'])
+    if c['lens'] is None:
+        y, _ = m.nn(x.cuda())
+        assert tuple(y.shape) == c['y'].shape
+        assert float((y.cpu() - torch.from_numpy(c['y'])).abs().max()) < tol
+    else:
+        for i, L in enumerate(c['lens']):
+            x[i, ..., L:] = 0
+        y, olens = m.nn(x.cuda(), torch.tensor(c['lens']))
+        y = y.cpu()
+        assert olens.tolist() == c['olens'].tolist()
+        for i, want in enumerate(c['ys']):
+            w = want.shape[3]
+            assert float((y[i:i + 1, ..., :w] - torch.from_numpy(want)).abs().max()) < tol, (name, i)
+
+
+@pytest.mark.parametrize('name', ['conv_pool', 'conv_stride2', 'conv_linear', 'conv_gn_pool', 'conv_even_str'])
+def test_networks_ending_in_an_image_return_fp32_from_the_split_plan(name):
+    """A bf16x3 plan whose LAST layer is a split-bf16 convolution (no sequence part) converts its planes back: the caller gets
+    fp32 NCHW like from every other plan (found by the residual-group case: the planes themselves came back)."""
+    c = CASES[name]
+    m = build_model(c['spec'], c['sd']).to('cuda')
+    m.nn.set_precision('bf16x3')
+    x = torch.from_numpy(c['x'])
+    lens = c['lens']
+    if lens is None:
+        y, _ = m.nn(x.cuda())
+        assert float((y.cpu() - torch.from_numpy(c['y'])).abs().max()) < 2e-4
+    else:
+        for i, L in enumerate(lens):
+            x[i, ..., L:] = 0
+        y, _ = m.nn(x.cuda(), torch.tensor(lens))
+        for i, want in enumerate(c['ys']):
+            w = want.shape[3]
+            assert float((y.cpu()[i:i + 1, ..., :w] - torch.from_numpy(want)).abs().max()) < 2e-4, (name, i)
+
+
+def test_split_bf16_kernels_take_over_behind_a_parallel_group():
+    from kraken_amd.engine import RecognitionEngine
+    import kraken_amd
+    c = GROUP_NETS['par_then_x3']
+    m = build_model(c['spec'], c['sd']).to('cuda')
+    m.nn.set_precision('bf16x3')
+    eng = RecognitionEngine(m, device=0, max_batch=3, max_width=64, slots=1)
+    eng.set_profiling(True)
+    eng.submit(torch.from_numpy(c['x']).cuda())
+    eng.collect()
+    names = [n_ for n_, _, _ in eng.layer_times()[0]]
+    eng.close()
+    assert m.nn.precision == kraken_amd._lib.PREC_BF16X3
+    # two member convolutions + the concatenation in f32, then the first split-bf16 convolution reads the fp32 tensor
+    assert names[:3] == ['conv', 'conv', 'concat'] and 'conv_x3' in names and 'lstm_rec_x3' in names and 'linear_x3' in names, names
+
+
+def test_summarising_x_refuses_seq_lens_like_the_reference():
+    """TransposedSummarizingRNN.forward raises when a seq_len exceeds the one column that is left (layers.py:543-545)."""
+    c = GROUP_NETS['sum_x_seq']
+    m = build_model(c['spec'], c['sd']).to('cuda')
+    x = torch.from_numpy(c['x']).cuda()
+    with pytest.raises(Exception, match='summarizing layer in x-axis'):
+        m.nn(x, torch.tensor([11, 7, 3]))
+    y, _ = m.nn(x)
+    assert tuple(y.shape) == c['y'].shape == (3, 3, 1, 1)
+
+
+def test_parallel_members_of_different_width_fail_like_torch_cat():
+    """Members whose output widths differ for the width of THIS call (the spec's width is variable, so the constructor cannot
+    know): torch.cat raises in the reference (layers.py:70); here krk_forward refuses with KRK_E_INVALID."""
+    import kraken_amd
+    m = build_model('[1,8,0,1 (Cr3,3,4 Cr3,4,4) Mp2,2]', seed=0).to('cuda')
+    with pytest.raises(kraken_amd._lib.KrakenAmdError, match='different widths'):
+        m.nn(torch.rand(1, 1, 8, 20).cuda())
 
 
 # ------------------------------------------------------------- (1) golden: benchmark networks

@@ -16,7 +16,7 @@ import kraken_amd
 from kraken_amd import _lib
 from kraken_amd.codec import KrakenCodecException, KrakenEncodeException, PytorchCodec
 from kraken_amd.vgsl import parse_vgsl
-from tests.helpers import load_golden
+from tests.helpers import layer_cases, load_golden
 from tests.specs import BENCH_A, BENCH_B, bench_codec
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,9 +60,14 @@ def test_custom_layer_names():
     ('[1,48,0,1 Cr3,3,32 O2c10]', ValueError),
     ('[1,48,0,1 Cr3,3,32 S2(3x0)1,3]', ValueError),
     ('[1,48,0,1 CTr3,3,32]', NotImplementedError),
-    ('[1,48,0,1 (Cr3,3,32 Cr3,3,32)]', NotImplementedError),
-    ('[1,48,0,1 Cr3,3,32 Lbxs20]', NotImplementedError),      # x-axis summarising (y-axis summarising is native)
-    ('[1,48,0,1 Cr3,3,32 A1,2]', NotImplementedError),
+    ('[1,48,0,1 Cr3,3,32 A0,2]', NotImplementedError),        # Addition over the batch axis (channels / height are native)
+    ('[1,48,0,1 Cr3,3,32 A2,2]', NotImplementedError),        # ... over the width
+    ('[1,48,0,1 Cr3,3,32 A4,2]', ValueError),
+    ('[1,48,0,1 Cr3,3,32 A1,50]', ValueError),                # a chunk larger than the axis
+    # the reference's own negative cases for groups (tests/test_vgsl.py:78-83, model.py:227-228, 867-868)
+    ('[1,48,0,1 Cr4,2,1,4,2 [Cr4,2,1,1,1 (Cr4,2,1,4,2 Cr3,3,2,1,1) S1(1x0)1,3 Lbx2 Do0.5] Lbx2]', ValueError),
+    ('[1,48,0,1 Cr3,3,8 (Cr3,3,4 Cr3,3,4]', ValueError),
+    ('[1,48,0,1 Cr3,3,8 [Cr3,3,4 Cr3,3,4 O1c10]', ValueError),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxo20]', NotImplementedError),
 ])
 def test_bad_or_unsupported_specs_raise(spec, exc):
@@ -76,10 +81,8 @@ def test_bad_or_unsupported_specs_raise(spec, exc):
 UNSUPPORTED_FORMS = [
     ('[1,48,0,1 CTr3,3,32 O2l4]', 'transposed', 'model.py:701-712 (transposed convolution)'),
     ('[1,48,0,1 Cm3,3,32 S1(1x0)1,3 O1c10]', 'softmax-activated', 'model.py:701 (channel-softmax convolution)'),
-    ('[1,48,0,1 Cr3,3,32 (Cr3,3,16 Cr5,5,16) S1(1x0)1,3 O1c10]', '(Cr3,3,16', 'model.py:876 (parallel block)'),
-    ('[1,48,0,1 Cr3,3,32 A1,2 S1(1x0)1,3 O1c10]', 'A1,2', 'model.py:622 (Addition)'),
+    ('[1,48,0,1 Cr3,3,32 A2,2 S1(1x0)1,3 O1c10]', 'A2,2', 'model.py:622 (Addition over the width; channels and height are native)'),
     ('[1,48,0,1 W0.5,10 S1(1x0)1,3 O1c10]', 'W0.5,10', 'model.py:677 (wav2vec mask)'),
-    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxs20 O1c10]', 'Lbxs20', 'model.py:579 (x-axis summarising)'),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxc20 O1c10]', 'Lbxc20', 'layers.py:498 (legacy 1-augmented LSTM)'),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxo20 O1c10]', 'Lbxo20', 'layers.py:146 (peephole LSTM)'),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbx800 O1c10]', 'Lbx800', 'hidden size above 768'),
@@ -94,6 +97,37 @@ def test_unsupported_vgsl_forms_are_refused_at_construction_naming_the_block(spe
     with pytest.raises(NotImplementedError) as e:
         kraken_amd.TorchVGSLModel(vgsl=spec)
     assert token in str(e.value), (what, str(e.value))
+
+
+GROUPS = layer_cases('groups.npz')
+
+
+@pytest.mark.parametrize('name', sorted(GROUPS))
+def test_nested_groups_are_named_like_the_reference(name):
+    """
+    A nested `[ ... ]` / `( ... )` group is registered under the space-joined names of the layers inside it (model.py:236), layer
+    indices run over the leaf layers only: the state-dict keys and the named spec stored with a model (`user_metadata['vgsl']`,
+    model.py:199) must be the reference's, or its weight files would not load.
+    """
+    c = GROUPS[name]
+    m = kraken_amd.TorchVGSLModel(vgsl=c['spec'])
+    assert sorted(m.state_dict()) == sorted(c['sd'])
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: v.shape for k, v in c['sd'].items()}
+    assert m.user_metadata['vgsl'] == c['vgsl']
+    # the named spec parses back into the same network (what load_model does with a stored file)
+    again = kraken_amd.TorchVGSLModel(vgsl=m.user_metadata['vgsl'])
+    assert sorted(again.state_dict()) == sorted(c['sd']) and again.user_metadata['vgsl'] == c['vgsl']
+
+
+def test_group_containers_index_like_the_reference():
+    """tests/test_vgsl.py:67-76 of the reference: nn[1] is the parallel group, its members are serial groups of three layers."""
+    m = kraken_amd.TorchVGSLModel(vgsl='[1,48,0,1 Cr4,2,1,4,2 ([Cr4,2,1,1,1 Do Cr3,3,2,1,1] [Cr4,2,1,1,1 Cr3,3,2,1,1 Do]) S1(1x0)1,3 Lbx2 Do0.5 Lbx2]')
+    assert len(m.nn) == 6 and m.nn[1].kind == 'parallel'
+    members = list(m.nn[1].children())
+    assert [g.kind for g in members] == ['series', 'series'] and [len(g) for g in members] == [3, 3]
+    assert m.output == (1, 4, 1, 1)      # the reshape leaves the variable width as 1 (model.py:739-777)
+    kinds = [s.kind for s in m.layer_specs]
+    assert kinds[1] == 'par_begin' and kinds.count('par_next') == 1 and kinds[9] == 'par_end'
 
 
 def test_one_augmented_output_layer_is_built_like_the_reference():

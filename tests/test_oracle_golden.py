@@ -18,6 +18,7 @@ LAYER_TOL = 2e-5
 CASES = layer_cases()
 CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, scaled-down BLLA segmenter
 CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes above 256, ...
+CASES.update(layer_cases('groups.npz'))       # round 4: nested [ ] / ( ) groups, Addition, x-axis summarising LSTMs
 
 
 def _zero_pad_x(x, lens):
