@@ -376,7 +376,9 @@ def mode_api(args, rank, local_rank):
         for label, dev_prep in (('api', True), ('api_host_preparation', False)):
             R.DEVICE_PREP = dev_prep
             best, reps = 0.0, []
-            for rep in range(4):                       # the first pass creates plans, pinned buffers and the allocator's blocks
+            # the first pass creates plans, pinned buffers and the allocator's blocks; a pass is 50..100 ms of wall time, so single
+            # passes scatter (collector pauses, thread start-up): best AND median of the warm passes are reported
+            for rep in range(8 if dev_prep else 3):
                 with warnings.catch_warnings():
                     warnings.simplefilter('ignore')
                     t0 = time.perf_counter()
@@ -388,7 +390,17 @@ def mode_api(args, rank, local_rank):
                 assert len(recs) == n and all(r.prediction for r in recs)
                 best = max(best, n / dt)
                 reps.append(round(n / dt, 1))
+                if rep == 0 and dev_prep and not os.environ.get('KRK_API_NOFREEZE'):
+                    # what a long-running service does once its models are loaded (gc.freeze: everything allocated so far leaves
+                    # the collector's generations): without it every other 60 ms pass pays a ~55 ms full collection of the
+                    # interpreter's heap (torch's modules), triggered by the ~15 container objects a record consists of
+                    import gc
+                    del recs
+                    gc.collect()
+                    gc.freeze()
+                    res['gc'] = 'gc.freeze() after the first pass'
             res[label + '_lines_per_s'] = round(best, 1)
+            res[label + '_median_warm_pass'] = round(float(np.median(reps[2:])), 1) if len(reps) > 3 else None
             res[label + '_all_passes'] = reps
         R.DEVICE_PREP = True
         # the same model with inputs resident in HBM (what the default mode measures)

@@ -222,6 +222,17 @@ int krk_recognize(krk_plan* plan, const float* x_dev, const int* lens_host,
  */
 int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int channels, const int* boxes_dev, int n,
                    int max_in_h, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream);
+/*
+ * krk_prep_lines for a page that is NOT packed [page_h][page_w][channels]: row y starts `row_stride` bytes behind row y - 1 and a
+ * pixel is `pix_stride` bytes.  pix_stride 4 with channels 3 reads R, G, B of Pillow's own storage of an 'RGB' image (R, G, B, X
+ * per pixel: the rows are uploaded as they lie in Pillow's memory, without the repacking of Image.tobytes / np.asarray);
+ * channels 1 with pix_stride 3 or 4 gives the 1-channel model Pillow's 'L' conversion of the colour pixel,
+ * (R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16 -- what the reference's im.crop(box).convert('L') holds
+ * (kraken/lib/dataset/utils.py:112-118; libImaging/Convert.c rgb2l).  Everything else as krk_prep_lines.
+ */
+int krk_prep_lines_fmt(const unsigned char* page_dev, int page_h, int page_w, long row_stride, int pix_stride, int channels,
+                       const int* boxes_dev, int n, int max_in_h, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev,
+                       void* stream);
 
 /*
  * The same preprocessing for line images that were cut out on the HOST (baseline / polygon extraction,
@@ -256,6 +267,18 @@ int krk_dewarp_measure(const unsigned char* crops_dev, const int* desc_dev, int 
                        double* scratch_dev, int* work_dev, int* info_dev, void* stream);
 int krk_dewarp_apply(const unsigned char* crops_dev, const int* desc_dev, int n, int max_w, const int* work_dev, const int* geo_dev,
                      int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream);
+/*
+ * The same two calls for lines that are crops of ONE uploaded page instead of packed images: desc[k][0] is the byte offset of
+ * the crop's first pixel in `page_dev`, a page row is `row_stride` bytes, a pixel `pix_stride` bytes (1: an 'L' page; 3 / 4: an
+ * RGB / RGBX page read through Pillow's 'L' conversion, see krk_prep_lines_fmt).  No per-line packing copy on the host: the
+ * lines of a bounding-box segmentation are views of the page (kraken/lib/segmentation.py:1630-1643 cuts them out one by one).
+ * row_stride 0 = packed images (then pix_stride must be 1): the calls above.
+ */
+int krk_dewarp_measure_page(const unsigned char* page_dev, long row_stride, int pix_stride, const int* desc_dev, int n, int max_w,
+                            int max_h, const double* weights_dev, double* scratch_dev, int* work_dev, int* info_dev, void* stream);
+int krk_dewarp_apply_page(const unsigned char* page_dev, long row_stride, int pix_stride, const int* desc_dev, int n, int max_w,
+                          const int* work_dev, const int* geo_dev, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev,
+                          void* stream);
 
 /*
  * Tail of the segmenter's forward (reference kraken/lib/vgsl/spred.py:268-272): the network's class logits (C, h, w) are

@@ -27,7 +27,8 @@ EXPORTS = ['krk_abi_version', 'krk_last_error', 'krk_device_count', 'krk_plan_cr
            'krk_plan_out_shape', 'krk_plan_olens', 'krk_forward', 'krk_greedy_decode', 'krk_recognize',
            'krk_plan_workspace_bytes', 'krk_plan_set_profiling', 'krk_plan_layer_ms', 'krk_plan_layer_name',
            'krk_plan_layer_flops', 'krk_plan_num_steps', 'krk_plan_front_event', 'krk_plan_wait_front',
-           'krk_plan_status', 'krk_prep_lines', 'krk_prep_crops', 'krk_upsample_sigmoid', 'krk_dewarp_measure', 'krk_dewarp_apply']
+           'krk_plan_status', 'krk_prep_lines', 'krk_prep_crops', 'krk_upsample_sigmoid', 'krk_dewarp_measure', 'krk_dewarp_apply',
+           'krk_prep_lines_fmt', 'krk_dewarp_measure_page', 'krk_dewarp_apply_page']
 
 
 class KrkLayer(C.Structure):
@@ -134,6 +135,13 @@ def load():
         lib.krk_dewarp_measure.restype = i32
         lib.krk_dewarp_apply.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp]
         lib.krk_dewarp_apply.restype = i32
+        i64 = C.c_long
+        lib.krk_prep_lines_fmt.argtypes = [vp, i32, i32, i64, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        lib.krk_prep_lines_fmt.restype = i32
+        lib.krk_dewarp_measure_page.argtypes = [vp, i64, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+        lib.krk_dewarp_measure_page.restype = i32
+        lib.krk_dewarp_apply_page.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp]
+        lib.krk_dewarp_apply_page.restype = i32
         if lib.krk_abi_version() != 1:
             raise ImportError('libkraken_amd.so ABI version mismatch; rebuild the extension')
         _lib = lib

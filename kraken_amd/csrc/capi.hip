@@ -2119,29 +2119,43 @@ static int prep_lut(const char* who, float** out);
 
 int krk_dewarp_measure(const unsigned char* crops_dev, const int* desc_dev, int n, int max_w, int max_h, const double* weights_dev,
                        double* scratch_dev, int* work_dev, int* info_dev, void* stream) {
-    if (!crops_dev || !desc_dev || !weights_dev || !scratch_dev || !work_dev || !info_dev || n < 0 || max_w <= 0 || max_h < 2)
+    return krk_dewarp_measure_page(crops_dev, 0, 1, desc_dev, n, max_w, max_h, weights_dev, scratch_dev, work_dev, info_dev, stream);
+}
+
+int krk_dewarp_apply(const unsigned char* crops_dev, const int* desc_dev, int n, int max_w, const int* work_dev, const int* geo_dev,
+                     int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream) {
+    return krk_dewarp_apply_page(crops_dev, 0, 1, desc_dev, n, max_w, work_dev, geo_dev, out_h, pad, batch_w, x_dev, flags_dev, stream);
+}
+
+int krk_dewarp_measure_page(const unsigned char* crops_dev, long row_stride, int pix_stride, const int* desc_dev, int n, int max_w, int max_h,
+                            const double* weights_dev, double* scratch_dev, int* work_dev, int* info_dev, void* stream) {
+    if (!crops_dev || !desc_dev || !weights_dev || !scratch_dev || !work_dev || !info_dev || n < 0 || max_w <= 0 || max_h < 2 ||
+        row_stride < 0 || (row_stride == 0 && pix_stride != 1))
         return fail(KRK_E_INVALID, "krk_dewarp_measure: bad argument");
     if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_dewarp_measure: no HIP device");
     int* mm = work_dev;
     int* ridge = work_dev + 2 * (size_t)n;
     int* centre = ridge + (size_t)n * max_w;
-    if (krk_launch_dewarp_measure(crops_dev, desc_dev, n, max_w, max_h, weights_dev, scratch_dev, mm, ridge, centre, info_dev, (hipStream_t)stream))
-        return fail(KRK_E_HIP, std::string("krk_dewarp_measure: launch failed: ") + hipGetErrorString(hipGetLastError()));
+    const int rc = krk_launch_dewarp_measure(crops_dev, (size_t)row_stride, pix_stride, desc_dev, n, max_w, max_h, weights_dev, scratch_dev, mm,
+                                             ridge, centre, info_dev, (hipStream_t)stream);
+    if (rc == -4) return fail(KRK_E_UNSUPPORTED, "krk_dewarp_measure: pixel stride must be 1, 3 or 4");
+    if (rc) return fail(KRK_E_HIP, std::string("krk_dewarp_measure: launch failed: ") + hipGetErrorString(hipGetLastError()));
     return KRK_OK;
 }
 
-int krk_dewarp_apply(const unsigned char* crops_dev, const int* desc_dev, int n, int max_w, const int* work_dev, const int* geo_dev,
-                     int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream) {
-    if (!crops_dev || !desc_dev || !work_dev || !geo_dev || !x_dev || !flags_dev || n < 0 || batch_w <= 0)
+int krk_dewarp_apply_page(const unsigned char* crops_dev, long row_stride, int pix_stride, const int* desc_dev, int n, int max_w,
+                          const int* work_dev, const int* geo_dev, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream) {
+    if (!crops_dev || !desc_dev || !work_dev || !geo_dev || !x_dev || !flags_dev || n < 0 || batch_w <= 0 || row_stride < 0 ||
+        (row_stride == 0 && pix_stride != 1))
         return fail(KRK_E_INVALID, "krk_dewarp_apply: bad argument");
     if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_dewarp_apply: no HIP device");
     float* lut = nullptr;
     if (int rc = prep_lut("krk_dewarp_apply", &lut)) return rc;
     const int* mm = work_dev;
     const int* centre = work_dev + 2 * (size_t)n + (size_t)n * max_w;
-    const int rc = krk_launch_dewarp_apply(crops_dev, desc_dev, n, max_w, mm, centre, geo_dev, lut, out_h, pad, batch_w, x_dev, flags_dev,
-                                           (hipStream_t)stream);
-    if (rc == -4) return fail(KRK_E_UNSUPPORTED, "krk_dewarp_apply: needs pad > 0 and out_h > 0");
+    const int rc = krk_launch_dewarp_apply(crops_dev, (size_t)row_stride, pix_stride, desc_dev, n, max_w, mm, centre, geo_dev, lut, out_h, pad,
+                                           batch_w, x_dev, flags_dev, (hipStream_t)stream);
+    if (rc == -4) return fail(KRK_E_UNSUPPORTED, "krk_dewarp_apply: needs pad > 0, out_h > 0 and a pixel stride of 1, 3 or 4");
     if (rc) return fail(KRK_E_HIP, std::string("krk_dewarp_apply: launch failed: ") + hipGetErrorString(hipGetLastError()));
     return KRK_OK;
 }
@@ -2164,14 +2178,22 @@ static int prep_lut(const char* who, float** out) {
 
 int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int channels, const int* boxes_dev, int n,
                    int max_in_h, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream) {
-    if (!page_dev || !boxes_dev || !x_dev || !flags_dev || n < 0 || batch_w <= 0)
+    return krk_prep_lines_fmt(page_dev, page_h, page_w, (long)page_w * channels, channels, channels, boxes_dev, n, max_in_h, out_h, pad, batch_w,
+                              x_dev, flags_dev, stream);
+}
+
+int krk_prep_lines_fmt(const unsigned char* page_dev, int page_h, int page_w, long row_stride, int pix_stride, int channels,
+                       const int* boxes_dev, int n, int max_in_h, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream) {
+    if (!page_dev || !boxes_dev || !x_dev || !flags_dev || n < 0 || batch_w <= 0 || row_stride <= 0)
         return fail(KRK_E_INVALID, "krk_prep_lines: bad argument");
     if (krk_device_count() <= 0) return fail(KRK_E_HIP, "krk_prep_lines: no HIP device");
     float* lut = nullptr;
     if (int rc = prep_lut("krk_prep_lines", &lut)) return rc;
-    const int rc = krk_launch_prep_lines(page_dev, page_h, page_w, channels, boxes_dev, n, max_in_h, lut, out_h, pad,
-                                         batch_w, x_dev, flags_dev, (hipStream_t)stream);
-    if (rc == -4) return fail(KRK_E_UNSUPPORTED, "krk_prep_lines: line geometry outside the kernel's range (height, scale, padding)");
+    const int rc = krk_launch_prep_lines(page_dev, page_h, page_w, (size_t)row_stride, pix_stride, channels, boxes_dev, n, max_in_h, lut, out_h,
+                                         pad, batch_w, x_dev, flags_dev, (hipStream_t)stream);
+    if (rc == -4)
+        return fail(KRK_E_UNSUPPORTED, "krk_prep_lines: line geometry outside the kernel's range (height, scale, padding) or a page format "
+                                       "it does not read (pixel stride)");
     if (rc) return fail(KRK_E_HIP, std::string("krk_prep_lines: launch failed: ") + hipGetErrorString(hipGetLastError()));
     return KRK_OK;
 }

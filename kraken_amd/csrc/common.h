@@ -290,18 +290,20 @@ int krk_launch_lstm_wp_b1(const LstmWsArgs& a, hipStream_t s);
 int krk_lstm_kg(int M, int blocks_per_wave);
 
 // line preprocessing on the device (prep_lines.hip): boxes_dev = [n][5] int32 (x0, y0, x1, y1, out_w)
-int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, int ch, const int* boxes_dev, int n, int max_in_h,
-                          const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
+// page row y starts rs bytes behind row y - 1, a pixel is ps bytes (ps == ch: packed; 4: Pillow's RGBX; ch 1 of ps >= 3: 'L' conversion)
+int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, size_t rs, int ps, int ch, const int* boxes_dev, int n,
+                          int max_in_h, const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
 
 // the same for a packed buffer of uint8 line images: desc_dev = [n][4] int32 (byte offset, width, height, out_w)
 int krk_launch_prep_crops(const unsigned char* crops, int ch, const int* desc_dev, int n, int max_in_h,
                           const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
 
 // CenterNormalizer dewarp of 1-channel lines (dewarp.hip): measure (centre line, spread) and normalize + float stage
-int krk_launch_dewarp_measure(const unsigned char* crops, const int* desc, int n, int maxw, int maxh, const double* wts, double* scratch,
-                              int* mm, int* ridge, int* centre, int* info, hipStream_t s);
-int krk_launch_dewarp_apply(const unsigned char* crops, const int* desc, int n, int maxw, const int* mm, const int* centre, const int* geo,
-                            const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
+// rs = 0: packed line images (a row is the line's own width); rs > 0: crops of one page with rows rs bytes apart; ps = bytes per pixel
+int krk_launch_dewarp_measure(const unsigned char* crops, size_t rs, int ps, const int* desc, int n, int maxw, int maxh, const double* wts,
+                              double* scratch, int* mm, int* ridge, int* centre, int* info, hipStream_t s);
+int krk_launch_dewarp_apply(const unsigned char* crops, size_t rs, int ps, const int* desc, int n, int maxw, const int* mm, const int* centre,
+                            const int* geo, const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s);
 
 // host-side launchers (implemented in the .hip files)
 int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);

@@ -33,6 +33,15 @@ namespace {
 __device__ __forceinline__ double dmul(double a, double b) { return a * b; }
 __device__ __forceinline__ double dadd(double a, double b) { return a + b; }
 
+// Where a line's pixels lie: packed images back to back (rs = 0: a row is the line's own w bytes, ps = 1) or crops of ONE uploaded
+// page (rs = bytes per page row, `off` = byte offset of the crop's first pixel; ps = 1: an 'L' page, ps = 3 / 4: an RGB / RGBX page
+// read through Pillow's 'L' conversion (R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16 -- what im.crop(box).convert('L') holds).
+struct Src { size_t rs; int ps; };
+__device__ __forceinline__ int px_at(const unsigned char* p, int y, int x, int w, Src f) {
+    const unsigned char* q = p + (size_t)y * (f.rs ? f.rs : (size_t)w) + (size_t)x * f.ps;
+    return f.ps < 3 ? (int)q[0] : (int)((q[0] * 19595u + q[1] * 38470u + q[2] * 7471u + 0x8000u) >> 16);
+}
+
 struct LineD { int off, w, h, soff, woff, r0, r1, r2; };
 __device__ __forceinline__ LineD line_of(const int* desc, int n) {
     const int* d = desc + 8 * n;
@@ -40,12 +49,16 @@ __device__ __forceinline__ LineD line_of(const int* desc, int n) {
 }
 
 // K0: top (max) and min of a line; one workgroup per line.  mm[n] = {top, min}
-__global__ void __launch_bounds__(256) dw_minmax_kernel(const unsigned char* crops, const int* desc, int* mm) {
+__global__ void __launch_bounds__(256) dw_minmax_kernel(const unsigned char* crops, Src f, const int* desc, int* mm) {
     const int n = blockIdx.x;
     const LineD L = line_of(desc, n);
     const unsigned char* p = crops + (size_t)(unsigned)L.off;
     int mx = 0, mn = 255;
-    for (int e = threadIdx.x; e < L.w * L.h; e += 256) { const int v = p[e]; mx = max(mx, v); mn = min(mn, v); }
+    for (int e = threadIdx.x; e < L.w * L.h; e += 256) {
+        const int y = e / L.w, x = e - y * L.w;
+        const int v = px_at(p, y, x, L.w, f);
+        mx = max(mx, v); mn = min(mn, v);
+    }
     __shared__ int smx[256], smn[256];
     smx[threadIdx.x] = mx; smn[threadIdx.x] = mn;
     __syncthreads();
@@ -57,7 +70,8 @@ __global__ void __launch_bounds__(256) dw_minmax_kernel(const unsigned char* cro
 }
 
 // K1: Gaussian along axis 0 (rows) of ink -> plane 0
-__global__ void __launch_bounds__(256) dw_gauss0_kernel(const unsigned char* crops, const int* desc, const int* mm, const double* wts, double* scratch) {
+__global__ void __launch_bounds__(256) dw_gauss0_kernel(const unsigned char* crops, Src f, const int* desc, const int* mm, const double* wts,
+                                                        double* scratch) {
     const int n = blockIdx.z;
     const LineD L = line_of(desc, n);
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -66,7 +80,7 @@ __global__ void __launch_bounds__(256) dw_gauss0_kernel(const unsigned char* cro
     const double top = (double)mm[2 * n], amax = (double)(mm[2 * n] - mm[2 * n + 1]);
     if (amax == 0.0) return;
     const double* w = wts + L.woff;                  // w[r0 + j], j = -r0 .. r0
-    auto ink = [&](int yy) -> double { return (yy < 0 || yy >= L.h) ? 0.0 : __ddiv_rn(dmul(top - (double)p[yy * L.w + x], 1.0), amax); };
+    auto ink = [&](int yy) -> double { return (yy < 0 || yy >= L.h) ? 0.0 : __ddiv_rn(dmul(top - (double)px_at(p, yy, x, L.w, f), 1.0), amax); };
     double t = dmul(ink(y), w[L.r0]);
     for (int j = min(L.r0, L.h); j >= 1; --j)        // beyond +-h both partners are outside: they add exactly 0
         t = dadd(t, dmul(dadd(ink(y - j), ink(y + j)), w[L.r0 - j]));
@@ -166,7 +180,8 @@ __global__ void __launch_bounds__(256) dw_centre_kernel(const int* desc, const i
 }
 
 // K7: r = int(1 + 4 * mean |y - centre| over ink pixels); band bounds.  info[n] = {r, ok, has ink, 0}; one workgroup per line
-__global__ void __launch_bounds__(256) dw_spread_kernel(const unsigned char* crops, const int* desc, const int* mm, const int* centre, int maxw, int* info) {
+__global__ void __launch_bounds__(256) dw_spread_kernel(const unsigned char* crops, Src f, const int* desc, const int* mm, const int* centre, int maxw,
+                                                        int* info) {
     const int n = blockIdx.x;
     const LineD L = line_of(desc, n);
     const int top = mm[2 * n];
@@ -179,7 +194,7 @@ __global__ void __launch_bounds__(256) dw_spread_kernel(const unsigned char* cro
         const int* c = centre + (size_t)n * maxw;
         for (int e = threadIdx.x; e < L.w * L.h; e += 256) {
             const int y = e / L.w, x = e - y * L.w;
-            if (p[e] != top) { sum += abs(y - c[x]); ++cnt; }
+            if (px_at(p, y, x, L.w, f) != top) { sum += abs(y - c[x]); ++cnt; }
         }
         for (int x = threadIdx.x; x < L.w; x += 256) { cmin = min(cmin, c[x]); cmax = max(cmax, c[x]); }
     }
@@ -205,7 +220,7 @@ __global__ void __launch_bounds__(256) dw_spread_kernel(const unsigned char* cro
 }
 
 // K8: normalize + the float stage.  geo [n][4] int32: r, out_w (int(scale * w)), use (0: leave zeros), 0.  One thread per output pixel.
-__global__ void __launch_bounds__(256) dw_apply_kernel(const unsigned char* crops, const int* desc, const int* mm, const int* centre, int maxw,
+__global__ void __launch_bounds__(256) dw_apply_kernel(const unsigned char* crops, Src f, const int* desc, const int* mm, const int* centre, int maxw,
                                                        const int* geo, const float* lut, int out_h, int pad, int batch_w, float* out, int* flags) {
     const int n = blockIdx.z;
     const LineD L = line_of(desc, n);
@@ -231,7 +246,7 @@ __global__ void __launch_bounds__(256) dw_apply_kernel(const unsigned char* crop
         auto band = [&](int yy, int x) -> double {      // float32 of the padded line: exact for 8-bit values
             if (yy >= bh || x >= bw) return top;       // past the last sample: weight 0
             const int row = c[x] + L.h - r + yy;       // row of the (3h)-row stack
-            return (row >= L.h && row < 2 * L.h) ? (double)p[(row - L.h) * L.w + x] : top;
+            return (row >= L.h && row < 2 * L.h) ? (double)px_at(p, row - L.h, x, L.w, f) : top;
         };
         double acc = dmul(band(y0, x0), dmul(1.0 - ty, 1.0 - tx));
         acc = dadd(acc, dmul(band(y0, x0 + 1), dmul(1.0 - ty, tx)));
@@ -248,27 +263,30 @@ __global__ void __launch_bounds__(256) dw_apply_kernel(const unsigned char* crop
 
 }  // namespace
 
-int krk_launch_dewarp_measure(const unsigned char* crops, const int* desc, int n, int maxw, int maxh, const double* wts, double* scratch,
-                              int* mm, int* ridge, int* centre, int* info, hipStream_t s) {
+int krk_launch_dewarp_measure(const unsigned char* crops, size_t rs, int ps, const int* desc, int n, int maxw, int maxh, const double* wts,
+                              double* scratch, int* mm, int* ridge, int* centre, int* info, hipStream_t s) {
     if (n <= 0) return 0;
+    if (ps != 1 && ps != 3 && ps != 4) return -4;
+    const Src f{rs, ps};
     const unsigned gx = (unsigned)((maxw + 255) / 256);
-    hipLaunchKernelGGL(dw_minmax_kernel, dim3(n), dim3(256), 0, s, crops, desc, mm);
-    hipLaunchKernelGGL(dw_gauss0_kernel, dim3(gx, maxh, n), dim3(256), 0, s, crops, desc, mm, wts, scratch);
+    hipLaunchKernelGGL(dw_minmax_kernel, dim3(n), dim3(256), 0, s, crops, f, desc, mm);
+    hipLaunchKernelGGL(dw_gauss0_kernel, dim3(gx, maxh, n), dim3(256), 0, s, crops, f, desc, mm, wts, scratch);
     hipLaunchKernelGGL(dw_gauss1_kernel, dim3(gx, maxh, n), dim3(256), 0, s, desc, mm, wts, scratch);
     hipLaunchKernelGGL(dw_unif0_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, scratch);
     hipLaunchKernelGGL(dw_unif1_kernel, dim3((unsigned)((maxh + 63) / 64), n), dim3(64), 0, s, desc, mm, scratch);
     hipLaunchKernelGGL(dw_ridge_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, scratch, ridge, maxw);
     hipLaunchKernelGGL(dw_centre_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, wts, ridge, centre, maxw);
-    hipLaunchKernelGGL(dw_spread_kernel, dim3(n), dim3(256), 0, s, crops, desc, mm, centre, maxw, info);
+    hipLaunchKernelGGL(dw_spread_kernel, dim3(n), dim3(256), 0, s, crops, f, desc, mm, centre, maxw, info);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int krk_launch_dewarp_apply(const unsigned char* crops, const int* desc, int n, int maxw, const int* mm, const int* centre, const int* geo,
-                            const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s) {
+int krk_launch_dewarp_apply(const unsigned char* crops, size_t rs, int ps, const int* desc, int n, int maxw, const int* mm, const int* centre,
+                            const int* geo, const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s) {
     if (n <= 0) return 0;
-    if (out_h < 1 || pad < 1) return -4;
+    if (out_h < 1 || pad < 1 || (ps != 1 && ps != 3 && ps != 4)) return -4;
+    const Src f{rs, ps};
     (void)hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), s);
-    hipLaunchKernelGGL(dw_apply_kernel, dim3((unsigned)((batch_w + 255) / 256), out_h, n), dim3(256), 0, s, crops, desc, mm, centre, maxw, geo, lut,
+    hipLaunchKernelGGL(dw_apply_kernel, dim3((unsigned)((batch_w + 255) / 256), out_h, n), dim3(256), 0, s, crops, f, desc, mm, centre, maxw, geo, lut,
                        out_h, pad, batch_w, out, flags);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -73,8 +73,13 @@ __device__ __forceinline__ unsigned clip8(int v) {
 // PACKED = true: every line brings its own crop -- `page` is a packed buffer of uint8 images, boxes [n][4] = byte offset,
 //                width, height, out_w (krk_prep_crops): what a host-side line extractor (baseline / polygon extraction, any
 //                producer of line images) hands over, 1 byte per pixel over PCIe instead of the 4 of a float tensor.
+// Page pixels: row y starts `rs` bytes after row y - 1, a pixel is `ps` bytes.  ps == ch: packed channels (what np.asarray(im)
+// gives); ps == 4 with ch == 3: Pillow's own storage of an 'RGB' image (R, G, B, X: the rows travel as they lie in Pillow's
+// memory); ch == 1 with ps >= 3: the 1-channel model reads Pillow's 'L' conversion of the colour pixel,
+// (R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16 (libImaging/Convert.c, bit for bit: tests/test_gpu_parity.py).
 template <bool PACKED>
 __global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __restrict__ page, int page_h, int page_w, int ch,
+                                                         size_t rs, int ps,
                                                          const int* __restrict__ boxes,
                                                          const float* __restrict__ lut, int out_h, int pad, int batch_w,
                                                          float* __restrict__ out, int* __restrict__ flags) {
@@ -86,6 +91,7 @@ __global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __
         page += (size_t)(unsigned)b[0];
         x0 = 0; y0 = 0; in_w = b[1]; in_h = b[2]; ow = b[3];
         page_w = in_w; page_h = in_h;
+        ps = ch; rs = (size_t)in_w * ch;
     } else {
         const int* b = boxes + 5 * n;
         x0 = b[0]; y0 = b[1]; in_w = b[2] - b[0]; in_h = b[3] - b[1]; ow = b[4];
@@ -122,6 +128,7 @@ __global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __
         khb[2 * j + 1] = xmax;
     }
     __syncthreads();
+    const bool luma = ch == 1 && ps >= 3;
     const int yfirst = kvb[0];
     const int ylast = kvb[2 * (out_h - 1)] + kvb[2 * (out_h - 1) + 1];
     const int rows = ylast - yfirst;
@@ -137,7 +144,11 @@ __global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __
             for (int x = 0; x < xmax; ++x) {
                 const int gx = x0 + xmin + x;
                 // Image.crop pads what lies outside the page with 0
-                const int px = (gy >= 0 && gy < page_h && gx >= 0 && gx < page_w) ? page[((size_t)gy * page_w + gx) * ch + c] : 0;
+                int px = 0;
+                if (gy >= 0 && gy < page_h && gx >= 0 && gx < page_w) {
+                    const unsigned char* q = page + (size_t)gy * rs + (size_t)gx * ps;
+                    px = luma ? (int)((q[0] * 19595u + q[1] * 38470u + q[2] * 7471u + 0x8000u) >> 16) : (int)q[c];
+                }
                 ss0 += px * k[x];
             }
             v = clip8(ss0);
@@ -170,16 +181,18 @@ __global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __
 }  // namespace
 
 // LDS: (out_h + COLS) * (MAX_K + 2) ints + ch * rows * COLS bytes
-int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, int ch, const int* boxes_dev, int n, int max_in_h,
-                          const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s) {
+int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, size_t rs, int ps, int ch, const int* boxes_dev, int n,
+                          int max_in_h, const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s) {
     if (n <= 0) return 0;
     if (out_h < 1 || out_h > 64 || pad < 1 || (ch != 1 && ch != 3) || max_in_h > MAX_ROWS) return -4;
+    if (ps < ch || ps > 4 || (ch == 1 && ps == 2) || rs < (size_t)page_w * ps) return -4;
     const size_t lds = (size_t)(out_h + COLS) * (MAX_K + 2) * sizeof(int) + (size_t)ch * (max_in_h + 2) * COLS;
     if (lds > 160 * 1024) return -4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_lines_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), s);
     dim3 grid((unsigned)((batch_w + COLS - 1) / COLS), (unsigned)n);
-    hipLaunchKernelGGL(prep_lines_kernel<false>, grid, dim3(256), lds, s, page, page_h, page_w, ch, boxes_dev, lut, out_h, pad, batch_w, out, flags);
+    hipLaunchKernelGGL(prep_lines_kernel<false>, grid, dim3(256), lds, s, page, page_h, page_w, ch, rs, ps, boxes_dev, lut, out_h, pad, batch_w,
+                       out, flags);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -193,6 +206,7 @@ int krk_launch_prep_crops(const unsigned char* crops, int ch, const int* desc_de
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_lines_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), s);
     dim3 grid((unsigned)((batch_w + COLS - 1) / COLS), (unsigned)n);
-    hipLaunchKernelGGL(prep_lines_kernel<true>, grid, dim3(256), lds, s, crops, 0, 0, ch, desc_dev, lut, out_h, pad, batch_w, out, flags);
+    hipLaunchKernelGGL(prep_lines_kernel<true>, grid, dim3(256), lds, s, crops, 0, 0, ch, (size_t)0, ch, desc_dev, lut, out_h, pad, batch_w, out,
+                       flags);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

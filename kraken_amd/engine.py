@@ -193,6 +193,19 @@ class RecognitionEngine:
         dev._krk_ready = ev
         return dev
 
+    def _page_format(self, page_dev: torch.Tensor):
+        """
+        (rows, width, bytes per pixel) of an uploaded page: (H, W) is an 'L' page, (H, W, 3) packed RGB, (H, W, 4) Pillow's own
+        R, G, B, X storage (``kraken_amd.pilmem``).  A 1-channel model reads colour pages through Pillow's 'L' conversion on the
+        device (``krk_prep_lines_fmt``); a 3-channel model needs a colour page.
+        """
+        if page_dev.dtype != torch.uint8 or page_dev.dim() not in (2, 3) or not page_dev.is_contiguous():
+            raise ValueError('page must be a contiguous uint8 tensor of shape (H, W) or (H, W, 3 | 4)')
+        ps = 1 if page_dev.dim() == 2 else int(page_dev.shape[2])
+        if ps not in (1, 3, 4) or (self.in_channels == 3 and ps == 1) or self.in_channels not in (1, 3):
+            raise ValueError(f'page has {ps} bytes per pixel, the model takes {self.in_channels} channel(s)')
+        return int(page_dev.shape[0]), int(page_dev.shape[1]), ps
+
     def submit_boxes(self, page_dev: torch.Tensor, boxes: np.ndarray, pad: int, want_probs: bool = False) -> int:
         """
         Recognises rectangular crops of an uploaded page: ``boxes`` int32 (n, 5) = x0, y0, x1, y1, resized width.  Crop,
@@ -208,19 +221,16 @@ class RecognitionEngine:
         slot.ensure_stage(n * c * h * w, host=False)
         slot.ensure_boxes(n)
         slot.boxes_host[:n].copy_(torch.from_numpy(boxes))
-        ph, pw = int(page_dev.shape[0]), int(page_dev.shape[1])
-        pc = 1 if page_dev.dim() == 2 else int(page_dev.shape[2])
-        if pc != c:
-            raise ValueError(f'page has {pc} channels, the model takes {c}')
+        ph, pw, ps = self._page_format(page_dev)
         page_dev.record_stream(slot.stream)          # the caller may drop the page before this slot's crops have run
         ready = getattr(page_dev, '_krk_ready', None)
         with torch.cuda.stream(slot.stream):
             if ready is not None:
                 slot.stream.wait_event(ready)
             slot.boxes_dev[:n].copy_(slot.boxes_host[:n], non_blocking=True)
-            _lib.check(self.lib.krk_prep_lines(page_dev.data_ptr(), ph, pw, pc, slot.boxes_dev.data_ptr(), n,
-                                               int((boxes[:, 3] - boxes[:, 1]).max()), h, int(pad), w,
-                                               slot.stage_dev.data_ptr(), slot.flags_dev.data_ptr(), slot.stream.cuda_stream))
+            _lib.check(self.lib.krk_prep_lines_fmt(page_dev.data_ptr(), ph, pw, pw * ps, ps, c, slot.boxes_dev.data_ptr(), n,
+                                                   int((boxes[:, 3] - boxes[:, 1]).max()), h, int(pad), w,
+                                                   slot.stage_dev.data_ptr(), slot.flags_dev.data_ptr(), slot.stream.cuda_stream))
             slot.flags_host[:n].copy_(slot.flags_dev[:n], non_blocking=True)
         slot.has_flags = True
         x = slot.stage_dev[:n * c * h * w].view(n, c, h, w)
@@ -285,13 +295,17 @@ class RecognitionEngine:
         """
         return self.measure_dewarp_begin(crops, pool).result()
 
-    def measure_dewarp_begin(self, crops: list, pool=None, ahead: int = 0):
+    def measure_dewarp_begin(self, crops, pool=None, ahead: int = 0, page: Optional[torch.Tensor] = None):
         """
         The same without the wait: enqueues upload + ``krk_dewarp_measure`` on the slot ``ahead`` places behind the next free one
         and returns a handle whose ``result()`` blocks for ``(r, ok, ink)``.  With ``ahead=1`` the measurement of batch k+1 is
         in flight while the host finishes batch k (``submit_dewarped`` of the slot in front) -- the device -> host read-back of a
         batch then costs the host nothing (round 4: it was 15 % of the API path's wall time).  Between a ``begin`` and the
         ``submit_dewarped`` of its slot nothing else may be submitted.
+
+        With ``page`` (a tensor from ``upload_page`` / ``upload_page_buffer``) ``crops`` is an int array (n, 4) of boxes
+        x0, y0, x1, y1 INSIDE that page: the lines are read where they lie (``krk_dewarp_measure_page``), nothing is packed or
+        uploaded per line; colour pages are read through Pillow's 'L' conversion.
         """
         from .transforms import dewarp_tables
         slot = self.slots[(self._next + ahead) % len(self.slots)]
@@ -300,42 +314,72 @@ class RecognitionEngine:
         if self.in_channels != 1:
             raise ValueError('the dewarp is defined for 1-channel models')
         n = len(crops)
-        tables, index = dewarp_tables(a.shape[0] for a in crops)
         desc = np.empty((n, 8), dtype=np.int32)
-        off = soff = 0
-        for k, a in enumerate(crops):
-            if a.dtype != np.uint8 or a.ndim != 2 or a.shape[0] < 2:
-                raise ValueError(f'crop {k}: expected a uint8 array of shape (h >= 2, w), got {a.dtype} {a.shape}')
-            ch, cw = int(a.shape[0]), int(a.shape[1])
-            woff, r0, r1, r2 = index[ch]
-            desc[k] = (off, cw, ch, soff, woff, r0, r1, r2)
-            off += (ch * cw + 15) & ~15
-            soff += 3 * ch * cw
-        maxw, maxh = int(desc[:, 1].max()), int(desc[:, 2].max())
-        slot.ensure_crops(off)
         dev = f'cuda:{self.device}'
-        buf = slot.crops_host.numpy()
-
-        def pack(lo_hi):
-            for k in range(*lo_hi):
-                a = crops[k]
-                buf[desc[k, 0]:desc[k, 0] + a.size] = np.ascontiguousarray(a).reshape(-1)
-        if pool is not None and n >= 32:
-            step = -(-n // 8)
-            list(pool.map(pack, [(a, min(a + step, n)) for a in range(0, n, step)]))
-        else:
-            pack((0, n))
         st = slot.__dict__.setdefault('dw', {})
+        if page is not None:
+            ph, pw, ps = self._page_format(page)
+            bx = np.ascontiguousarray(crops, dtype=np.int64).reshape(n, 4)
+            cw, chh = bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]
+            if (bx[:, 0] < 0).any() or (bx[:, 1] < 0).any() or (bx[:, 2] > pw).any() or (bx[:, 3] > ph).any() or (chh < 2).any() or \
+                    (cw < 1).any():
+                raise ValueError('dewarp boxes must lie inside the page and be at least 2 rows high')
+            if ph * pw * ps >= 1 << 32:
+                raise ValueError('page of 4 GiB or more: crop offsets are 32-bit')
+            tables, index = dewarp_tables(int(v) for v in chh)
+            tab = np.array([index[int(v)] for v in chh], dtype=np.int64).reshape(n, 4)
+            area = 3 * chh * cw
+            desc[:, 0] = ((bx[:, 1] * pw + bx[:, 0]) * ps).astype(np.uint32).view(np.int32)
+            desc[:, 1], desc[:, 2] = cw, chh
+            desc[:, 3] = np.concatenate(([0], np.cumsum(area)[:-1]))
+            desc[:, 4:8] = tab
+            soff = int(area.sum())
+            page.record_stream(slot.stream)
+            src = (page, pw * ps, ps)
+        else:
+            tables, index = dewarp_tables(a.shape[0] for a in crops)
+            off = soff = 0
+            for k, a in enumerate(crops):
+                if a.dtype != np.uint8 or a.ndim != 2 or a.shape[0] < 2:
+                    raise ValueError(f'crop {k}: expected a uint8 array of shape (h >= 2, w), got {a.dtype} {a.shape}')
+                ch, cw = int(a.shape[0]), int(a.shape[1])
+                woff, r0, r1, r2 = index[ch]
+                desc[k] = (off, cw, ch, soff, woff, r0, r1, r2)
+                off += (ch * cw + 15) & ~15
+                soff += 3 * ch * cw
+            slot.ensure_crops(off)
+            buf = slot.crops_host.numpy()
+
+            def pack(lo_hi):
+                for k in range(*lo_hi):
+                    a = crops[k]
+                    buf[desc[k, 0]:desc[k, 0] + a.size] = np.ascontiguousarray(a).reshape(-1)
+            if pool is not None and n >= 32:
+                step = -(-n // 8)
+                list(pool.map(pack, [(a, min(a + step, n)) for a in range(0, n, step)]))
+            else:
+                pack((0, n))
+            src = (slot.crops_dev, 0, 1)
+        maxw, maxh = int(desc[:, 1].max()), int(desc[:, 2].max())
+        if soff >= 1 << 31:
+            raise ValueError('dewarp batch too large: the scratch offsets are 32-bit (bound the batch by pixels)')
+        st['src'] = src
         with torch.cuda.stream(slot.stream):
-            slot.crops_dev[:off].copy_(slot.crops_host[:off], non_blocking=True)
+            if page is not None:
+                ready = getattr(page, '_krk_ready', None)
+                if ready is not None:
+                    slot.stream.wait_event(ready)
+            else:
+                slot.crops_dev[:off].copy_(slot.crops_host[:off], non_blocking=True)
             st['desc'] = torch.from_numpy(desc).to(dev, non_blocking=True)
             st['wts'] = torch.from_numpy(tables).to(dev, non_blocking=True)
             if st.get('scratch') is None or st['scratch'].numel() < soff:
                 st['scratch'] = torch.empty(int(soff * 1.25) + 1024, dtype=torch.float64, device=dev)
             st['work'] = torch.empty(2 * n + 2 * n * maxw, dtype=torch.int32, device=dev)
             info = torch.empty((n, 4), dtype=torch.int32, device=dev)
-            _lib.check(self.lib.krk_dewarp_measure(slot.crops_dev.data_ptr(), st['desc'].data_ptr(), n, maxw, maxh, st['wts'].data_ptr(),
-                                                   st['scratch'].data_ptr(), st['work'].data_ptr(), info.data_ptr(), slot.stream.cuda_stream))
+            _lib.check(self.lib.krk_dewarp_measure_page(src[0].data_ptr(), src[1], src[2], st['desc'].data_ptr(), n, maxw, maxh,
+                                                        st['wts'].data_ptr(), st['scratch'].data_ptr(), st['work'].data_ptr(),
+                                                        info.data_ptr(), slot.stream.cuda_stream))
             info_h = torch.empty((n, 4), dtype=torch.int32).pin_memory() if st.get('info_h') is None or st['info_h'].shape[0] < n \
                 else st['info_h']
             st['info_h'] = info_h
@@ -370,8 +414,10 @@ class RecognitionEngine:
         dev = f'cuda:{self.device}'
         with torch.cuda.stream(slot.stream):
             geo_d = torch.from_numpy(geo).to(dev, non_blocking=True)
-            _lib.check(self.lib.krk_dewarp_apply(slot.crops_dev.data_ptr(), st['desc'].data_ptr(), n, maxw, st['work'].data_ptr(), geo_d.data_ptr(),
-                                                 h, int(pad), w, slot.stage_dev.data_ptr(), slot.flags_dev.data_ptr(), slot.stream.cuda_stream))
+            src = st['src']
+            _lib.check(self.lib.krk_dewarp_apply_page(src[0].data_ptr(), src[1], src[2], st['desc'].data_ptr(), n, maxw, st['work'].data_ptr(),
+                                                      geo_d.data_ptr(), h, int(pad), w, slot.stage_dev.data_ptr(), slot.flags_dev.data_ptr(),
+                                                      slot.stream.cuda_stream))
             slot.flags_host[:n].copy_(slot.flags_dev[:n], non_blocking=True)
             geo_d.record_stream(slot.stream)
         slot.has_flags = True

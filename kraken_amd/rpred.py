@@ -42,6 +42,7 @@ import torch
 from PIL import Image
 
 from . import ctc_decoder as _ctc
+from . import pilmem
 from .containers import BaselineOCRRecord, BBoxOCRRecord
 from .transforms import ImageInputTransforms
 
@@ -53,6 +54,7 @@ ENGINE_BATCH = 256     # lines per device batch (results do not depend on it: ma
 ENGINE_SLOTS = 3       # device batches in flight per recogniser
 DEVICE_PREP = True     # crop / resize / pad / invert eligible lines on the device (krk_prep_lines) instead of with PIL
 DEVICE_DEWARP = True   # ... and the CenterNormalizer dewarp of 1-channel bbox lines (krk_dewarp_measure / krk_dewarp_apply) instead of scipy
+PAGE_ROWS = True       # upload the page's rows straight from Pillow's memory (kraken_amd.pilmem) instead of through np.asarray(im)
 DEWARP_BATCH_PIXELS = 32 * 1024 * 1024   # pixels per device dewarp batch (krk_dewarp_measure: 24 bytes of fp64 scratch per pixel, 32-bit offsets)
 PREP_THREADS = 4       # host threads preparing line images when the caller does not say (``num_line_workers``); PIL holds the GIL in its
                        # conversions: 2..6 threads give the same throughput, 16 and more lose 40 % to contention
@@ -136,6 +138,21 @@ class _Pending:
     box: Optional[tuple] = None         # ... prepared on the device: (x0, y0, x1, y1, resized width) into the uploaded page
     mode: str = ''                      # PIL mode of the page the device crops from
     crop: object = None                 # ... or a uint8 line image cut out on the host, resized / padded / inverted on the device
+
+
+class _PageCrop:
+    """A dewarp line that is a box of the page the device holds: shape like the uint8 array a host-side crop would be, its first
+    pixel looked up on demand (only a UNIFORM line needs it, LinePipeline.dewarp_finish)."""
+    __slots__ = ('box', 'shape', 'size', '_first')
+
+    def __init__(self, box, first):
+        self.box = box
+        self.shape = (box[3] - box[1], box[2] - box[0])
+        self.size = self.shape[0] * self.shape[1]
+        self._first = first
+
+    def first(self) -> int:
+        return self._first()
 
 
 class LazyList(collections.abc.Sequence):
@@ -379,11 +396,15 @@ class LinePipeline:
         """
         return self.dewarp_finish(items, self.dewarp_begin(items), pad)
 
-    def dewarp_begin(self, items: list, ahead: int = 0):
+    def dewarp_begin(self, items: list, ahead: int = 0, page=None, top: int = 0):
         """Upload + measurement of one dewarp batch, not waited for (engine.measure_dewarp_begin); ``ahead=1``: a batch that was
-        begun before is still to be finished (``dewarp_finish``) -- nothing else may be submitted in between."""
+        begun before is still to be finished (``dewarp_finish``) -- nothing else may be submitted in between.  With ``page`` (device
+        tensor whose first row is row ``top`` of the image) the items are _PageCrop boxes read from it."""
         while self.engine.free_slots() < 1 + ahead:
             self._collect_one()
+        if page is not None:
+            boxes = np.asarray([(a.box[0], a.box[1] - top, a.box[2], a.box[3] - top) for _, a in items], dtype=np.int64)
+            return self.engine.measure_dewarp_begin(boxes, pool=self.pool, ahead=ahead, page=page)
         return self.engine.measure_dewarp_begin([a for _, a in items], pool=self.pool, ahead=ahead)
 
     def dewarp_finish(self, items: list, measured, pad: int):
@@ -395,7 +416,7 @@ class LinePipeline:
             # a UNIFORM crop (ink False: max == min) is the reference's flat line only when it is white: any other value becomes a
             # non-flat tensor once the white padding is added (kraken/rpred.py:221 tests the PADDED tensor) and is recognised --
             # solid black crops do occur on binarised pages.  Those take the reference's own transform on the host.
-            to_host = (i and not o) or (not i and a.size > 0 and int(a.flat[0]) != 255)
+            to_host = (i and not o) or (not i and a.size > 0 and (a.first() if isinstance(a, _PageCrop) else int(a.flat[0])) != 255)
             if to_host:
                 host.add(k)                                  # (band outside the padded stack: the reference's own code decides)
             elif o and i:
@@ -471,6 +492,9 @@ class _RecognitionRun:
         self._pages: dict = {}     # PIL mode -> the page as a device tensor (device-side line preparation)
         self._gray = None          # the page as one uint8 'L' array, converted band by band (bbox lines of a dewarping model)
         self._gray_done: set = set()
+        # Pillow's row table of the page (None: np.asarray path).  '1' / 'L' pages are one byte per pixel, 'RGB' / 'RGBX' / 'RGBA'
+        # four: R, G, B, X -- uploaded as they are, the kernels take the pixel stride (and Pillow's 'L' conversion for 1-channel models)
+        self._rows = pilmem.image_rows(im) if (PAGE_ROWS and DEVICE_PREP and hasattr(im, 'getpixel')) else None
 
     # -- device-side preparation (krk_prep_lines): rectangular crops of a fixed-height model, no dewarp ------------
     def _transform_on_device_ok(self, net, ts) -> bool:
@@ -512,6 +536,8 @@ class _RecognitionRun:
             return False
         if extract_polygons is not _EXTRACT_POLYGONS or not (DEVICE_PREP and DEVICE_DEWARP):
             return False
+        if self._rows is not None:
+            return False                               # the lines are read from the uploaded page itself (_dewarp_box_on_page)
         ts = getattr(self, 'ts', None)
         tss = list(ts.values()) if isinstance(ts, dict) else [ts]
         return any(getattr(t, '_center_norm', False) and getattr(t, '_mode', '') == 'L' for t in tss)
@@ -545,7 +571,9 @@ class _RecognitionRun:
         (pixel for pixel `im.crop(box).convert('L')`: the conversion is point-wise).  None: the general path decides (boxes
         touching the page border are padded by PIL, invalid ones give the reference's empty records).
         """
-        if self._gray is None or not ts._center_norm or not self._transform_on_device_ok(net, ts):
+        on_page = self._rows is not None and DEVICE_DEWARP and self.bounds.type != 'baselines' and \
+            self.bounds.text_direction.startswith('horizontal') and extract_polygons is _EXTRACT_POLYGONS
+        if (self._gray is None and not on_page) or not ts._center_norm or not self._transform_on_device_ok(net, ts):
             return None
         box = line.bbox
         if box is None or len(box) != 4:
@@ -556,10 +584,15 @@ class _RecognitionRun:
             return None
         w, h = x1 - x0, y1 - y0
         step = self.GRAY_ROWS
-        if h < 2 or h > 192 or w > 16384 or any(k not in self._gray_done for k in range(y0 // step, (y1 - 1) // step + 1)):
+        if h < 2 or h > 192 or w > 16384:
             return None
-        return _Pending(idx, line, tag, net, None, (w, h), image=self.im.crop((x0, y0, x1, y1)) if want_image else None, width=0,
-                        mode='dewarp', crop=self._gray[y0:y1, x0:x1])
+        image = self.im.crop((x0, y0, x1, y1)) if want_image else None
+        if on_page:
+            # a crop of the page the DEVICE holds (krk_dewarp_measure_page): no pixel is touched on the host
+            return _Pending(idx, line, tag, net, None, (w, h), image=image, width=0, mode='dewarp', box=(x0, y0, x1, y1, 0))
+        if any(k not in self._gray_done for k in range(y0 // step, (y1 - 1) // step + 1)):
+            return None
+        return _Pending(idx, line, tag, net, None, (w, h), image=image, width=0, mode='dewarp', crop=self._gray[y0:y1, x0:x1])
 
     def _crop_for_device(self, idx: int, line, tag: str, net, ts, box, box_size, want_image: bool = False):
         """
@@ -603,9 +636,21 @@ class _RecognitionRun:
             return self._pages[mode], 0
         if whole:
             y0, y1 = 0, H
+        eng = self._pipe(net).engine
+        rows = self._rows
+        if rows is not None and (rows.pixelsize == 1 if mode == 'L' and self.im.mode in ('1', 'L') else
+                                 rows.pixelsize == 4 and self.im.mode in ('RGB', 'RGBX', 'RGBA')):
+            # the band's rows as they lie in Pillow's memory: one memmove per block run, in parallel on the pool, into the pinned
+            # upload buffer.  Colour pages travel as R, G, B, X; the kernels take the pixel stride and, for a 1-channel model,
+            # Pillow's 'L' conversion (krk_prep_lines_fmt / krk_dewarp_*_page)
+            buf = eng.page_buffer((y1 - y0, W) if rows.pixelsize == 1 else (y1 - y0, W, 4))
+            pilmem.copy_rows(rows, y0, y1, buf.reshape(-1), self._pool)
+            dev = eng.upload_page_buffer()
+            if whole:
+                self._pages[mode] = dev
+            return dev, y0
         # PIL -> numpy runs at ~1 GB/s per thread: the band is converted in 256-row pieces by the worker pool, every piece
         # straight into the engine's pinned upload buffer
-        eng = self._pipe(net).engine
         buf = eng.page_buffer((y1 - y0, W) if mode == 'L' else (y1 - y0, W, 3))
         step = 256
 
@@ -733,8 +778,8 @@ class _RecognitionRun:
             for i, item in zip(idxs, items):
                 if isinstance(item, _Pending):
                     self._pending[i] = item
-                    shape = (('crop', item.mode) if item.crop is not None else ('dev', item.mode)) if item.tensor is None \
-                        else tuple(item.tensor.shape[:2])
+                    shape = (('crop', item.mode) if (item.crop is not None or item.mode == 'dewarp') else ('dev', item.mode)) \
+                        if item.tensor is None else tuple(item.tensor.shape[:2])
                     groups.setdefault((id(item.net), shape), []).append(item)
                 else:
                     self._results[i] = item
@@ -758,9 +803,18 @@ class _RecognitionRun:
     def _submit_dewarp(self, group: list):
         """Lines of a 1-channel model on a bbox segmentation: dewarp on the device; the few lines whose band does not fit the
         reference's padded stack (or that are flat) take the reference's host transform, which also decides their record."""
+        on_page = [p for p in group if p.crop is None]
+        if on_page and len(on_page) < len(group):       # lines cut out on the host (boxes touching the page border ...) and boxes of
+            self._submit_dewarp([p for p in group if p.crop is not None])      # the uploaded page: one kind per batch
+            group = on_page
         net = group[0].net
         pipe = self._pipe(net)
         ts = self.ts[group[0].tag] if isinstance(getattr(self, 'ts', None), (dict, defaultdict)) else self.ts
+        page, top = None, 0
+        if on_page:
+            page, top = self._strip_on_device(net, 'L', [p.box for p in group])
+            for p in group:
+                p.crop = _PageCrop(p.box, partial(self._page_gray_at, p.box[0], p.box[1]))
         # a dewarp batch is bounded by lines AND by pixels: krk_dewarp_measure keeps 3 fp64 planes per pixel of scratch behind
         # 32-bit offsets (a batch of 256 lines at the per-line maximum of 192 x 16384 would ask for 19 GB)
         parts, cur, px = [], [], 0
@@ -782,10 +836,10 @@ class _RecognitionRun:
         for part in parts + [None]:
             nxt = None
             if part is not None and not two and begun is None:       # a one-slot engine: both halves of a batch back to back
-                begun = (part, pipe.dewarp_begin([(p.idx, p.crop) for p in part]))
+                begun = (part, pipe.dewarp_begin([(p.idx, p.crop) for p in part], page=page, top=top))
                 part = None
             if part is not None:
-                nxt = (part, pipe.dewarp_begin([(p.idx, p.crop) for p in part], ahead=1 if begun else 0))
+                nxt = (part, pipe.dewarp_begin([(p.idx, p.crop) for p in part], ahead=1 if begun else 0, page=page, top=top))
             if begun is not None:
                 bpart, handle = begun
                 widths, host = pipe.dewarp_finish([(p.idx, p.crop) for p in bpart], handle, self.pad)
@@ -796,7 +850,11 @@ class _RecognitionRun:
             begun = nxt
         for p in to_host:
             del self._pending[p.idx]
-            box = Image.fromarray(np.ascontiguousarray(p.crop), 'L')
+            if isinstance(p.crop, _PageCrop):
+                box = self.im.crop(p.crop.box[:4])
+                box = box if box.mode == 'L' else box.convert('L')
+            else:
+                box = Image.fromarray(np.ascontiguousarray(p.crop), 'L')
             try:
                 t = ts(box)
             except Exception:
@@ -810,6 +868,13 @@ class _RecognitionRun:
             q = dataclasses.replace(p, tensor=t, crop=None, mode='', width=t.shape[2])
             self._pending[p.idx] = q
             pipe.submit([(q.idx, q.tensor)])
+
+    def _page_gray_at(self, x: int, y: int) -> int:
+        """Pillow's 'L' value of one page pixel (libImaging/Convert.c rgb2l for colour pages)."""
+        v = self.im.getpixel((x, y))
+        if isinstance(v, (tuple, list)):
+            return (v[0] * 19595 + v[1] * 38470 + v[2] * 7471 + 0x8000) >> 16 if len(v) >= 3 else int(v[0])
+        return int(v)
 
     def _fill(self):
         while self._cursor not in self._results:

@@ -1095,6 +1095,159 @@ def test_device_line_preprocessing_is_bit_exact(mode):
     assert flags.cpu().tolist() == [int(w.max() != w.min()) for w in want]
 
 
+@pytest.mark.parametrize('model_mode,page_fmt', [('RGB', 'rgbx'), ('L', 'rgbx'), ('L', 'rgb')])
+def test_device_line_preprocessing_reads_pillows_own_rows_bit_exact(model_mode, page_fmt):
+    """
+    krk_prep_lines_fmt on a colour page that was NOT repacked: R, G, B, X rows as they lie in Pillow's memory (pixel stride 4,
+    uploaded through kraken_amd.pilmem) for a 3-channel model, and -- pixel stride 4 or 3 -- Pillow's 'L' conversion of the
+    colour pixel on the device for a 1-channel model.  Against PIL crop (+ convert('L')) + ImageInputTransforms, bit for bit.
+    """
+    from kraken_amd import _lib, pilmem
+    from kraken_amd.transforms import ImageInputTransforms
+    page = _rgb_page()
+    ch = 1 if model_mode == 'L' else 3
+    boxes = _boxes(40, page, seed=4) + [(0, 0, 900, 48), (5, 5, 400, 29), (850, 1380, 960, 1430), (0, 100, 37, 612), (-7, -3, 300, 40)]
+    ts = ImageInputTransforms(1, 48, 0, ch, (16, 0), valid_norm=False)
+    want, rows = [], []
+    for b in boxes:
+        w, h = b[2] - b[0], b[3] - b[1]
+        ow = int(w * 48 / h)
+        want.append(ts(page.crop(b)))            # (the transform converts to the model's mode itself)
+        rows.append((*b, ow))
+    W, H = page.size
+    if page_fmt == 'rgbx':
+        t = pilmem.image_rows(page)
+        assert t is not None and t.pixelsize == 4
+        host = np.empty((H, W, 4), np.uint8)
+        pilmem.copy_rows(t, 0, H, host.reshape(-1))
+        assert np.array_equal(host[:, :, :3], np.asarray(page))
+    else:
+        host = np.asarray(page)
+    ps = host.shape[2]
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    pg = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+    bx = torch.tensor(rows, dtype=torch.int32, device=dev)
+    wmax = max(r[4] for r in rows) + 32
+    out = torch.full((len(rows), ch, 48, wmax), -7.0, device=dev)
+    flags = torch.full((len(rows),), -1, dtype=torch.int32, device=dev)
+    _lib.check(lib.krk_prep_lines_fmt(pg.data_ptr(), H, W, W * ps, ps, ch, bx.data_ptr(), len(rows),
+                                      max(r[3] - r[1] for r in rows), 48, 16, wmax, out.data_ptr(), flags.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream))
+    got = out.cpu()
+    for i, w in enumerate(want):
+        assert torch.equal(got[i, :, :, :w.shape[2]], w), (i, rows[i], (got[i, :, :, :w.shape[2]] - w).abs().max())
+        assert got[i, :, :, w.shape[2]:].abs().sum() == 0
+    assert flags.cpu().tolist() == [int(w.max() != w.min()) for w in want]
+
+
+@pytest.mark.parametrize('page_mode', ['L', 'RGB'])
+def test_dewarp_reads_the_lines_from_the_uploaded_page(page_mode):
+    """krk_dewarp_measure_page / krk_dewarp_apply_page on boxes of ONE uploaded page ('L': 1 byte per pixel; 'RGB': Pillow's
+    R, G, B, X rows read through its 'L' conversion) == the packed-crop calls on im.crop(box).convert('L'): same measurements,
+    bit-identical network inputs."""
+    from PIL import Image
+    from kraken_amd import pilmem
+    from kraken_amd.engine import RecognitionEngine
+    rng = np.random.RandomState(11)
+    rows, boxes, y = [], [], 0
+    for i in range(24):
+        h, w = int(rng.randint(20, 100)), int(rng.randint(150, 800))
+        x0 = int(rng.randint(0, 800 - w + 1))
+        line = np.full((h, 800), 255, np.uint8)
+        line[:, x0:x0 + w] = _wavy_line(rng, h, w)
+        rows.append(line)
+        boxes.append((x0, y, x0 + w, y + h))
+        y += h
+    gray = np.vstack(rows)
+    if page_mode == 'L':
+        page = Image.fromarray(gray, 'L')
+    else:       # a colour page whose 'L' conversion is NOT just one of its channels
+        rgb = np.stack([gray, np.roll(gray, 3, axis=1), np.minimum(gray, 200)], axis=2)
+        page = Image.fromarray(rgb, 'RGB')
+    crops = [np.asarray(page.crop(b).convert('L')) for b in boxes]
+    t = pilmem.image_rows(page)
+    assert t is not None
+    W, H = page.size
+    host = np.empty((H, W) if t.pixelsize == 1 else (H, W, 4), np.uint8)
+    pilmem.copy_rows(t, 0, H, host.reshape(-1))
+    m = build_model('[1,48,0,1 Cr3,13,32 Mp2,2 Cr3,13,32 S1(1x0)1,3 Lbx16 O1c9]', seed=0).to('cuda')
+    m.nn.set_precision('bf16x3')
+    eng = RecognitionEngine(m, device=0, max_batch=64, max_width=512, slots=1)
+
+    def run(begin):
+        r, ok, ink = begin().result()
+        ticket = eng.submit_dewarped(r, ok & ink, 16)
+        slot = eng.slots[ticket]
+        slot.stream.synchronize()
+        x = slot.keep.cpu().clone()
+        eng.collect(ticket)
+        return r, ok, ink, x
+    a = run(lambda: eng.measure_dewarp_begin(crops))
+    pg = torch.from_numpy(host).to('cuda:0')
+    b = run(lambda: eng.measure_dewarp_begin(np.asarray(boxes), page=pg))
+    eng.close()
+    for u, v in zip(a[:3], b[:3]):
+        assert u.tolist() == v.tolist()
+    assert a[3].shape == b[3].shape and torch.equal(a[3], b[3])
+    assert (a[1] & a[2]).sum() >= 20
+
+
+@pytest.mark.parametrize('page_mode,spec', [('RGB', BENCH_A), ('1', BENCH_A), ('RGBA', 'rgb'), ('L', BENCH_A)])
+def test_rpred_reads_the_page_from_pillows_rows_and_gives_the_same_records(page_mode, spec, monkeypatch):
+    """
+    rpred with the page's rows uploaded straight from Pillow's memory (kraken_amd.pilmem; colour pages as R, G, B, X, the 'L'
+    conversion of a 1-channel model on the device, dewarped lines read from the page) against the same run with the page going
+    through np.asarray(im) / im.convert: identical records -- and the fast path must actually have been taken.
+    """
+    import warnings
+    from PIL import Image
+    from kraken_amd import pilmem, rpred as R
+    from kraken_amd.containers import BBoxLine, Segmentation
+    from kraken_amd.models import TorchSeqRecognizer
+    if spec == 'rgb':
+        m = build_model(RGB_SPEC, codec={chr(0x61 + i): [i + 1] for i in range(26)}, seed=3)
+    else:
+        m = build_model(spec, codec=bench_codec(), seed=0)
+    m.seg_type, m.model_type = 'bbox', ['recognition']
+    net = TorchSeqRecognizer(m, device='cuda')
+    rng = np.random.RandomState(21)
+    rows, boxes, y = [], [], 0
+    for i in range(70):
+        h, w = int(rng.randint(30, 90)), int(rng.randint(200, 1000))
+        rows.append(np.pad(_wavy_line(rng, h, w), ((0, 0), (0, 1000 - w)), constant_values=255))
+        boxes.append((0, y, w, y + h))
+        y += h
+    gray = np.vstack(rows)
+    if page_mode == 'L':
+        page = Image.fromarray(gray, 'L')
+    elif page_mode == '1':
+        page = Image.fromarray(gray > 128)
+    else:
+        rgb = np.stack([gray, np.roll(gray, 2, axis=1), np.minimum(gray, 220)], axis=2)
+        page = Image.fromarray(rgb, 'RGB').convert(page_mode)
+    seg = Segmentation(type='bbox', imagename='p', text_direction='horizontal-lr', script_detection=False,
+                       lines=[BBoxLine(id=f'l{i}', bbox=list(b)) for i, b in enumerate(boxes)])
+    moved = []
+    real = pilmem.copy_rows
+    monkeypatch.setattr(pilmem, 'copy_rows', lambda t, y0, y1, *a, **k: (moved.append((y1 - y0) * t.linesize), real(t, y0, y1, *a, **k))[1])
+
+    def records():
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return list(R.rpred(net, page, seg, bidi_reordering=False))
+    fast = records()
+    assert sum(moved) >= page.size[0] * page.size[1] * (1 if page_mode in ('1', 'L') else 4) * 0.9
+    monkeypatch.setattr(R, 'PAGE_ROWS', False)
+    n = len(moved)
+    slow = records()
+    assert len(moved) == n
+    assert sum(bool(r.prediction) for r in fast) >= 60
+    for i, (a, b) in enumerate(zip(fast, slow)):
+        assert a.prediction == b.prediction and list(a.cuts) == list(b.cuts), i
+        np.testing.assert_allclose(a.confidences, b.confidences, atol=1e-6)
+
+
 @pytest.mark.parametrize('mode', ['L', 'RGB'])
 def test_device_preparation_of_host_cut_crops_is_bit_exact(mode):
     """

@@ -486,3 +486,61 @@ def test_identity_op_is_parsed_and_named_like_the_reference():
     # names produced by the unmodified reference for this spec (probed with tests/golden/_refshim.py)
     assert [s.name for s in specs] == ['C_0', 'I_1', 'Mp_2', 'foo', 'S_4', 'L_5', 'O_6']
     assert [s.kind for s in specs][1] == 'dropout' and specs[1].params.get('identity')
+
+
+# ----------------------------------------------------------------------------------------- Pillow's rows (kraken_amd/pilmem.py)
+@pytest.mark.parametrize('mode,shape', [('L', (5000, 777)), ('RGB', (9000, 1201, 3)), ('RGBA', (100, 33, 4)), ('L', (1, 1)),
+                                        ('RGB', (3, 5, 3)), ('1', (50, 70))])
+def test_pillow_rows_are_read_where_they_lie(mode, shape):
+    """The probed row table gives exactly np.asarray(im) -- over several allocation blocks (9000 x 1201 RGB = 3 blocks of rows),
+    for whole images and bands, through a thread pool or not."""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from kraken_amd import pilmem
+    rng = np.random.default_rng(1)
+    arr = rng.integers(0, 256, shape, dtype=np.uint8)
+    im = Image.fromarray(arr > 127) if mode == '1' else Image.fromarray(arr, mode)
+    want = np.asarray(im.convert('L')) if mode == '1' else arr
+    want = want if want.ndim == 3 else want[:, :, None]
+    t = pilmem.image_rows(im)
+    assert t is not None and (t.width, t.height) == im.size and t.pixelsize == (1 if mode in ('1', 'L') else 4)
+    H = shape[0]
+    dst = np.empty((H, t.linesize), np.uint8)
+    with ThreadPoolExecutor(4) as pool:
+        pilmem.copy_rows(t, 0, H, dst, pool, piece=1 << 20)
+    assert np.array_equal(dst.reshape(H, shape[1], t.pixelsize)[:, :, :want.shape[2]], want)
+    y0, y1 = H // 3, min(H // 3 + max(1, H // 2), H)
+    band = np.empty((y1 - y0) * t.linesize, np.uint8)
+    pilmem.copy_rows(t, y0, y1, band)
+    assert np.array_equal(band.reshape(y1 - y0, shape[1], t.pixelsize)[:, :, :want.shape[2]], want[y0:y1])
+    with pytest.raises(ValueError):
+        pilmem.copy_rows(t, 0, H + 1, dst)
+    with pytest.raises(ValueError):
+        pilmem.copy_rows(t, 0, H, np.empty(H * t.linesize - 1, np.uint8))
+
+
+def test_pillow_rows_refuse_what_they_cannot_verify(monkeypatch):
+    """Modes with another storage, objects that are not Pillow images, and a struct layout that does not read back as the image's:
+    None (the caller keeps np.asarray) -- never a guess."""
+    import io
+    from PIL import Image
+    from kraken_amd import pilmem
+    for mode in ('P', 'I', 'F', 'LA', 'CMYK', 'I;16'):
+        assert pilmem.image_rows(Image.new(mode, (10, 10))) is None, mode
+    assert pilmem.image_rows(object()) is None
+    assert pilmem.image_rows(np.zeros((4, 4), np.uint8)) is None
+    im = Image.new('RGB', (64, 40), (1, 2, 3))
+    assert pilmem.image_rows(im) is not None
+    monkeypatch.setattr(pilmem, '_LAYOUTS', ((16, 20, 28, 48, 72, 76), (8, 12, 16, 40, 64, 68)))     # wrong offsets: nothing validates
+    assert pilmem.image_rows(im) is None
+    monkeypatch.undo()
+    monkeypatch.setattr(pilmem, '_samples_agree', lambda im_, t: False)      # pixels that do not read back: refused as well
+    assert pilmem.image_rows(im) is None
+    monkeypatch.undo()
+    # a file that is decoded lazily
+    buf = io.BytesIO()
+    Image.fromarray(np.random.default_rng(0).integers(0, 256, (30, 20, 3), dtype=np.uint8), 'RGB').save(buf, 'PNG')
+    buf.seek(0)
+    lazy = Image.open(buf)
+    t = pilmem.image_rows(lazy)
+    assert t is not None and (t.width, t.height) == (20, 30)

@@ -39,7 +39,13 @@ class StubEngine:
         return arr
 
     def page_buffer(self, shape):
-        self.buf = np.empty(shape, np.uint8)
+        # like the engine: two alternating buffers that are kept (pinned there; here at least already touched)
+        need = int(np.prod(shape))
+        pool = self.__dict__.setdefault('_pg', [None, None])
+        self._pg_i = 1 - self.__dict__.get('_pg_i', 0)
+        if pool[self._pg_i] is None or pool[self._pg_i].size < need:
+            pool[self._pg_i] = np.zeros(need + need // 4, np.uint8)
+        self.buf = pool[self._pg_i][:need].reshape(shape)
         return self.buf
 
     def upload_page_buffer(self):
@@ -48,6 +54,30 @@ class StubEngine:
     def submit_boxes(self, page, boxes, pad, want_probs=False):
         self.k += 1
         self.q[self.k] = len(boxes)
+        return self.k
+
+    # the dewarp path of 1-channel models (--mode L): measurement and normalisation are device work, the host sees their handles
+    in_height = 48
+    slots = (0, 1, 2)
+
+    def measure_dewarp_begin(self, crops, pool=None, ahead=0, page=None):
+        n = len(crops)
+        if page is None and pool is not None:           # packed crops: the packing copies are host work
+            buf = np.empty(sum(a.size for a in crops), np.uint8)
+            off = 0
+            for a in crops:
+                buf[off:off + a.size] = np.ascontiguousarray(a).reshape(-1)
+                off += a.size
+        self._dw_n = n
+
+        class H:
+            def result(_s):
+                return np.full(n, 12, np.int32), np.ones(n, bool), np.ones(n, bool)
+        return H()
+
+    def submit_dewarped(self, r, use, pad, want_probs=False):
+        self.k += 1
+        self.q[self.k] = self._dw_n
         return self.k
 
     def collect(self, t):
@@ -69,12 +99,16 @@ def main():
     ap.add_argument('--workers', type=int, default=16)
     ap.add_argument('--profile', action='store_true')
     ap.add_argument('--bidi', action='store_true')
+    ap.add_argument('--mode', default='RGB', choices=['RGB', 'L'], help='RGB: 3-channel model, rectangular crops; L: 1-channel model, dewarped lines')
+    ap.add_argument('--no-rows', action='store_true', help='np.asarray(im) instead of Pillow\'s row table (kraken_amd.pilmem)')
     args = ap.parse_args()
-    page, seg = bench._page_of_lines(args.lines, 1200 - 32, 48, 'RGB')
+    if args.no_rows:
+        R.PAGE_ROWS = False
+    page, seg = bench._page_of_lines(args.lines, 1200 - 32, 48, args.mode)
     eng = StubEngine()
     R._engine_for = lambda net, temperature: eng
     R._fused_ok = lambda net: True
-    net = types.SimpleNamespace(nn=types.SimpleNamespace(input=(1, 3, 48, 0), one_channel_mode='L', use_legacy_polygons=False,
+    net = types.SimpleNamespace(nn=types.SimpleNamespace(input=(1, 3 if args.mode == 'RGB' else 1, 48, 0), one_channel_mode='L', use_legacy_polygons=False,
                                                          nn=types.SimpleNamespace(recognize=None)),
                                 seg_type="bbox", codec=PytorchCodec(bench_codec()), decoder=_ctc.greedy_decoder, temperature=1.0)
 
