@@ -69,37 +69,111 @@ __global__ void __launch_bounds__(256) dw_minmax_kernel(const unsigned char* cro
     if (threadIdx.x == 0) { mm[2 * n] = smx[0]; mm[2 * n + 1] = smn[0]; }
 }
 
-// K1: Gaussian along axis 0 (rows) of ink -> plane 0
+// K1: Gaussian along axis 0 (rows) of ink -> plane 0.  A workgroup takes 64 columns of one line: the ink values of the tile
+// ((top - pixel) / amax, one fp64 DIVISION each) are computed once into LDS -- the first version divided twice per tap, h times per
+// pixel -- and every thread then runs scipy's symmetric accumulation for the rows y = g, g + 4, ... of its column.  Same operations
+// in the same order per output as before (tests: bit-equal to scipy).  LDS: h * 64 doubles (+ the weights).
 __global__ void __launch_bounds__(256) dw_gauss0_kernel(const unsigned char* crops, Src f, const int* desc, const int* mm, const double* wts,
                                                         double* scratch) {
-    const int n = blockIdx.z;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+    const int n = blockIdx.y;
     const LineD L = line_of(desc, n);
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= L.w || y >= L.h) return;
-    const unsigned char* p = crops + (size_t)(unsigned)L.off;
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + c;
+    if (blockIdx.x * 64 >= L.w) return;
     const double top = (double)mm[2 * n], amax = (double)(mm[2 * n] - mm[2 * n + 1]);
     if (amax == 0.0) return;
+    double* ink = reinterpret_cast<double*>(dw_smem);              // [h][64]
+    double* wl = ink + (size_t)L.h * 64;                            // [r0 + 1]: w[r0 - j] at wl[j]
+    const unsigned char* p = crops + (size_t)(unsigned)L.off;
+    for (int y = g; y < L.h; y += 4)
+        ink[y * 64 + c] = x < L.w ? __ddiv_rn(dmul(top - (double)px_at(p, y, x, L.w, f), 1.0), amax) : 0.0;
     const double* w = wts + L.woff;                  // w[r0 + j], j = -r0 .. r0
-    auto ink = [&](int yy) -> double { return (yy < 0 || yy >= L.h) ? 0.0 : __ddiv_rn(dmul(top - (double)px_at(p, yy, x, L.w, f), 1.0), amax); };
-    double t = dmul(ink(y), w[L.r0]);
-    for (int j = min(L.r0, L.h); j >= 1; --j)        // beyond +-h both partners are outside: they add exactly 0
-        t = dadd(t, dmul(dadd(ink(y - j), ink(y + j)), w[L.r0 - j]));
-    (scratch + L.soff)[(size_t)y * L.w + x] = t;
+    const int J = min(L.r0, L.h);                    // beyond +-h both partners are outside: they add exactly 0
+    for (int j = threadIdx.x; j <= J; j += 256) wl[j] = w[L.r0 - j];
+    __syncthreads();
+    if (x >= L.w) return;
+    double* out = scratch + L.soff;
+    for (int y = g; y < L.h; y += 4) {
+        double t = dmul(ink[y * 64 + c], wl[0]);
+        for (int j = J; j >= 1; --j) {
+            const int ya = y - j, yb = y + j;
+            const double lo = ya < 0 ? 0.0 : ink[ya * 64 + c], hi = yb >= L.h ? 0.0 : ink[yb * 64 + c];
+            t = dadd(t, dmul(dadd(lo, hi), wl[j]));
+        }
+        out[(size_t)y * L.w + x] = t;
+    }
 }
 
-// K2: Gaussian along axis 1 (columns) plane 0 -> plane 1 (= blur)
-__global__ void __launch_bounds__(256) dw_gauss1_kernel(const int* desc, const int* mm, const double* wts, double* scratch) {
+// K2: Gaussian along axis 1 (columns) plane 0 -> plane 1 (= blur).  sigma = h: 4 h taps to either side, ~390 for a 48-row line --
+// the heaviest kernel of the measurement (2.8 ms per 256-line batch as one thread per output reading global memory).
+// One wave takes 256 consecutive outputs of one row, FOUR ADJACENT ONES PER LANE: the left operand of output i at tap j is the
+// left operand of output i + 1 at tap j + 1, so walking j downwards a lane needs one new value on the left and one on the right
+// per tap for all four outputs -- 2 LDS reads for 12 fp64 operations.  The row segment and its halo (zeros outside the line) are
+// staged in LDS split by index mod 4 (plane k holds the elements 4 q + k): the four values a lane fetches per group of four taps
+// are then the SAME q in the four planes, lanes read consecutive doubles (no bank conflicts), and no index arithmetic depends on
+// the tap.  The accumulation per output is scipy's correlate1d (symmetric case) operation for operation: centre tap first, then
+// the pairs from the outermost inwards.
+constexpr int G1_TILE = 256;
+__global__ void __launch_bounds__(64) dw_gauss1_kernel(const int* desc, const int* mm, const double* wts, double* scratch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
     const int n = blockIdx.z;
     const LineD L = line_of(desc, n);
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= L.w || y >= L.h || mm[2 * n] == mm[2 * n + 1]) return;
+    const int x0 = blockIdx.x * G1_TILE, y = blockIdx.y;
+    if (x0 >= L.w || y >= L.h || mm[2 * n] == mm[2 * n + 1]) return;
+    const int J = min(L.r1, L.w);
+    const int Jp = (J + 3) & ~3;                                   // halo, a multiple of 4 elements
+    const int Q = (G1_TILE + 2 * Jp) / 4;                          // doubles per plane
+    double* pl = reinterpret_cast<double*>(dw_smem);              // [4][Q]: pl[k][q] = a[x0 - Jp + 4 q + k]
+    double* wl = pl + 4 * Q;                                       // [J + 1]: w[r1 - j] at wl[j]
     const double* a = scratch + L.soff + (size_t)y * L.w;
     const double* w = wts + L.woff + (2 * L.r0 + 1);
-    auto at = [&](int xx) -> double { return (xx < 0 || xx >= L.w) ? 0.0 : a[xx]; };
-    double t = dmul(a[x], w[L.r1]);
-    for (int j = min(L.r1, L.w); j >= 1; --j)
-        t = dadd(t, dmul(dadd(at(x - j), at(x + j)), w[L.r1 - j]));
-    (scratch + L.soff + (size_t)L.h * L.w)[(size_t)y * L.w + x] = t;
+    for (int e = threadIdx.x; e < G1_TILE + 2 * Jp; e += 64) {
+        const int xx = x0 - Jp + e;
+        pl[(e & 3) * Q + (e >> 2)] = (xx < 0 || xx >= L.w) ? 0.0 : a[xx];
+    }
+    for (int j = threadIdx.x; j <= J; j += 64) wl[j] = w[L.r1 - j];
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int qc = Jp / 4 + t;                                     // the lane's own four elements: pl[0..3][qc]
+    auto el = [&](int rel) -> double {                             // element 4 t + rel of the tile (rel may be negative)
+        const int e = Jp + 4 * t + rel;
+        return pl[(e & 3) * Q + (e >> 2)];
+    };
+    double acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = dmul(pl[i * Q + qc], wl[0]);
+    int j = J;
+    for (; (j & 3) != 0; --j) {                                    // the taps above the last multiple of 4: generic reads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = dadd(acc[i], dmul(dadd(el(i - j), el(i + j)), wl[j]));
+    }
+    if (j >= 4) {
+        // j is a multiple of 4: left operands of the four outputs = plane i at q = qc - j/4, right ones at q = qc + j/4
+        double lw[8], rw[8];                                       // lw[i] = element 4 t - j + i, rw[4 + i] = element 4 t + j + i
+        int ql = qc - j / 4, qr = qc + j / 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lw[i] = pl[i * Q + ql]; rw[4 + i] = pl[i * Q + qr]; }
+        for (; j >= 4; j -= 4) {
+            ++ql; --qr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { lw[4 + i] = pl[i * Q + ql]; rw[i] = pl[i * Q + qr]; }   // the next four on either side
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {                       // taps j, j - 1, j - 2, j - 3
+                const double wj = wl[j - s4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = dadd(acc[i], dmul(dadd(lw[i + s4], rw[4 + i - s4]), wj));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { lw[i] = lw[4 + i]; rw[4 + i] = rw[i]; }
+        }
+    }
+    double* out = scratch + L.soff + (size_t)L.h * L.w + (size_t)y * L.w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = x0 + 4 * t + i;
+        if (x < L.w) out[x] = acc[i];
+    }
 }
 
 // K3: uniform filter along axis 0 (size int(h/2)) of blur (plane 1) -> plane 0; one thread per column, sequential like scipy
@@ -122,7 +196,11 @@ __global__ void __launch_bounds__(256) dw_unif0_kernel(const int* desc, const in
     }
 }
 
-// K4: uniform filter along axis 1 (size w) plane 0 -> plane 2; one thread per row
+// K4: uniform filter along axis 1 (size w) plane 0 -> plane 2; one thread per row, scipy's running sum: t += new - old.
+// The window is as wide as the row, so a step never has both its entering and its leaving sample inside the row: the walk is
+// three branch-free loops (the window fills; samples enter on the right; samples leave on the left) whose loads do not depend on
+// the running sum -- unrolled, they are in flight ahead of the adds (the first version tested both bounds at every step and ran as
+// a chain of dependent load latencies, 0.6 ms per batch).  Arithmetic per step as before, including the additions of +-0.0.
 __global__ void __launch_bounds__(64) dw_unif1_kernel(const int* desc, const int* mm, double* scratch) {
     const int n = blockIdx.y;
     const LineD L = line_of(desc, n);
@@ -131,13 +209,21 @@ __global__ void __launch_bounds__(64) dw_unif1_kernel(const int* desc, const int
     const double* a = scratch + L.soff + (size_t)y * L.w;
     double* o = scratch + L.soff + (size_t)2 * L.h * L.w + (size_t)y * L.w;
     const int size = L.w, s1 = size / 2;
-    auto ext = [&](int l) -> double { const int xx = l - s1; return (xx < 0 || xx >= L.w) ? 0.0 : a[xx]; };
+    const int last = size - 1 - s1;              // ext(l) = a[l - s1] inside the row, 0.0 outside: the first window ends at a[last]
     const double dsize = (double)size;
-    double t = 0.0;
-    for (int l = 0; l < size; ++l) t = dadd(t, ext(l));
+    double t = 0.0;                              // (the s1 leading zeros of the first window: 0.0 + 0.0 = 0.0)
+#pragma unroll 8
+    for (int k = 0; k <= last; ++k) t = dadd(t, a[k]);
     o[0] = __ddiv_rn(t, dsize);
-    for (int l = 1; l < L.w; ++l) {
-        t = dadd(t, dadd(ext(l + size - 1), -ext(l - 1)));
+    const int enter_end = min(s1, L.w - 1);
+#pragma unroll 8
+    for (int l = 1; l <= enter_end; ++l) {       // a[l + last] enters, what leaves lies left of the row
+        t = dadd(t, dadd(a[l + last], -0.0));
+        o[l] = __ddiv_rn(t, dsize);
+    }
+#pragma unroll 8
+    for (int l = s1 + 1; l < L.w; ++l) {         // nothing enters any more, a[l - 1 - s1] leaves
+        t = dadd(t, dadd(0.0, -a[l - 1 - s1]));
         o[l] = __ddiv_rn(t, dsize);
     }
 }
@@ -225,17 +311,23 @@ __global__ void __launch_bounds__(256) dw_apply_kernel(const unsigned char* crop
     const int n = blockIdx.z;
     const LineD L = line_of(desc, n);
     const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+    const int r = geo[4 * n], ow = geo[4 * n + 1], use = geo[4 * n + 2];
+    // the zoom factor is a per-line constant: two fp64 divisions, done by one lane per workgroup (they were done per output pixel)
+    __shared__ double zs;
+    if (threadIdx.x == 0) {
+        const double scale = __ddiv_rn(dmul((double)out_h, 1.0), (double)max(2 * r, 1));
+        zs = __ddiv_rn(1.0, scale);
+    }
+    __syncthreads();
     if (X >= batch_w) return;
     float* o = out + ((size_t)n * out_h + Y) * batch_w + X;
-    const int r = geo[4 * n], ow = geo[4 * n + 1], use = geo[4 * n + 2];
     const int xx = X - pad;
     if (!use || xx < 0 || xx >= ow) { *o = 0.f; return; }         // white padding (1 - 255/255) and the batch padding right of the line
     const unsigned char* p = crops + (size_t)(unsigned)L.off;
     const int* c = centre + (size_t)n * maxw;
     const double top = (double)mm[2 * n];
     const int bh = 2 * r, bw = L.w;
-    const double scale = __ddiv_rn(dmul((double)out_h, 1.0), (double)bh);
-    const double z = __ddiv_rn(1.0, scale);
+    const double z = zs;
     const double cy = dmul((double)Y, z), cx = dmul((double)xx, z);
     float val;
     if (cy < 0.0 || cy > (double)(bh - 1) || cx < 0.0 || cx > (double)(bw - 1)) {
@@ -270,8 +362,15 @@ int krk_launch_dewarp_measure(const unsigned char* crops, size_t rs, int ps, con
     const Src f{rs, ps};
     const unsigned gx = (unsigned)((maxw + 255) / 256);
     hipLaunchKernelGGL(dw_minmax_kernel, dim3(n), dim3(256), 0, s, crops, f, desc, mm);
-    hipLaunchKernelGGL(dw_gauss0_kernel, dim3(gx, maxh, n), dim3(256), 0, s, crops, f, desc, mm, wts, scratch);
-    hipLaunchKernelGGL(dw_gauss1_kernel, dim3(gx, maxh, n), dim3(256), 0, s, desc, mm, wts, scratch);
+    // LDS of the two Gaussian passes, sized for the tallest / widest line of the batch (r0 <= h, r1 = int(4 h + 0.5) <= w clipped)
+    const int r1max = (int)(4.0 * maxh + 0.5);
+    const size_t lds0 = ((size_t)maxh * 64 + (size_t)maxh + 1) * sizeof(double);
+    const size_t lds1 = ((size_t)G1_TILE + 3 * (size_t)(std::min(r1max, maxw) + 4) + 1) * sizeof(double);
+    if (lds0 > 160 * 1024 || lds1 > 160 * 1024) return -4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw_gauss0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw_gauss1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipLaunchKernelGGL(dw_gauss0_kernel, dim3((unsigned)((maxw + 63) / 64), n), dim3(256), lds0, s, crops, f, desc, mm, wts, scratch);
+    hipLaunchKernelGGL(dw_gauss1_kernel, dim3((unsigned)((maxw + G1_TILE - 1) / G1_TILE), maxh, n), dim3(64), lds1, s, desc, mm, wts, scratch);
     hipLaunchKernelGGL(dw_unif0_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, scratch);
     hipLaunchKernelGGL(dw_unif1_kernel, dim3((unsigned)((maxh + 63) / 64), n), dim3(64), 0, s, desc, mm, scratch);
     hipLaunchKernelGGL(dw_ridge_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, scratch, ridge, maxw);
