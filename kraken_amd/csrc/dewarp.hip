@@ -196,35 +196,80 @@ __global__ void __launch_bounds__(256) dw_unif0_kernel(const int* desc, const in
     }
 }
 
-// K4: uniform filter along axis 1 (size w) plane 0 -> plane 2; one thread per row, scipy's running sum: t += new - old.
-// The window is as wide as the row, so a step never has both its entering and its leaving sample inside the row: the walk is
-// three branch-free loops (the window fills; samples enter on the right; samples leave on the left) whose loads do not depend on
-// the running sum -- unrolled, they are in flight ahead of the adds (the first version tested both bounds at every step and ran as
-// a chain of dependent load latencies, 0.6 ms per batch).  Arithmetic per step as before, including the additions of +-0.0.
+// K4: uniform filter along axis 1 (size w) plane 0 -> plane 2: scipy's running sum per row, t += entering - leaving, which no
+// parallel scan reproduces bit for bit -- a row is a sequential walk.  The window is as wide as the row, so a step never has both
+// an entering and a leaving sample inside the row, and the walk is two passes over the row: pass 1 adds a[0 .. w-1] (the window
+// fills, o[0] after a[last]; then samples enter: o[k - last] after a[k]), pass 2 subtracts a[0 .. w-2-s1] (o[k + s1 + 1] after a[k]).
+// One wave walks 64 rows, a lane per row.  Lane-per-row global accesses touch 64 different cache lines per instruction and the
+// walk then runs at one memory latency per 8 steps (0.6 ms per batch as first written); here the wave moves 64 x 32 tiles
+// cooperatively -- coalesced 256-byte row pieces, the next tile's loads in flight while this one is walked from LDS -- and writes
+// the outputs of a tile back the same way.  Arithmetic per step as scipy's (including the additions of +-0.0).
+constexpr int U1_COLS = 32, U1_PITCH = U1_COLS + 1;
 __global__ void __launch_bounds__(64) dw_unif1_kernel(const int* desc, const int* mm, double* scratch) {
+    __shared__ double tin[2][64 * U1_PITCH];
+    __shared__ double tout[64 * U1_PITCH];
     const int n = blockIdx.y;
     const LineD L = line_of(desc, n);
-    const int y = blockIdx.x * 64 + threadIdx.x;
-    if (y >= L.h || mm[2 * n] == mm[2 * n + 1]) return;
-    const double* a = scratch + L.soff + (size_t)y * L.w;
-    double* o = scratch + L.soff + (size_t)2 * L.h * L.w + (size_t)y * L.w;
-    const int size = L.w, s1 = size / 2;
-    const int last = size - 1 - s1;              // ext(l) = a[l - s1] inside the row, 0.0 outside: the first window ends at a[last]
+    const int y0 = blockIdx.x * 64;
+    if (y0 >= L.h || mm[2 * n] == mm[2 * n + 1]) return;
+    const int lane = threadIdx.x;
+    const int rows = min(64, L.h - y0);
+    const double* a = scratch + L.soff + (size_t)y0 * L.w;
+    double* o = scratch + L.soff + (size_t)2 * L.h * L.w + (size_t)y0 * L.w;
+    const int w = L.w, size = w, s1 = size / 2, last = size - 1 - s1;
     const double dsize = (double)size;
-    double t = 0.0;                              // (the s1 leading zeros of the first window: 0.0 + 0.0 = 0.0)
-#pragma unroll 8
-    for (int k = 0; k <= last; ++k) t = dadd(t, a[k]);
-    o[0] = __ddiv_rn(t, dsize);
-    const int enter_end = min(s1, L.w - 1);
-#pragma unroll 8
-    for (int l = 1; l <= enter_end; ++l) {       // a[l + last] enters, what leaves lies left of the row
-        t = dadd(t, dadd(a[l + last], -0.0));
-        o[l] = __ddiv_rn(t, dsize);
-    }
-#pragma unroll 8
-    for (int l = s1 + 1; l < L.w; ++l) {         // nothing enters any more, a[l - 1 - s1] leaves
-        t = dadd(t, dadd(0.0, -a[l - 1 - s1]));
-        o[l] = __ddiv_rn(t, dsize);
+    const int lr = lane >> 5, lc = lane & 31;          // a load / store instruction covers two rows x 32 columns
+    // the two passes as ONE stream of tiles: tiles [0, n1) cover a[0 .. w-1], tiles [n1, n1 + n2) cover a[0 .. w-2-s1]
+    const int len2 = w - 1 - s1;                       // samples that leave (may be 0)
+    const int n1 = (w + U1_COLS - 1) / U1_COLS, n2 = (len2 + U1_COLS - 1) / U1_COLS;
+    double reg[32];
+    auto fetch = [&](int tile) {                       // tile -> registers (zeros outside the pass / the rows)
+        const bool second = tile >= n1;
+        const int c0 = (second ? tile - n1 : tile) * U1_COLS, lim = second ? len2 : w;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int r = 2 * q + lr, c = c0 + lc;
+            reg[q] = (r < rows && c < lim) ? a[(size_t)r * w + c] : 0.0;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tin[buf][(2 * q + lr) * U1_PITCH + lc] = reg[q];
+    };
+    double t = 0.0;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int tile = 0; tile < n1 + n2; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < n1 + n2) fetch(tile + 1);       // in flight while this tile is walked
+        const bool second = tile >= n1;
+        const int c0 = (second ? tile - n1 : tile) * U1_COLS, lim = second ? len2 : w;
+        const int cnt = min(U1_COLS, lim - c0);
+        // outputs of this tile: pass 1: o[k - last] for k >= last; pass 2: o[k + s1 + 1]
+        const int ob = second ? c0 + s1 + 1 : max(c0 - last, 0);
+        const int skip = second ? 0 : max(last - c0, 0);           // leading samples of the tile that produce no output
+        const double* mine = &tin[buf][lane * U1_PITCH];
+        if (!second) {
+            for (int k = 0; k < cnt; ++k) {
+                t = dadd(t, mine[k]);
+                if (k >= skip) tout[lane * U1_PITCH + k - skip] = __ddiv_rn(t, dsize);
+            }
+        } else {
+            for (int k = 0; k < cnt; ++k) {
+                t = dadd(t, dadd(0.0, -mine[k]));
+                tout[lane * U1_PITCH + k] = __ddiv_rn(t, dsize);
+            }
+        }
+        __syncthreads();
+        const int nout = cnt - skip;
+#pragma unroll 4
+        for (int q = 0; q < 32; ++q) {
+            const int r = 2 * q + lr;
+            if (r < rows && lc < nout) o[(size_t)r * w + ob + lc] = tout[r * U1_PITCH + lc];
+        }
+        if (tile + 1 < n1 + n2) stage(buf ^ 1);
+        __syncthreads();
     }
 }
 

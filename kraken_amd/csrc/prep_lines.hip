@@ -132,28 +132,44 @@ __global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __
     const int yfirst = kvb[0];
     const int ylast = kvb[2 * (out_h - 1)] + kvb[2 * (out_h - 1) + 1];
     const int rows = ylast - yfirst;
-    // horizontal pass: tmp[c][r][j] for the source rows the vertical pass reads
-    for (int e = tid; e < ch * rows * COLS; e += 256) {
-        const int j = e % COLS, r = (e / COLS) % rows, c = e / (COLS * rows);
+    // horizontal pass: tmp[c][r][j] for the source rows the vertical pass reads.  One thread per (row, column) does ALL channels:
+    // the tap loop, its bounds tests and the weight reads are shared by the channels (they were repeated per channel), and a
+    // 4-byte pixel is one load
+    for (int e = tid; e < rows * COLS; e += 256) {
+        const int j = e % COLS, r = e / COLS;
         const int xmin = khb[2 * j], xmax = khb[2 * j + 1];
-        unsigned v = 255;
+        unsigned v0 = 255, v1 = 255, v2 = 255;
         if (xmax > 0) {
             const int gy = y0 + yfirst + r;
-            int ss0 = 1 << (PREC_BITS - 1);
+            int s0 = 1 << (PREC_BITS - 1), s1 = s0, s2 = s0;
             const int* k = kh + j * MAX_K;
-            for (int x = 0; x < xmax; ++x) {
-                const int gx = x0 + xmin + x;
-                // Image.crop pads what lies outside the page with 0
-                int px = 0;
-                if (gy >= 0 && gy < page_h && gx >= 0 && gx < page_w) {
-                    const unsigned char* q = page + (size_t)gy * rs + (size_t)gx * ps;
-                    px = luma ? (int)((q[0] * 19595u + q[1] * 38470u + q[2] * 7471u + 0x8000u) >> 16) : (int)q[c];
+            // Image.crop pads what lies outside the page with 0
+            if (gy >= 0 && gy < page_h) {
+                const unsigned char* row = page + (size_t)gy * rs;
+                for (int x = 0; x < xmax; ++x) {
+                    const int gx = x0 + xmin + x;
+                    if (gx < 0 || gx >= page_w) continue;
+                    const int kx = k[x];
+                    if (ps == 4) {
+                        const unsigned px = *reinterpret_cast<const unsigned*>(row + (size_t)gx * 4);     // R | G << 8 | B << 16 | X << 24
+                        const unsigned R = px & 255u, G = (px >> 8) & 255u, B = (px >> 16) & 255u;
+                        if (luma) s0 += (int)((R * 19595u + G * 38470u + B * 7471u + 0x8000u) >> 16) * kx;
+                        else { s0 += (int)R * kx; s1 += (int)G * kx; s2 += (int)B * kx; }
+                    } else {
+                        const unsigned char* q = row + (size_t)gx * ps;
+                        if (luma) s0 += (int)((q[0] * 19595u + q[1] * 38470u + q[2] * 7471u + 0x8000u) >> 16) * kx;
+                        else if (ch == 1) s0 += (int)q[0] * kx;
+                        else { s0 += (int)q[0] * kx; s1 += (int)q[1] * kx; s2 += (int)q[2] * kx; }
+                    }
                 }
-                ss0 += px * k[x];
             }
-            v = clip8(ss0);
+            v0 = clip8(s0); v1 = clip8(s1); v2 = clip8(s2);
         }
-        tmp[(c * rows + r) * COLS + j] = (unsigned char)v;
+        tmp[(0 * rows + r) * COLS + j] = (unsigned char)v0;
+        if (ch == 3) {
+            tmp[(1 * rows + r) * COLS + j] = (unsigned char)v1;
+            tmp[(2 * rows + r) * COLS + j] = (unsigned char)v2;
+        }
     }
     __syncthreads();
     // vertical pass + white padding + float + invert
