@@ -77,6 +77,7 @@ extern "C" {
 #define KRK_ACT_TANH      2
 #define KRK_ACT_LEAKY     3   /* torch.nn.LeakyReLU() default slope 0.01 */
 #define KRK_ACT_SIGMOID   4   /* == LINEAR in forward */
+#define KRK_ACT_SOFTMAX   5   /* torch.nn.Softmax(dim=1) over the channels (Cm..., the O2s... heatmap head; layers.py:814-816): f32 plan */
 
 /* LSTM directions */
 #define KRK_DIR_FWD       0

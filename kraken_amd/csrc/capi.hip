@@ -49,8 +49,8 @@ int fail(int code, const std::string& msg) {
             return fail(KRK_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
-enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG, S_UNSPLIT, S_ALIAS, S_CONCAT, S_ADD };
-const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img", "unsplit", "alias", "concat", "add"};
+enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG, S_UNSPLIT, S_ALIAS, S_CONCAT, S_ADD, S_SOFTMAXC };
+const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img", "unsplit", "alias", "concat", "add", "softmax"};
 
 
 
@@ -843,7 +843,10 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
     if (!L.w[0] || !L.w[1]) return fail(KRK_E_INVALID, where + ": conv weights missing");
     if (L.cout <= 0 || L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0 || L.dh <= 0 || L.dw <= 0)
         return fail(KRK_E_INVALID, where + ": bad conv geometry");
-    if (L.act < 0 || L.act > KRK_ACT_SIGMOID) return fail(KRK_E_UNSUPPORTED, where + ": activation");
+    if (L.act < 0 || L.act > KRK_ACT_SOFTMAX) return fail(KRK_E_UNSUPPORTED, where + ": activation");
+    // Softmax over the channels (Cm..., O2s...): a linear convolution and a pass over its fp32 NCHW output; nothing fuses across it
+    const bool softmax = L.act == KRK_ACT_SOFTMAX;
+    if (softmax && (x3 || split_fmt)) return fail(KRK_E_UNSUPPORTED, where + ": channel-softmax convolution on split-bf16 planes");
     if (x3 && split_fmt && C % 16) {   // conv_x3 wants 16-channel K blocks; the tap kernel takes multiples of 4 after conv1_x3
         const bool taps_ok = !p->steps.empty() && p->steps.back().kind == S_CONV && p->steps.back().cg.c1x3 &&
                              krk_conv_taps_supported(C, L.cout, L.kh, L.kw, L.sh, L.sw, L.dh, L.dw) &&
@@ -861,7 +864,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
     g.kh = L.kh; g.kw = L.kw; g.sh = L.sh; g.sw = L.sw; g.dh = L.dh; g.dw = L.dw;
     g.ph = (L.dh * (L.kh - 1)) / 2;
     g.pw = (L.dw * (L.kw - 1)) / 2;
-    g.act = map_act(L.act);
+    g.act = softmax ? ACT_LINEAR : map_act(L.act);
     s.len_in = stage;
     new_stage(0, L.kw, L.sw, L.dw, g.pw);
     const int Ho = conv_out(H, L.kh, L.sh, L.dh, g.ph);
@@ -878,7 +881,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
             g.out_seq = true;
             ++i;
         }
-    } else if (i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
+    } else if (!softmax && i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC) {
         g.out_seq = true;
         ++i;
     }
@@ -930,6 +933,14 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
         H = g.Hy;
     }
     p->steps.push_back(std::move(s));
+    if (softmax) {
+        Step m;
+        m.kind = S_SOFTMAXC;
+        m.C = C; m.H = H;
+        m.outC = C; m.outH = H;
+        m.len_in = m.len_out = stage;
+        p->steps.push_back(std::move(m));
+    }
     return KRK_OK;
 }
 
@@ -1260,7 +1271,8 @@ int PlanBuilder::build() {
         // parallel groups and additions work on fp32 tensors: like the GroupNorm part, everything up to the last of them runs on
         // the exact-f32 kernels and the split-bf16 ones take over behind it
         if (layers[k].op == KRK_OP_GROUPNORM || (layers[k].op >= KRK_OP_PAR_BEGIN && layers[k].op <= KRK_OP_ADD) ||
-            (layers[k].op == KRK_OP_LSTM && layers[k].kh == 1 && layers[k].kw == 0))
+            (layers[k].op == KRK_OP_LSTM && layers[k].kh == 1 && layers[k].kw == 0) ||
+            (layers[k].op == KRK_OP_CONV && layers[k].act == KRK_ACT_SOFTMAX))
             last_f32_only = k;
     }
     for (i = 0; i < n_layers; ++i) {
@@ -1737,6 +1749,9 @@ int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int W
         case S_ROWS2IMG:
             if (mark("rows2img", 0)) return kFailed;
             return krk_launch_rows2img(cur, outp, N, s.C, s.H, Win, s.yaxis, s.yaxis ? lens_at(s.len_in) : nullptr, s.last_only, stream);
+        case S_SOFTMAXC:
+            if (mark("softmax", 0)) return kFailed;
+            return krk_launch_softmax_c(cur, outp, N, s.C, s.H, Win, lens_at(s.len_in), stream);
         case S_ADD: {
             if (mark("add", 0)) return kFailed;
             // channels of an image: N blocks of C*H*W, pieces of chunk*H*W; channels of sequence rows: N*T rows of C, pieces of

@@ -594,6 +594,28 @@ __global__ void __launch_bounds__(256) concat_kernel(const float* __restrict__ x
     }
 }
 
+// torch.nn.Softmax(dim=1) of an NCHW tensor (ActConv2D with nl = 'm', reference layers.py:814-816, 853): one thread per pixel,
+// channels HW floats apart (consecutive threads = consecutive pixels: coalesced); exp(x - max) / sum in fp32 like ATen's host
+// softmax.  Columns at or beyond a line's valid width stay zero (the masked-padding rule every layer keeps).
+__global__ void __launch_bounds__(256) softmax_c_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W,
+                                                        const int* __restrict__ lens) {
+    const int n = blockIdx.y;
+    const size_t HW = (size_t)H * W;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < HW; q += (size_t)gridDim.x * 256) {
+        const float* xp = x + (size_t)n * C * HW + q;
+        float* yp = y + (size_t)n * C * HW + q;
+        if (lens && (int)(q % W) >= lens[n]) {
+            for (int c = 0; c < C; ++c) yp[(size_t)c * HW] = 0.f;
+            continue;
+        }
+        float mx = xp[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, xp[(size_t)c * HW]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(xp[(size_t)c * HW] - mx);
+        for (int c = 0; c < C; ++c) yp[(size_t)c * HW] = expf(xp[(size_t)c * HW] - mx) / sum;
+    }
+}
+
 // Addition (reference layers.py:205-210): y[o][j] = sum_k x[o][k*inner + j], k = 0..nk-1 in ascending order; a block of the
 // input is `in_stride` floats (>= nk*inner: what is left behind the last whole piece is dropped)
 __global__ void __launch_bounds__(256) chunk_sum_kernel(const float* __restrict__ x, float* __restrict__ y, size_t inner, int nk,
@@ -613,6 +635,13 @@ int krk_launch_concat(const float* x, float* y, size_t outer, size_t inner, size
     if (!total) return 0;
     const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(concat_kernel, dim3(blocks), dim3(256), 0, s, x, y, inner, stride, off, total);
+    return last_ok();
+}
+
+int krk_launch_softmax_c(const float* x, float* y, int N, int C, int H, int W, const int* lens, hipStream_t s) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)H * W + 255) / 256, 4096);
+    hipLaunchKernelGGL(softmax_c_kernel, dim3(blocks, (unsigned)N), dim3(256), 0, s, x, y, C, H, W, lens);
     return last_ok();
 }
 

@@ -120,8 +120,6 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
     if kind == 'conv':
         if g['trans']:
             raise NotImplementedError('transposed convolutions are not supported by the HIP executor')
-        if g['nl'] == 'm':
-            raise NotImplementedError('softmax-activated convolutions are not supported by the HIP executor')
         ky, kx, out = int(g['ky']), int(g['kx']), int(g['out'])
         sy, sx = (int(g['sy']), int(g['sx'])) if g['sx'] else (1, 1)
         dy, dx = (int(g['dy']), int(g['dx'])) if g['dx'] else (1, 1)
@@ -172,16 +170,18 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
     elif kind == 'rnn':
         # 'G' parses as a GRU but the reference builds the same torch.nn.LSTM for it (layers.py:504-511, model.py:579-593):
         # an alias, layer name G_<idx>
-        if g['legacy']:
-            raise NotImplementedError(f'RNN variant "{block}" (legacy clstm / ocropy cell) is not supported '
-                                      'by the HIP executor')
+        # 'c': the clstm layout -- a constant 1 in front of every input vector instead of biases (layers.py:498-499, 522-524,
+        # nn.LSTM(bias=False)): the first weight column IS the bias; folded when the plan is compiled.  'o': ocropy's peephole cell
+        if g['legacy'] == 'o':
+            raise NotImplementedError(f'RNN variant "{block}" (legacy ocropy peephole cell) is not supported by the HIP executor')
         hidden = int(g['out'])
         if hidden > 768:
             raise NotImplementedError(f'recurrent layer "{block}": hidden sizes above 768 are not supported by the HIP recurrent kernels')
         # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523);
         # 's' keeps only the last step of every column (:537-539): (N, C, H, W) -> (N, O, 1, W)
         # on the x axis 's' keeps the last COLUMN: (N, C, H, W) -> (N, O, H, 1) (get_shape, :549-561)
-        p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'], summarize=bool(g['sum']))
+        p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'], summarize=bool(g['sum']),
+                 legacy='clstm' if g['legacy'] == 'c' else None)
         oc = hidden * (2 if g['dir'] == 'b' else 1)
         oshape = (n, oc, h, w) if not g['sum'] else ((n, oc, 1, w) if g['axis'] == 'y' else (n, oc, h, 1))
     else:  # output
@@ -193,10 +193,9 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
         if g['aug'] and dim == 2:
             raise NotImplementedError(f'1-augmented heatmap output "{block}" is not supported by the HIP executor')
         if dim == 2:
-            if typ != 'l':
-                raise NotImplementedError('softmax heatmap outputs are not supported by the HIP executor')
-            kind = 'conv'   # 1x1 ActConv2D with (skipped) sigmoid, reference model.py:806-811
-            p = dict(kernel=(1, 1), out=out, stride=(1, 1), dilation=(1, 1), nl='s', padding=(0, 0),
+            # 1x1 ActConv2D: 'l' with the (skipped) sigmoid, 's' with a softmax over the classes (reference model.py:806-811)
+            kind = 'conv'
+            p = dict(kernel=(1, 1), out=out, stride=(1, 1), dilation=(1, 1), nl='s' if typ == 'l' else 'm', padding=(0, 0),
                      output_type=typ)
         else:
             kind = 'linear'
@@ -345,8 +344,9 @@ class _GroupNormHolder(nn.Module):
 class _RnnHolder(nn.Module):
     def __init__(self, spec: LayerSpec):
         super().__init__()
-        self.layer = nn.LSTM(spec.in_shape[1], spec.params['hidden'],
-                             bidirectional=spec.params['direction'] == 'b', batch_first=True, bias=True)
+        legacy = spec.params.get('legacy') is not None
+        self.layer = nn.LSTM(spec.in_shape[1] + (1 if legacy else 0), spec.params['hidden'],
+                             bidirectional=spec.params['direction'] == 'b', batch_first=True, bias=not legacy)
 
 
 class _LinearHolder(nn.Module):
@@ -375,7 +375,8 @@ class _Group(nn.Module):
 
 
 _HOLDERS = {'conv': _ConvHolder, 'groupnorm': _GroupNormHolder, 'rnn': _RnnHolder, 'linear': _LinearHolder}
-_ACTS = {'l': _lib.ACT_LINEAR, 'r': _lib.ACT_RELU, 't': _lib.ACT_TANH, 'lr': _lib.ACT_LEAKY, 's': _lib.ACT_SIGMOID}
+_ACTS = {'l': _lib.ACT_LINEAR, 'r': _lib.ACT_RELU, 't': _lib.ACT_TANH, 'lr': _lib.ACT_LEAKY, 's': _lib.ACT_SIGMOID,
+         'm': _lib.ACT_SOFTMAX}
 # The reference builds nn.LSTM(bidirectional = direction == 'b') and never flips the sequence, so an
 # 'r' layer runs forward like 'f' (kraken/lib/vgsl/layers.py:496-511); mirrored here on purpose.
 _DIRS = {'f': _lib.DIR_FWD, 'r': _lib.DIR_FWD, 'b': _lib.DIR_BIDI}
@@ -434,8 +435,12 @@ class _Plan:
                 d.kh = 1 if p.get('summarize') else 0          # include/kraken_amd.h: keep only the last step (L?ys / L?xs)
                 sfx = [''] + (['_reverse'] if p['direction'] == 'b' else [])
                 for s in sfx:
-                    arrays += [_f32(getattr(mod.layer, f'weight_ih_l0{s}')), _f32(getattr(mod.layer, f'weight_hh_l0{s}')),
-                               _f32(getattr(mod.layer, f'bias_ih_l0{s}')), _f32(getattr(mod.layer, f'bias_hh_l0{s}'))]
+                    w_ih, w_hh = _f32(getattr(mod.layer, f'weight_ih_l0{s}')), _f32(getattr(mod.layer, f'weight_hh_l0{s}'))
+                    if p.get('legacy'):      # x' = [1, x], no biases: gates = W[:, 0] + W[:, 1:] x + W_hh h
+                        arrays += [np.ascontiguousarray(w_ih[:, 1:]), w_hh, np.ascontiguousarray(w_ih[:, 0]),
+                                   np.zeros(w_ih.shape[0], np.float32)]
+                    else:
+                        arrays += [w_ih, w_hh, _f32(getattr(mod.layer, f'bias_ih_l0{s}')), _f32(getattr(mod.layer, f'bias_hh_l0{s}'))]
             elif spec.kind == 'linear':
                 d.op = _lib.OP_LINEAR
                 d.cout = p['out']

@@ -73,6 +73,9 @@ def conv2d(x, w, b, stride=(1, 1), dilation=(1, 1), act='l'):
         out = np.tanh(out)
     elif act == 'lr':
         out = np.where(out > 0, out, F32(0.01) * out)
+    elif act == 'm':                                   # torch.nn.Softmax(dim=1), layers.py:814-816
+        e = np.exp(out - out.max(axis=1, keepdims=True)).astype(F32)
+        out = e / e.sum(axis=1, keepdims=True, dtype=F32)
     elif act not in ('l', 's'):
         raise NotImplementedError(act)
     return out.astype(F32)
@@ -237,7 +240,13 @@ def forward(specs, sd, x, lens=None):
         elif k == 'rnn':
             ws = []
             for sfx in [''] + (['_reverse'] if p['direction'] == 'b' else []):
-                ws.append(tuple(sd[f'nn.{nm}.layer.{w}_l0{sfx}'] for w in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')))
+                if p.get('legacy') == 'clstm':
+                    # a constant 1 in front of every input vector, no biases (layers.py:498-499, 522-524): the first weight
+                    # column acts as the bias
+                    w_ih = np.asarray(sd[f'nn.{nm}.layer.weight_ih_l0{sfx}'], F32)
+                    ws.append((w_ih[:, 1:], sd[f'nn.{nm}.layer.weight_hh_l0{sfx}'], w_ih[:, 0], np.zeros(w_ih.shape[0], F32)))
+                else:
+                    ws.append(tuple(sd[f'nn.{nm}.layer.{w}_l0{sfx}'] for w in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')))
             if x.shape[2] != 1 or p.get('axis', 'x') == 'y':
                 # rows as sequences + seq_lens: the reference raises (layers.py:528-530); columns as sequences: seq_lens pass
                 # through untouched (every column runs its full height) and the width mask below zeroes the padding columns

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 _ACT = {'l': lambda v: v, 's': lambda v: v, 'r': torch.relu, 't': torch.tanh,
-        'lr': lambda v: F.leaky_relu(v, 0.01)}
+        'lr': lambda v: F.leaky_relu(v, 0.01), 'm': lambda v: torch.softmax(v, dim=1)}
 
 
 def _mask(x, lens):
@@ -46,8 +46,9 @@ class CpuRecognizer:
         self.rnn = {}
         for s in self.specs:
             if s.kind == 'rnn':
-                m = torch.nn.LSTM(s.in_shape[1], s.params['hidden'], bidirectional=s.params['direction'] == 'b',
-                                  batch_first=True)
+                legacy = s.params.get('legacy') is not None      # clstm: a 1 in front of the input, no biases (layers.py:498-511)
+                m = torch.nn.LSTM(s.in_shape[1] + (1 if legacy else 0), s.params['hidden'], bidirectional=s.params['direction'] == 'b',
+                                  batch_first=True, bias=not legacy)
                 m.load_state_dict({k.split('.layer.')[1]: v for k, v in self.sd.items()
                                    if k.startswith(f'nn.{getattr(s, "key", s.name)}.layer.')})
                 m.eval()
@@ -106,6 +107,8 @@ class CpuRecognizer:
                 n, c, h, w = x.shape
                 if s.params.get('axis', 'x') == 'y':     # `transpose`: HNWC -> WNHC, columns are the sequences (:521-523)
                     seq = x.permute(2, 0, 3, 1).transpose(0, 2).reshape(w * n, h, c)
+                    if s.params.get('legacy'):
+                        seq = torch.cat([torch.ones(seq.shape[:2] + (1,)), seq], dim=2)
                     o, _ = self.rnn[nm](seq)
                     o = o.reshape(w, n, h, -1)
                     if s.params.get('summarize'):           # keep the last step of every column (:537-539)
@@ -115,6 +118,8 @@ class CpuRecognizer:
                         x = _mask(x, cur)
                     continue
                 seq = x.permute(2, 0, 3, 1).reshape(h * n, w, c)
+                if s.params.get('legacy'):                  # ones in front of the features (layers.py:522-524)
+                    seq = torch.cat([torch.ones(seq.shape[:2] + (1,)), seq], dim=2)
                 if cur is not None:
                     packed = pack_padded_sequence(seq, cur.cpu().clamp(min=1), batch_first=True, enforce_sorted=False)
                     o, _ = self.rnn[nm](packed)

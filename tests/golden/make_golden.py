@@ -180,6 +180,13 @@ GROUP_CASES = {
     'add_seq':      ('[1,1,0,12 Lbx6 A3,6 O1c4]', 3, 17, [17, 9, 4]),
     'sum_x_img':    ('[1,6,0,2 Lfxs4]', 2, 13, None),
     'sum_x_seq':    ('[1,1,0,9 Lbxs5 O1c3]', 3, 11, None),
+    # channel-softmax convolutions (nl 'm', layers.py:814-816) and the softmax heatmap head O2s (model.py:806-811)
+    'conv_softmax': ('[1,8,0,2 Cm3,3,5 Cr3,3,4]', 2, 19, [19, 12]),
+    'heat_softmax': ('[1,12,0,3 Cr3,3,8 Mp2,2 O2s4]', 2, 21, None),
+    # the clstm legacy layout: a constant 1 in front of every input vector, no biases (layers.py:498-511, 522-524)
+    'clstm':        ('[1,1,0,12 Lbxc10]', 3, 17, [17, 9, 4]),
+    'clstm_stack':  ('[1,8,0,1 Cr3,3,4 S1(1x0)1,3 Lfxc8 Lbxc6 O1c5]', 3, 23, [23, 15, 8]),
+    'clstm_y':      ('[1,6,0,2 Lfyc4]', 2, 9, None),
 }
 
 

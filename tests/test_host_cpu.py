@@ -80,14 +80,11 @@ def test_bad_or_unsupported_specs_raise(spec, exc):
 # forward call.  (Table in DESIGN.md section 7.)
 UNSUPPORTED_FORMS = [
     ('[1,48,0,1 CTr3,3,32 O2l4]', 'transposed', 'model.py:701-712 (transposed convolution)'),
-    ('[1,48,0,1 Cm3,3,32 S1(1x0)1,3 O1c10]', 'softmax-activated', 'model.py:701 (channel-softmax convolution)'),
     ('[1,48,0,1 Cr3,3,32 A2,2 S1(1x0)1,3 O1c10]', 'A2,2', 'model.py:622 (Addition over the width; channels and height are native)'),
     ('[1,48,0,1 W0.5,10 S1(1x0)1,3 O1c10]', 'W0.5,10', 'model.py:677 (wav2vec mask)'),
-    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxc20 O1c10]', 'Lbxc20', 'layers.py:498 (legacy 1-augmented LSTM)'),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxo20 O1c10]', 'Lbxo20', 'layers.py:146 (peephole LSTM)'),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbx800 O1c10]', 'Lbx800', 'hidden size above 768'),
     ('[1,48,0,1 Cr3,3,32 S3(4x8)1,3 O1c10]', 'S3(4x8)1,3', 'model.py:748 (general reshape)'),
-    ('[1,48,0,1 Cr3,3,32 O2s4]', 'softmax heatmap', 'model.py:806 (softmax heatmap head)'),
     ('[1,48,0,1 Cr3,3,32 O2la4]', 'O2la4', 'model.py:788 (1-augmented heatmap head)'),
 ]
 
