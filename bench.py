@@ -175,7 +175,7 @@ def roofline_of(engine, precision):
             return max(hit, key=lambda e: e.get('total_ms', 0)) if hit else None
 
         def cus_of(kname, v):          # CUs a launch occupies: the recurrent cluster kernels hold 4 CUs per 32 lines and direction
-            return 64.0 if kname.startswith(('lstm_ws', 'lstm_wp')) else 256.0
+            return 64.0 if kname.startswith('lstm_ws') else 256.0
 
         for gname in groups:
             kname = KERNEL_OF.get(gname, gname)

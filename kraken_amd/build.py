@@ -15,9 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 BUILD = os.path.join(CSRC, '_build')
 LIB = os.path.join(HERE, 'libkraken_amd.so')
-SOURCES = ['conv_mfma.hip', 'conv_x3.hip', 'conv_x3p.hip', 'conv_x6.hip', 'conv1_x3.hip', 'conv_taps_x3.hip', 'gemm_x3.hip', 'gemm_x3w.hip', 'norm_x3.hip', 'lstm_rec.hip', 'lstm_small.hip', 'lstm_x3.hip', 'lstm_ws.hip', 'lstm_wp.hip', 'misc_kernels.hip', 'c1gn.hip', 'prep_lines.hip', 'dewarp.hip', 'capi.hip']
+SOURCES = ['conv_mfma.hip', 'conv_x3.hip', 'conv_x3p.hip', 'conv_x6.hip', 'conv1_x3.hip', 'conv_taps_x3.hip', 'gemm_x3.hip', 'gemm_x3w.hip', 'norm_x3.hip', 'lstm_rec.hip', 'lstm_small.hip', 'lstm_x3.hip', 'lstm_ws.hip', 'misc_kernels.hip', 'c1gn.hip', 'prep_lines.hip', 'dewarp.hip', 'capi.hip']
 # sources compiled a second time with -DKRK_BF16_ONE: the plain-bf16 plan's launchers (name_b1), see csrc/common.h
-ONE_TERM = ['conv1_x3.hip', 'conv_taps_x3.hip', 'conv_x3.hip', 'conv_x3p.hip', 'gemm_x3.hip', 'gemm_x3w.hip', 'lstm_ws.hip', 'lstm_wp.hip']
+ONE_TERM = ['conv1_x3.hip', 'conv_taps_x3.hip', 'conv_x3.hip', 'conv_x3p.hip', 'gemm_x3.hip', 'gemm_x3w.hip', 'lstm_ws.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'kraken_amd.h')]
 ARCH = 'gfx950'

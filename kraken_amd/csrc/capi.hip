@@ -29,12 +29,6 @@ namespace {
 
 thread_local std::string g_err;
 #ifdef KRK_ABLATE
-unsigned long long* g_wp_tl = nullptr;      // timeline stamps of the last lstm_wp launch (dev tool)
-extern "C" int krk_debug_wp_timeline(unsigned long long* host, int n) {
-    if (!g_wp_tl) return -1;
-    if (hipDeviceSynchronize() != hipSuccess) return -2;
-    return hipMemcpy(host, g_wp_tl, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
-}
 #endif
 
 int fail(int code, const std::string& msg) {
@@ -483,9 +477,6 @@ struct Step {
     void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
     // weight-stationary cluster kernel (lstm_ws.hip): per-wave resident fragments, exchange granules, ticket counter
     void* d_wrecws = nullptr;
-    void* d_wrecwp = nullptr;   // pipelined cluster kernel (lstm_wp.hip): [dir][slice CS][wave 8][kb] fragments, one block per wave
-    int wp_bpc = 0;
-    DevBuf wp_ctrl;             // its per-launch claim block (arrival counters, mailboxes), zeroed before every launch
     DevBuf ws_gran;
     unsigned* ws_ctrl = nullptr;
     unsigned ws_tickets = 0, ws_epoch = 0;
@@ -652,23 +643,6 @@ int upload_lstm_x3(Step& st, const float* const* whh) {
         HIPCHK(hipMemset(st.ws_ctrl, 0, 64));
         st.ws_bpc = BPC;
     }
-    if (krk_lstm_wp_supported(H, Hp)) {
-        // lstm_wp.hip: [dir][slice CS][wave 8][kb][plane][lane][8]; slice r owns blocks [r*BPC, (r+1)*BPC), wave w of it block r*BPC + w
-        const int CS = krk_lstm_wp_slices(Hp), BPC = (NB + CS - 1) / CS;
-        std::vector<uint16_t> pw((size_t)st.ndir * CS * 8 * NKB * 1024, 0);
-        for (int d = 0; d < st.ndir; ++d)
-            for (int r = 0; r < CS; ++r)
-                for (int w = 0; w < 8; ++w) {
-                    const int b = r * BPC + w;
-                    if (w >= BPC || b >= NB) continue;
-                    for (int kb = 0; kb < NKB; ++kb)
-                        std::memcpy(&pw[((((size_t)d * CS + r) * 8 + w) * NKB + kb) * 1024],
-                                    &pack[(((size_t)d * NKB + kb) * NB + b) * 1024], 1024 * sizeof(uint16_t));
-                }
-        HIPCHK(hipMalloc(&st.d_wrecwp, pw.size() * sizeof(uint16_t)));
-        HIPCHK(hipMemcpy(st.d_wrecwp, pw.data(), pw.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        st.wp_bpc = BPC;
-    }
     return KRK_OK;
 }
 
@@ -694,10 +668,8 @@ void free_step(Step& s) {
     if (s.d_wrec16) (void)hipFree(s.d_wrec16);
     if (s.d_wrecx3) (void)hipFree(s.d_wrecx3);
     if (s.d_wrecws) (void)hipFree(s.d_wrecws);
-    if (s.d_wrecwp) (void)hipFree(s.d_wrecwp);
     if (s.ws_ctrl) (void)hipFree(s.ws_ctrl);
     s.ws_gran.release();
-    s.wp_ctrl.release();
     s.out.release();
     s.aux.release();
     s.aux2.release();
@@ -1397,7 +1369,7 @@ int krk_plan_status(krk_plan* plan) {
         const unsigned word = *(volatile unsigned*)plan->err_host;
         *(volatile unsigned*)plan->err_host = 0;
         char msg[256];
-        snprintf(msg, sizeof msg, "a recurrent cluster kernel timed out waiting for its peers (lstm_ws / lstm_wp exchange, word 0x%08x); the "
+        snprintf(msg, sizeof msg, "a recurrent cluster kernel timed out waiting for its peers (lstm_ws exchange, word 0x%08x); the "
                                   "results of the batches in flight on this plan are invalid", word);
         return fail(KRK_E_HIP, msg);
     }
@@ -1509,7 +1481,7 @@ void split_strides(const ConvGeom& g, int Wo_, int Wy_, long& sn, long& sr, long
 struct Probes {
     int x3_dbg = env_int("KRK_X3_DBG");          // ablation bits of the split-bf16 conv / projection kernels (-DKRK_ABLATE builds)
     int lstm_dbg = env_int("KRK_LSTM_DBG");      // ablation bits of the recurrent kernels
-    int lstm_v = env_int("KRK_LSTM_V", 0);       // 0: by hidden size (see recurrence_x3); 3: cluster kernel lstm_ws.hip; 4: pipelined XCD-local kernel lstm_wp.hip; 1: streaming kernel
+    int lstm_v = env_int("KRK_LSTM_V", 0);       // 0: by hidden size (see recurrence_x3); 3: cluster kernel lstm_ws.hip; 1: streaming kernel
     int lstm_g = env_int("KRK_LSTM_G", 2);       // 4: four 16-line groups per cluster
     int lstm_m = env_int("KRK_LSTM_M");          // f32 plan: force 16- or 32-line tiles
     int gemm_w = env_int("KRK_GEMM_W", 0);       // wide-tile projection kernel (gemm_x3w.hip): 0 never (default: alone it is 6-10 % faster than
@@ -1894,50 +1866,15 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     l.xtiled = 1;
     l.otiled = s.out_tiled ? 1 : 0;
     l.dbg = probe.lstm_dbg;
-    // Which cluster kernel: lstm_ws.hip (4-CU clusters, two blocks per wave, cross-XCD sc1 exchange) is the faster one on wide
-    // layers (H = 200: 0.46 vs 0.50 ms per layer at N = 256, T = 150); on narrow layers its time step is a handful of MFMAs and its
-    // optimistic exchange intermittently runs into its own one-second spin bound (tools/ws_flake.py: 5..50 timeouts in 100 forwards
-    // of a two-layer H = 8 net, in the round-2 build as well, hidden until forward() began to check the status word).  lstm_wp.hip
-    // (XCD-local clusters, dedicated gather waves, every wait behind a barrier) showed none in 900: it takes H <= 128.
-    const int lstm_v = probe.lstm_v ? probe.lstm_v : (l.NKB <= 4 ? 4 : 3);
-    if (s.d_wrecwp && lstm_v == 4) {
-        // the granules carry a 4-bit sequence tag (lstm_wp.hip): the buffer starts every launch zeroed, tag 0 is never used
-        const size_t gbytes = krk_lstm_wp_gran_bytes(Ns, s.ndir, s.Hp);
-        if (s.ws_gran.ensure(gbytes)) return nomem();
-        if (int r = hip(hipMemsetAsync(s.ws_gran.p, 0, gbytes, stream), "hipMemsetAsync")) return r;
-        LstmWsArgs w;
-        w.xp = l.xp; w.wp = (const __bf16*)s.d_wrecwp; w.out = l.out; w.out_plane = l.out_plane; w.lens = l.lens;
-        w.N = l.N; w.T = l.T; w.H = l.H; w.Hp = l.Hp; w.NKB = l.NKB; w.NB = l.NB; w.G = l.G;
-        w.ndir = l.ndir; w.dirmode = l.dirmode; w.xstride = l.xstride; w.ostride = l.ostride; w.hrow = l.hrow;
-        w.BPC = s.wp_bpc;
-        w.gran = (unsigned long long*)s.ws_gran.p;
-        w.nclusters = krk_lstm_wp_clusters(Ns, s.ndir);
-        w.mbox = krk_lstm_wp_mbox(w.nclusters, s.Hp);
-        const size_t cbytes = krk_lstm_wp_ctrl_bytes(w.nclusters, s.Hp);
-        if (s.wp_ctrl.ensure(cbytes)) return nomem();
-        if (int r = hip(hipMemsetAsync(s.wp_ctrl.p, 0, cbytes, stream), "hipMemsetAsync")) return r;
-        w.ctrl = (unsigned*)s.wp_ctrl.p;
-        w.ticket_base = 0;
-        s.ws_epoch = s.ws_epoch % 65535u + 1u;
-        w.epoch = s.ws_epoch;
-        w.err = p->err_dev;
-        w.otiled = l.otiled;
-        w.dbg = l.dbg;
-        w.tl = nullptr;
-#ifdef KRK_ABLATE
-        {   // timeline stamps of the last launch (tools/wp_timeline.py reads them back through krk_debug_wp_timeline)
-            static unsigned long long* tl = nullptr;
-            if (!tl && hipMalloc((void**)&tl, 32 * 32 * 8) != hipSuccess) tl = nullptr;
-            if (tl) (void)hipMemsetAsync(tl, 0, 32 * 32 * 8, stream);
-            w.tl = tl;
-            g_wp_tl = tl;
-        }
-#endif
-        int rc = one ? krk_launch_lstm_wp_b1(w, stream) : krk_launch_lstm_wp(w, stream);
-        if (rc == 0) return 0;
-        if (rc != -4) return rc;
-    }
-    if (!s.d_wrecws || (lstm_v != 3 && lstm_v != 4)) return krk_launch_lstm_x3(l, stream);
+    // Which kernel (tools/lstm_narrow_probe.py, profiles/r04_lstm_narrow_probe.txt; N = 256, T = 150, ms per launch):
+    //   H     16     32     64     96    128    200
+    //   x3   0.15   0.13   0.22   0.36   0.51   1.29     streaming kernel (lstm_x3.hip): W_hh through L1 every step
+    //   ws   0.31   0.30   0.29   0.31   0.32   0.46     weight-stationary 4-CU clusters (lstm_ws.hip)
+    // Up to 64 hidden units the recurrent weights (<= 64 KB split) stream faster than a cluster exchanges; above, the cluster kernel.
+    // (Round 3's third kernel, lstm_wp.hip -- XCD-local clusters, deferred gates, gather waves -- tied lstm_ws at H = 200 and lost
+    // to one of the two everywhere else: 0.22 / 0.24 / 0.26 / 0.33 / 0.36 ms; removed in round 4)
+    const int lstm_v = probe.lstm_v ? probe.lstm_v : (s.Hp <= 64 ? 1 : 3);
+    if (!s.d_wrecws || lstm_v != 3) return krk_launch_lstm_x3(l, stream);
     // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time barely
     // moves (it is not exchange bound), so a launch takes twice as long on half the CUs: same chip time, worse latency, fewer
     // lines/s through the pipelined engine.  KRK_LSTM_G=4 keeps it probeable.

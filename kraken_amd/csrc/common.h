@@ -266,8 +266,6 @@ struct LstmWsArgs {
     unsigned epoch;       // launch number folded into the granule tags (never 0)
     unsigned* err;        // mapped host word: set to 1 if an exchange wait timed out
     int otiled;           // 1: output rows tile-time-major (ceil(N/16)*16*T rows per piece), whole 256-byte runs per (piece, step)
-    int nclusters, mbox;  // lstm_wp.hip: work items (clusters) of the launch; mailboxes per XCD in the ctrl block
-    unsigned long long* tl;   // -DKRK_ABLATE only: timeline stamps of cluster 0 / slice 0 (tools/wp_timeline.py), else null
     int dbg;              // probe bits (-DKRK_ABLATE build, env KRK_LSTM_DBG): 1 no exchange reads, 2 no gate math / publish, 4 no MFMA, 8 no xproj loads, 16 no output pass, 32 no step barrier
 };
 bool krk_lstm_ws_supported(int H, int Hp);
@@ -276,15 +274,6 @@ size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC, int groups);
 int krk_launch_lstm_ws(const LstmWsArgs& a, int groups, hipStream_t s);
 int krk_launch_lstm_ws_b1(const LstmWsArgs& a, int groups, hipStream_t s);
 
-// pipelined cluster kernel (lstm_wp.hip): CS slices, one gate-column block per wave, gates deferred by a stage, gather waves
-bool krk_lstm_wp_supported(int H, int Hp);
-int krk_lstm_wp_slices(int Hp);
-int krk_lstm_wp_clusters(int N, int ndir);
-int krk_lstm_wp_mbox(int nclusters, int Hp);
-size_t krk_lstm_wp_ctrl_bytes(int nclusters, int Hp);
-size_t krk_lstm_wp_gran_bytes(int N, int ndir, int Hp);
-int krk_launch_lstm_wp(const LstmWsArgs& a, hipStream_t s);
-int krk_launch_lstm_wp_b1(const LstmWsArgs& a, hipStream_t s);
 
 // K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel
 int krk_lstm_kg(int M, int blocks_per_wave);

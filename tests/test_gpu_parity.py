@@ -854,8 +854,8 @@ def test_recurrent_kernel_variants_agree(bench_a_x3, monkeypatch):
     x = synth_input(40, 256).cuda()          # 40 lines: one full 32-line cluster / tile + a ragged one
     lens = torch.tensor([256 - 3 * i for i in range(40)])
     base = bench_a_x3.nn.recognize(x, lens)[0].tuples()
-    # (V=4: the pipelined XCD-local cluster kernel lstm_wp.hip, the default of narrow layers; V=3: lstm_ws.hip, the default here)
-    for env in ({'KRK_LSTM_V': '3', 'KRK_LSTM_G': '4'}, {'KRK_LSTM_V': '4'}, {'KRK_LSTM_V': '1'}, {'KRK_LSTM_V': '1', 'KRK_LSTM_STREAM_G': '2'}):
+    # (V=3: lstm_ws.hip, the default here; V=1: the streaming kernel lstm_x3.hip, the default up to 64 hidden units)
+    for env in ({'KRK_LSTM_V': '3', 'KRK_LSTM_G': '4'}, {'KRK_LSTM_V': '1'}, {'KRK_LSTM_V': '1', 'KRK_LSTM_STREAM_G': '2'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = bench_a_x3.nn.recognize(x, lens)[0].tuples()
@@ -865,11 +865,14 @@ def test_recurrent_kernel_variants_agree(bench_a_x3, monkeypatch):
         assert _max_conf_diff(got, base) < 1e-5, env
 
 
-def test_narrow_recurrent_layers_never_hit_the_exchange_timeout():
+@pytest.mark.parametrize('forced', [None, '3'])
+def test_narrow_recurrent_layers_never_hit_the_exchange_timeout(forced, monkeypatch):
     """
-    Round 3: forward() now reports the cluster kernels' exchange-timeout word, which showed that lstm_ws.hip intermittently runs
-    into its spin bound on narrow layers (a time step of a handful of MFMAs).  Narrow layers take lstm_wp.hip (every wait behind a
-    barrier): 60 forwards of the two-layer H = 8 net that failed 5..50 times in 100 must all succeed and agree.
+    Round 3: forward() reports the cluster kernel's exchange-timeout word, which showed that lstm_ws.hip intermittently ran into
+    its spin bound on narrow layers: 5..50 of 100 forwards of this two-layer H = 8 net.  Round 4: the cause was a flow-control hole
+    (a cluster slice without a gate-column block published nothing, so nobody waited for it: DESIGN.md section 3.3), fixed with a
+    heartbeat granule.  60 forwards must all succeed and agree -- on the default route (narrow layers stream their recurrent
+    weights, lstm_x3.hip) and with the cluster kernel FORCED onto the narrow layers (KRK_LSTM_V=3), where the hole was.
     """
     import kraken_amd
     spec = '[1,10,0,1 Cr1,16,32 Mp2,2 Cr3,11,32 Cr3,13,16 S1(1x0)1,3 Lbx8 Lbx8 O1c11]'
@@ -879,6 +882,8 @@ def test_narrow_recurrent_layers_never_hit_the_exchange_timeout():
     m.to('cuda')
     x = synth_input(4, 517, h=10).cuda()
     lens = torch.tensor([517, 516, 260, 31])
+    if forced:
+        monkeypatch.setenv('KRK_LSTM_V', forced)
     first = None
     for _ in range(60):
         y, _ = m.nn(x, lens)            # raises on a timed-out exchange

@@ -26,6 +26,10 @@ SPECS = [
     '[1,16,0,1 Cr3,11,20 Mp2,2 Cr3,11,28 Cr3,3,16 S1(1x0)1,3 Lbx56 Lbx104 O1c40]',
     '[1,12,0,1 Cr3,12,16 Cr3,12,32 Gn8 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx16 Lfx32 O1c8]',
     '[1,48,0,1 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,64 Mp2,2 Cr3,9,64 S1(1x0)1,3 Lbx200 Lbx200 O1c50]',
+    # round 4: a residual group in front of the split-bf16 part, parallel convolutions of different reach, narrow recurrent layers
+    # (streaming kernel) and a clstm cell
+    '[1,24,0,1 Cr3,3,16 (I [Cr3,3,16 Cl3,3,16]) A3,16 Mp2,2 Cr3,7,32 Mp2,2 Cr3,3,32 S1(1x0)1,3 Lbx48 Lbx32 O1c19]',
+    '[1,16,0,1 (Cr3,3,8 Cr5,9,8 [Cr1,1,4 Cr3,13,16]) Mp2,2 Cr3,5,32 Cr3,3,16 S1(1x0)1,3 Lfxc48 Lbx64 O1c23]',
 ]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()) if '--time-seed' in sys.argv else 0)

@@ -67,7 +67,7 @@ if __name__ == '__main__':
         sys.exit(0)
     import numpy as np
     os.makedirs('gpurun_out', exist_ok=True)
-    variants = [('v1', dict(KRK_LSTM_V=1)), ('ws g2', dict(KRK_LSTM_V=3, KRK_LSTM_G=2)), ('ws g4', dict(KRK_LSTM_V=3, KRK_LSTM_G=4)), ('wp', dict(KRK_LSTM_V=4))]
+    variants = [('v1', dict(KRK_LSTM_V=1)), ('ws g2', dict(KRK_LSTM_V=3, KRK_LSTM_G=2)), ('ws g4', dict(KRK_LSTM_V=3, KRK_LSTM_G=4))]
     if '--ablate' in sys.argv:
         lib = os.path.abspath('kraken_amd/libkraken_amd_ablate.so')
         for name, env in variants[1:]:

@@ -23,7 +23,7 @@ import os
 import re
 import sys
 
-HALVED_READ_KERNELS = ('lstm_f32_kernel', 'lstm_x3_kernel', 'lstm_ws_kernel', 'lstm_wp_kernel')   # calibrated: xproj stream reads half
+HALVED_READ_KERNELS = ('lstm_f32_kernel', 'lstm_x3_kernel', 'lstm_ws_kernel')   # calibrated: xproj stream reads half
 
 
 def short(name):
