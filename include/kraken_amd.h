@@ -314,6 +314,9 @@ int krk_plan_num_steps(const krk_plan* plan);
  * (its workspaces are plan-owned); different plans are independent.
  */
 int krk_plan_status(krk_plan* plan);
+/* 1 if a forward call of this plan can launch the cluster kernel, i.e. if krk_plan_status can ever report anything: callers that
+ * would synchronise only to read the status word (a plain nn(x) call) need not when this is 0. */
+int krk_plan_has_exchange(const krk_plan* plan);
 
 /* Cross-batch scheduling for callers that keep several plans in flight on separate streams
  * (kraken_amd/engine.py; no reference analogue -- the reference runs one batch at a time,

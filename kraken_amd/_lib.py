@@ -28,7 +28,7 @@ EXPORTS = ['krk_abi_version', 'krk_last_error', 'krk_device_count', 'krk_plan_cr
            'krk_plan_workspace_bytes', 'krk_plan_set_profiling', 'krk_plan_layer_ms', 'krk_plan_layer_name',
            'krk_plan_layer_flops', 'krk_plan_num_steps', 'krk_plan_front_event', 'krk_plan_wait_front',
            'krk_plan_status', 'krk_prep_lines', 'krk_prep_crops', 'krk_upsample_sigmoid', 'krk_dewarp_measure', 'krk_dewarp_apply',
-           'krk_prep_lines_fmt', 'krk_dewarp_measure_page', 'krk_dewarp_apply_page']
+           'krk_prep_lines_fmt', 'krk_dewarp_measure_page', 'krk_dewarp_apply_page', 'krk_plan_has_exchange']
 
 
 class KrkLayer(C.Structure):
@@ -125,6 +125,8 @@ def load():
         lib.krk_plan_wait_front.restype = i32
         lib.krk_plan_status.argtypes = [vp]
         lib.krk_plan_status.restype = i32
+        lib.krk_plan_has_exchange.argtypes = [vp]
+        lib.krk_plan_has_exchange.restype = i32
         lib.krk_prep_lines.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
         lib.krk_prep_lines.restype = i32
         lib.krk_prep_crops.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]

@@ -1376,6 +1376,15 @@ int krk_plan_status(krk_plan* plan) {
     return KRK_OK;
 }
 
+int krk_plan_has_exchange(const krk_plan* plan) {
+    if (!plan) return 0;
+    // lstm_ws.hip is the only kernel that waits for other workgroups; it takes the recurrent layers above 64 hidden units that run on
+    // the bf16 cores (recurrence_x3) -- and any the KRK_LSTM_V probe switch forces onto it
+    for (const auto& s : plan->steps)
+        if (s.kind == S_LSTM && s.rec_x3 && s.d_wrecws && (s.Hp > 64 || getenv("KRK_LSTM_V"))) return 1;
+    return 0;
+}
+
 void* krk_plan_front_event(krk_plan* plan) { return plan ? (void*)plan->front_ev : nullptr; }
 
 int krk_plan_wait_front(krk_plan* plan, void* event) {

@@ -460,9 +460,9 @@ class _Plan:
         self.handle = handle
         self.device = device
         self._lib = lib
-        # plans with a recurrent layer on the split-bf16 kernels may run the cluster kernel (lstm_ws), whose only failure
-        # signal is the status word (krk_plan_status)
-        self.has_status = precision != _lib.PREC_F32 and any(s.kind == 'rnn' for s in specs)
+        # plans with a wide recurrent layer on the split-bf16 kernels run the cluster kernel (lstm_ws), whose only failure signal
+        # is the status word (krk_plan_status); the others have nothing to report and nn(x) need not synchronise for it
+        self.has_status = bool(lib.krk_plan_has_exchange(handle))
 
     def out_shape(self, W: int):
         c, h, w = C.c_int(), C.c_int(), C.c_int()

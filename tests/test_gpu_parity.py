@@ -891,6 +891,8 @@ def test_narrow_recurrent_layers_never_hit_the_exchange_timeout(forced, monkeypa
         if first is None:
             first = y
         assert torch.equal(y, first)
+    # only a plan that can launch the cluster kernel has a status word to report (and makes nn(x) synchronise for it)
+    assert m.nn._plan.has_status == bool(forced)
 
 
 @pytest.mark.parametrize('lens', [None, [400, 333]])
