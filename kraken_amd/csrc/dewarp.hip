@@ -49,20 +49,22 @@ __device__ __forceinline__ LineD line_of(const int* desc, int n) {
 }
 
 // K0: top (max) and min of a line; one workgroup per line.  mm[n] = {top, min}
-__global__ void __launch_bounds__(256) dw_minmax_kernel(const unsigned char* crops, Src f, const int* desc, int* mm) {
+// (one workgroup per line -- a batch is 256 of them, one per CU -- so it is a wide one: 1024 threads keep 16 waves' loads in flight)
+constexpr int DW_WIDE = 1024;
+__global__ void __launch_bounds__(DW_WIDE) dw_minmax_kernel(const unsigned char* crops, Src f, const int* desc, int* mm) {
     const int n = blockIdx.x;
     const LineD L = line_of(desc, n);
     const unsigned char* p = crops + (size_t)(unsigned)L.off;
     int mx = 0, mn = 255;
-    for (int e = threadIdx.x; e < L.w * L.h; e += 256) {
-        const int y = e / L.w, x = e - y * L.w;
-        const int v = px_at(p, y, x, L.w, f);
-        mx = max(mx, v); mn = min(mn, v);
-    }
-    __shared__ int smx[256], smn[256];
+    for (int y = threadIdx.x >> 6; y < L.h; y += DW_WIDE / 64)          // a wave per row: consecutive lanes, consecutive pixels
+        for (int x = threadIdx.x & 63; x < L.w; x += 64) {
+            const int v = px_at(p, y, x, L.w, f);
+            mx = max(mx, v); mn = min(mn, v);
+        }
+    __shared__ int smx[DW_WIDE], smn[DW_WIDE];
     smx[threadIdx.x] = mx; smn[threadIdx.x] = mn;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = DW_WIDE / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) { smx[threadIdx.x] = max(smx[threadIdx.x], smx[threadIdx.x + s]); smn[threadIdx.x] = min(smn[threadIdx.x], smn[threadIdx.x + s]); }
         __syncthreads();
     }
@@ -311,27 +313,26 @@ __global__ void __launch_bounds__(256) dw_centre_kernel(const int* desc, const i
 }
 
 // K7: r = int(1 + 4 * mean |y - centre| over ink pixels); band bounds.  info[n] = {r, ok, has ink, 0}; one workgroup per line
-__global__ void __launch_bounds__(256) dw_spread_kernel(const unsigned char* crops, Src f, const int* desc, const int* mm, const int* centre, int maxw,
-                                                        int* info) {
+__global__ void __launch_bounds__(DW_WIDE) dw_spread_kernel(const unsigned char* crops, Src f, const int* desc, const int* mm, const int* centre,
+                                                            int maxw, int* info) {
     const int n = blockIdx.x;
     const LineD L = line_of(desc, n);
     const int top = mm[2 * n];
-    __shared__ long long ssum[256];
-    __shared__ int scnt[256], smin[256], smax[256];
-    long long sum = 0;
+    __shared__ long long ssum[DW_WIDE];
+    __shared__ int scnt[DW_WIDE], smin[DW_WIDE], smax[DW_WIDE];
+    long long sum = 0;                                  // integer sums: any order gives the same total
     int cnt = 0, cmin = 1 << 30, cmax = -(1 << 30);
     if (top != mm[2 * n + 1]) {
         const unsigned char* p = crops + (size_t)(unsigned)L.off;
         const int* c = centre + (size_t)n * maxw;
-        for (int e = threadIdx.x; e < L.w * L.h; e += 256) {
-            const int y = e / L.w, x = e - y * L.w;
-            if (px_at(p, y, x, L.w, f) != top) { sum += abs(y - c[x]); ++cnt; }
-        }
-        for (int x = threadIdx.x; x < L.w; x += 256) { cmin = min(cmin, c[x]); cmax = max(cmax, c[x]); }
+        for (int y = threadIdx.x >> 6; y < L.h; y += DW_WIDE / 64)
+            for (int x = threadIdx.x & 63; x < L.w; x += 64)
+                if (px_at(p, y, x, L.w, f) != top) { sum += abs(y - c[x]); ++cnt; }
+        for (int x = threadIdx.x; x < L.w; x += DW_WIDE) { cmin = min(cmin, c[x]); cmax = max(cmax, c[x]); }
     }
     ssum[threadIdx.x] = sum; scnt[threadIdx.x] = cnt; smin[threadIdx.x] = cmin; smax[threadIdx.x] = cmax;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = DW_WIDE / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
             ssum[threadIdx.x] += ssum[threadIdx.x + s]; scnt[threadIdx.x] += scnt[threadIdx.x + s];
             smin[threadIdx.x] = min(smin[threadIdx.x], smin[threadIdx.x + s]); smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + s]);
@@ -406,7 +407,7 @@ int krk_launch_dewarp_measure(const unsigned char* crops, size_t rs, int ps, con
     if (ps != 1 && ps != 3 && ps != 4) return -4;
     const Src f{rs, ps};
     const unsigned gx = (unsigned)((maxw + 255) / 256);
-    hipLaunchKernelGGL(dw_minmax_kernel, dim3(n), dim3(256), 0, s, crops, f, desc, mm);
+    hipLaunchKernelGGL(dw_minmax_kernel, dim3(n), dim3(DW_WIDE), 0, s, crops, f, desc, mm);
     // LDS of the two Gaussian passes, sized for the tallest / widest line of the batch (r0 <= h, r1 = int(4 h + 0.5) <= w clipped)
     const int r1max = (int)(4.0 * maxh + 0.5);
     const size_t lds0 = ((size_t)maxh * 64 + (size_t)maxh + 1) * sizeof(double);
@@ -420,7 +421,7 @@ int krk_launch_dewarp_measure(const unsigned char* crops, size_t rs, int ps, con
     hipLaunchKernelGGL(dw_unif1_kernel, dim3((unsigned)((maxh + 63) / 64), n), dim3(64), 0, s, desc, mm, scratch);
     hipLaunchKernelGGL(dw_ridge_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, scratch, ridge, maxw);
     hipLaunchKernelGGL(dw_centre_kernel, dim3(gx, n), dim3(256), 0, s, desc, mm, wts, ridge, centre, maxw);
-    hipLaunchKernelGGL(dw_spread_kernel, dim3(n), dim3(256), 0, s, crops, f, desc, mm, centre, maxw, info);
+    hipLaunchKernelGGL(dw_spread_kernel, dim3(n), dim3(DW_WIDE), 0, s, crops, f, desc, mm, centre, maxw, info);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
