@@ -190,8 +190,7 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
             raise ValueError('categorical output not supported, yet.')
         if typ == 'c' and dim == 2:
             raise ValueError('CTC not supported for heatmap output')
-        if g['aug'] and dim == 2:
-            raise NotImplementedError(f'1-augmented heatmap output "{block}" is not supported by the HIP executor')
+        # (a heatmap head ignores the 'a' flag: build_output reads it on the LinSoftmax branch only, model.py:806-816)
         if dim == 2:
             # 1x1 ActConv2D: 'l' with the (skipped) sigmoid, 's' with a softmax over the classes (reference model.py:806-811)
             kind = 'conv'

@@ -85,7 +85,6 @@ UNSUPPORTED_FORMS = [
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbxo20 O1c10]', 'Lbxo20', 'layers.py:146 (peephole LSTM)'),
     ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbx800 O1c10]', 'Lbx800', 'hidden size above 768'),
     ('[1,48,0,1 Cr3,3,32 S3(4x8)1,3 O1c10]', 'S3(4x8)1,3', 'model.py:748 (general reshape)'),
-    ('[1,48,0,1 Cr3,3,32 O2la4]', 'O2la4', 'model.py:788 (1-augmented heatmap head)'),
 ]
 
 
@@ -125,6 +124,15 @@ def test_group_containers_index_like_the_reference():
     assert m.output == (1, 4, 1, 1)      # the reshape leaves the variable width as 1 (model.py:739-777)
     kinds = [s.kind for s in m.layer_specs]
     assert kinds[1] == 'par_begin' and kinds.count('par_next') == 1 and kinds[9] == 'par_end'
+
+
+def test_augmented_flag_of_a_heatmap_head_is_ignored_like_in_the_reference():
+    """`O2la4`: build_output reads the 'a' flag on the LinSoftmax branch only (model.py:806-816): a heatmap head with it is the same
+    1x1 convolution as without, named after its type letter."""
+    a = kraken_amd.TorchVGSLModel(vgsl='[1,48,0,1 Cr3,3,32 O2la4]')
+    b = kraken_amd.TorchVGSLModel(vgsl='[1,48,0,1 Cr3,3,32 O2l4]')
+    assert sorted(a.state_dict()) == sorted(b.state_dict()) == ['nn.C_0.co.bias', 'nn.C_0.co.weight', 'nn.l_1.co.bias', 'nn.l_1.co.weight']
+    assert tuple(a.state_dict()['nn.l_1.co.weight'].shape) == (4, 32, 1, 1) and a.output == b.output
 
 
 def test_one_augmented_output_layer_is_built_like_the_reference():
