@@ -809,6 +809,15 @@ struct PlanBuilder {
     int build();
 };
 
+// Can this (already planned) convolution hand its output to the tap kernel, i.e. write [N][H][C][pitch] planes?  conv1_x3.hip does
+// (one grayscale channel in); so does the exact-f32 kernel when it is a plan's first split-bf16 layer -- RGB recognisers, first
+// layers outside conv1_x3's geometry (round 4: their second convolution ran on the generic channel-as-K kernel, 1.8 ms per
+// 256-line batch where the tap kernel takes 0.5).  KRK_NO_F32_NHCW keeps the round-3 routing.
+bool feeds_taps(const ConvGeom& g) {
+    if (g.c1x3) return true;
+    return g.split_out && !g.x3 && !g.taps && !g.x6 && !g.out_seq && !getenv("KRK_NO_F32_NHCW");
+}
+
 // ActConv2D (reference layers.py:791-860), with a directly following 2x2/2 MaxPool and/or the S reshape fused in
 int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
     if (seq) return fail(KRK_E_UNSUPPORTED, where + ": convolution after a sequence layer");
@@ -820,7 +829,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
     const bool softmax = L.act == KRK_ACT_SOFTMAX;
     if (softmax && (x3 || split_fmt)) return fail(KRK_E_UNSUPPORTED, where + ": channel-softmax convolution on split-bf16 planes");
     if (x3 && split_fmt && C % 16) {   // conv_x3 wants 16-channel K blocks; the tap kernel takes multiples of 4 after conv1_x3
-        const bool taps_ok = !p->steps.empty() && p->steps.back().kind == S_CONV && p->steps.back().cg.c1x3 &&
+        const bool taps_ok = !p->steps.empty() && p->steps.back().kind == S_CONV && feeds_taps(p->steps.back().cg) &&
                              krk_conv_taps_supported(C, L.cout, L.kh, L.kw, L.sh, L.sw, L.dh, L.dw) &&
                              !(i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC);
         if (!taps_ok) leave_x3();
@@ -875,7 +884,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
         if (first && g.out_seq) return fail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs >= 2 convolutions before the reshape");
         g.split_out = true;
         s.in_split = !first;
-        if (!first && !g.out_seq && !p->steps.empty() && p->steps.back().kind == S_CONV && p->steps.back().cg.c1x3 &&
+        if (!first && !g.out_seq && !p->steps.empty() && p->steps.back().kind == S_CONV && feeds_taps(p->steps.back().cg) &&
             krk_conv_taps_supported(g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw) && !getenv("KRK_NO_CONV_TAPS")) {
             g.taps = true;
             p->steps.back().cg.out_nhcw = true;
@@ -1669,6 +1678,13 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         a.y_split = outp;
         a.y_plane = out_elems;
         split_strides(g, a.Wo, a.Wy, a.y_sn, a.y_sr, a.y_sc);
+        if (g.out_nhcw) {      // [N][H][C][pitch] planes for the tap kernel, which reads whole pitched rows: the columns between the
+            const long pitch = nhcw_pitch(a.Wy);       // tensor width and the pitch are zeroed here (the kernel stores columns < Wy only)
+            a.y_sn = (long)g.Hy * g.Cout * pitch; a.y_sr = (long)g.Cout * pitch; a.y_sc = 1; a.y_cs = pitch;
+            if (pitch > a.Wy)
+                if (int r = hip(hipMemset2DAsync((__bf16*)outp + a.Wy, (size_t)pitch * 2, 0, (size_t)(pitch - a.Wy) * 2,
+                                                 2 * (size_t)N * g.Hy * g.Cout, stream), "hipMemset2DAsync")) return r;
+        }
     }
     s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
     if (mark("conv", s.flops)) return kFailed;

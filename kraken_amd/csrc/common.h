@@ -119,6 +119,7 @@ struct ConvArgs {
     void* y_split;
     size_t y_plane;
     long y_sn, y_sr, y_sc;
+    long y_cs = 1;        // element stride between output channels: 1 = channels-last; the row pitch for the [N][H][C][pitch] planes the tap kernel reads
 };
 
 // ------------------------------------------------------- split-bf16 ("bf16x3") conv/GEMM

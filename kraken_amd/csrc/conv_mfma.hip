@@ -283,8 +283,17 @@ __global__ void __launch_bounds__(256, 2) conv_f32_kernel(const ConvArgs a) {
                         lv[i] = (__bf16)(v - (float)h);
                     }
                     if (st && co < a.Cout) {
-                        *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
-                        *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                        if (a.y_cs == 1) {
+                            *reinterpret_cast<bf16x4*>(yh + base + co) = hv;
+                            *reinterpret_cast<bf16x4*>(yl + base + co) = lv;
+                        } else {        // [N][H][C][pitch] planes for conv_taps_x3.hip: consecutive lanes are consecutive columns
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (co + i < a.Cout) {
+                                    yh[base + (size_t)(co + i) * a.y_cs] = hv[i];
+                                    yl[base + (size_t)(co + i) * a.y_cs] = lv[i];
+                                }
+                        }
                     }
                 }
             }

@@ -626,6 +626,48 @@ def test_x3_plan_continues_on_f32_kernels_where_it_has_to():
         m.nn.set_precision('fp8')
 
 
+@pytest.mark.parametrize('spec,w,first', [
+    # an RGB recogniser: the first layer reads three channels (the exact-f32 kernel), the second is BENCH-A's 3x13 tap geometry
+    ('[1,48,0,3 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,64 S1(1x0)1,3 Lbx32 O1c19]', 301, 'conv'),
+    # one channel, but a first layer outside conv1_x3's geometry (7 kernel rows): same hand-over, no pool in between, width 203
+    ('[1,20,0,1 Cr7,5,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 203, 'conv'),
+    # a GroupNorm part in front: the first split-bf16 layer reads fp32 NCHW from the GroupNorm
+    ('[1,16,0,1 Cr3,3,8 Gn4 Cr3,5,16 Cr3,12,20 S1(1x0)1,3 Lbx16 O1c7]', 77, None),
+])
+def test_tap_kernel_takes_over_behind_an_exact_f32_first_layer(spec, w, first, monkeypatch):
+    """
+    conv_taps_x3.hip reads [N][H][C][pitch] planes.  conv1_x3.hip writes them for grayscale first layers; round 4 lets the exact-f32
+    kernel (RGB input, first layers outside conv1_x3's geometry, the layer behind a GroupNorm part) write them too -- channel stride =
+    the pitch, the columns between width and pitch zeroed -- so that the second convolution runs on the tap kernel instead of the
+    generic channel-as-K one.  Against the CPU oracle on a ragged batch, against the round-3 routing (KRK_NO_F32_NHCW), and the
+    kernel names say which kernels ran.
+    """
+    from kraken_amd.engine import RecognitionEngine
+    m = build_model(spec, seed=5).to('cuda')
+    m.nn.set_precision('bf16x3')
+    c, h = m.input[1], m.input[2]
+    x = torch.rand(5, c, h, w, generator=torch.Generator().manual_seed(2))
+    lens = [w, w - 1, w // 2 + 3, 40, w - 64]
+    for i, L in enumerate(lens):
+        x[i, ..., L:] = 0
+    want, wl = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()}).forward(x, lens)
+    got, ol = m.nn(x.cuda(), torch.tensor(lens))
+    assert ol.tolist() == [int(v) for v in wl]
+    for i in range(5):
+        assert float((got.cpu()[i, ..., :ol[i]] - want[i, ..., :ol[i]]).abs().max()) < (1e-3 if 'Gn' in spec else 2e-4), i
+    eng = RecognitionEngine(m, device=0, max_batch=8, max_width=w, slots=1)
+    eng.set_profiling(True)
+    eng.submit(x.cuda(), np.asarray(lens, np.int32))
+    eng.collect()
+    names = [n_ for n_, _, _ in eng.layer_times()[0]]
+    eng.close()
+    assert (first is None or names[0] == first) and 'conv_taps_x3' in names, names
+    monkeypatch.setenv('KRK_NO_F32_NHCW', '1')
+    m.nn.invalidate()
+    old, _ = m.nn(x.cuda(), torch.tensor(lens))
+    assert float((old - got).abs().max()) < 1e-4      # (two kernels, two summation orders of the same split products)
+
+
 def test_x3_plan_keeps_everything_up_to_the_last_groupnorm_on_the_f32_cores():
     """
     GroupNorm amplifies the error of its input by |x| / sigma: an all-split plan left the 1e-3 gate on rare lines of random
