@@ -542,6 +542,14 @@ class _RecognitionRun:
         tss = list(ts.values()) if isinstance(ts, dict) else [ts]
         return any(getattr(t, '_center_norm', False) and getattr(t, '_mode', '') == 'L' for t in tss)
 
+    def _dewarps(self) -> bool:
+        """Does this run put lines through the CenterNormalizer dewarp (1-channel models on a bbox segmentation)?"""
+        if self.bounds.type == 'baselines':
+            return False
+        ts = getattr(self, 'ts', None)
+        tss = list(ts.values()) if isinstance(ts, dict) else [ts]
+        return any(getattr(t, '_center_norm', False) for t in tss)
+
     def _ensure_gray(self, idxs):
         """Main thread, before a chunk is prepared: converts the page rows the chunk's boxes touch (pool: 256-row pieces)."""
         W, H = self.im.size
@@ -763,7 +771,11 @@ class _RecognitionRun:
     def _advance(self):
         """Prepares + submits the next chunk (the device keeps working on earlier ones meanwhile), or waits for results."""
         if self._prepared < self.len:
-            idxs = range(self._prepared, min(self._prepared + self._chunk, self.len))
+            # the first chunk is ONE batch: the device starts after a third of the page band has been copied and uploaded (a page is
+            # a handful of batches: its first result waits for all the host work in front of the first submission)
+            # (not for dewarped lines: their batches are pipelined in pairs inside a chunk, _submit_dewarp)
+            chunk = self._batch if self._prepared == 0 and not self._dewarps() else self._chunk
+            idxs = range(self._prepared, min(self._prepared + chunk, self.len))
             if self._gray_wanted():
                 self._ensure_gray(idxs)
             if self._pool and len(idxs) > 1:

@@ -632,7 +632,7 @@ def test_x3_plan_continues_on_f32_kernels_where_it_has_to():
     # one channel, but a first layer outside conv1_x3's geometry (7 kernel rows): same hand-over, no pool in between, width 203
     ('[1,20,0,1 Cr7,5,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 203, 'conv'),
     # a GroupNorm part in front: the first split-bf16 layer reads fp32 NCHW from the GroupNorm
-    ('[1,16,0,1 Cr3,3,8 Gn4 Cr3,5,16 Cr3,12,20 S1(1x0)1,3 Lbx16 O1c7]', 77, None),
+    ('[1,16,0,1 Cr3,3,8 Gn4 Cr3,5,16 Cr3,12,20 Cr3,3,16 S1(1x0)1,3 Lbx16 O1c7]', 77, None),
 ])
 def test_tap_kernel_takes_over_behind_an_exact_f32_first_layer(spec, w, first, monkeypatch):
     """

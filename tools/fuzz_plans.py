@@ -34,9 +34,12 @@ SPECS = [
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()) if '--time-seed' in sys.argv else 0)
 t0, n_cases, worst = time.time(), 0, 0.0
-worst_by = {}
+worst_by, worst_cpu_by, n_cpu = {}, {}, 0
 models = []
+only = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--only=')]      # --only=<index into SPECS>
 for i, spec in enumerate(SPECS):
+    if only and i not in only:
+        continue
     torch.manual_seed(i)
     m = kraken_amd.TorchVGSLModel(vgsl=spec)
     ref = CpuRecognizer(m.layer_specs, {k: v.clone() for k, v in m.state_dict().items()})
@@ -60,7 +63,7 @@ while time.time() - t0 < budget:
         m.nn.set_precision(prec)
         y, ol = m.nn(x.cuda(), None if lens is None else torch.tensor(lens))
         out[prec] = (y.cpu(), None if ol is None else ol.tolist())
-    check_cpu = n_cases % 4 == 0
+    check_cpu = n_cases % 4 == 0 or bool(only)
     want = ref.forward(x, lens) if check_cpu else None
     for i in range(n):
         L = out['f32'][1][i] if lens else out['f32'][0].shape[3]
@@ -71,10 +74,16 @@ while time.time() - t0 < budget:
         # two plans differ only by what the sequence layers' split operands add; the 1e-3 bound is the parity gate itself
         assert d < (1e-3 if 'Gn' in spec else 2e-4), (spec, n, w, lens, i, d)
         if check_cpu:
+            # the exact-f32 plan against torch's CPU operators: summation orders differ by ~1e-6 per layer, and a GroupNorm
+            # amplifies what reaches it by |x| / sigma of the group -- on the two-GroupNorm network rare lines reach 3e-4
+            # (profiles/r04_head_fuzz_two_groupnorms.txt); the bound for such networks is the parity gate itself
             dc = (out['f32'][0][i, ..., :L] - want[0][i, ..., :L]).abs().max().item()
-            assert dc < (2e-4 if 'Gn' in spec else 5e-5), ('f32 vs cpu', spec, n, w, lens, i, dc)
+            worst_cpu_by[spec[:40]] = max(worst_cpu_by.get(spec[:40], 0.0), dc)
+            assert dc < (1e-3 if 'Gn' in spec else 5e-5), ('f32 vs cpu', spec, n, w, lens, i, dc)
+    n_cpu += check_cpu
     assert out['f32'][1] == out['bf16x3'][1]
     n_cases += 1
 print(f'{n_cases} random cases, worst |f32 - bf16x3| = {worst:.2e}: OK')
+print(f'({n_cpu} of them also against the CPU oracle)   spec: worst |f32 - bf16x3|, worst |f32 - cpu|')
 for k, v in worst_by.items():
-    print(f'   {k:40s} {v:.2e}')
+    print(f'   {k:40s} {v:.2e}  {worst_cpu_by.get(k, float("nan")):.2e}')
