@@ -824,9 +824,19 @@ class _RecognitionRun:
         ts = self.ts[group[0].tag] if isinstance(getattr(self, 'ts', None), (dict, defaultdict)) else self.ts
         page, top = None, 0
         if on_page:
-            page, top = self._strip_on_device(net, 'L', [p.box for p in group])
-            for p in group:
-                p.crop = _PageCrop(p.box, partial(self._page_gray_at, p.box[0], p.box[1]))
+            W, H = self.im.size
+            rows = min(max(p.box[3] for p in group), H) - max(min(p.box[1] for p in group), 0)
+            rows = H if rows > 0.6 * H else rows                  # (_strip_on_device uploads the whole page then)
+            if rows * W * (self._rows.pixelsize if self._rows is not None else 1) >= 1 << 32:
+                # crop offsets into the uploaded band are 32-bit (krk_dewarp_measure_page): a band of 4 GiB or more travels as
+                # packed crops cut out on the host instead
+                for p in group:
+                    box = self.im.crop(p.box[:4])
+                    p.crop = np.asarray(box if box.mode == 'L' else box.convert('L'), dtype=np.uint8)
+            else:
+                page, top = self._strip_on_device(net, 'L', [p.box for p in group])
+                for p in group:
+                    p.crop = _PageCrop(p.box, partial(self._page_gray_at, p.box[0], p.box[1]))
         # a dewarp batch is bounded by lines AND by pixels: krk_dewarp_measure keeps 3 fp64 planes per pixel of scratch behind
         # 32-bit offsets (a batch of 256 lines at the per-line maximum of 192 x 16384 would ask for 19 GB)
         parts, cur, px = [], [], 0
