@@ -482,6 +482,7 @@ struct Step {
     unsigned ws_tickets = 0, ws_epoch = 0;
     int ws_bpc = 0;
     float* d_wrecsm = nullptr;  // recurrent weights for lstm_small.hip (Hp <= 32): register-resident A fragments
+    void* d_wrecsmx = nullptr;  // ... split bf16 for its bf16x3 variant (plans whose arithmetic is split-bf16)
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
     bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
     bool split_rows = false;    // TOSEQ: fp32 NCHW in, K-blocked split sequence rows out (toseq_split_f32)
@@ -646,6 +647,28 @@ int upload_lstm_x3(Step& st, const float* const* whh) {
     return KRK_OK;
 }
 
+// lstm_small_x3_kernel: [dir][block b][plane][lane][8]: W[gate column 16 b + (lane & 15)][unit 4 j + (lane >> 4)], j = 0..7, split bf16
+int upload_lstm_small_x3(Step& st, const float* const* whh) {
+    const int H = st.hidden, NB = st.Hp / 4;
+    std::vector<uint16_t> pack((size_t)st.ndir * NB * 2 * 64 * 8, 0);
+    for (int d = 0; d < st.ndir; ++d)
+        for (int b = 0; b < NB; ++b)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int col = 16 * b + (lane & 15), k = 4 * j + (lane >> 4);
+                    const int u = col >> 2, gt = col & 3;
+                    if (u >= H || k >= H) continue;
+                    const float v = whh[d][((size_t)gt * H + u) * H + k];
+                    const uint16_t hi = f2bf(v);
+                    const size_t base = ((((size_t)d * NB + b) * 2) * 64 + lane) * 8 + j;
+                    pack[base] = hi;
+                    pack[base + 64 * 8] = f2bf(v - bf2f(hi));
+                }
+    HIPCHK(hipMalloc(&st.d_wrecsmx, pack.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(st.d_wrecsmx, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return KRK_OK;
+}
+
 int upload(float** dst, const std::vector<float>& v) {
     HIPCHK(hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * sizeof(float)));
     if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -662,6 +685,7 @@ void free_step(Step& s) {
     if (s.d_c1w) (void)hipFree(s.d_c1w);
     if (s.d_c1b) (void)hipFree(s.d_c1b);
     if (s.d_wrecsm) (void)hipFree(s.d_wrecsm);
+    if (s.d_wrecsmx) (void)hipFree(s.d_wrecsmx);
     if (s.d_gamma) (void)hipFree(s.d_gamma);
     if (s.d_beta) (void)hipFree(s.d_beta);
     if (s.d_wrec32) (void)hipFree(s.d_wrec32);
@@ -1095,6 +1119,8 @@ int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
     if (!s.rec_x3 && krk_lstm_small_supported(s.Hp) && !getenv("KRK_NO_LSTM_SMALL")) {
         pack_lstm_small(s, whh, pk);
         if (upload(&s.d_wrecsm, pk) != KRK_OK) return KRK_E_HIP;
+        // a split-bf16 plan runs these small recurrences on the bf16 cores too (the 2-D LSTMs of the segmenter, a small final LSTM)
+        if (want_x3 && !getenv("KRK_NO_LSTM_SMALL_X3") && upload_lstm_small_x3(s, whh) != KRK_OK) return KRK_E_HIP;
     }
     s.outC = s.ndir * s.hidden;
     C = s.outC;
@@ -1944,7 +1970,8 @@ int Pass::recurrence_f32(Step& s, float* outp, int Ns, int T, int G) {
     if (s.d_wrecsm) {   // hidden size <= 32: one wave per 16 sequences, weights / h / c in registers
         l.wp = s.d_wrecsm;
         l.NG = l.NB = 0;
-        return krk_launch_lstm_small(l, stream);
+        const int rc = s.d_wrecsmx ? krk_launch_lstm_small_x3(l, s.d_wrecsmx, stream) : krk_launch_lstm_small(l, stream);
+        if (rc != -4) return rc;            // (an output of 2 GiB or more: the generic kernel below)
     }
     if (s.Hp > 256) {   // generic-width kernel: 16-line tiles, K groups of 4 steps (krk_lstm_kg(16, > 13 blocks per wave) == 4)
         l.wp = s.d_wrec16;

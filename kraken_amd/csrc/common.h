@@ -229,6 +229,8 @@ struct LstmArgs {
 // small hidden sizes (Hp <= 32, lstm_small.hip): wp = [ndir][Hp/4 blocks][Hp/4 K steps][64 lanes]
 bool krk_lstm_small_supported(int Hp);
 int krk_launch_lstm_small(const LstmArgs& a, hipStream_t s);
+// the same on the bf16 cores with split operands (bf16x3 plans): wx = [ndir][Hp/4 blocks][hi|lo][64 lanes][8] bf16, K slot (g, j) = unit 4 j + g
+int krk_launch_lstm_small_x3(const LstmArgs& a, const void* wx, hipStream_t s);
 
 // split-bf16 recurrent kernel (lstm_x3.hip), 16-line tiles
 struct LstmX3Args {

@@ -152,6 +152,37 @@ def test_networks_ending_in_an_image_return_fp32_from_the_split_plan(name):
             assert float((y.cpu()[i:i + 1, ..., :w] - torch.from_numpy(want)).abs().max()) < 2e-4, (name, i)
 
 
+IMAGE_LSTM_NETS = layer_cases('image_lstm.npz')
+
+
+@pytest.mark.parametrize('name', sorted(IMAGE_LSTM_NETS))
+def test_image_lstms_in_the_split_bf16_plan_against_reference_golden(name, monkeypatch):
+    """LSTMs over image rows / columns (the segmenter's Lbx32 / Lby32) in a bf16x3 plan: projection on the split-bf16 GEMM, the small
+    recurrence on the bf16 cores with split operands (lstm_small_x3_kernel: h and c in registers, K slots permuted so that a lane's
+    cell outputs ARE its next B operand).  Against the reference's outputs, and against the exact-f32 recurrence of the same plan."""
+    c = IMAGE_LSTM_NETS[name]
+    m = build_model(c['spec'], c['sd']).to('cuda')
+    m.nn.set_precision('bf16x3')
+    tol = 1e-3 if 'Gn' in c['spec'] else 2e-4
+    x = torch.from_numpy(c['x'])
+    lens = c['lens']
+    if lens is not None:
+        for i, L in enumerate(lens):
+            x[i, ..., L:] = 0
+    y, _ = m.nn(x.cuda(), None if lens is None else torch.tensor(lens))
+    y = y.cpu()
+    if lens is None:
+        assert float((y - torch.from_numpy(c['y'])).abs().max()) < tol
+    else:
+        for i, want in enumerate(c['ys']):
+            w = want.shape[3]
+            assert float((y[i:i + 1, ..., :w] - torch.from_numpy(want)).abs().max()) < tol, (name, i)
+    monkeypatch.setenv('KRK_NO_LSTM_SMALL_X3', '1')
+    m.nn.invalidate()
+    y32, _ = m.nn(x.cuda(), None if lens is None else torch.tensor(lens))
+    assert float((y32.cpu() - y).abs().max()) < tol
+
+
 def test_split_bf16_kernels_take_over_behind_a_parallel_group():
     from kraken_amd.engine import RecognitionEngine
     import kraken_amd
