@@ -441,8 +441,47 @@ def transforms_fixture(path):
     print('wrote', path)
 
 
+def spec_names_fixture(path, n=80, seed=7):
+    """Randomly nested specs (serial / parallel groups to depth 3, Addition-free leaves that keep H and W) through the reference's
+    parser: the state-dict keys + shapes, the named spec and the output shape it derives -- or the fact that it refuses the spec.
+    tests/test_host_cpu.py::test_random_nested_specs_parse_like_the_reference compares kraken_amd's parser against them."""
+    import random
+    rng = random.Random(seed)
+
+    def leaf():
+        return rng.choice(['Cr3,3,%d' % rng.choice([4, 8, 12]), 'Cl1,1,%d' % rng.choice([4, 8]), 'Ct3,5,%d' % rng.choice([4, 8]),
+                           'Do', 'Do0.2', 'I', 'Gn2'])
+
+    def series(depth):
+        return '[' + ' '.join(block(depth - 1) for _ in range(rng.randint(1, 3))) + ']'
+
+    def parallel(depth):
+        return '(' + ' '.join((rng.choice([leaf(), series(depth - 1)]) if depth > 0 else leaf()) for _ in range(rng.randint(2, 3))) + ')'
+
+    def block(depth):
+        if depth <= 0:
+            return leaf()
+        r = rng.random()
+        return leaf() if r < 0.4 else (series(depth) if r < 0.7 else parallel(depth))
+
+    out = []
+    for _ in range(n):
+        body = ' '.join(block(3) for _ in range(rng.randint(1, 4)))
+        tail = rng.choice(['', ' S1(1x0)1,3 Lbx8 O1c5', ' Mp2,2 S1(1x0)1,3 Lfx6', ' O2l3'])
+        spec = f'[1,12,0,{rng.choice([1, 2, 3])} Cr3,3,4 {body}{tail}]'
+        try:
+            m = ref_vgsl.TorchVGSLModel(vgsl=spec)
+            out.append({'spec': spec, 'ok': True, 'keys': {k: list(v.shape) for k, v in m.state_dict().items()},
+                        'vgsl': m.user_metadata['vgsl'], 'output': list(m.output)})
+        except Exception as e:
+            out.append({'spec': spec, 'ok': False, 'error': type(e).__name__})
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=0)
+    print('wrote', path, len(out), 'specs,', sum(r['ok'] for r in out), 'accepted by the reference')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'codec', 'transforms']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'spec_names', 'codec', 'transforms']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -462,6 +501,8 @@ if __name__ == '__main__':
         layer_fixture(os.path.join(HERE, 'breadth.npz'), BREADTH_CASES)
     if 'groups' in which:
         layer_fixture(os.path.join(HERE, 'groups.npz'), GROUP_CASES)
+    if 'spec_names' in which:
+        spec_names_fixture(os.path.join(HERE, 'spec_names.json'))
     if 'codec' in which:
         codec_fixture(os.path.join(HERE, 'codec.npz'))
     if 'transforms' in which:

@@ -115,6 +115,23 @@ def test_nested_groups_are_named_like_the_reference(name):
     assert sorted(again.state_dict()) == sorted(c['sd']) and again.user_metadata['vgsl'] == c['vgsl']
 
 
+def test_random_nested_specs_parse_like_the_reference():
+    """80 randomly nested specs (tests/golden/make_golden.py: spec_names_fixture): where the reference builds a model, the same
+    state-dict keys and shapes, named spec and output shape; where it refuses the spec, a ValueError here too."""
+    import os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'spec_names.json')) as f:
+        cases = json.load(f)
+    assert len(cases) >= 60 and sum(c['ok'] for c in cases) >= 30 and sum(not c['ok'] for c in cases) >= 5
+    for c in cases:
+        if not c['ok']:
+            with pytest.raises(ValueError):
+                kraken_amd.TorchVGSLModel(vgsl=c['spec'])
+            continue
+        m = kraken_amd.TorchVGSLModel(vgsl=c['spec'])
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == c['keys'], c['spec']
+        assert m.user_metadata['vgsl'] == c['vgsl'] and list(m.output) == c['output'], c['spec']
+
+
 def test_group_containers_index_like_the_reference():
     """tests/test_vgsl.py:67-76 of the reference: nn[1] is the parallel group, its members are serial groups of three layers."""
     m = kraken_amd.TorchVGSLModel(vgsl='[1,48,0,1 Cr4,2,1,4,2 ([Cr4,2,1,1,1 Do Cr3,3,2,1,1] [Cr4,2,1,1,1 Cr3,3,2,1,1 Do]) S1(1x0)1,3 Lbx2 Do0.5 Lbx2]')
