@@ -39,7 +39,7 @@ done; done
 for i in 0 1 2; do (KRK_LSTM_V=3 timeout 300 python tools/ws_flake.py 350 $i 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_exchange_timeouts_lstm_ws_forced_narrow.txt); done
 (KRK_CONV_X6=0 timeout 200 python tools/fuzz_plans.py 60 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz_f32_convs_same_seed.txt)
 (timeout 200 python tools/fuzz_plans.py 60 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz_x6_convs_same_seed.txt)
-(timeout 200 python tools/lstm_ws_probe.py --wp 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lstm_probe.txt)
+(timeout 200 python tools/lstm_ws_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lstm_probe.txt)
 (timeout 150 python tools/ws_flake.py 100 2>&1 | grep -v amdgpu.ids > $O/${TAG}_exchange_timeouts_default.txt)
 (timeout 60 python tools/batch_invariance.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_batch_invariance.txt)
 (timeout 200 python tools/fuzz_plans.py ${FUZZ:-100} --time-seed 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz.txt)

@@ -75,20 +75,16 @@ if __name__ == '__main__':
                 r = run(dict(env, KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
                 print('ablate', name, 'dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
         sys.exit(0)
-    if '--wp' in sys.argv:             # round 3: the pipelined cluster kernel against the streaming and the round-2 cluster kernel
-        variants = [variants[0], variants[1], variants[3]]
-        sizes = ((256, 150), (40, 60), (7, 33), (1024, 150), (100, 300))
-        if '--one' in sys.argv:       # just the BENCH-A shape
-            sizes = sizes[:1]
-    elif '--quick' in sys.argv:          # correctness at three sizes + the phase prices of the default (g2) variant
+    if '--quick' in sys.argv:            # correctness at three sizes + the phase prices of the default (g2) variant
         lib = os.path.abspath('kraken_amd/libkraken_amd_ablate.so')
         for dbg in (0, 64, 128, 4, 16, 32, 1):     # 1 no exchange, 4 no MFMA, 16 no output pass, 32 no barrier; gather asked at slot start (64) / after the last block (128)
             r = run(dict(variants[1][1], KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
             print('ablate ws g2 dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
-        variants = [variants[0], variants[1], variants[3]]
+        variants = variants[:2]
         sizes = ((256, 150), (40, 60), (7, 33))
-    elif '--wp' not in sys.argv:
-        sizes = ((256, 150), (64, 150), (1024, 150), (40, 60), (7, 33))
+    else:
+        variants = variants[:2]        # (the 4-groups-per-cluster variant is probed by tests/test_gpu_parity.py)
+        sizes = ((256, 150), (40, 60), (7, 33), (1024, 150), (100, 300))
     for N, T in sizes:
         ref = None
         for name, env in variants:
