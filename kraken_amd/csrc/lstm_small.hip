@@ -161,16 +161,20 @@ __global__ void __launch_bounds__(64) lstm_small_x3_kernel(const LstmArgs a, con
             bh[j] = hi;
             bl[j] = (__bf16)(h[j] - (float)hi);
         }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        const bool on = s < len;
+        const int t = rev ? len - 1 - s : s;
+        // the three MFMAs of block b + 1 are issued in front of the cell update of block b (whose accumulator is complete): the step
+        // is bound by the eight cell updates, the matrix work runs in their shadow.  (bh / bl hold the PREVIOUS step's h: h[] may be
+        // overwritten block by block.)
+        auto mma = [&](int b) {
             acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[b], bh, acc[b], 0, 0, 0);
             acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[b], bl, acc[b], 0, 0, 0);
             acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[b], bh, acc[b], 0, 0, 0);
-        }
-        const bool on = s < len;
-        const int t = rev ? len - 1 - s : s;
+        };
+        mma(0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
+            if (b + 1 < NB) mma(b + 1);
             const float hv = krk_lstm_cell(acc[b], c[b]);
             h[b] = hv;
             const int unit = 4 * b + us;
