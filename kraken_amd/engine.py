@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .vgsl import DecodedBatch, TorchVGSLModel, _Plan
+from .vgsl import DecodedBatch, TorchVGSLModel
 
 
 class _Slot:
