@@ -441,6 +441,43 @@ def transforms_fixture(path):
     print('wrote', path)
 
 
+def random_group_cases(n=14, seed=11):
+    """Randomly nested small networks the reference accepts (the generator of spec_names_fixture, another seed): numeric goldens
+    for arbitrary nesting, next to the hand-written GROUP_CASES."""
+    import random
+    rng = random.Random(seed)
+
+    def leaf():
+        return rng.choice(['Cr3,3,%d' % rng.choice([4, 8]), 'Cl1,1,%d' % rng.choice([4, 8]), 'Ct3,5,%d' % rng.choice([4, 8]), 'Do', 'I', 'Gn2'])
+
+    def series(depth):
+        return '[' + ' '.join(block(depth - 1) for _ in range(rng.randint(1, 3))) + ']'
+
+    def parallel(depth):
+        return '(' + ' '.join((rng.choice([leaf(), series(depth - 1)]) if depth > 0 else leaf()) for _ in range(rng.randint(2, 3))) + ')'
+
+    def block(depth):
+        if depth <= 0:
+            return leaf()
+        r = rng.random()
+        return leaf() if r < 0.35 else (series(depth) if r < 0.6 else parallel(depth))
+
+    cases = {}
+    while len(cases) < n:
+        body = ' '.join(block(3) for _ in range(rng.randint(1, 3)))
+        tail = rng.choice([' S1(1x0)1,3 Lbx8 O1c5', ' Mp2,2 S1(1x0)1,3 Lfx6', ' O2l3', ' Cr3,3,4'])
+        spec = f'[1,12,0,{rng.choice([1, 2, 3])} Cr3,3,4 {body}{tail}]'
+        if '(' not in spec:
+            continue
+        try:
+            ref_vgsl.TorchVGSLModel(vgsl=spec)
+        except Exception:
+            continue
+        w = rng.choice([19, 26, 33])
+        cases[f'rnd{len(cases):02d}'] = (spec, 2, w, [w, w - 7] if rng.random() < 0.5 else None)
+    return cases
+
+
 def spec_names_fixture(path, n=80, seed=7):
     """Randomly nested specs (serial / parallel groups to depth 3, Addition-free leaves that keep H and W) through the reference's
     parser: the state-dict keys + shapes, the named spec and the output shape it derives -- or the fact that it refuses the spec.
@@ -481,7 +518,7 @@ def spec_names_fixture(path, n=80, seed=7):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'spec_names', 'codec', 'transforms']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -501,6 +538,8 @@ if __name__ == '__main__':
         layer_fixture(os.path.join(HERE, 'breadth.npz'), BREADTH_CASES)
     if 'groups' in which:
         layer_fixture(os.path.join(HERE, 'groups.npz'), GROUP_CASES)
+    if 'groups_random' in which:
+        layer_fixture(os.path.join(HERE, 'groups_random.npz'), random_group_cases())
     if 'spec_names' in which:
         spec_names_fixture(os.path.join(HERE, 'spec_names.json'))
     if 'codec' in which:

@@ -26,6 +26,7 @@ CASES = layer_cases()
 CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, scaled-down BLLA segmenter
 CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes above 256, ...
 CASES.update(layer_cases('groups.npz'))       # round 4: nested [ ] / ( ) groups, Addition, x-axis summarising LSTMs
+CASES.update(layer_cases('groups_random.npz'))   # ... and 14 randomly nested networks (identity members, groups inside groups inside groups)
 
 
 def _keys(tuples):
@@ -101,6 +102,7 @@ def test_x3_kernels_against_reference_golden(name, prec):
 
 
 GROUP_NETS = layer_cases('groups.npz')
+GROUP_NETS.update(layer_cases('groups_random.npz'))
 
 
 @pytest.mark.parametrize('name', sorted(GROUP_NETS))

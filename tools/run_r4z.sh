@@ -1,4 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out/r4z
-python bench.py --steps 4000 --no-cpu-baseline > gpurun_out/r4z/bench_steps4000.json 2>/dev/null
-tail -1 gpurun_out/r4z/bench_steps4000.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('4000 steps', d['value'], d['ms_per_step'])"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "rnd" 2>&1 | tail -12 > gpurun_out/r4z/tests_rnd.txt
+cat gpurun_out/r4z/tests_rnd.txt
