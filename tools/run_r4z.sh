@@ -1,4 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out/r4z
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "rnd" 2>&1 | tail -12 > gpurun_out/r4z/tests_rnd.txt
-cat gpurun_out/r4z/tests_rnd.txt
+(timeout 260 python tools/fuzz_plans.py 170 --time-seed 2>&1 | grep -v amdgpu.ids | tail -20 > gpurun_out/r4z/fuzz.txt); cat gpurun_out/r4z/fuzz.txt
