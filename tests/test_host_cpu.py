@@ -566,3 +566,30 @@ def test_pillow_rows_refuse_what_they_cannot_verify(monkeypatch):
     lazy = Image.open(buf)
     t = pilmem.image_rows(lazy)
     assert t is not None and (t.width, t.height) == (20, 30)
+
+
+def test_pillow_rows_random_images_and_bands():
+    """Random sizes, modes and bands (hypothesis): the row table always reproduces np.asarray(im) -- or is refused."""
+    from hypothesis import given, settings, strategies as st
+    from PIL import Image
+    from kraken_amd import pilmem
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.sampled_from(['L', 'RGB', 'RGBA', '1']), st.integers(1, 97), st.integers(1, 300), st.integers(0, 2 ** 31 - 1), st.data())
+    def check(mode, w, h, seed, data):
+        rng = np.random.default_rng(seed)
+        ch = {'L': 1, '1': 1, 'RGB': 3, 'RGBA': 4}[mode]
+        arr = rng.integers(0, 256, (h, w) if ch == 1 else (h, w, ch), dtype=np.uint8)
+        im = Image.fromarray(arr > 127) if mode == '1' else Image.fromarray(arr, mode)
+        t = pilmem.image_rows(im)
+        assert t is not None
+        y0 = data.draw(st.integers(0, h - 1))
+        y1 = data.draw(st.integers(y0, h))
+        dst = np.zeros((y1 - y0) * t.linesize + 3, np.uint8)          # (+3: the copy must not write past its rows)
+        dst[-3:] = 77
+        pilmem.copy_rows(t, y0, y1, dst[:(y1 - y0) * t.linesize])
+        want = np.asarray(im.convert('L')) if mode == '1' else arr
+        want = want if want.ndim == 3 else want[:, :, None]
+        got = dst[:-3].reshape(y1 - y0, w, t.pixelsize)[:, :, :want.shape[2]]
+        assert np.array_equal(got, want[y0:y1]) and dst[-3:].tolist() == [77, 77, 77]
+    check()
