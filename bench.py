@@ -59,6 +59,10 @@ def parse():
     ap.add_argument('--precision', default='bf16x3', choices=['f32', 'bf16x3', 'bf16'],
                     help='f32: exact f32 MFMA; bf16x3 (headline): split-bf16 operands on the bf16 MFMA, f32 accumulate (fp32-class); '
                          'bf16: OPT-IN plain bf16 operands (strings-identical gate, logits ~1e-2: outside the parity gate, never the headline)')
+    ap.add_argument('--data', default='noise', choices=['noise', 'strokes', 'dense'],
+                    help="synthetic input set (SURVEY.md 8d): 'noise' = U(0,1) pixels (the headline); 'strokes' = zeros with 5 %% of the "
+                         "columns set to U(0.5,1) (run lengths of real lines); 'dense' = noise through a recogniser whose OUTPUT layer is "
+                         "re-biased so that a line decodes to >= 60 characters (the host codec / record side at real text density)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-input', action='store_true',
                     help='hand every batch over as a pinned HOST tensor (PCIe-inclusive rate; DESIGN.md quotes it, `value` never does)')
@@ -76,29 +80,80 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(model, width, n_lines):
+def synth_lines(n, width, seed, data='noise'):
+    """One batch of the synthetic input sets of SURVEY.md section 8d: [n, 1, 48, width] fp32 in [0, 1]."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, 1, 48, width, generator=g)          # 'noise' (and 'dense'): the tensor tests/golden/bench_lines.npz pins for seed 1234
+    if data == 'strokes':
+        on = torch.rand(n, 1, 1, width, generator=g) < 0.05
+        x = torch.where(on, 0.5 + 0.5 * x, torch.zeros(()))
+    return x
+
+
+def densify(model, x, target=0.45):
+    """
+    --data dense: a random-init recogniser decodes ~7 characters per 1200-px line (its argmax hardly moves along the line), a real
+    line of that width carries 60-80.  Re-bias the OUTPUT layer (weights untouched, same kernels, same FLOPs): every class's bias
+    becomes minus its mean logit over a calibration batch -- the argmax then follows the fluctuation along the line -- and the
+    blank's bias is raised until it wins `target` of the steps.  Deterministic for a seed; the CPU leg gets the same state dict.
+    """
+    _, _, logits, _ = model.nn.recognize(x, None, want_logits=True)          # [n, C, T]
+    z = logits.float()
+    mean = z.mean(dim=(0, 2))
+    zc = z - mean[None, :, None]
+    gap = (zc[:, 1:, :].max(dim=1).values - zc[:, 0, :]).flatten()
+    lift = torch.quantile(gap, target)
+    lin = [m for m in model.nn.modules() if hasattr(m, 'lin')][-1].lin
+    with torch.no_grad():
+        delta = -mean
+        delta[0] += lift
+        lin.bias.add_(delta.to(lin.bias.device, lin.bias.dtype))
+    model.nn.invalidate()
+
+
+def _kraken_recognizer(model):
+    """kraken's own TorchSeqRecognizer over the SAME weights, when an installed kraken imports (never on the driver's GPU box:
+    /root/reference does not travel there).  Returns None otherwise."""
+    try:
+        from kraken.lib import vgsl as kvgsl
+        from kraken.lib.models import TorchSeqRecognizer as KRecognizer
+        net = kvgsl.TorchVGSLModel(vgsl=model.spec, codec=model.codec.c2l)
+        net.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+        net.eval()
+        return KRecognizer(net, device='cpu')
+    except Exception:
+        return None
+
+
+def cpu_baseline(model, width, n_lines, data='noise'):
     """
     kraken's CPU path (torch CPU operators + Python greedy decode + codec) on a bounded sample: the batched shape at the
-    best intra-op thread count of a sweep, and the legacy rpred shape (one line per call).
+    best intra-op thread count of a sweep, and the legacy rpred shape (one line per call).  kind 'reference' = an installed
+    kraken's TorchSeqRecognizer.predict_string (kraken/lib/models.py:138-149) on the same weights; kind 'port' =
+    oracle/torch_port.py, the restatement pinned to it.  Returns (record, strings of the sample).
     """
-    from oracle.torch_port import CpuRecognizer
-    ref = CpuRecognizer(model.layer_specs, {k: v.cpu() for k, v in model.state_dict().items()})
-    g = torch.Generator().manual_seed(1234)
-    x = torch.rand(n_lines, 1, 48, width, generator=g)
+    kref = _kraken_recognizer(model)
+    if kref is None:
+        from oracle.torch_port import CpuRecognizer
+        ref = CpuRecognizer(model.layer_specs, {k: v.cpu() for k, v in model.state_dict().items()})
+    x = synth_lines(max(n_lines, 1), width, 1234, data)[:n_lines]       # == the first lines of the first timed batch of rank 0
     lens = [width] * n_lines
 
     def run(xs, ls):
-        tuples = ref.predict_labels(xs, ls)
+        with torch.inference_mode():
+            if kref is not None:
+                return kref.predict_string(xs, torch.tensor(ls) if ls is not None else None)
+            tuples = ref.predict_labels(xs, ls)
         return [''.join(c for c, *_ in model.codec.decode(t)) for t in tuples]
 
     ncpu = os.cpu_count() or 1
     saved = torch.get_num_threads()
-    sweep = {}
+    sweep, strings = {}, None
     for t in sorted({min(t, ncpu) for t in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(t)
         run(x[:2], lens[:2])                      # warm-up
         t0 = time.perf_counter()
-        run(x, lens)
+        strings = run(x, lens)
         sweep[t] = n_lines / (time.perf_counter() - t0)
     best_t = max(sweep, key=sweep.get)
     torch.set_num_threads(best_t)
@@ -108,13 +163,20 @@ def cpu_baseline(model, width, n_lines):
         run(x[i:i + 1], None)
     legacy = k / (time.perf_counter() - t0)
     torch.set_num_threads(saved)
-    return {'value': round(sweep[best_t], 2), 'unit': 'lines/s', 'cores': best_t, 'host_cpus': ncpu, 'kind': 'port',
-            'why_port': 'kraken itself (/root/reference) is not importable on the GPU box; the port runs the same torch-CPU operators and is '
-                        'checked bit-for-bit against kraken in the authoring container (tests/golden/make_golden.py, tests/test_oracle_golden.py)',
-            'thread_sweep': {str(t): round(v, 2) for t, v in sweep.items()},
-            'legacy_one_line_per_call': round(legacy, 2),
-            'sample': f'{n_lines} lines 1x48x{width} in one batch, fp32, best of the thread sweep: torch-CPU forward + softmax + '
-                      f'groupby greedy decode + codec (oracle/torch_port.py = kraken lib/models.py:138-149); legacy = {k} lines, one per call'}
+    what = ('kraken.lib.models.TorchSeqRecognizer.predict_string of the installed kraken' if kref is not None else
+            'oracle/torch_port.py = kraken lib/models.py:138-149')
+    rec = {'value': round(sweep[best_t], 2), 'unit': 'lines/s', 'cores': best_t, 'host_cpus': ncpu,
+           'kind': 'reference' if kref is not None else 'port',
+           'thread_sweep': {str(t): round(v, 2) for t, v in sweep.items()},
+           'legacy_one_line_per_call': round(legacy, 2),
+           'sample': f'{n_lines} lines 1x48x{width} ({data}) in one batch, fp32, best of the thread sweep: torch-CPU forward + softmax + '
+                     f'groupby greedy decode + codec ({what}); legacy = {k} lines, one per call'}
+    if kref is None:
+        rec['why_port'] = ('kraken itself is not importable on this box (pip install kraken, or put a checkout on PYTHONPATH, and this '
+                           'leg runs kraken.lib.models.TorchSeqRecognizer instead: kind "reference"); the port runs the same torch-CPU '
+                           'operators and is checked against kraken in the authoring container (tests/golden/make_golden.py, '
+                           'tests/test_oracle_golden.py)')
+    return rec, strings
 
 
 # kernels behind the launch groups (rocprofv3 kernel names)
@@ -251,8 +313,11 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
     stub = args.stub_engine
     dev = torch.device('cpu') if stub else torch.device(f'cuda:{local_rank}')
     N, W = args.batch, args.width
-    g = torch.Generator().manual_seed(1234 + rank)
-    xs = [torch.rand(N, 1, 48, W, generator=g).to(dev) for _ in range(1 if stub else 4)]   # resident in HBM before timing; rotated
+    # resident in HBM before timing; rotated.  Batch 0 of rank 0 is synth_lines(N, W, 1234): the tensor the CPU leg samples and,
+    # for --data noise at 256 x 1200, the one tests/golden/bench_lines.npz pins line by line against kraken
+    xs = [synth_lines(N, W, 1234 + rank + 1000 * b, args.data).to(dev) for b in range(1 if stub else 4)]
+    if args.data == 'dense' and not stub:
+        densify(model, xs[0][:64])
     # the product's sharded recogniser (kraken_amd/dist.py): one pipelined engine per rank, one gather of decoded tuples
     sr = kdist.ShardedRecognizer(model, device=local_rank, batch=N, slots=args.slots, max_width=W,
                                  engine_factory=(lambda: _StubEngine(rank, args.slots)) if stub else None)
@@ -260,11 +325,15 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
     if args.host_input:
         xs = [x.cpu().pin_memory() for x in xs]
     codec = model.codec
-    n_chars = [0]
+    n_chars, host_s, first = [0], [0.0], []
 
     def to_text(decoded, olens):
+        t0 = time.perf_counter()
         strings = codec.decode_strings(decoded)        # host codec: label tuples -> text, inside the timed region
+        host_s[0] += time.perf_counter() - t0
         n_chars[0] += sum(map(len, strings))
+        if not first:
+            first.append(strings)                      # the first batch of the timed region (= xs[0]): checked against the CPU leg
 
     def barrier():
         if use_dist:
@@ -276,7 +345,8 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
     if use_dist:
         sr.gather(done[-2:], force=args.force_dist)      # untimed: RCCL builds its communicator on first use
     engine.set_profiling(True)
-    n_chars[0] = 0
+    n_chars[0], host_s[0] = 0, 0.0
+    first.clear()
     barrier()
     t0 = time.perf_counter()
     done = sr.stream((xs[i % len(xs)] for i in range(args.steps)), to_text)
@@ -300,15 +370,26 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
         'metric': METRIC, 'value': round(value, 1), 'unit': 'lines/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': DTYPES[args.precision],
-        'data': 'synthetic' + (' (pinned host input per step: PCIe-inclusive)' if args.host_input else ''),
+        'data': 'synthetic' + {'noise': '', 'strokes': ' (strokes: 5 % of the columns U(0.5,1), the rest 0)', 'dense': ' (noise; OUTPUT layer re-biased to decode at real text density)'}[args.data] + (' (pinned host input per step: PCIe-inclusive)' if args.host_input else ''),
         'config': {'workload': f'BENCH-A VGSL recogniser (3.17M params, random init seed 0), {N} lines 1x48x{W} per GPU '
                                f'per step, greedy CTC decode, label tuples to host, host codec to strings',
                    'inputs': 'pinned host tensors, copied per step (PCIe-inclusive)' if args.host_input else 'resident in HBM before the timed region',
-                   'lines_per_gpu_step': N, 'width': W, 'slots': args.slots, 'precision': args.precision,
+                   'lines_per_gpu_step': N, 'width': W, 'input_set': args.data, 'slots': args.slots, 'precision': args.precision,
                    'parallelism': f'dp{world}', 'whole_path_tflops': round(value * 2.778e-3 * (W / 1200.0), 2)},
         'ranks_in_collective': ranks_seen, 'collective_backend': torch.distributed.get_backend() if use_dist else None,
         'gather_ms': round(gather_ms, 3), 'gathered_lines': gathered_lines, 'decoded_chars': int(n_chars[0]),
+        'chars_per_line': round(n_chars[0] / max(1, N * args.steps), 2),
+        'host_us_per_line': {'codec_strings': round(1e6 * host_s[0] / max(1, N * args.steps), 3)},
     }
+    out['_first_strings'] = first[0] if first else []
+    if not stub and done:
+        # the host side at this text density, outside the timed region: label tuples -> LineResult (text + cut positions +
+        # confidences per line: what the record assembly of rpred consumes, kraken lib/codec.py:148-195 + rpred.py:226-250)
+        from kraken_amd.rpred import _decode_lines
+        t0 = time.perf_counter()
+        for decoded, olens in done[:8]:
+            _decode_lines(codec, decoded, olens)
+        out['host_us_per_line']['line_results'] = round(1e6 * (time.perf_counter() - t0) / (N * len(done[:8])), 3)
     if stub:
         out['data'] = 'STUB ENGINE -- plumbing test without a GPU, no device work: `value` is meaningless'
         out['dtype'] = 'none (stub)'
@@ -533,6 +614,17 @@ def share_device_product_check(model, rank, world):
             'nonempty': sum(bool(r.text) for r in got)}
 
 
+def golden_strings(args):
+    """kraken's own strings for the first timed batch of rank 0, when the run is the pinned configuration (BASELINE config 2)."""
+    if args.data != 'noise' or args.batch != 256 or args.width != 1200:
+        return None
+    try:
+        z = np.load(os.path.join(ROOT, 'tests', 'golden', 'bench_lines.npz'), allow_pickle=False)
+        return json.loads(str(z['cfg2_strings']))
+    except Exception:
+        return None
+
+
 def launch_ranks(args) -> int:
     """
     `python bench.py --gpus N` without a launcher: become the launcher.  Spawns N copies of this command, one rank per GPU
@@ -629,8 +721,19 @@ def main():
         out = mode_config4(args, model, local_rank)
     else:
         out = mode_engine(args, model, rank, world, local_rank, use_dist, kdist)
+    first_strings = out.pop('_first_strings', None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'engine' and not stub:
-        out['cpu_baseline'] = cpu_baseline(model, args.width, args.cpu_lines)
+        out['cpu_baseline'], cpu_strings = cpu_baseline(model, args.width, args.cpu_lines, args.data)
+        # the number above is tied to parity: the strings of the first timed batch against the CPU leg's strings of the same lines
+        k = min(len(cpu_strings), len(first_strings or []))
+        out['parity_checked'] = {'lines': k, 'identical': sum(a == b for a, b in zip(first_strings[:k], cpu_strings[:k])),
+                                 'against': f"cpu_baseline leg ({out['cpu_baseline']['kind']}), same lines, same weights"}
+    if rank == 0 and first_strings and args.mode == 'engine' and not stub:
+        g = golden_strings(args)
+        if g is not None:
+            out.setdefault('parity_checked', {})['kraken_golden'] = {
+                'lines': len(g), 'identical': sum(a == b for a, b in zip(first_strings, g)),
+                'source': 'tests/golden/bench_lines.npz: cfg2_strings, made by the unmodified reference (tests/golden/make_golden.py)'}
     if world > 1:
         out['host_cpus_per_rank'] = cpus_kept
     if args.share_device:

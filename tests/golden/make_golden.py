@@ -22,6 +22,8 @@ Nothing here runs on the GPU box; the fixtures travel instead.  What is pinned:
   image_lstm.npz   LSTMs over image rows / columns (Lxx, Lxy on 4-D inputs) and a scaled-down BLLA segmenter.
                    strides, dilation (incl. the Cr4,2,*,4,2 form of tests/test_vgsl.py:71), max-pool
                    floor cases, masked GroupNorm, the S1(1x0)1,3 reshape, f/r/b LSTMs with ragged lens.
+  bench_lines.npz  BASELINE configs 2 and 4 line by line: kraken's tuples, strings and top-2 margins for all 256 lines of
+                   the benchmark tensor and for 1024 distinct ragged lines (batch 1 each).
   codec.npz        PytorchCodec.decode / encode known answers incl. multi-label codes.
   transforms.npz   ImageInputTransforms outputs (dewarp + fixed-height paths) for synthetic line images.
 """
@@ -122,6 +124,70 @@ def bench_fixture(spec, path, seed=0, cases=None):
         for i in range(len(widths))])
     np.savez_compressed(path, **out)
     print('wrote', path, {k: (v.shape if hasattr(v, 'shape') else '') for k, v in out.items() if 'logits' in k})
+
+
+@torch.inference_mode()
+def bench_lines_fixture(path, seed=0):
+    """
+    BASELINE.json configs 2 and 4 pinned LINE BY LINE against kraken: the reference's greedy tuples,
+    its predict_string output and the smallest top-2 logit margin of every line, for
+      cfg2  all 256 lines of synth_input(256, 1200) -- the tensor bench.py times (kraken/lib/models.py:138-149);
+      cfg4  1024 DISTINCT ragged lines, W ~ U{400..2400} (RandomState(40), sorted as the width-bucketing pipeline sees them),
+            line i = synth_input(1, W_i, seed=50000 + i), each through the reference at batch 1 (its per-line rpred result,
+            kraken/lib/vgsl/rpred.py:129-131).
+    """
+    torch.manual_seed(seed)
+    net = ref_vgsl.TorchVGSLModel(vgsl=BENCH_A, codec=bench_codec())
+    net.eval()
+    rec = RefRecognizer(net, device='cpu')
+    out = {'spec': BENCH_A, 'seed': seed,
+           'state_digest': json.dumps({k: digest(v) for k, v in net.state_dict().items()})}
+
+    def one(x, lens):
+        logits, olens = net.nn(x, lens)
+        probs = logits.softmax(1).squeeze(2)
+        dec = ref_greedy(probs, olens)
+        top2 = logits.squeeze(2).topk(2, dim=1).values            # [n, 2, T]
+        margin = (top2[:, 0] - top2[:, 1])
+        if olens is not None:
+            for i, l in enumerate(olens.tolist()):
+                margin[i, l:] = float('inf')
+        return dec, margin.min(dim=1).values, rec.predict_string(x, lens)
+
+    x = synth_input(256, 1200)
+    dec, mar, strs = [], [], []
+    for lo in range(0, 256, 16):
+        d, m, s = one(x[lo:lo + 16], torch.tensor([1200] * 16))
+        dec += d
+        mar.append(m)
+        strs += s
+    flat, counts = tuples_to_arr(dec)
+    out['cfg2_xdigest'] = digest(x)
+    out['cfg2_tuples'] = flat.astype(np.float32)
+    out['cfg2_counts'] = counts
+    out['cfg2_margin'] = torch.cat(mar).numpy()
+    out['cfg2_strings'] = json.dumps(strs)
+
+    rng = np.random.RandomState(40)
+    widths = np.sort(rng.randint(400, 2401, size=1024))
+    dec, mar, strs, dig = [], [], [], hashlib.sha256()
+    for i, w in enumerate(widths.tolist()):
+        xi = synth_input(1, w, seed=50000 + i)
+        dig.update(np.ascontiguousarray(xi.numpy()).tobytes())
+        d, m, s = one(xi, None)
+        dec += d
+        mar.append(m)
+        strs += s
+    flat, counts = tuples_to_arr(dec)
+    out['cfg4_widths'] = widths.astype(np.int32)
+    out['cfg4_xdigest'] = dig.hexdigest()
+    out['cfg4_tuples'] = flat.astype(np.float32)
+    out['cfg4_counts'] = counts
+    out['cfg4_margin'] = torch.cat(mar).numpy()
+    out['cfg4_strings'] = json.dumps(strs)
+    np.savez_compressed(path, **out)
+    print('wrote', path, 'cfg2 tuples', out['cfg2_tuples'].shape, 'cfg4 tuples', out['cfg4_tuples'].shape,
+          'min margins', float(out['cfg2_margin'].min()), float(out['cfg4_margin'].min()))
 
 
 IMAGE_LSTM_CASES = {
@@ -518,7 +584,7 @@ def spec_names_fixture(path, n=80, seed=7):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms', 'bench_lines']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -528,6 +594,8 @@ if __name__ == '__main__':
     if 'bench_b' in which:
         bench_fixture(BENCH_B, os.path.join(HERE, 'bench_b.npz'),
                       cases=(('n4w400', 4, 400, [0, 3]), ('n16w800', 16, 800, [7])))
+    if 'bench_lines' in which:
+        bench_lines_fixture(os.path.join(HERE, 'bench_lines.npz'))
     if 'layers' in which:
         layer_fixture(os.path.join(HERE, 'layers.npz'))
     if 'image_lstm' in which:

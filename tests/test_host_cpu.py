@@ -593,3 +593,26 @@ def test_pillow_rows_random_images_and_bands():
         got = dst[:-3].reshape(y1 - y0, w, t.pixelsize)[:, :, :want.shape[2]]
         assert np.array_equal(got, want[y0:y1]) and dst[-3:].tolist() == [77, 77, 77]
     check()
+
+
+def test_bench_cpu_leg_is_kraken_itself_when_kraken_imports():
+    """bench.py's cpu_baseline: kind 'reference' (kraken.lib.models.TorchSeqRecognizer on the same weights) when kraken imports --
+    here through the golden generator's import shim -- and kind 'port' otherwise, with the same strings (missing #7)."""
+    import subprocess
+    import sys
+    from tests.golden import _refshim
+    if not _refshim.available():
+        pytest.skip('no reference checkout on this box')
+    code = (
+        "import sys, json, torch; sys.path.insert(0, '.')\n"
+        "import bench, kraken_amd\n"
+        "from kraken_amd.specs import BENCH_A, bench_codec\n"
+        "torch.manual_seed(0); m = kraken_amd.TorchVGSLModel(vgsl=BENCH_A, codec=bench_codec())\n"
+        "port, s_port = bench.cpu_baseline(m, 200, 3)\n"
+        "from tests.golden import _refshim; _refshim.install()\n"
+        "ref, s_ref = bench.cpu_baseline(m, 200, 3)\n"
+        "print(json.dumps([port['kind'], ref['kind'], s_port == s_ref, len(s_ref), 'why_port' in port, 'why_port' in ref]))\n")
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1]) == ['port', 'reference', True, 3, True, False]

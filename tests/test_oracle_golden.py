@@ -96,6 +96,35 @@ def test_oracles_on_bench_networks(spec, fixture):
         assert abs(a[3] - b[3]) < 1e-4
 
 
+def test_port_on_the_line_by_line_fixture_of_configs_2_and_4():
+    """oracle/torch_port.py (what bench.py's cpu_baseline leg and its in-bench parity check run) against kraken's tuples and
+    strings of bench_lines.npz: eight lines of the benchmark tensor, six ragged lines in one masked batch."""
+    from kraken_amd.codec import PytorchCodec
+    from tests.specs import bench_codec
+    z = load_golden('bench_lines.npz')
+    m = _bench_model(BENCH_A)
+    assert json.loads(str(z['state_digest'])).keys() == m.state_dict().keys()
+    _, specs = parse_vgsl(BENCH_A)
+    ref = CpuRecognizer(specs, {k: v.numpy() for k, v in m.state_dict().items()})
+    codec = PytorchCodec(bench_codec())
+    want = arr_to_tuples(z['cfg2_tuples'], z['cfg2_counts'])
+    strs = json.loads(str(z['cfg2_strings']))
+    x = synth_input(256, 1200)[:8]
+    got = ref.predict_labels(x, [1200] * 8)
+    assert [[t[:3] for t in l] for l in got] == [[t[:3] for t in l] for l in want[:8]]
+    assert [''.join(c for c, *_ in codec.decode(l)) for l in got] == strs[:8]
+    want = arr_to_tuples(z['cfg4_tuples'], z['cfg4_counts'])
+    strs = json.loads(str(z['cfg4_strings']))
+    widths = z['cfg4_widths'].tolist()
+    pick = [i for i in (0, 100, 333, 512, 800, 1023) if z['cfg4_margin'][i] > 1e-5]
+    xb = torch.zeros(len(pick), 1, 48, max(widths[i] for i in pick))
+    for k, i in enumerate(pick):
+        xb[k, ..., :widths[i]] = synth_input(1, widths[i], seed=50000 + i)[0]
+    got = ref.predict_labels(xb, [widths[i] for i in pick])
+    assert [[t[:3] for t in l] for l in got] == [[t[:3] for t in want[i]] for i in pick]
+    assert [''.join(c for c, *_ in codec.decode(l)) for l in got] == [strs[i] for i in pick]
+
+
 def test_oracles_ragged_equals_per_line_reference():
     """Masked padding == the reference's per-line (batch 1) result, for BENCH-A ragged widths."""
     z = load_golden('bench_a.npz')
