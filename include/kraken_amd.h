@@ -317,6 +317,14 @@ int krk_plan_status(krk_plan* plan);
 /* 1 if a forward call of this plan can launch the cluster kernel, i.e. if krk_plan_status can ever report anything: callers that
  * would synchronise only to read the status word (a plain nn(x) call) need not when this is 0. */
 int krk_plan_has_exchange(const krk_plan* plan);
+/* Which recurrent kernel the split-bf16 LSTM layers of THIS plan take from the next forward call on: KRK_RECURRENCE_AUTO (by
+ * hidden size: the cluster kernel above 64 units) or KRK_RECURRENCE_STREAMING (lstm_x3.hip: no inter-workgroup exchange, so
+ * krk_plan_status has nothing to report and krk_plan_has_exchange returns 0).  Per plan, hence per engine slot and thread-safe
+ * across plans: this is how a caller re-runs ONE batch after an exchange timeout without touching other plans or the process
+ * environment.  No reference analogue (torch.nn.LSTM has one CPU kernel, kraken/lib/vgsl/layers.py:513-547). */
+#define KRK_RECURRENCE_AUTO 0
+#define KRK_RECURRENCE_STREAMING 1
+int krk_plan_set_recurrence(krk_plan* plan, int variant);
 
 /* Cross-batch scheduling for callers that keep several plans in flight on separate streams
  * (kraken_amd/engine.py; no reference analogue -- the reference runs one batch at a time,

@@ -28,7 +28,8 @@ EXPORTS = ['krk_abi_version', 'krk_last_error', 'krk_device_count', 'krk_plan_cr
            'krk_plan_workspace_bytes', 'krk_plan_set_profiling', 'krk_plan_layer_ms', 'krk_plan_layer_name',
            'krk_plan_layer_flops', 'krk_plan_num_steps', 'krk_plan_front_event', 'krk_plan_wait_front',
            'krk_plan_status', 'krk_prep_lines', 'krk_prep_crops', 'krk_upsample_sigmoid', 'krk_dewarp_measure', 'krk_dewarp_apply',
-           'krk_prep_lines_fmt', 'krk_dewarp_measure_page', 'krk_dewarp_apply_page', 'krk_plan_has_exchange']
+           'krk_prep_lines_fmt', 'krk_dewarp_measure_page', 'krk_dewarp_apply_page', 'krk_plan_has_exchange',
+           'krk_plan_set_recurrence']
 
 
 class KrkLayer(C.Structure):
@@ -56,19 +57,46 @@ def is_exchange_timeout(e: Exception) -> bool:
     return isinstance(e, KrakenAmdError) and 'timed out waiting for its peers' in str(e)
 
 
+RECURRENCE_AUTO, RECURRENCE_STREAMING = 0, 1
+
+
 class streaming_recurrence:
-    """Context: forward calls made inside use the streaming recurrent kernel (lstm_x3.hip, no inter-workgroup exchange) instead of
-    the cluster kernels -- the one retry after an exchange timeout.  The switch is the library's per-call probe KRK_LSTM_V."""
+    """Context: forward calls of ``plan`` (a handle) made inside use the streaming recurrent kernel (lstm_x3.hip, no inter-workgroup
+    exchange) instead of the cluster kernel -- the one retry after an exchange timeout.  The switch is a field of THAT plan
+    (krk_plan_set_recurrence): other plans, engine slots and threads are not touched, and nothing is written to the process
+    environment (KRK_LSTM_V stays what it is: a debugging probe)."""
+
+    def __init__(self, plan_handle):
+        self.handle = plan_handle
 
     def __enter__(self):
-        self._old = os.environ.get('KRK_LSTM_V')
-        os.environ['KRK_LSTM_V'] = '1'
+        check(load().krk_plan_set_recurrence(self.handle, RECURRENCE_STREAMING))
 
     def __exit__(self, *exc):
-        if self._old is None:
-            os.environ.pop('KRK_LSTM_V', None)
-        else:
-            os.environ['KRK_LSTM_V'] = self._old
+        load().krk_plan_set_recurrence(self.handle, RECURRENCE_AUTO)
+
+
+def checked_run(plan_handle, run, wait, log=None):
+    """
+    The one policy for a batch whose recurrent cluster kernel gave up waiting for its peers, shared by ``nn(x)``,
+    ``nn.recognize`` and ``RecognitionEngine.collect``: ``run()`` enqueues the batch, ``wait()`` blocks until it has completed;
+    the plan's status word is read then, and an exchange timeout re-runs THIS batch once on the streaming kernel (a warning, not
+    a lost page).  Anything else -- and a second failure -- raises.
+    """
+    lib = load()
+    run()
+    wait()
+    try:
+        check(lib.krk_plan_status(plan_handle))
+    except KrakenAmdError as e:
+        if not is_exchange_timeout(e):
+            raise
+        if log is not None:
+            log.warning(f'{e}; running this batch again on the streaming recurrent kernel')
+        with streaming_recurrence(plan_handle):
+            run()
+            wait()
+        check(lib.krk_plan_status(plan_handle))
 
 
 _lib = None
@@ -127,6 +155,8 @@ def load():
         lib.krk_plan_status.restype = i32
         lib.krk_plan_has_exchange.argtypes = [vp]
         lib.krk_plan_has_exchange.restype = i32
+        lib.krk_plan_set_recurrence.argtypes = [vp, i32]
+        lib.krk_plan_set_recurrence.restype = i32
         lib.krk_prep_lines.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
         lib.krk_prep_lines.restype = i32
         lib.krk_prep_crops.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]

@@ -533,6 +533,7 @@ struct krk_plan {
     // device-side failure word (mapped host memory): set by a kernel that gave up waiting (lstm_ws.hip exchange timeout)
     unsigned* err_host = nullptr;
     unsigned* err_dev = nullptr;
+    int recurrence = KRK_RECURRENCE_AUTO;   // krk_plan_set_recurrence: which recurrent kernel the split-bf16 layers of THIS plan take
     bool profiling = false;
     std::vector<hipEvent_t> events;          // one per profiled launch + 1
     std::vector<const char*> prof_names;     // kernel group of each profiled launch of the last call
@@ -1412,12 +1413,20 @@ int krk_plan_status(krk_plan* plan) {
 }
 
 int krk_plan_has_exchange(const krk_plan* plan) {
-    if (!plan) return 0;
+    if (!plan || plan->recurrence == KRK_RECURRENCE_STREAMING) return 0;
     // lstm_ws.hip is the only kernel that waits for other workgroups; it takes the recurrent layers above 64 hidden units that run on
     // the bf16 cores (recurrence_x3) -- and any the KRK_LSTM_V probe switch forces onto it
     for (const auto& s : plan->steps)
         if (s.kind == S_LSTM && s.rec_x3 && s.d_wrecws && (s.Hp > 64 || getenv("KRK_LSTM_V"))) return 1;
     return 0;
+}
+
+int krk_plan_set_recurrence(krk_plan* plan, int variant) {
+    if (!plan) return fail(KRK_E_INVALID, "krk_plan_set_recurrence: null plan");
+    if (variant != KRK_RECURRENCE_AUTO && variant != KRK_RECURRENCE_STREAMING)
+        return fail(KRK_E_INVALID, "krk_plan_set_recurrence: variant must be KRK_RECURRENCE_AUTO or KRK_RECURRENCE_STREAMING");
+    plan->recurrence = variant;
+    return KRK_OK;
 }
 
 void* krk_plan_front_event(krk_plan* plan) { return plan ? (void*)plan->front_ev : nullptr; }
@@ -1924,7 +1933,8 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     // Up to 64 hidden units the recurrent weights (<= 64 KB split) stream faster than a cluster exchanges; above, the cluster kernel.
     // (Round 3's third kernel, lstm_wp.hip -- XCD-local clusters, deferred gates, gather waves -- tied lstm_ws at H = 200 and lost
     // to one of the two everywhere else: 0.22 / 0.24 / 0.26 / 0.33 / 0.36 ms; removed in round 4)
-    const int lstm_v = probe.lstm_v ? probe.lstm_v : (s.Hp <= 64 ? 1 : 3);
+    // the plan's own setting (krk_plan_set_recurrence: the one retry after an exchange timeout) wins over the process-wide probe
+    const int lstm_v = p->recurrence == KRK_RECURRENCE_STREAMING ? 1 : probe.lstm_v ? probe.lstm_v : (s.Hp <= 64 ? 1 : 3);
     if (!s.d_wrecws || lstm_v != 3) return krk_launch_lstm_x3(l, stream);
     // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time barely
     // moves (it is not exchange bound), so a launch takes twice as long on half the CUs: same chip time, worse latency, fewer

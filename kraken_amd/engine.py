@@ -414,7 +414,9 @@ class RecognitionEngine:
         dev = f'cuda:{self.device}'
         with torch.cuda.stream(slot.stream):
             geo_d = torch.from_numpy(geo).to(dev, non_blocking=True)
-            src = st['src']
+            src = st.pop('src')          # the slot lets go of the page / band tensor here (a full RGBX page is > 100 MB of HBM per slot)
+            if src[0] is not slot.crops_dev:
+                src[0].record_stream(slot.stream)
             _lib.check(self.lib.krk_dewarp_apply_page(src[0].data_ptr(), src[1], src[2], st['desc'].data_ptr(), n, maxw, st['work'].data_ptr(),
                                                       geo_d.data_ptr(), h, int(pad), w, slot.stage_dev.data_ptr(), slot.flags_dev.data_ptr(),
                                                       slot.stream.cuda_stream))
@@ -508,11 +510,17 @@ class RecognitionEngine:
                 raise
             import logging
             logging.getLogger(__name__).warning(f'{e}; running the batch again on the streaming recurrent kernel')
-            keep_next, inflight = self._next, list(self._inflight)
-            self._next = ticket
-            with _lib.streaming_recurrence():
-                self._launch(slot, x, lens, slot.want_probs, False)
-            self._inflight, self._next = deque(inflight), keep_next
+            # the retry is not a new batch of the pipeline: it neither waits for another plan's convolution front nor enters the
+            # ring of fronts the next submissions order themselves by
+            keep_next, inflight, fronts, chain = self._next, list(self._inflight), list(self._fronts), self.chain_fronts
+            self._next, self.chain_fronts = ticket, False
+            try:
+                with _lib.streaming_recurrence(slot.plan.handle):  # this slot's plan only: the other slots keep the cluster kernel
+                    self._launch(slot, x, lens, slot.want_probs, False)
+                    slot.event.synchronize()
+            finally:
+                self._inflight, self._next, self.chain_fronts = deque(inflight), keep_next, chain
+                self._fronts[:] = fronts
             slot.event.synchronize()
             slot.busy, slot.keep, slot.keep_lens = False, None, None
             _lib.check(self.lib.krk_plan_status(slot.plan.handle))

@@ -705,24 +705,17 @@ class HipSequential(nn.Module):
         with torch.cuda.device(dev):
             out = torch.empty((N, w, c) if seq_out else (N, c, h, w), dtype=torch.float32, device=xd.device)
             stream = torch.cuda.current_stream().cuda_stream
-            _lib.check(plan._lib.krk_forward(plan.handle, xd.data_ptr(), lens.ctypes.data if lens is not None else None,
-                                             N, W, stream, out.data_ptr()))
+
+            def run():
+                _lib.check(plan._lib.krk_forward(plan.handle, xd.data_ptr(), lens.ctypes.data if lens is not None else None,
+                                                 N, W, stream, out.data_ptr()))
             if plan.has_status:
                 # the recurrent cluster kernel reports a timed-out exchange through the plan's status word only: callers of
                 # nn(x) (custom decoders, the segmenter) must not receive such logits silently.  One retry on the streaming
-                # kernel (no exchange) before giving up
-                torch.cuda.current_stream().synchronize()
-                try:
-                    _lib.check(plan._lib.krk_plan_status(plan.handle))
-                except _lib.KrakenAmdError as e:
-                    if not _lib.is_exchange_timeout(e):
-                        raise
-                    logger.warning(f'{e}; running this batch again on the streaming recurrent kernel')
-                    with _lib.streaming_recurrence():
-                        _lib.check(plan._lib.krk_forward(plan.handle, xd.data_ptr(), lens.ctypes.data if lens is not None else None,
-                                                         N, W, stream, out.data_ptr()))
-                    torch.cuda.current_stream().synchronize()
-                    _lib.check(plan._lib.krk_plan_status(plan.handle))
+                # kernel (no exchange) before giving up (_lib.checked_run: the same policy as recognize() and the engine)
+                _lib.checked_run(plan.handle, run, torch.cuda.current_stream().synchronize, logger)
+            else:
+                run()
         olens = None
         if lens is not None:
             olens = torch.from_numpy(plan.olens(lens))
@@ -782,15 +775,22 @@ class HipSequential(nn.Module):
             dec = _lib.KrkDecodeOut(labels.data_ptr(), starts.data_ptr(), ends.data_ptr(), confs.data_ptr(),
                                     counts.data_ptr(), T)
             stream = torch.cuda.current_stream().cuda_stream
-            _lib.check(plan._lib.krk_recognize(plan.handle, xd.data_ptr(),
-                                               lens.ctypes.data if lens is not None else None, N, W,
-                                               float(temperature), stream,
-                                               logits.data_ptr() if want_logits else None,
-                                               probs.data_ptr() if want_probs else None,
-                                               olens.ctypes.data, C.byref(dec)))
-            packed = torch.stack([labels, starts, ends, confs.view(torch.int32)]).cpu().numpy()
-            cnt = counts.cpu().numpy()
-            _lib.check(plan._lib.krk_plan_status(plan.handle))
+            host = {}
+
+            def run():
+                _lib.check(plan._lib.krk_recognize(plan.handle, xd.data_ptr(),
+                                                   lens.ctypes.data if lens is not None else None, N, W,
+                                                   float(temperature), stream,
+                                                   logits.data_ptr() if want_logits else None,
+                                                   probs.data_ptr() if want_probs else None,
+                                                   olens.ctypes.data, C.byref(dec)))
+
+            def wait():            # the copies to the host wait for the batch
+                host['packed'] = torch.stack([labels, starts, ends, confs.view(torch.int32)]).cpu().numpy()
+                host['cnt'] = counts.cpu().numpy()
+            # an exchange timeout of the cluster kernel is retried once on the streaming kernel, as in forward() and the engine
+            _lib.checked_run(plan.handle, run, wait, logger)
+            packed, cnt = host['packed'], host['cnt']
         batch = DecodedBatch(packed[0], packed[1], packed[2], packed[3].view(np.float32), cnt)
         return (batch, olens,
                 logits.permute(0, 2, 1) if want_logits else None,

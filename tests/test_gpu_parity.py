@@ -1831,3 +1831,80 @@ def test_exchange_timeout_is_retried_once_on_the_streaming_kernel(bench_a, monke
     assert np.array_equal(got.labels[k], want.labels[k]) and np.array_equal(got.starts[k], want.starts[k])
     np.testing.assert_allclose(got.confs[k], want.confs[k], atol=1e-4)
     eng.close()
+
+
+def test_exchange_timeout_retry_is_per_plan_on_every_entry_point(bench_a_x3, monkeypatch):
+    """
+    ADVICE r4: the retry used to flip the process-wide KRK_LSTM_V (putenv racing getenv in other threads, every other plan forced
+    onto the streaming kernel meanwhile), and `recognize()` did not retry at all.  Now ONE helper (_lib.checked_run) serves nn(x) and
+    nn.recognize, and it -- like the engine -- switches only the plan of the failed batch (krk_plan_set_recurrence), restores it, and
+    leaves the environment alone.  The status word is faked once per call; results must equal an undisturbed run.
+    """
+    import os
+    from kraken_amd import _lib, engine as E
+    lib = _lib.load()
+    m = bench_a_x3
+    x = synth_input(5, 400, seed=77).cuda()
+    lens = torch.tensor([400, 391, 250, 122, 64])
+    want_logits, want_olens = m.nn(x, lens)
+    want_logits = want_logits.clone()
+    want = _keys(m.nn.recognize(x, lens)[0].tuples())
+    handle = m.nn.plan(0).handle
+    assert lib.krk_plan_has_exchange(handle) == 1
+    real_check, real_status, real_set = _lib.check, lib.krk_plan_status, lib.krk_plan_set_recurrence
+    armed, calls = {'n': 0}, []
+
+    def status(h):
+        rc = real_status(h)
+        if armed['n'] > 0 and rc == 0:
+            armed['n'] -= 1
+            armed['fire'] = True
+        return rc
+
+    def flaky(rc):
+        if armed.pop('fire', False):
+            raise _lib.KrakenAmdError(_lib.KRK_E_HIP, 'a recurrent cluster kernel timed out waiting for its peers (injected)')
+        return real_check(rc)
+
+    def set_rec(h, v):
+        calls.append((h, v, lib.krk_plan_has_exchange(h)))
+        return real_set(h, v)
+
+    monkeypatch.setattr(lib, 'krk_plan_status', status)
+    monkeypatch.setattr(lib, 'krk_plan_set_recurrence', set_rec)
+    monkeypatch.setattr(_lib, 'check', flaky)
+    # nn(x)
+    armed['n'] = 1
+    got_logits, got_olens = m.nn(x, lens)
+    assert armed['n'] == 0 and [c[1] for c in calls] == [1, 0] and all(c[0] == handle for c in calls)
+    assert got_olens.tolist() == want_olens.tolist()
+    assert (got_logits - want_logits).abs().max().item() < 2e-5          # streaming vs cluster kernel: the same arithmetic plan
+    # nn.recognize
+    calls.clear()
+    armed['n'] = 1
+    got = _keys(m.nn.recognize(x, lens)[0].tuples())
+    assert armed['n'] == 0 and [c[1] for c in calls] == [1, 0]
+    assert got == want
+    # the engine: the failed slot's plan only; the other slot's plan keeps the cluster kernel while the retry runs
+    eng = E.RecognitionEngine(m, device=0, max_batch=8, max_width=400, slots=2)
+    eng.submit(x, lens.numpy().astype(np.int32))
+    eng.submit(x, lens.numpy().astype(np.int32))
+    for t in list(eng._inflight):
+        eng.slots[t].event.synchronize()
+    other = eng.slots[eng._inflight[1]].plan.handle
+    seen = []
+    monkeypatch.setattr(lib, 'krk_plan_set_recurrence', lambda h, v: (seen.append((h, v, lib.krk_plan_has_exchange(other))), real_set(h, v))[1])
+    armed['n'] = 1
+    b0, _ = eng.collect()
+    b1, _ = eng.collect()
+    assert armed['n'] == 0 and [s[1] for s in seen] == [1, 0] and all(s[0] != other and s[2] == 1 for s in seen)
+    assert _keys(b0.tuples()) == want and _keys(b1.tuples()) == want
+    assert lib.krk_plan_has_exchange(eng.slots[0].plan.handle) == 1 and lib.krk_plan_has_exchange(eng.slots[1].plan.handle) == 1
+    eng.close()
+    assert 'KRK_LSTM_V' not in os.environ
+    # a second failure in a row still raises
+    armed['n'] = 2
+    with pytest.raises(_lib.KrakenAmdError):
+        m.nn.recognize(x, lens)
+    armed['n'] = 0
+    assert lib.krk_plan_has_exchange(handle) == 1                          # ... and the plan is back on the cluster kernel

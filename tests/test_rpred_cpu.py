@@ -337,3 +337,22 @@ def test_a_failed_batch_frees_the_engine(monkeypatch):
             list(it)
         assert not _StubEngine.made[0].in_use and not _StubEngine.made[0].q
         assert len(list(R.mm_rpred(defaultdict(lambda: net), page(), seg(boxes), bidi_reordering=False))) == 100
+
+
+def test_width_buckets_cover_every_line_once_widest_first_and_respect_both_limits():
+    """BASELINE config 4's bucketing rule (reference: width-sorted fixed-size batches, kraken/lib/vgsl/rpred.py:129-131)."""
+    from kraken_amd.rpred import width_buckets
+    rng = np.random.RandomState(40)
+    widths = rng.randint(400, 2401, size=1024)
+    for max_lines, px in ((256, 0), (128, 0), (512, 307200), (64, 50000), (7, 0)):
+        b = width_buckets(widths, max_lines, px)
+        assert sorted(np.concatenate(b).tolist()) == list(range(1024))
+        tops = [int(widths[i].max()) for i in b]
+        assert tops == sorted(tops, reverse=True)                       # widest bucket first
+        for i, idx in enumerate(b):
+            assert 1 <= len(idx) <= max_lines
+            assert px == 0 or len(idx) == 1 or len(idx) * int(widths[idx].max()) <= px
+            if i + 1 < len(b):
+                assert widths[idx].min() >= widths[b[i + 1]].max()      # buckets partition the sorted order
+    assert width_buckets([], 8) == []
+    assert [x.tolist() for x in width_buckets([5, 5, 5], 2)] == [[2], [0, 1]]
