@@ -55,7 +55,7 @@ def parse():
     ap.add_argument('--mode', default='engine', choices=['engine', 'api', 'config4'])
     ap.add_argument('--batch', type=int, default=256, help='lines per GPU per step')
     ap.add_argument('--width', type=int, default=1200)
-    ap.add_argument('--slots', type=int, default=3, help='batches in flight per GPU (streams); 3 since the recurrent cluster kernel halved the per-batch latency (r2: 93.7 k vs 87.4 k lines/s at 4 over 20 steps)')
+    ap.add_argument('--slots', type=int, default=None, help='batches in flight per GPU (streams); default 3 (config4: 4, r5 sweep: 128-line buckets x 4 slots 83.8 k lines/s, 256 x 3 79.9 k); 3 since the recurrent cluster kernel halved the per-batch latency (r2: 93.7 k vs 87.4 k lines/s at 4 over 20 steps)')
     ap.add_argument('--precision', default='bf16x3', choices=['f32', 'bf16x3', 'bf16'],
                     help='f32: exact f32 MFMA; bf16x3 (headline): split-bf16 operands on the bf16 MFMA, f32 accumulate (fp32-class); '
                          'bf16: OPT-IN plain bf16 operands (strings-identical gate, logits ~1e-2: outside the parity gate, never the headline)')
@@ -76,12 +76,15 @@ def parse():
                     help='PLUMBING ONLY: all --gpus N ranks run on HIP device 0 (gloo collective: RCCL refuses two ranks per device). Two real '
                          'processes, two real engines, ShardedRecognizer.stream + gather, recognize_lines in input order -- on a one-GPU box. '
                          'The line is labelled as such and is NEVER a scaling number')
-    ap.add_argument('--bucket-lines', type=int, default=256, help='--mode config4: most lines per device batch')
+    ap.add_argument('--bucket-lines', type=int, default=128, help='--mode config4: most lines per device batch')
     ap.add_argument('--bucket-px', type=int, default=0, help='--mode config4: most padded pixels (lines x widest line) per device batch; 0 = no limit')
     ap.add_argument('--no-pcie', action='store_true', help='--mode config4: skip the host-image leg')
     ap.add_argument('--api-lines', type=int, default=2048, help='--mode api: bbox lines on the synthetic page')
     ap.add_argument('--api-workers', type=int, default=6, help='--mode api: host threads preparing lines (PIL conversions hold the GIL: more than ~6 threads only contend, 16 cost 40 %)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.slots is None:
+        args.slots = 4 if args.mode == 'config4' else 3
+    return args
 
 
 def synth_lines(n, width, seed, data='noise'):
