@@ -80,7 +80,7 @@ def parse():
     ap.add_argument('--bucket-px', type=int, default=0, help='--mode config4: most padded pixels (lines x widest line) per device batch; 0 = no limit')
     ap.add_argument('--no-pcie', action='store_true', help='--mode config4: skip the host-image leg')
     ap.add_argument('--api-lines', type=int, default=2048, help='--mode api: bbox lines on the synthetic page')
-    ap.add_argument('--api-workers', type=int, default=6, help='--mode api: host threads preparing lines (PIL conversions hold the GIL: more than ~6 threads only contend, 16 cost 40 %)')
+    ap.add_argument('--api-workers', type=int, default=6, help='--mode api: host threads preparing lines (PIL conversions hold the GIL: more than ~6 threads only contend, 16 cost 40 %%)')
     args = ap.parse_args()
     if args.slots is None:
         args.slots = 4 if args.mode == 'config4' else 3
