@@ -477,7 +477,7 @@ struct Step {
     void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
     // weight-stationary cluster kernel (lstm_ws.hip): per-wave resident fragments, exchange granules, ticket counter
     void* d_wrecws = nullptr;
-    DevBuf ws_gran;
+    DevBuf ws_gran, wq_ctrl;
     unsigned* ws_ctrl = nullptr;
     unsigned ws_tickets = 0, ws_epoch = 0;
     int ws_bpc = 0;
@@ -695,6 +695,7 @@ void free_step(Step& s) {
     if (s.d_wrecws) (void)hipFree(s.d_wrecws);
     if (s.ws_ctrl) (void)hipFree(s.ws_ctrl);
     s.ws_gran.release();
+    s.wq_ctrl.release();
     s.out.release();
     s.aux.release();
     s.aux2.release();
@@ -1935,7 +1936,7 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     // to one of the two everywhere else: 0.22 / 0.24 / 0.26 / 0.33 / 0.36 ms; removed in round 4)
     // the plan's own setting (krk_plan_set_recurrence: the one retry after an exchange timeout) wins over the process-wide probe
     const int lstm_v = p->recurrence == KRK_RECURRENCE_STREAMING ? 1 : probe.lstm_v ? probe.lstm_v : (s.Hp <= 64 ? 1 : 3);
-    if (!s.d_wrecws || lstm_v != 3) return krk_launch_lstm_x3(l, stream);
+    if (!s.d_wrecws || (lstm_v != 3 && lstm_v != 4)) return krk_launch_lstm_x3(l, stream);
     // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time barely
     // moves (it is not exchange bound), so a launch takes twice as long on half the CUs: same chip time, worse latency, fewer
     // lines/s through the pipelined engine.  KRK_LSTM_G=4 keeps it probeable.
@@ -1961,7 +1962,39 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     w.err = p->err_dev;
     w.otiled = l.otiled;
     w.dbg = l.dbg;
-    int rc = one ? krk_launch_lstm_ws_b1(w, groups, stream) : krk_launch_lstm_ws(w, groups, stream);
+    int rc;
+    w.stamps = nullptr;
+    w.nclusters = w.mbox = 0;
+    if (lstm_v == 4) {
+        w.wp = (const __bf16*)s.d_wrecx3;
+        w.nclusters = (Ns + 31) / 32 * s.ndir;
+        w.mbox = krk_lstm_wq_mbox(w.nclusters);
+        const size_t cbytes = krk_lstm_wq_ctrl_bytes(w.nclusters);
+        if (s.wq_ctrl.ensure(cbytes)) return nomem();
+        if (int r = hip(hipMemsetAsync(s.wq_ctrl.p, 0, cbytes, stream), "hipMemsetAsync")) return r;
+        w.ctrl = (unsigned*)s.wq_ctrl.p;
+#ifdef KRK_STAMP
+        static unsigned long long* stamps = nullptr;          // probe (KRK_LSTM_DBG bit 256): phase cycle sums of workgroup 0, printed per launch
+        if (probe.lstm_dbg & 256) {
+            if (!stamps) (void)hipHostMalloc((void**)&stamps, 4 * 8 * sizeof(unsigned long long), hipHostMallocMapped);
+            if (stamps) { std::memset(stamps, 0, 4 * 8 * sizeof(unsigned long long)); (void)hipHostGetDevicePointer((void**)&w.stamps, stamps, 0); }
+        }
+#endif
+        rc = one ? krk_launch_lstm_wq_b1(w, stream) : krk_launch_lstm_wq(w, stream);
+#ifdef KRK_STAMP
+        if (w.stamps && rc == 0) {
+            (void)hipStreamSynchronize(stream);
+            for (int wv = 0; wv < 4; ++wv) {
+                const unsigned long long* q = stamps + wv * 8;
+                const double n = q[6] ? (double)q[6] : 1.0;
+                fprintf(stderr, "wq stamps wave %d: slots %llu | cycles per slot: barrier %.0f  lds+block0 %.0f  blocks1.. %.0f  last cell %.0f  gather %.0f  between %.0f | polls %llu\n",
+                        wv, q[6], q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5] / n, q[7]);
+            }
+        }
+#endif
+    } else {
+        rc = one ? krk_launch_lstm_ws_b1(w, groups, stream) : krk_launch_lstm_ws(w, groups, stream);
+    }
     if (rc == -4) rc = krk_launch_lstm_x3(l, stream);
     return rc;
 }
