@@ -1404,6 +1404,10 @@ int krk_plan_status(krk_plan* plan) {
     if (!plan) return fail(KRK_E_INVALID, "krk_plan_status: null plan");
     if (plan->err_host && *(volatile unsigned*)plan->err_host != 0) {
         const unsigned word = *(volatile unsigned*)plan->err_host;
+#ifdef KRK_STAMP
+        { const volatile unsigned* e = plan->err_host;
+          fprintf(stderr, "exchange timeout: slice/group/step 0x%08x want 0x%08x saw 0x%08x wave/lane/pair 0x%08x granule offset %u cluster %u\n", e[1], e[2], e[3], e[4], e[5], e[6]); }
+#endif
         *(volatile unsigned*)plan->err_host = 0;
         char msg[256];
         snprintf(msg, sizeof msg, "a recurrent cluster kernel timed out waiting for its peers (lstm_ws exchange, word 0x%08x); the "
@@ -1936,7 +1940,7 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     // to one of the two everywhere else: 0.22 / 0.24 / 0.26 / 0.33 / 0.36 ms; removed in round 4)
     // the plan's own setting (krk_plan_set_recurrence: the one retry after an exchange timeout) wins over the process-wide probe
     const int lstm_v = p->recurrence == KRK_RECURRENCE_STREAMING ? 1 : probe.lstm_v ? probe.lstm_v : (s.Hp <= 64 ? 1 : 3);
-    if (!s.d_wrecws || (lstm_v != 3 && lstm_v != 4)) return krk_launch_lstm_x3(l, stream);
+    if (!s.d_wrecws || lstm_v < 3 || lstm_v > 5) return krk_launch_lstm_x3(l, stream);
     // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time barely
     // moves (it is not exchange bound), so a launch takes twice as long on half the CUs: same chip time, worse latency, fewer
     // lines/s through the pipelined engine.  KRK_LSTM_G=4 keeps it probeable.
@@ -1965,7 +1969,7 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     int rc;
     w.stamps = nullptr;
     w.nclusters = w.mbox = 0;
-    if (lstm_v == 4) {
+    if (lstm_v == 4 || lstm_v == 5) {
         w.wp = (const __bf16*)s.d_wrecx3;
         w.nclusters = (Ns + 31) / 32 * s.ndir;
         w.mbox = krk_lstm_wq_mbox(w.nclusters);
@@ -1980,7 +1984,7 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
             if (stamps) { std::memset(stamps, 0, 4 * 8 * sizeof(unsigned long long)); (void)hipHostGetDevicePointer((void**)&w.stamps, stamps, 0); }
         }
 #endif
-        rc = one ? krk_launch_lstm_wq_b1(w, stream) : krk_launch_lstm_wq(w, stream);
+        rc = one ? krk_launch_lstm_wq_b1(w, lstm_v == 5 ? 8 : 4, stream) : krk_launch_lstm_wq(w, lstm_v == 5 ? 8 : 4, stream);
 #ifdef KRK_STAMP
         if (w.stamps && rc == 0) {
             (void)hipStreamSynchronize(stream);

@@ -281,8 +281,8 @@ int krk_launch_lstm_ws_b1(const LstmWsArgs& a, int groups, hipStream_t s);
 // one wave per SIMD, weights in AGPRs (lstm_wq.hip); a.wp = the streaming kernel's fragment layout
 int krk_lstm_wq_mbox(int nclusters);
 size_t krk_lstm_wq_ctrl_bytes(int nclusters);     // zeroed by the host before every launch
-int krk_launch_lstm_wq(const LstmWsArgs& a, hipStream_t s);
-int krk_launch_lstm_wq_b1(const LstmWsArgs& a, hipStream_t s);
+int krk_launch_lstm_wq(const LstmWsArgs& a, int waves, hipStream_t s);      // waves per workgroup: 4 (one per SIMD) or 8
+int krk_launch_lstm_wq_b1(const LstmWsArgs& a, int waves, hipStream_t s);
 
 
 // K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel

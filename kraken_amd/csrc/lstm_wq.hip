@@ -77,20 +77,22 @@ __device__ __forceinline__ void wq_wait() {
 __device__ __forceinline__ void wq_pin(u32x4& hi, u32x4& lo) { asm("" : "+a"(hi), "+a"(lo)); }   // not volatile: free to move with its MFMAs
 __device__ __forceinline__ bf16x8 wq_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-// NKB K blocks of 32, BPW gate-column blocks per wave (4 waves: local block = wave + 4 i), two 16-line groups per cluster
-template <int NKB, int BPW>
-__global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
+// NKB K blocks of 32, NW waves per workgroup (4: one per SIMD, 512 registers each; 8: two per SIMD, 256 each), BPW gate-column
+// blocks per wave (local block = wave + NW i), two 16-line groups per cluster
+template <int NKB, int BPW, int NW>
+__global__ void __launch_bounds__(64 * NW) lstm_wq_kernel(const LstmWsArgs a) {
+    constexpr int NT = 64 * NW;
     constexpr int NG = 2;
-    // a lane gathers NGP granule PAIRS per (group, step): 3 peers x BPC*32 pairs / 256 lanes, BPC <= 4 BPW
+    // a lane gathers NGP granule PAIRS per (group, step): 3 peers x BPC*32 pairs / NT lanes, BPC <= NW BPW
     constexpr int NGP = (3 * BPW + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     // h in LDS as in lstm_ws.hip, per (group, parity): [plane hi|lo][K octet 4][line 16][K block: 16 bytes each, odd count]
     constexpr int RSO = 16 * (NKB | 1);
     constexpr int OS = 16 * RSO;
     constexpr int plane = 4 * OS;
-    // every plane is followed by a 1 KB dump strip (one dword per thread): masked writes -- absent blocks, padding units, heartbeat
+    // every plane is followed by a dump strip (one dword per thread): masked writes -- absent blocks, padding units, heartbeat
     // pairs -- go there through the SAME address arithmetic as real ones (lo = hi + planeP), no select in the time loop
-    constexpr int planeP = plane + 1024;
+    constexpr int planeP = plane + 4 * NT;
     constexpr int hbuf = 2 * planeP;
     auto lds_of = [&](int ln, int unit) -> unsigned {        // byte offset of (line, unit) inside a buffer's hi plane
         return (unsigned)(((unit & 31) >> 3) * OS + ln * RSO + (unit >> 5) * 16 + (unit & 7) * 2);
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
     unsigned char* hs = smem8;              // [group NG][parity 2][hbuf]
     int* lens_s = reinterpret_cast<int*>(smem8 + 2 * NG * hbuf);        // [16 * NG]
     unsigned* misc = reinterpret_cast<unsigned*>(lens_s + 16 * NG);     // [0] ticket
-    const unsigned xs_off = (unsigned)(2 * NG * hbuf + 16 * NG * 4 + 16 + 256) & ~255u;   // xproj landing ring [slot parity 2][wave 4][BPW][64 lanes x 16 B]
+    const unsigned xs_off = (unsigned)(2 * NG * hbuf + 16 * NG * 4 + 16 + 256) & ~255u;   // xproj landing ring [slot parity 2][wave NW][BPW][64 lanes x 16 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
         misc[0] = c;
         misc[1] = sl;
     }
-    for (int e = tid; e < NG * hbuf / 2; e += 256) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // 2*NG*hbuf bytes
+    for (int e = tid; e < NG * hbuf / 2; e += NT) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // 2*NG*hbuf bytes
     __syncthreads();
     const int cluster = (int)__builtin_amdgcn_readfirstlane(misc[0]), slice = (int)__builtin_amdgcn_readfirstlane(misc[1]);
     if (cluster >= a.nclusters) return;                          // surplus workgroup
@@ -172,10 +174,10 @@ __global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
     const unsigned dump_off = (unsigned)plane + (unsigned)tid * 4u;      // inside every h buffer: the strip behind the hi plane
     const int BPC = a.BPC;
 
-    // which of this wave's blocks exist (wave-uniform): local block wave + 4i < BPC, global block < NB
+    // which of this wave's blocks exist (wave-uniform): local block wave + NW i < BPC, global block < NB
     bool bval[BPW];
 #pragma unroll
-    for (int i = 0; i < BPW; ++i) bval[i] = (wave + 4 * i < BPC) && (slice * BPC + wave + 4 * i < a.NB);
+    for (int i = 0; i < BPW; ++i) bval[i] = (wave + NW * i < BPC) && (slice * BPC + wave + NW * i < a.NB);
 
     // ---- weights: resident in AGPRs for the whole launch, straight from the streaming kernel's layout
     // [dir][kb][block][plane][lane][8] (capi.hip: upload_lstm_x3).  The loads WRITE accumulator registers (constraint "=a"): a
@@ -187,7 +189,7 @@ __global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
         const i32x4 wrs = wq_srd(a.wp + (size_t)dir * NKB * a.NB * 1024, (unsigned)NKB * kb_bytes);
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
-            const unsigned vo = bval[i] ? (unsigned)(slice * BPC + wave + 4 * i) * 2048u + (unsigned)lane * 16u : kOOBwq;
+            const unsigned vo = bval[i] ? (unsigned)(slice * BPC + wave + NW * i) * 2048u + (unsigned)lane * 16u : kOOBwq;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
                 asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024"
@@ -205,14 +207,14 @@ __global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
     const unsigned x_row = 16u * (unsigned)a.xstride * 4u;                                    // bytes per (tile, step)
     unsigned xso[BPW];                       // byte offset of the wave's blocks inside a line's row (wave-uniform: soffset)
 #pragma unroll
-    for (int i = 0; i < BPW; ++i) xso[i] = __builtin_amdgcn_readfirstlane(bval[i] ? (unsigned)(slice * BPC + wave + 4 * i) * 64u : 0u);
+    for (int i = 0; i < BPW; ++i) xso[i] = __builtin_amdgcn_readfirstlane(bval[i] ? (unsigned)(slice * BPC + wave + NW * i) * 64u : 0u);
     int x_len[NG];                           // the length of this lane's line in both groups (0: the group lies past N)
 #pragma unroll
     for (int g = 0; g < NG; ++g) x_len[g] = g < ntiles ? lens_s[16 * g + line] : 0;
     auto load_x = [&](int g, int s) {
         const int t = rev ? (x_len[g] - 1 - s) : s;
         const unsigned vo = x_lane + (s < x_len[g] ? (unsigned)(g * a.T + t) * x_row : 0u);
-        const unsigned l0 = __builtin_amdgcn_readfirstlane(xs_off + (unsigned)(((g & 1) * 4 + wave) * BPW) * 1024u);
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(xs_off + (unsigned)(((g & 1) * NW + wave) * BPW) * 1024u);
         unsigned keep;                       // M0 = the LDS base of a copy; saved, stepped per block, restored
         if constexpr (BPW == 1)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -243,11 +245,11 @@ __global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
     auto gran_of = [&](int sl, int ul, int ln) -> unsigned {      // byte offset of the granule of (slice, local unit, line)
         return ((unsigned)sl * slice_gran + (((unsigned)(ul >> 1) * 16u + (unsigned)ln) * 2u + (unsigned)(ul & 1))) * 8u;
     };
-    // what this lane publishes for block i: unit_local = (wave + 4i)*4 + us, its own line
+    // what this lane publishes for block i: unit_local = (wave + NW i)*4 + us, its own line
     unsigned pub_vo[BPW], own_lds[BPW];
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
-        const int ul = (wave + 4 * i) * 4 + us;
+        const int ul = (wave + NW * i) * 4 + us;
         const int unit = slice * BPC * 4 + ul;
         pub_vo[i] = bval[i] ? gran_of(slice, ul, line) : kOOBwq;
         own_lds[i] = (bval[i] && unit < NKB * 32) ? lds_of(line, unit) : dump_off;
@@ -256,12 +258,12 @@ __global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
     // 1, line 0 of its own region -- and every peer gathers it (to nowhere): the flow control of the two parity buffers needs it
     const bool empty_slice = slice * BPC >= a.NB;
     if (empty_slice && wave == 0 && line == 0 && us < 2) pub_vo[0] = gran_of(slice, us, 0);
-    // what this lane gathers: pair q = tid + 256 k over [peer 3][BPC*2 unit pairs][16 lines]
+    // what this lane gathers: pair q = tid + NT k over [peer 3][BPC*2 unit pairs][16 lines]
     const unsigned slice_pairs = slice_gran >> 1;
     unsigned g_vo[NGP], g_lds[NGP], g_need[NGP];   // granule byte offset (kOOBwq: none), LDS byte offset of the pair's hi dword (dump strip: nowhere), all ones if the pair's tags count
 #pragma unroll
     for (int k = 0; k < NGP; ++k) {
-        const unsigned q = (unsigned)tid + 256u * k;
+        const unsigned q = (unsigned)tid + (unsigned)NT * k;
         const unsigned p = q / slice_pairs, rem = q - p * slice_pairs;
         const int sl = (slice + 1 + (int)p) & 3;
         const int ul = 2 * (int)(rem >> 4), ln = (int)(rem & 15);
@@ -396,7 +398,7 @@ __global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
         wq_wait<2 * BPW>();
         f32x4 xv[BPW];
 #pragma unroll
-        for (int i = 0; i < BPW; ++i) xv[i] = *reinterpret_cast<const f32x4*>(smem8 + xs_off + (((g & 1) * 4 + wave) * BPW + i) * 1024 + lane * 16);
+        for (int i = 0; i < BPW; ++i) xv[i] = *reinterpret_cast<const f32x4*>(smem8 + xs_off + (((g & 1) * NW + wave) * BPW + i) * 1024 + lane * 16);
         unsigned sp_vo = kOOBwq;
         u32x4 sp_v = u32x4{0u, 0u, 0u, 0u};
         if (!KRK_DBGBIT(a, 16)) sp_v = store_read(g, s - 1, hb, sp_vo);
@@ -491,14 +493,14 @@ __global__ void __launch_bounds__(256) lstm_wq_kernel(const LstmWsArgs a) {
 #endif
 }
 
-template <int NKB, int BPW>
+template <int NKB, int BPW, int NW>
 int launch_wq(const LstmWsArgs& a, hipStream_t s) {
     const int nclusters = a.nclusters;
-    const size_t lds = (((size_t)2 * 2 * 2 * (4 * 16 * 16 * (NKB | 1) + 1024) + 32 * sizeof(int) + 16 + 256) & ~(size_t)255) + (size_t)2 * 4 * BPW * 1024;
-    auto kfn = lstm_wq_kernel<NKB, BPW>;
+    const size_t lds = (((size_t)2 * 2 * 2 * (4 * 16 * 16 * (NKB | 1) + 256 * NW) + 32 * sizeof(int) + 16 + 256) & ~(size_t)255) + (size_t)2 * NW * BPW * 1024;
+    auto kfn = lstm_wq_kernel<NKB, BPW, NW>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nclusters * 4 + 24), dim3(256), lds, s, a);     // 8 x 3 surplus workgroups: see the cluster claim
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nclusters * 4 + 24), dim3(64 * NW), lds, s, a);     // 8 x 3 surplus workgroups: see the cluster claim
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -512,14 +514,21 @@ size_t krk_lstm_wq_ctrl_bytes(int nclusters) { return (size_t)(16 + 8 * krk_lstm
 #endif
 
 // a.wp = the streaming kernel's fragments (upload_lstm_x3: [dir][kb][block][plane][lane][8]); everything else as krk_launch_lstm_ws
-int KRK_FN(krk_launch_lstm_wq)(const LstmWsArgs& a, hipStream_t s) {
+int KRK_FN(krk_launch_lstm_wq)(const LstmWsArgs& a, int waves, hipStream_t s) {
     if (!krk_lstm_ws_supported(a.H, a.Hp)) return -4;
     if ((size_t)a.out_plane * 4 >= 0x80000000ull) return -4;                 // 32-bit buffer offsets
     if (a.T >= 0xFFFF) return -4;                                             // 16-bit step tags
     if (a.nclusters != (a.N + 31) / 32 * a.ndir || a.mbox != krk_lstm_wq_mbox(a.nclusters)) return -4;
+    // NB = Hp/4 in (8(NKB-1), 8 NKB]; BPC = ceil(NB/4) in {2 NKB - 1, 2 NKB}; BPW = ceil(BPC / waves)
+    if (waves == 8) {
+        const int bpw = (a.BPC + 7) / 8;
+#define KRK_WQ(NKB_, BPW_) if (a.NKB == NKB_ && bpw == BPW_) return launch_wq<NKB_, BPW_, 8>(a, s)
+        KRK_WQ(1, 1); KRK_WQ(2, 1); KRK_WQ(3, 1); KRK_WQ(4, 1); KRK_WQ(5, 2); KRK_WQ(6, 2); KRK_WQ(7, 2);
+#undef KRK_WQ
+        return -4;
+    }
     const int bpw = (a.BPC + 3) / 4;
-#define KRK_WQ(NKB_, BPW_) if (a.NKB == NKB_ && bpw == BPW_) return launch_wq<NKB_, BPW_>(a, s)
-    // NB = Hp/4 in (8(NKB-1), 8 NKB]; BPC = ceil(NB/4) in {2 NKB - 1, 2 NKB}; BPW = ceil(BPC/4)
+#define KRK_WQ(NKB_, BPW_) if (a.NKB == NKB_ && bpw == BPW_) return launch_wq<NKB_, BPW_, 4>(a, s)
     KRK_WQ(1, 1); KRK_WQ(2, 1); KRK_WQ(3, 2); KRK_WQ(4, 2); KRK_WQ(5, 3); KRK_WQ(6, 3); KRK_WQ(7, 4);
 #undef KRK_WQ
     return -4;
