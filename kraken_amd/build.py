@@ -15,9 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 BUILD = os.path.join(CSRC, '_build')
 LIB = os.path.join(HERE, 'libkraken_amd.so')
-SOURCES = ['conv_mfma.hip', 'conv_x3.hip', 'conv_x3p.hip', 'conv_x6.hip', 'conv1_x3.hip', 'conv_taps_x3.hip', 'gemm_x3.hip', 'gemm_x3w.hip', 'norm_x3.hip', 'lstm_rec.hip', 'lstm_small.hip', 'lstm_x3.hip', 'lstm_ws.hip', 'lstm_wq.hip', 'misc_kernels.hip', 'c1gn.hip', 'prep_lines.hip', 'dewarp.hip', 'capi.hip']
+SOURCES = ['conv_mfma.hip', 'conv_x3.hip', 'conv_x3p.hip', 'conv_x6.hip', 'conv1_x3.hip', 'conv_taps_x3.hip', 'gemm_x3.hip', 'norm_x3.hip', 'lstm_rec.hip', 'lstm_small.hip', 'lstm_x3.hip', 'lstm_ws.hip', 'misc_kernels.hip', 'c1gn.hip', 'prep_lines.hip', 'dewarp.hip', 'capi.hip']
 # sources compiled a second time with -DKRK_BF16_ONE: the plain-bf16 plan's launchers (name_b1), see csrc/common.h
-ONE_TERM = ['conv1_x3.hip', 'conv_taps_x3.hip', 'conv_x3.hip', 'conv_x3p.hip', 'gemm_x3.hip', 'gemm_x3w.hip', 'lstm_ws.hip', 'lstm_wq.hip']
+ONE_TERM = ['conv1_x3.hip', 'conv_taps_x3.hip', 'conv_x3.hip', 'conv_x3p.hip', 'gemm_x3.hip', 'lstm_ws.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'kraken_amd.h')]
 ARCH = 'gfx950'
@@ -39,7 +39,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, ablate: bool = False, stamp: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
     """
     Compiles every HIP source for gfx950 and links the C-ABI library. Returns its path.
 
@@ -47,12 +47,9 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False, stam
     branches (``KRK_DBGBIT``, common.h) compiled in -- a measuring tool (tools/lstm_probe.py), selected with
     ``KRAKEN_AMD_LIB``; the release library has no probe code in its hot loops.
     """
-    # ``stamp=True``: ``libkraken_amd_stamp.so`` = the RELEASE kernels plus per-phase cycle stamps in lstm_wq.hip (KRK_LSTM_DBG=256
-    # prints them per launch); the ablation build's run-time branches cost more than the phases they skip there
-    tag = '_ablate' if ablate else '_stamp' if stamp else ''
-    bdir = BUILD + tag
-    lib_path = LIB.replace('.so', tag + '.so')
-    flags = FLAGS + (['-DKRK_ABLATE'] if ablate else []) + (['-DKRK_STAMP'] if stamp else [])
+    bdir = BUILD + ('_ablate' if ablate else '')
+    lib_path = LIB.replace('.so', '_ablate.so') if ablate else LIB
+    flags = FLAGS + (['-DKRK_ABLATE'] if ablate else [])
     os.makedirs(bdir, exist_ok=True)
     hipcc = _hipcc()
     objs, jobs = [], []
@@ -85,7 +82,7 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False, stam
 
 if __name__ == '__main__':
     try:
-        print(build(force='--force' in sys.argv, verbose=True, ablate='--ablate' in sys.argv, stamp='--stamp' in sys.argv))
+        print(build(force='--force' in sys.argv, verbose=True, ablate='--ablate' in sys.argv))
     except Exception as e:                      # a failed build must be the LAST thing on the screen, not a stale .so
         print(str(e)[-3000:], file=sys.stderr)
         print('BUILD FAILED', flush=True)

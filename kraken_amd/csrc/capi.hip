@@ -15,13 +15,12 @@
 #include <string>
 #include <vector>
 
-// phase cycle counters of the instrumented kernels (common.h KRK_PHASES): which = 0 conv_x3p, 1 gemm_x3w; returns the count
+// phase cycle counters of the instrumented kernel (common.h KRK_PHASES): conv_x3p; returns the count
 int krk_phase_stats_x3p(unsigned long long* out, int reset);
-int krk_phase_stats_x3w(unsigned long long* out, int reset);
 #ifdef KRK_ABLATE
 extern "C" int krk_debug_phase_stats(int which, unsigned long long* out, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -2;
-    return which == 0 ? krk_phase_stats_x3p(out, reset) : krk_phase_stats_x3w(out, reset);
+    return which == 0 ? krk_phase_stats_x3p(out, reset) : -1;
 }
 #endif
 
@@ -107,8 +106,6 @@ struct ConvGeom {
     int x6CBpad = 1;
     void* d_wx3 = nullptr;
     void* d_wx5 = nullptr;    // conv_taps_x3.hip, five-group packing (kw <= 13)
-    void* d_wx3w = nullptr;   // gemm_x3w.hip: the same weights in column groups of wtn (256 | 320) for the wide-tile kernel
-    int wtn = 0;
     bool c1x3 = false;        // one-channel first convolution on the bf16 cores (conv1_x3.hip); weights in d_wx3
     bool taps = false;        // wide-kernel convolution with taps as K (conv_taps_x3.hip); reads NHCW planes
     bool out_nhcw = false;    // conv1_x3 writes [N][H][C][pitch] planes for a following taps convolution
@@ -411,7 +408,7 @@ int upload_conv_taps_weights(ConvGeom& g, const float* w) {
     return KRK_OK;
 }
 
-// gemm_x3.hip / gemm_x3w.hip weight order: [column group of tn][K/16][plane][k-half][column][8] (bf16); `w` is (rows, K) f32.
+// gemm_x3.hip weight order: [column group of tn][K/16][plane][k-half][column][8] (bf16); `w` is (rows, K) f32.
 int pack_gemm_x3_weights(const ConvGeom& g, const float* w, const std::vector<int>* rowmap, int tn, void** dst) {
     const int ncg = (g.Cout + tn - 1) / tn, nkb = g.Cin / 16;
     const size_t rec = (size_t)32 * tn;            // elements per (column group, K step): 2 planes x 2 k-halves x tn x 8
@@ -442,14 +439,7 @@ int pack_gemm_x3_weights(const ConvGeom& g, const float* w, const std::vector<in
 
 int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
     if (g.Cin % 16) return fail(KRK_E_UNSUPPORTED, "bf16x3: input features must be a multiple of 16");
-    if (int rc = pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3)) return rc;
-    // wide outputs (the LSTM input projections) also get the wide-tile kernel's order; which kernel runs is decided per call
-    // by the number of rows (Pass::projection)
-    if (g.Cout >= 512 && env_int("KRK_GEMM_W", 0) != 0) {
-        g.wtn = krk_gemm_x3w_tn(g.Cout);
-        if (int rc = pack_gemm_x3_weights(g, w, rowmap, g.wtn, &g.d_wx3w)) return rc;
-    }
-    return KRK_OK;
+    return pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3);
 }
 
 struct Step {
@@ -477,7 +467,7 @@ struct Step {
     void* d_wrecx3 = nullptr;   // recurrent weights, split bf16, 16x16x32 fragment order
     // weight-stationary cluster kernel (lstm_ws.hip): per-wave resident fragments, exchange granules, ticket counter
     void* d_wrecws = nullptr;
-    DevBuf ws_gran, wq_ctrl;
+    DevBuf ws_gran;
     unsigned* ws_ctrl = nullptr;
     unsigned ws_tickets = 0, ws_epoch = 0;
     int ws_bpc = 0;
@@ -681,7 +671,6 @@ void free_step(Step& s) {
     if (s.cg.d_b) (void)hipFree(s.cg.d_b);
     if (s.cg.d_wx3) (void)hipFree(s.cg.d_wx3);
     if (s.cg.d_wx5) (void)hipFree(s.cg.d_wx5);
-    if (s.cg.d_wx3w) (void)hipFree(s.cg.d_wx3w);
     if (s.cg.d_wx6) (void)hipFree(s.cg.d_wx6);
     if (s.d_c1w) (void)hipFree(s.d_c1w);
     if (s.d_c1b) (void)hipFree(s.d_c1b);
@@ -695,7 +684,6 @@ void free_step(Step& s) {
     if (s.d_wrecws) (void)hipFree(s.d_wrecws);
     if (s.ws_ctrl) (void)hipFree(s.ws_ctrl);
     s.ws_gran.release();
-    s.wq_ctrl.release();
     s.out.release();
     s.aux.release();
     s.aux2.release();
@@ -1404,10 +1392,6 @@ int krk_plan_status(krk_plan* plan) {
     if (!plan) return fail(KRK_E_INVALID, "krk_plan_status: null plan");
     if (plan->err_host && *(volatile unsigned*)plan->err_host != 0) {
         const unsigned word = *(volatile unsigned*)plan->err_host;
-#ifdef KRK_STAMP
-        { const volatile unsigned* e = plan->err_host;
-          fprintf(stderr, "exchange timeout: slice/group/step 0x%08x want 0x%08x saw 0x%08x wave/lane/pair 0x%08x granule offset %u cluster %u\n", e[1], e[2], e[3], e[4], e[5], e[6]); }
-#endif
         *(volatile unsigned*)plan->err_host = 0;
         char msg[256];
         snprintf(msg, sizeof msg, "a recurrent cluster kernel timed out waiting for its peers (lstm_ws exchange, word 0x%08x); the "
@@ -1524,7 +1508,6 @@ void fill_gemm(const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane
     a.tileT = 0;
     a.nlines = 0;
     a.dbg = dbg;
-    a.stagger = 0;
     a.nbuf = env_int("KRK_GEMM_SPREAD", 1) ? 3 : 2;   // gemm_x3.hip reads nbuf == 2 as "copies in front of the MFMAs" (A/B probe)
 }
 
@@ -1542,13 +1525,8 @@ struct Probes {
     int lstm_v = env_int("KRK_LSTM_V", 0);       // 0: by hidden size (see recurrence_x3); 3: cluster kernel lstm_ws.hip; 1: streaming kernel
     int lstm_g = env_int("KRK_LSTM_G", 2);       // 4: four 16-line groups per cluster
     int lstm_m = env_int("KRK_LSTM_M");          // f32 plan: force 16- or 32-line tiles
-    int gemm_w = env_int("KRK_GEMM_W", 0);       // wide-tile projection kernel (gemm_x3w.hip): 0 never (default: alone it is 6-10 % faster than
-                                                 // gemm_x3, but one 110 KB workgroup per CU shuts the other batches' kernels out: 111.2 k vs 113.1 k
-                                                 // lines/s on the pipelined bench, profiles/r04_kernel_matrix.txt), 1 where packed, -1 by size
     int conv_x6 = env_int("KRK_CONV_X6", 1);     // 0: the exact-f32 kernel also where the three-plane kernel (conv_x6.hip) is planned
     int taps_dma = env_int("KRK_TAPS_DMA", 1);   // conv_taps_x3.hip: input tile through raw-buffer -> LDS copies (0: register staging)
-    int gemm_nbuf = env_int("KRK_GEMM_NBUF", 3); // wide-tile projection kernel: LDS buffers (3 | 4)
-    int gemm_stag = env_int("KRK_GEMM_STAG", 0); // wide-tile projection kernel: start delay (cycles) per workgroup phase
     int conv_x3p = env_int("KRK_CONV_X3P", 1);   // 0: conv_x3.hip also where the pipelined kernel (conv_x3p.hip) covers the geometry
 };
 
@@ -1834,19 +1812,10 @@ int Pass::split_input(Step& s, const float* cur, size_t in_elems, const void** x
     return 0;
 }
 
-// split-bf16 row projection: the wide-tile kernel (gemm_x3w.hip) when its 256 x wtn tiles fill the chip, else gemm_x3.hip
+// split-bf16 row projection (gemm_x3.hip).  Round 4's wide-tile variant (gemm_x3w.hip: 256 x 320 tiles, eight waves) won 9 % alone and
+// lost 1.7 % on the pipelined bench -- one 110 KB workgroup per CU shuts the other batches' kernels out -- and left the tree in round 5
+// (git show be5f925:kraken_amd/csrc/gemm_x3w.hip).
 int Pass::projection(const ConvGeom& g, GemmX3Args& a) {
-    const int gw = probe.gemm_w;                 // KRK_GEMM_W: 0 never, 1 whenever the weights are packed for it, -1 (default) by size
-    if (g.d_wx3w && gw != 0) {
-        const int ncg = (g.Cout + g.wtn - 1) / g.wtn;
-        if (gw > 0 || (long)a.ntiles * ncg >= 256) {
-            a.w = (const __bf16*)g.d_wx3w;
-            a.ncg = ncg;
-            a.stagger = probe.gemm_stag;
-            a.nbuf = probe.gemm_nbuf;
-            return one ? krk_launch_gemm_x3w_b1(a, g.wtn, stream) : krk_launch_gemm_x3w(a, g.wtn, stream);
-        }
-    }
     return one ? krk_launch_gemm_x3_b1(a, stream) : krk_launch_gemm_x3(a, stream);
 }
 
@@ -1940,7 +1909,7 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     // to one of the two everywhere else: 0.22 / 0.24 / 0.26 / 0.33 / 0.36 ms; removed in round 4)
     // the plan's own setting (krk_plan_set_recurrence: the one retry after an exchange timeout) wins over the process-wide probe
     const int lstm_v = p->recurrence == KRK_RECURRENCE_STREAMING ? 1 : probe.lstm_v ? probe.lstm_v : (s.Hp <= 64 ? 1 : 3);
-    if (!s.d_wrecws || lstm_v < 3 || lstm_v > 5) return krk_launch_lstm_x3(l, stream);
+    if (!s.d_wrecws || lstm_v != 3) return krk_launch_lstm_x3(l, stream);
     // 16-line groups per cluster: 2.  With 4 (64 lines on 4 CUs, the exchange three slots old when read) the slot time barely
     // moves (it is not exchange bound), so a launch takes twice as long on half the CUs: same chip time, worse latency, fewer
     // lines/s through the pipelined engine.  KRK_LSTM_G=4 keeps it probeable.
@@ -1966,39 +1935,7 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     w.err = p->err_dev;
     w.otiled = l.otiled;
     w.dbg = l.dbg;
-    int rc;
-    w.stamps = nullptr;
-    w.nclusters = w.mbox = 0;
-    if (lstm_v == 4 || lstm_v == 5) {
-        w.wp = (const __bf16*)s.d_wrecx3;
-        w.nclusters = (Ns + 31) / 32 * s.ndir;
-        w.mbox = krk_lstm_wq_mbox(w.nclusters);
-        const size_t cbytes = krk_lstm_wq_ctrl_bytes(w.nclusters);
-        if (s.wq_ctrl.ensure(cbytes)) return nomem();
-        if (int r = hip(hipMemsetAsync(s.wq_ctrl.p, 0, cbytes, stream), "hipMemsetAsync")) return r;
-        w.ctrl = (unsigned*)s.wq_ctrl.p;
-#ifdef KRK_STAMP
-        static unsigned long long* stamps = nullptr;          // probe (KRK_LSTM_DBG bit 256): phase cycle sums of workgroup 0, printed per launch
-        if (probe.lstm_dbg & 256) {
-            if (!stamps) (void)hipHostMalloc((void**)&stamps, 4 * 8 * sizeof(unsigned long long), hipHostMallocMapped);
-            if (stamps) { std::memset(stamps, 0, 4 * 8 * sizeof(unsigned long long)); (void)hipHostGetDevicePointer((void**)&w.stamps, stamps, 0); }
-        }
-#endif
-        rc = one ? krk_launch_lstm_wq_b1(w, lstm_v == 5 ? 8 : 4, stream) : krk_launch_lstm_wq(w, lstm_v == 5 ? 8 : 4, stream);
-#ifdef KRK_STAMP
-        if (w.stamps && rc == 0) {
-            (void)hipStreamSynchronize(stream);
-            for (int wv = 0; wv < 4; ++wv) {
-                const unsigned long long* q = stamps + wv * 8;
-                const double n = q[6] ? (double)q[6] : 1.0;
-                fprintf(stderr, "wq stamps wave %d: slots %llu | cycles per slot: barrier %.0f  lds+block0 %.0f  blocks1.. %.0f  last cell %.0f  gather %.0f  between %.0f | polls %llu\n",
-                        wv, q[6], q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5] / n, q[7]);
-            }
-        }
-#endif
-    } else {
-        rc = one ? krk_launch_lstm_ws_b1(w, groups, stream) : krk_launch_lstm_ws(w, groups, stream);
-    }
+    int rc = one ? krk_launch_lstm_ws_b1(w, groups, stream) : krk_launch_lstm_ws(w, groups, stream);
     if (rc == -4) rc = krk_launch_lstm_x3(l, stream);
     return rc;
 }

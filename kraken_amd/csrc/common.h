@@ -203,15 +203,10 @@ struct GemmX3Args {
     int nlines;           // tileT < 0: lines that exist (rows of the padding lines of the last 16-line tile are dropped)
     int act;
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no MFMA, 2 no copies, 4 no stores, 8 no LDS reads
-    int stagger;          // gemm_x3w.hip probe (KRK_GEMM_STAG): start delay in cycles per phase ((workgroup / 8) % 4)
-    int nbuf;             // gemm_x3w.hip: LDS buffers (3 | 4), copies nbuf - 1 steps ahead
+    int nbuf;             // 3; 2 = probe (KRK_GEMM_SPREAD=0): all six copies of a K step in front of its MFMAs
 };
 int krk_launch_gemm_x3(const GemmX3Args& a, hipStream_t s);
 int krk_launch_gemm_x3_b1(const GemmX3Args& a, hipStream_t s);
-// wide-tile variant (gemm_x3w.hip): a.w packed in column groups of tn = krk_gemm_x3w_tn(Cout), a.ncg = groups of tn
-int krk_gemm_x3w_tn(int cout);
-int krk_launch_gemm_x3w(const GemmX3Args& a, int tn, hipStream_t s);
-int krk_launch_gemm_x3w_b1(const GemmX3Args& a, int tn, hipStream_t s);
 
 // ----------------------------------------------------------------------- LSTM
 struct LstmArgs {
@@ -270,19 +265,12 @@ struct LstmWsArgs {
     unsigned* err;        // mapped host word: set to 1 if an exchange wait timed out
     int otiled;           // 1: output rows tile-time-major (ceil(N/16)*16*T rows per piece), whole 256-byte runs per (piece, step)
     int dbg;              // probe bits (-DKRK_ABLATE build, env KRK_LSTM_DBG): 1 no exchange reads, 2 no gate math / publish, 4 no MFMA, 8 no xproj loads, 16 no output pass, 32 no step barrier
-    int nclusters, mbox;  // lstm_wq.hip: work items (clusters) of the launch; mailboxes per XCD in ctrl (krk_lstm_wq_mbox)
-    unsigned long long* stamps;   // -DKRK_STAMP build (python -m kraken_amd.build --stamp), KRK_LSTM_DBG bit 256: per-wave phase cycle sums of workgroup 0 (lstm_wq.hip), else null
 };
 bool krk_lstm_ws_supported(int H, int Hp);
 int krk_lstm_ws_clusters(int N, int ndir, int groups);
 size_t krk_lstm_ws_gran_bytes(int N, int ndir, int BPC, int groups);
 int krk_launch_lstm_ws(const LstmWsArgs& a, int groups, hipStream_t s);
 int krk_launch_lstm_ws_b1(const LstmWsArgs& a, int groups, hipStream_t s);
-// one wave per SIMD, weights in AGPRs (lstm_wq.hip); a.wp = the streaming kernel's fragment layout
-int krk_lstm_wq_mbox(int nclusters);
-size_t krk_lstm_wq_ctrl_bytes(int nclusters);     // zeroed by the host before every launch
-int krk_launch_lstm_wq(const LstmWsArgs& a, int waves, hipStream_t s);      // waves per workgroup: 4 (one per SIMD) or 8
-int krk_launch_lstm_wq_b1(const LstmWsArgs& a, int waves, hipStream_t s);
 
 
 // K-steps whose B fragments one lane loads contiguously (dwordx4 granules) in the recurrent kernel

@@ -29,13 +29,12 @@ python bench.py --mode api --no-cpu-baseline > $O/${TAG}_bench_api.json 2>/dev/n
 (timeout 200 python tools/bench_b_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bench_b.txt)
 (KRK_NO_C1GN=1 KRK_NO_CONV_X6=1 KRK_NO_TOSEQ_SPLIT=1 timeout 200 python tools/bench_b_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bench_b_round3_kernels.txt)
 python bench.py --gpus 2 --share-device --no-cpu-baseline > $O/${TAG}_two_ranks_one_device.json 2> $O/two_ranks.err
-(timeout 300 python tools/kernel_ab.py "KRK_GEMM_W=0,KRK_CONV_X3P=0,KRK_TAPS_DMA=0" "KRK_GEMM_W=0,KRK_CONV_X3P=1,KRK_TAPS_DMA=1" "KRK_GEMM_W=1,KRK_CONV_X3P=1,KRK_TAPS_DMA=1" 2>&1 | grep -v amdgpu.ids > $O/${TAG}_kernel_ab_alone.txt)
+(timeout 300 python tools/kernel_ab.py "KRK_CONV_X3P=0,KRK_TAPS_DMA=0" "KRK_CONV_X3P=1,KRK_TAPS_DMA=1" 2>&1 | grep -v amdgpu.ids > $O/${TAG}_kernel_ab_alone.txt)
 for rep in 1 2; do for cfg in "0 0 0" "0 1 0" "0 1 1" "1 1 1"; do set -- $cfg
-  echo "KRK_GEMM_W=$1 KRK_CONV_X3P=$2 KRK_TAPS_DMA=$3 rep $rep:" $(KRK_GEMM_W=$1 KRK_CONV_X3P=$2 KRK_TAPS_DMA=$3 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'lines/s', d['ms_per_step'], 'ms/step')") >> $O/${TAG}_kernel_matrix.txt
+  echo "KRK_CONV_X3P=$2 KRK_TAPS_DMA=$3 rep $rep:" $(KRK_CONV_X3P=$2 KRK_TAPS_DMA=$3 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'lines/s', d['ms_per_step'], 'ms/step')") >> $O/${TAG}_kernel_matrix.txt
 done; done
 [ -f kraken_amd/libkraken_amd_ablate.so ] || python -m kraken_amd.build --ablate > /dev/null 2>&1
 (timeout 200 python tools/phase_stats.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_phase_stats.txt)
-(timeout 200 python tools/phase_stats.py KRK_GEMM_W=1 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_phase_stats.txt)
 for i in 0 1 2; do (KRK_LSTM_V=3 timeout 300 python tools/ws_flake.py 350 $i 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_exchange_timeouts_lstm_ws_forced_narrow.txt); done
 (KRK_CONV_X6=0 timeout 200 python tools/fuzz_plans.py 60 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz_f32_convs_same_seed.txt)
 (timeout 200 python tools/fuzz_plans.py 60 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fuzz_x6_convs_same_seed.txt)

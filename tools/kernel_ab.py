@@ -1,7 +1,7 @@
 """Dev tool (GPU): per-launch-group times of BENCH-A ALONE (one batch in flight) under several probe-switch settings, interleaved
 in ONE process (the switches of `struct Probes`, capi.hip, are read once per forward call), plus the difference of the logits
 between the settings.  Usage:
-    python tools/kernel_ab.py "KRK_GEMM_W=0" "KRK_GEMM_W=1" [--rounds 7] [--spec A|B] [--n 256] [--w 1200]
+    python tools/kernel_ab.py "KRK_CONV_X3P=0" "KRK_CONV_X3P=1" [--rounds 7] [--spec A|B] [--n 256] [--w 1200]
 Each argument is a comma-separated list of NAME=VALUE; the first setting is the reference for the logit difference."""
 import os
 import sys

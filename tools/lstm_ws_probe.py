@@ -67,10 +67,10 @@ if __name__ == '__main__':
         sys.exit(0)
     import numpy as np
     os.makedirs('gpurun_out', exist_ok=True)
-    variants = [('v1', dict(KRK_LSTM_V=1)), ('ws g2', dict(KRK_LSTM_V=3, KRK_LSTM_G=2)), ('wq', dict(KRK_LSTM_V=4)), ('wq8', dict(KRK_LSTM_V=5)), ('ws g4', dict(KRK_LSTM_V=3, KRK_LSTM_G=4))]
+    variants = [('v1', dict(KRK_LSTM_V=1)), ('ws g2', dict(KRK_LSTM_V=3, KRK_LSTM_G=2)), ('ws g4', dict(KRK_LSTM_V=3, KRK_LSTM_G=4))]
     if '--ablate' in sys.argv:
         lib = os.path.abspath('kraken_amd/libkraken_amd_ablate.so')
-        for name, env in variants[1:4]:
+        for name, env in variants[1:2]:
             for dbg in (0, 1, 2, 4, 8, 16, 32, 3, 7, 23, 55):
                 r = run(dict(env, KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
                 print('ablate', name, 'dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
@@ -80,10 +80,10 @@ if __name__ == '__main__':
         for dbg in (0, 64, 128, 4, 16, 32, 1):     # 1 no exchange, 4 no MFMA, 16 no output pass, 32 no barrier; gather asked at slot start (64) / after the last block (128)
             r = run(dict(variants[1][1], KRAKEN_AMD_LIB=lib, KRK_LSTM_DBG=dbg), 256, 150)
             print('ablate ws g2 dbg', dbg, r.get('lstm_rec_x3', r), flush=True)
-        variants = variants[:4]
+        variants = variants[:2]
         sizes = ((256, 150), (40, 60), (7, 33))
     else:
-        variants = variants[:4]        # (the 4-groups-per-cluster variant is probed by tests/test_gpu_parity.py)
+        variants = variants[:2]        # (the 4-groups-per-cluster variant is probed by tests/test_gpu_parity.py)
         sizes = ((256, 150), (40, 60), (7, 33), (1024, 150), (100, 300))
     for N, T in sizes:
         ref = None

@@ -1,4 +1,4 @@
-"""Dev tool (GPU, -DKRK_ABLATE build): where the waves of conv_x3p.hip / gemm_x3w.hip spend their cycles on BENCH-A (one batch in
+"""Dev tool (GPU, -DKRK_ABLATE build): where the waves of conv_x3p.hip spend their cycles on BENCH-A (one batch in
 flight).  Probe bit 64 makes every wave sum the shader cycles of its phases (common.h KRK_PHASES); printed per kernel as the mean
 cycles per wave and the share of the wave's lifetime.
     python -m kraken_amd.build --ablate && python tools/phase_stats.py [NAME=VALUE,...]"""
@@ -31,8 +31,7 @@ for which in (0, 1):
 reps = 3
 for _ in range(reps):
     m.nn(x)
-names = {0: ('conv_x3p (both launches)', ['prologue', 'copy waits', 'barrier', 'copy issue', 'reads+MFMA', 'epilogue']),
-         1: ('gemm_x3w (3 launches)', ['prologue', 'copy waits', 'barriers', 'copy issue', 'fragment reads', 'MFMAs', 'epilogue'])}
+names = {0: ('conv_x3p (both launches)', ['prologue', 'copy waits', 'barrier', 'copy issue', 'reads+MFMA', 'epilogue'])}
 for which in (0, 1):
     n = lib.krk_debug_phase_stats(which, buf, 1)
     title, ph = names[which]
