@@ -59,7 +59,8 @@ extern "C" {
 #define KRK_OP_MAXPOOL    2   /* MaxPool    layers.py:367  */
 #define KRK_OP_GROUPNORM  3   /* GroupNorm  layers.py:955  */
 #define KRK_OP_RESHAPE_HC 4   /* Reshape S1(1x0)1,3: fold height into channels, layers.py:285 */
-#define KRK_OP_LSTM       5   /* TransposedSummarizingRNN (L{f,r,b}x) layers.py:462 */
+#define KRK_OP_LSTM       5   /* TransposedSummarizingRNN (L{f,r,b}x) layers.py:462; act = 1: the legacy ocropy peephole cell
+                               * (layers.py:72-186), w[4d+3] = its peephole vectors (i, f, o: 3 x hidden) instead of b_hh */
 #define KRK_OP_LINEAR     6   /* LinSoftmax (logits, no softmax) layers.py:679 */
 /* A parallel group `( a b ... )` (MultiParamParallel, layers.py:56-71; model.py:876-905) is written into the layer list as
  * PAR_BEGIN, the layers of member a, PAR_NEXT, the layers of member b, ..., PAR_END: every member reads the tensor in front of

@@ -472,6 +472,7 @@ struct Step {
     unsigned ws_tickets = 0, ws_epoch = 0;
     int ws_bpc = 0;
     float* d_wrecsm = nullptr;  // recurrent weights for lstm_small.hip (Hp <= 32): register-resident A fragments
+    float* d_peep = nullptr;    // ocropy peephole cell: [ndir][3 (i, f, o)][Hp] peephole weights (lstm_big_kernel)
     void* d_wrecsmx = nullptr;  // ... split bf16 for its bf16x3 variant (plans whose arithmetic is split-bf16)
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
     bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
@@ -555,11 +556,12 @@ int stage_value(const krk_plan& p, int v0, int stage, F step, std::vector<int>& 
     return v[stage];
 }
 
-void pack_lstm_recurrent(const Step& st, const float* const* whh, int M, std::vector<float>& pack) {
+// kg_force > 0: the K-group size the kernel expects whatever the block count (lstm_big_kernel: 4)
+void pack_lstm_recurrent(const Step& st, const float* const* whh, int M, std::vector<float>& pack, int kg_force = 0) {
     const int H = st.hidden, Hp = st.Hp, G = 4 * Hp;
     const int KPI = (M == 32) ? 2 : 4;
     const int NB = G / M;
-    const int KG = krk_lstm_kg(M, (NB + 3) / 4);
+    const int KG = kg_force > 0 ? kg_force : krk_lstm_kg(M, (NB + 3) / 4);
     const int KS = Hp / KPI, NG = (KS + KG - 1) / KG;
     pack.assign((size_t)st.ndir * NG * NB * 64 * KG, 0.f);
     for (int d = 0; d < st.ndir; ++d)
@@ -675,6 +677,7 @@ void free_step(Step& s) {
     if (s.d_c1w) (void)hipFree(s.d_c1w);
     if (s.d_c1b) (void)hipFree(s.d_c1b);
     if (s.d_wrecsm) (void)hipFree(s.d_wrecsm);
+    if (s.d_peep) (void)hipFree(s.d_peep);
     if (s.d_wrecsmx) (void)hipFree(s.d_wrecsmx);
     if (s.d_gamma) (void)hipFree(s.d_gamma);
     if (s.d_beta) (void)hipFree(s.d_beta);
@@ -1073,7 +1076,12 @@ int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
     s.Hp = (s.hidden + 7) / 8 * 8;
     if (s.Hp > 768)
         return fail(KRK_E_UNSUPPORTED, where + ": hidden size > 768 not implemented by the recurrent kernels");
-    const bool big = s.Hp > 256;     // lstm_big_kernel (exact f32, generic width); the projections run in the plan's arithmetic
+    // act = 1 on an LSTM layer: the legacy ocropy peephole cell (reference layers.py:72-186): w[4d + 3] holds the peephole vectors
+    // (i, f, o: 3 x hidden) instead of a second bias; the generic-width f32 kernel runs it
+    if (L.act != 0 && L.act != 1) return fail(KRK_E_INVALID, where + ": LSTM cell variant");
+    const bool peep = L.act == 1;
+    if (peep && s.ndir != 2) return fail(KRK_E_INVALID, where + ": the ocropy peephole cell is bidirectional");
+    const bool big = s.Hp > 256 || peep;   // lstm_big_kernel (exact f32, generic width); the projections run in the plan's arithmetic
     const int H_ = s.hidden, G = 4 * s.Hp;
     g.Cout = s.ndir * G;
     plan_conv_geom(g);
@@ -1086,7 +1094,7 @@ int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
                 const int col = d * G + 4 * u + gt, row = gt * H_ + u;
                 rowmap[col] = col;  // identity on the staged matrix below
                 std::memcpy(&wih[(size_t)col * C], L.w[4 * d + 0] + (size_t)row * C, (size_t)C * sizeof(float));
-                bsum[col] = L.w[4 * d + 2][row] + L.w[4 * d + 3][row];
+                bsum[col] = L.w[4 * d + 2][row] + (peep ? 0.f : L.w[4 * d + 3][row]);
             }
     if (upload_conv_weights(g, wih.data(), nullptr, &rowmap, &bsum) != KRK_OK) return KRK_E_HIP;
     if (x3) {
@@ -1103,10 +1111,17 @@ int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
         pack_lstm_recurrent(s, whh, 32, pk);
         if (upload(&s.d_wrec32, pk) != KRK_OK) return KRK_E_HIP;
     }
-    pack_lstm_recurrent(s, whh, 16, pk);
+    pack_lstm_recurrent(s, whh, 16, pk, big ? 4 : 0);      // lstm_big_kernel reads K groups of 4 at any width
     if (upload(&s.d_wrec16, pk) != KRK_OK) return KRK_E_HIP;
     if (s.rec_x3 && upload_lstm_x3(s, whh) != KRK_OK) return KRK_E_HIP;
-    if (!s.rec_x3 && krk_lstm_small_supported(s.Hp) && !getenv("KRK_NO_LSTM_SMALL")) {
+    if (peep) {
+        std::vector<float> pv((size_t)s.ndir * 3 * s.Hp, 0.f);
+        for (int d = 0; d < s.ndir; ++d)
+            for (int k = 0; k < 3; ++k)
+                std::memcpy(&pv[((size_t)d * 3 + k) * s.Hp], L.w[4 * d + 3] + (size_t)k * H_, (size_t)H_ * sizeof(float));
+        if (upload(&s.d_peep, pv) != KRK_OK) return KRK_E_HIP;
+    }
+    if (!big && !s.rec_x3 && krk_lstm_small_supported(s.Hp) && !getenv("KRK_NO_LSTM_SMALL")) {
         pack_lstm_small(s, whh, pk);
         if (upload(&s.d_wrecsm, pk) != KRK_OK) return KRK_E_HIP;
         // a split-bf16 plan runs these small recurrences on the bf16 cores too (the 2-D LSTMs of the segmenter, a small final LSTM)
@@ -1951,13 +1966,14 @@ int Pass::recurrence_f32(Step& s, float* outp, int Ns, int T, int G) {
     l.xstride = s.ndir * G;
     l.ostride = s.ndir * s.hidden;
     l.dbg = probe.lstm_dbg;
+    l.peep = s.d_peep;
     if (s.d_wrecsm) {   // hidden size <= 32: one wave per 16 sequences, weights / h / c in registers
         l.wp = s.d_wrecsm;
         l.NG = l.NB = 0;
         const int rc = s.d_wrecsmx ? krk_launch_lstm_small_x3(l, s.d_wrecsmx, stream) : krk_launch_lstm_small(l, stream);
         if (rc != -4) return rc;            // (an output of 2 GiB or more: the generic kernel below)
     }
-    if (s.Hp > 256) {   // generic-width kernel: 16-line tiles, K groups of 4 steps (krk_lstm_kg(16, > 13 blocks per wave) == 4)
+    if (s.Hp > 256 || s.d_peep) {   // generic-width kernel: 16-line tiles, K groups of 4 steps (krk_lstm_kg(16, > 13 blocks per wave) == 4)
         l.wp = s.d_wrec16;
         l.NB = G / 16;
         l.NG = (s.Hp / 4 + 3) / 4;

@@ -219,6 +219,7 @@ struct LstmArgs {
     int ndir, dirmode;    // 1|2 directions; 0 fwd, 1 rev, 2 bidi
     int xstride, ostride;
     int dbg;              // probe bits (env KRK_LSTM_DBG): 1 no GEMM, 2 no gate math, 4 no output pass, 8 no x prefetch
+    const float* peep = nullptr;   // lstm_big_kernel: [ndir][3][Hp] peephole weights of the ocropy cell (i, f, o), else null
 };
 
 // small hidden sizes (Hp <= 32, lstm_small.hip): wp = [ndir][Hp/4 blocks][Hp/4 K steps][64 lanes]

@@ -306,6 +306,30 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hcur[(KPI * (g * KG + e) + khalf) * LS + arow], w[e], acc, 0, 0, 0);
             }
             const int unit = b * 4 + ul;
+            if (a.peep) {
+                // ocropy's peephole cell (reference layers.py:72-103): i and f look at c, the output gate at the NEW c and is not
+                // squashed: c' = sig(f + w_f c) c + sig(i + w_i c) tanh(g); h = (o + w_o c') tanh(c')
+                const float* pw = a.peep + (size_t)dir * 3 * a.Hp;
+                const float wp = gate < 2 ? pw[gate * a.Hp + unit] : 0.f, wo = pw[2 * a.Hp + unit];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float cp = cs[unit * LS + irow[r]];
+                    const float z = acc[r] + wp * cp;
+                    float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * z));
+                    gv = (gate == 2) ? (2.f * gv - 1.f) : (gate == 3 ? z : gv);
+                    const float gi = quad_bcast<0x00>(gv);
+                    const float gf = quad_bcast<0x55>(gv);
+                    const float gg = quad_bcast<0xAA>(gv);
+                    const float zo = quad_bcast<0xFF>(gv);
+                    const float c = gf * cp + gi * gg;
+                    const float h = (zo + wo * c) * krk_tanh(c);
+                    if (gate == 0) {
+                        cs[unit * LS + irow[r]] = c;
+                        hnext[unit * LS + irow[r]] = h;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * acc[r]));

@@ -172,16 +172,19 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
         # an alias, layer name G_<idx>
         # 'c': the clstm layout -- a constant 1 in front of every input vector instead of biases (layers.py:498-499, 522-524,
         # nn.LSTM(bias=False)): the first weight column IS the bias; folded when the plan is compiled.  'o': ocropy's peephole cell
-        if g['legacy'] == 'o':
-            raise NotImplementedError(f'RNN variant "{block}" (legacy ocropy peephole cell) is not supported by the HIP executor')
+        # (layers.py:72-186, selected at :506-507): i and f look at c, the output gate at the new c and is NOT squashed; always
+        # bidirectional, no biases, the same constant 1 in front of the input
         hidden = int(g['out'])
+        if g['legacy'] == 'o' and g['dir'] != 'b':
+            # the reference builds PeepholeBidiLSTM whatever the direction letter and then fails to reshape its 2 x hidden outputs
+            raise ValueError(f'RNN variant "{block}": the ocropy peephole cell is bidirectional (the reference fails on any other direction)')
         if hidden > 768:
             raise NotImplementedError(f'recurrent layer "{block}": hidden sizes above 768 are not supported by the HIP recurrent kernels')
         # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523);
         # 's' keeps only the last step of every column (:537-539): (N, C, H, W) -> (N, O, 1, W)
         # on the x axis 's' keeps the last COLUMN: (N, C, H, W) -> (N, O, H, 1) (get_shape, :549-561)
         p = dict(hidden=hidden, direction=g['dir'], cell=g['cell'], axis=g['axis'], summarize=bool(g['sum']),
-                 legacy='clstm' if g['legacy'] == 'c' else None)
+                 legacy={'c': 'clstm', 'o': 'ocropy'}.get(g['legacy']))
         oc = hidden * (2 if g['dir'] == 'b' else 1)
         oshape = (n, oc, h, w) if not g['sum'] else ((n, oc, 1, w) if g['axis'] == 'y' else (n, oc, h, 1))
     else:  # output
@@ -340,10 +343,25 @@ class _GroupNormHolder(nn.Module):
         self.layer = nn.GroupNorm(spec.params['groups'], spec.in_shape[1])
 
 
+class _PeepholeParams(nn.Module):
+    """Parameter holder with the names of the reference's PeepholeBidiLSTM (layers.py:146-170): per direction weight_ih / weight_hh and
+    the three peephole vectors weight_ip / weight_fp / weight_op; no biases."""
+
+    def __init__(self, input_size: int, hidden: int):
+        super().__init__()
+        for sfx in ('', '_reverse'):
+            for name, shape in (('weight_ih', (4 * hidden, input_size)), ('weight_hh', (4 * hidden, hidden)),
+                                ('weight_ip', (hidden,)), ('weight_fp', (hidden,)), ('weight_op', (hidden,))):
+                setattr(self, f'{name}_l0{sfx}', nn.Parameter(torch.zeros(shape)))
+
+
 class _RnnHolder(nn.Module):
     def __init__(self, spec: LayerSpec):
         super().__init__()
         legacy = spec.params.get('legacy') is not None
+        if spec.params.get('legacy') == 'ocropy':
+            self.layer = _PeepholeParams(spec.in_shape[1] + 1, spec.params['hidden'])
+            return
         self.layer = nn.LSTM(spec.in_shape[1] + (1 if legacy else 0), spec.params['hidden'],
                              bidirectional=spec.params['direction'] == 'b', batch_first=True, bias=not legacy)
 
@@ -435,7 +453,11 @@ class _Plan:
                 sfx = [''] + (['_reverse'] if p['direction'] == 'b' else [])
                 for s in sfx:
                     w_ih, w_hh = _f32(getattr(mod.layer, f'weight_ih_l0{s}')), _f32(getattr(mod.layer, f'weight_hh_l0{s}'))
-                    if p.get('legacy'):      # x' = [1, x], no biases: gates = W[:, 0] + W[:, 1:] x + W_hh h
+                    if p.get('legacy') == 'ocropy':   # the same folded 1, and the peephole vectors (i, f, o) in the slot of b_hh
+                        d.act = 1                     # include/kraken_amd.h: an LSTM layer with act = 1 is the ocropy peephole cell
+                        arrays += [np.ascontiguousarray(w_ih[:, 1:]), w_hh, np.ascontiguousarray(w_ih[:, 0]),
+                                   np.concatenate([_f32(getattr(mod.layer, f'weight_{g_}p_l0{s}')) for g_ in 'ifo'])]
+                    elif p.get('legacy'):    # x' = [1, x], no biases: gates = W[:, 0] + W[:, 1:] x + W_hh h
                         arrays += [np.ascontiguousarray(w_ih[:, 1:]), w_hh, np.ascontiguousarray(w_ih[:, 0]),
                                    np.zeros(w_ih.shape[0], np.float32)]
                     else:

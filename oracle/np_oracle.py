@@ -123,7 +123,7 @@ def _sigmoid(v):
     return (1.0 / (1.0 + np.exp(-v))).astype(F32)
 
 
-def lstm(x, weights, hidden, direction='b', lens=None):
+def lstm(x, weights, hidden, direction='b', lens=None, peephole=False):
     """
     TransposedSummarizingRNN.forward, kraken/lib/vgsl/layers.py:513-547, for L{f,r,b}x on an input of
     height 1: torch.nn.LSTM(batch_first, 1 layer) over the width axis with pack_padded_sequence /
@@ -131,6 +131,8 @@ def lstm(x, weights, hidden, direction='b', lens=None):
     c' = sig(f) c + sig(i) tanh(g); h' = sig(o) tanh(c'); the reverse direction starts at each
     line's own last valid step; padded outputs are 0.
     x (N,C,1,W) -> (N, D*hidden, 1, W).  weights: list per direction of (w_ih, w_hh, b_ih, b_hh).
+    peephole: PeepholeLSTMCell, layers.py:72-103 (legacy ocropy models): i and f add w_ip c / w_fp c, the output gate adds w_op c'
+    and is NOT squashed -- hy = (o + w_op c') tanh(c'); weights[d] = (w_ih, w_hh, b_ih, (w_ip, w_fp, w_op)).
     """
     N, Cin, Hh, W = x.shape
     assert Hh == 1
@@ -140,7 +142,12 @@ def lstm(x, weights, hidden, direction='b', lens=None):
     dirs = {'f': [False], 'r': [False], 'b': [False, True], 'rev': [True]}[direction]
     out = np.zeros((N, W, hidden * len(dirs)), F32)
     for d, rev in enumerate(dirs):
-        w_ih, w_hh, b_ih, b_hh = (np.asarray(a, F32) for a in weights[d])
+        if peephole:
+            w_ih, w_hh, b_ih = (np.asarray(a, F32) for a in weights[d][:3])
+            w_ip, w_fp, w_op = (np.asarray(a, F32) for a in weights[d][3])
+            b_hh = np.zeros(4 * hidden, F32)
+        else:
+            w_ih, w_hh, b_ih, b_hh = (np.asarray(a, F32) for a in weights[d])
         xp = (seq.reshape(-1, Cin) @ w_ih.T + b_ih).reshape(N, W, 4 * hidden).astype(F32)
         for n in range(N):
             L = W if lens is None else int(lens[n])
@@ -150,13 +157,17 @@ def lstm(x, weights, hidden, direction='b', lens=None):
             for t in steps:
                 g = xp[n, t] + (w_hh @ h + b_hh).astype(F32)
                 i, f, gg, o = g[:hidden], g[hidden:2 * hidden], g[2 * hidden:3 * hidden], g[3 * hidden:]
-                c = _sigmoid(f) * c + _sigmoid(i) * np.tanh(gg).astype(F32)
-                h = _sigmoid(o) * np.tanh(c).astype(F32)
+                if peephole:
+                    c = _sigmoid(f + w_fp * c) * c + _sigmoid(i + w_ip * c) * np.tanh(gg).astype(F32)
+                    h = ((o + w_op * c) * np.tanh(c)).astype(F32)
+                else:
+                    c = _sigmoid(f) * c + _sigmoid(i) * np.tanh(gg).astype(F32)
+                    h = _sigmoid(o) * np.tanh(c).astype(F32)
                 out[n, t, d * hidden:(d + 1) * hidden] = h
     return np.ascontiguousarray(out.transpose(0, 2, 1))[:, :, None, :]
 
 
-def lstm_image(x, weights, hidden, direction='b', axis='x'):
+def lstm_image(x, weights, hidden, direction='b', axis='x', peephole=False):
     """
     TransposedSummarizingRNN.forward on a 4-D image (kraken/lib/vgsl/layers.py:519-547): with axis 'x' every image
     row (n, h) is one sequence over W (NCHW -> HNWC -> (H*N, W, C)); with axis 'y' (`transpose`, :521-523) every
@@ -165,9 +176,9 @@ def lstm_image(x, weights, hidden, direction='b', axis='x'):
     """
     N, C, H, W = x.shape
     if axis == 'y':
-        return lstm_image(x.transpose(0, 1, 3, 2), weights, hidden, direction, 'x').transpose(0, 1, 3, 2)
+        return lstm_image(x.transpose(0, 1, 3, 2), weights, hidden, direction, 'x', peephole).transpose(0, 1, 3, 2)
     rows = x.transpose(0, 2, 1, 3).reshape(N * H, C, 1, W)            # one height-1 "line" per image row
-    o = lstm(rows, weights, hidden, direction, None)                   # (N*H, D*hidden, 1, W)
+    o = lstm(rows, weights, hidden, direction, None, peephole)         # (N*H, D*hidden, 1, W)
     return np.ascontiguousarray(o[:, :, 0, :].reshape(N, H, -1, W).transpose(0, 2, 1, 3))
 
 
@@ -240,7 +251,11 @@ def forward(specs, sd, x, lens=None):
         elif k == 'rnn':
             ws = []
             for sfx in [''] + (['_reverse'] if p['direction'] == 'b' else []):
-                if p.get('legacy') == 'clstm':
+                if p.get('legacy') == 'ocropy':
+                    w_ih = np.asarray(sd[f'nn.{nm}.layer.weight_ih_l0{sfx}'], F32)
+                    ws.append((w_ih[:, 1:], sd[f'nn.{nm}.layer.weight_hh_l0{sfx}'], w_ih[:, 0],
+                               tuple(sd[f'nn.{nm}.layer.weight_{g_}p_l0{sfx}'] for g_ in 'ifo')))
+                elif p.get('legacy') == 'clstm':
                     # a constant 1 in front of every input vector, no biases (layers.py:498-499, 522-524): the first weight
                     # column acts as the bias
                     w_ih = np.asarray(sd[f'nn.{nm}.layer.weight_ih_l0{sfx}'], F32)
@@ -251,11 +266,11 @@ def forward(specs, sd, x, lens=None):
                 # rows as sequences + seq_lens: the reference raises (layers.py:528-530); columns as sequences: seq_lens pass
                 # through untouched (every column runs its full height) and the width mask below zeroes the padding columns
                 assert cur is None or p.get('axis', 'x') == 'y', 'seq_lens with an LSTM over image rows (the reference raises)'
-                x = lstm_image(x, ws, p['hidden'], p['direction'], p.get('axis', 'x'))
+                x = lstm_image(x, ws, p['hidden'], p['direction'], p.get('axis', 'x'), p.get('legacy') == 'ocropy')
                 if p.get('summarize'):                      # o[:, :, -1, :].unsqueeze(2), layers.py:537-539
                     x = x[:, :, -1:, :] if p.get('axis', 'x') == 'y' else x[:, :, :, -1:]
             else:
-                x = lstm(x, ws, p['hidden'], p['direction'], cur)
+                x = lstm(x, ws, p['hidden'], p['direction'], cur, p.get('legacy') == 'ocropy')
                 if p.get('summarize'):
                     # the reference raises when a seq_len exceeds the one column that is left (layers.py:543-545)
                     assert cur is None or max(cur) <= 1, 'Do not use summarizing layer in x-axis with batching/sequences'

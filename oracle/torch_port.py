@@ -37,6 +37,33 @@ def _mask(x, lens):
     return x * keep[:, None, None, :].to(x.dtype)
 
 
+def _peephole_bidi(seq, w, hidden, lens=None):
+    """PeepholeBidiLSTM.forward (kraken/lib/vgsl/layers.py:72-186) on (B, W, In) sequences with the reference's own tensor
+    operations per step; `lens` (the reference has no packed form of this cell): every line runs over its own valid steps, the
+    reverse direction from its own end, outputs past the end are 0 -- the masked-padding rule of this package."""
+    B, W, _ = seq.shape
+    out = torch.zeros(B, W, 2 * hidden)
+    L = torch.full((B,), W, dtype=torch.long) if lens is None else torch.as_tensor(lens).long().clamp(min=0, max=W)
+    for d, sfx in enumerate(('', '_reverse')):
+        w_ih, w_hh, w_ip, w_fp, w_op = (w[f'weight_{k}_l0{sfx}'] for k in ('ih', 'hh', 'ip', 'fp', 'op'))
+        hx, cx = torch.zeros(B, hidden), torch.zeros(B, hidden)
+        for s in range(W):
+            t = (L - 1 - s) if d == 1 else torch.full((B,), s, dtype=torch.long)
+            on = (s < L)
+            x_t = seq[torch.arange(B), t.clamp(min=0)]
+            gates = F.linear(x_t, w_ih) + F.linear(hx, w_hh)
+            i, f, g, o = gates.chunk(4, 1)
+            i = torch.sigmoid(i + w_ip.unsqueeze(0) * cx)
+            f = torch.sigmoid(f + w_fp.unsqueeze(0) * cx)
+            cy = f * cx + i * torch.tanh(g)
+            hy = (o + w_op.unsqueeze(0) * cy) * torch.tanh(cy)
+            hx = torch.where(on[:, None], hy, hx)
+            cx = torch.where(on[:, None], cy, cx)
+            idx = on.nonzero().flatten()
+            out[idx, t[idx], d * hidden:(d + 1) * hidden] = hy[idx]
+    return out
+
+
 class CpuRecognizer:
     """Executes a parsed VGSL layer list (kraken_amd.vgsl.parse_vgsl) with torch CPU operators."""
 
@@ -45,7 +72,10 @@ class CpuRecognizer:
         self.sd = {k: torch.as_tensor(v).float() for k, v in state_dict.items()}
         self.rnn = {}
         for s in self.specs:
-            if s.kind == 'rnn':
+            if s.kind == 'rnn' and s.params.get('legacy') == 'ocropy':
+                key = getattr(s, 'key', s.name)
+                self.rnn[key] = {k.split('.layer.')[1]: v for k, v in self.sd.items() if k.startswith(f'nn.{key}.layer.')}
+            elif s.kind == 'rnn':
                 legacy = s.params.get('legacy') is not None      # clstm: a 1 in front of the input, no biases (layers.py:498-511)
                 m = torch.nn.LSTM(s.in_shape[1] + (1 if legacy else 0), s.params['hidden'], bidirectional=s.params['direction'] == 'b',
                                   batch_first=True, bias=not legacy)
@@ -109,7 +139,10 @@ class CpuRecognizer:
                     seq = x.permute(2, 0, 3, 1).transpose(0, 2).reshape(w * n, h, c)
                     if s.params.get('legacy'):
                         seq = torch.cat([torch.ones(seq.shape[:2] + (1,)), seq], dim=2)
-                    o, _ = self.rnn[nm](seq)
+                    if s.params.get('legacy') == 'ocropy':
+                        o = _peephole_bidi(seq, self.rnn[nm], s.params['hidden'])
+                    else:
+                        o, _ = self.rnn[nm](seq)
                     o = o.reshape(w, n, h, -1)
                     if s.params.get('summarize'):           # keep the last step of every column (:537-539)
                         o = o[:, :, -1, :].unsqueeze(2)
@@ -120,7 +153,9 @@ class CpuRecognizer:
                 seq = x.permute(2, 0, 3, 1).reshape(h * n, w, c)
                 if s.params.get('legacy'):                  # ones in front of the features (layers.py:522-524)
                     seq = torch.cat([torch.ones(seq.shape[:2] + (1,)), seq], dim=2)
-                if cur is not None:
+                if s.params.get('legacy') == 'ocropy':
+                    o = _peephole_bidi(seq, self.rnn[nm], s.params['hidden'], cur)
+                elif cur is not None:
                     packed = pack_padded_sequence(seq, cur.cpu().clamp(min=1), batch_first=True, enforce_sorted=False)
                     o, _ = self.rnn[nm](packed)
                     o, _ = pad_packed_sequence(o, batch_first=True, total_length=w)

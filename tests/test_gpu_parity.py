@@ -27,6 +27,7 @@ CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, s
 CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes above 256, ...
 CASES.update(layer_cases('groups.npz'))       # round 4: nested [ ] / ( ) groups, Addition, x-axis summarising LSTMs
 CASES.update(layer_cases('groups_random.npz'))   # ... and 14 randomly nested networks (identity members, groups inside groups inside groups)
+CASES.update(layer_cases('forms_r5.npz'))        # round 5: the forms that were still refused (ocropy peephole cell, ...)
 
 
 def _sha(t) -> str:
@@ -108,6 +109,7 @@ def test_x3_kernels_against_reference_golden(name, prec):
 
 GROUP_NETS = layer_cases('groups.npz')
 GROUP_NETS.update(layer_cases('groups_random.npz'))
+GROUP_NETS.update(layer_cases('forms_r5.npz'))       # round 5: the ocropy peephole cell, ... (exact-f32 kernels inside a bf16x3 plan)
 
 
 @pytest.mark.parametrize('name', sorted(GROUP_NETS))
@@ -132,7 +134,7 @@ def test_groups_in_the_split_bf16_plan_against_reference_golden(name):
             x[i, ..., L:] = 0
         y, olens = m.nn(x.cuda(), torch.tensor(c['lens']))
         y = y.cpu()
-        assert olens.tolist() == c['olens'].tolist()
+        assert c['olens'] is None or olens.tolist() == c['olens'].tolist()
         for i, want in enumerate(c['ys']):
             w = want.shape[3]
             assert float((y[i:i + 1, ..., :w] - torch.from_numpy(want)).abs().max()) < tol, (name, i)

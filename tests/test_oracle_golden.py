@@ -20,6 +20,7 @@ CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, s
 CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes above 256, ...
 CASES.update(layer_cases('groups.npz'))       # round 4: nested [ ] / ( ) groups, Addition, x-axis summarising LSTMs
 CASES.update(layer_cases('groups_random.npz'))   # ... and 14 randomly nested networks (identity members, groups inside groups inside groups)
+CASES.update(layer_cases('forms_r5.npz'))        # round 5: the forms that were still refused (ocropy peephole cell, ...)
 
 
 def _zero_pad_x(x, lens):
