@@ -69,7 +69,10 @@ extern "C" {
 #define KRK_OP_PAR_BEGIN  7
 #define KRK_OP_PAR_NEXT   8
 #define KRK_OP_PAR_END    9
-#define KRK_OP_ADD        10  /* Addition layers.py:188-223: cout = chunk size, kh = 0 channels / 1 height */
+#define KRK_OP_ADD        10  /* Addition layers.py:188-223: cout = chunk size, kh = 0 channels / 1 height / 2 width */
+#define KRK_OP_CONVT      11  /* ActConv2D(transposed=True) layers.py:826-834: fields as KRK_OP_CONV (sh, sw = the up-sampling
+                               * factors); w[0] = the kernel of the EQUIVALENT convolution, (cout, cin, kh, kw) with both spatial
+                               * axes flipped -- torch's ConvTranspose2d weight (cin, cout, kh, kw) transposed and flipped */
 
 /* activations of ActConv2D (layers.py:808-825).  'sigmoid' is skipped in the
  * reference's forward (layers.py:850-852) and is therefore identical to LINEAR. */

@@ -17,7 +17,7 @@ KRK_OK = 0
 KRK_E_INVALID, KRK_E_HIP, KRK_E_NOMEM, KRK_E_UNSUPPORTED = -1, -2, -3, -4
 
 OP_CONV, OP_MAXPOOL, OP_GROUPNORM, OP_RESHAPE_HC, OP_LSTM, OP_LINEAR = 1, 2, 3, 4, 5, 6
-OP_PAR_BEGIN, OP_PAR_NEXT, OP_PAR_END, OP_ADD = 7, 8, 9, 10
+OP_PAR_BEGIN, OP_PAR_NEXT, OP_PAR_END, OP_ADD, OP_CONVT = 7, 8, 9, 10, 11
 ACT_LINEAR, ACT_RELU, ACT_TANH, ACT_LEAKY, ACT_SIGMOID, ACT_SOFTMAX = 0, 1, 2, 3, 4, 5
 DIR_FWD, DIR_REV, DIR_BIDI = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2

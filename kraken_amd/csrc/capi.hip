@@ -42,8 +42,8 @@ int fail(int code, const std::string& msg) {
             return fail(KRK_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
-enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG, S_UNSPLIT, S_ALIAS, S_CONCAT, S_ADD, S_SOFTMAXC };
-const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img", "unsplit", "alias", "concat", "add", "softmax"};
+enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG, S_UNSPLIT, S_ALIAS, S_CONCAT, S_ADD, S_SOFTMAXC, S_UPZERO };
+const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img", "unsplit", "alias", "concat", "add", "softmax", "zero_insert"};
 
 
 
@@ -509,7 +509,7 @@ struct krk_plan {
     std::vector<Step> steps;
     int nstages = 1;  // length-table rows: 0 = input widths
     // how lengths evolve: stage s+1 = f(stage s) for the steps that change the width
-    struct LenOp { int kind; int k, s, d, p; int from; };  // kind 0: conv (clamp min 1), 1: pool, 2: one column (L?xs)
+    struct LenOp { int kind; int k, s, d, p; int from; };  // kind 0: conv (clamp min 1), 1: pool, 2: one column (L?xs), 3: zero insertion of a transposed convolution ((L - 1) s + 1), 4: k columns (Addition over the width)
     std::vector<LenOp> lenops;                     // lenops[i] produces stage i+1 from stage `from` <= i (a tree: parallel groups)
     int out_stage = 0;                             // the stage of the plan's output
     DevBuf d_lens;
@@ -537,12 +537,16 @@ namespace {
 
 int width_after(const krk_plan::LenOp& op, int L) {
     if (op.kind == 2) return std::min(L, 1);
+    if (op.kind == 3) return L > 0 ? (L - 1) * op.s + 1 : 0;
+    if (op.kind == 4) return L;               // Addition.forward hands the seq_lens through untouched (reference layers.py:205-210)
     if (op.kind == 0) return std::max(conv_out(L, op.k, op.s, op.d, op.p), 1);
     return floordiv(L - (op.k - 1) - 1, op.s) + 1;
 }
 // tensor width (not clamped: shapes follow torch's conv/pool arithmetic)
 int shape_after(const krk_plan::LenOp& op, int W) {
     if (op.kind == 2) return std::min(W, 1);
+    if (op.kind == 3) return W > 0 ? (W - 1) * op.s + 1 : 0;
+    if (op.kind == 4) return op.k;
     if (op.kind == 0) return conv_out(W, op.k, op.s, op.d, op.p);
     return floordiv(W - (op.k - 1) - 1, op.s) + 1;
 }
@@ -816,7 +820,8 @@ struct PlanBuilder {
         split_fmt = false;
     }
 
-    int conv(const krk_layer& L, const std::string& where);
+    int conv(const krk_layer& L, const std::string& where, int ph_force = -1, int pw_force = -1);
+    int conv_transposed(const krk_layer& L, const std::string& where);
     int maxpool(const krk_layer& L, const std::string& where);
     int groupnorm(const krk_layer& L, const std::string& where);
     int reshape(const krk_layer& L, const std::string& where);
@@ -836,7 +841,7 @@ bool feeds_taps(const ConvGeom& g) {
 }
 
 // ActConv2D (reference layers.py:791-860), with a directly following 2x2/2 MaxPool and/or the S reshape fused in
-int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
+int PlanBuilder::conv(const krk_layer& L, const std::string& where, int ph_force, int pw_force) {
     if (seq) return fail(KRK_E_UNSUPPORTED, where + ": convolution after a sequence layer");
     if (!L.w[0] || !L.w[1]) return fail(KRK_E_INVALID, where + ": conv weights missing");
     if (L.cout <= 0 || L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0 || L.dh <= 0 || L.dw <= 0)
@@ -860,8 +865,8 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where) {
     g.H = H;
     g.Cout = L.cout;
     g.kh = L.kh; g.kw = L.kw; g.sh = L.sh; g.sw = L.sw; g.dh = L.dh; g.dw = L.dw;
-    g.ph = (L.dh * (L.kh - 1)) / 2;
-    g.pw = (L.dw * (L.kw - 1)) / 2;
+    g.ph = ph_force >= 0 ? ph_force : (L.dh * (L.kh - 1)) / 2;
+    g.pw = pw_force >= 0 ? pw_force : (L.dw * (L.kw - 1)) / 2;
     g.act = softmax ? ACT_LINEAR : map_act(L.act);
     s.len_in = stage;
     new_stage(0, L.kw, L.sw, L.dw, g.pw);
@@ -1250,9 +1255,52 @@ int PlanBuilder::par_end(const std::string& where) {
     return KRK_OK;
 }
 
+// Transposed convolution (ActConv2D(transposed=True), reference layers.py:826-834, model.py:701-712): ConvTranspose2d(stride s, padding
+// p = d (k - 1) / 2, dilation d) == zeros inserted between the input's pixels (s - 1 per gap), then an ordinary convolution with the
+// spatially flipped, (in, out)-swapped kernel, stride 1, dilation d, padding d (k - 1) - p.  The caller hands the weights over in that
+// convolution's order (kraken_amd/vgsl.py); exact f32 (nothing in kraken's recognisers uses it: correctness, not speed).
+int PlanBuilder::conv_transposed(const krk_layer& L, const std::string& where) {
+    if (seq) return fail(KRK_E_UNSUPPORTED, where + ": convolution after a sequence layer");
+    if (split_fmt) return fail(KRK_E_UNSUPPORTED, where + ": transposed convolution on split-bf16 planes");
+    if (L.kh <= 0 || L.kw <= 0 || L.sh <= 0 || L.sw <= 0 || L.dh <= 0 || L.dw <= 0) return fail(KRK_E_INVALID, where + ": bad conv geometry");
+    const int ph = (L.dh * (L.kh - 1)) / 2, pw = (L.dw * (L.kw - 1)) / 2;
+    if (L.sh > 1 || L.sw > 1) {
+        Step z;
+        z.kind = S_UPZERO;
+        z.C = C; z.H = H;
+        z.sh = L.sh; z.sw = L.sw;
+        z.outC = C;
+        z.outH = H > 0 ? (H - 1) * L.sh + 1 : 0;
+        z.len_in = stage;
+        new_stage(3, 1, L.sw, 1, 0);
+        z.len_out = stage;
+        z.out_is_seq = false;
+        H = z.outH;
+        p->steps.push_back(std::move(z));
+    }
+    krk_layer C2 = L;
+    C2.op = KRK_OP_CONV;
+    C2.sh = C2.sw = 1;
+    return conv(C2, where, L.dh * (L.kh - 1) - ph, L.dw * (L.kw - 1) - pw);
+}
+
 // Addition (reference layers.py:188-223): unfold(dim, chunk, chunk).sum(dim) -- out[j] = sum_k in[k*chunk + j]
 int PlanBuilder::addition(const krk_layer& L, const std::string& where) {
     if (split_fmt) return fail(KRK_E_UNSUPPORTED, where + ": addition on split-bf16 planes");
+    if (L.kh == 2) {     // over the width: the tensor is `chunk` columns wide from here on, the pieces are counted per call (W / chunk)
+        if (seq) return fail(KRK_E_UNSUPPORTED, where + ": addition over the width of a sequence");
+        if (L.cout < 1) return fail(KRK_E_INVALID, where + ": addition with chunk " + std::to_string(L.cout));
+        Step a;
+        a.kind = S_ADD;
+        a.C = C; a.H = H;
+        a.add_axis = 2; a.chunk = L.cout; a.nk = 0;
+        a.outC = C; a.outH = H;
+        a.len_in = stage;
+        new_stage(4, L.cout, 1, 1, 0);
+        a.len_out = stage;
+        p->steps.push_back(std::move(a));
+        return KRK_OK;
+    }
     const int size = L.kh == 0 ? C : H;
     if (L.kh < 0 || L.kh > 1 || L.cout < 1 || L.cout > size)
         return fail(KRK_E_INVALID, where + ": addition with chunk " + std::to_string(L.cout) + " on an axis of " + std::to_string(size));
@@ -1282,7 +1330,7 @@ int PlanBuilder::build() {
         if (layers[k].op == KRK_OP_GROUPNORM) last_gn = k;
         // parallel groups and additions work on fp32 tensors: like the GroupNorm part, everything up to the last of them runs on
         // the exact-f32 kernels and the split-bf16 ones take over behind it
-        if (layers[k].op == KRK_OP_GROUPNORM || (layers[k].op >= KRK_OP_PAR_BEGIN && layers[k].op <= KRK_OP_ADD) ||
+        if (layers[k].op == KRK_OP_GROUPNORM || (layers[k].op >= KRK_OP_PAR_BEGIN && layers[k].op <= KRK_OP_CONVT) ||
             (layers[k].op == KRK_OP_LSTM && layers[k].kh == 1 && layers[k].kw == 0) ||
             (layers[k].op == KRK_OP_CONV && layers[k].act == KRK_ACT_SOFTMAX))
             last_f32_only = k;
@@ -1310,6 +1358,7 @@ int PlanBuilder::build() {
             case KRK_OP_PAR_NEXT: rc = par_next(where); break;
             case KRK_OP_PAR_END: rc = par_end(where); break;
             case KRK_OP_ADD: rc = addition(L, where); break;
+            case KRK_OP_CONVT: rc = conv_transposed(L, where); break;
             default: rc = fail(KRK_E_UNSUPPORTED, where + ": unknown op " + std::to_string(L.op));
         }
         if (rc) return rc;
@@ -1779,6 +1828,9 @@ int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int W
         case S_ROWS2IMG:
             if (mark("rows2img", 0)) return kFailed;
             return krk_launch_rows2img(cur, outp, N, s.C, s.H, Win, s.yaxis, s.yaxis ? lens_at(s.len_in) : nullptr, s.last_only, stream);
+        case S_UPZERO:
+            if (mark("zero_insert", 0)) return kFailed;
+            return krk_launch_upzero(cur, outp, (size_t)N * s.C, s.H, Win, s.sh, s.sw, s.outH, Wout, stream);
         case S_SOFTMAXC:
             if (mark("softmax", 0)) return kFailed;
             return krk_launch_softmax_c(cur, outp, N, s.C, s.H, Win, lens_at(s.len_in), stream);
@@ -1786,6 +1838,11 @@ int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int W
             if (mark("add", 0)) return kFailed;
             // channels of an image: N blocks of C*H*W, pieces of chunk*H*W; channels of sequence rows: N*T rows of C, pieces of
             // chunk; height: N*C planes of H*W, pieces of chunk*W
+            if (s.add_axis == 2) {
+                if (Win < s.chunk) return hard(KRK_E_INVALID, "forward: addition over the width with chunk " + std::to_string(s.chunk) +
+                                                              " on a tensor of " + std::to_string(Win) + " columns");
+                return krk_launch_chunk_sum(cur, outp, (size_t)N * s.C * s.H, (size_t)s.chunk, Win / s.chunk, (size_t)Win, stream);
+            }
             if (s.add_axis == 1)
                 return krk_launch_chunk_sum(cur, outp, (size_t)N * s.C, (size_t)s.chunk * Win, s.nk, (size_t)s.H * Win, stream);
             if (s.out_is_seq)

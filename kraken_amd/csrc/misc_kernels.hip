@@ -645,6 +645,27 @@ int krk_launch_softmax_c(const float* x, float* y, int N, int C, int H, int W, c
     return last_ok();
 }
 
+namespace {
+// zero insertion (transposed convolution = zero insertion + convolution, capi.hip conv_transposed): HBM-bound, one thread per output
+__global__ void __launch_bounds__(256) upzero_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int sh, int sw, int Ho,
+                                                     int Wo, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int X = (int)(e % Wo), Y = (int)((e / Wo) % Ho);
+        const size_t pl = e / ((size_t)Wo * Ho);
+        const bool on = (Y % sh == 0) && (X % sw == 0);
+        y[e] = on ? x[(pl * H + Y / sh) * W + X / sw] : 0.f;
+    }
+}
+}  // namespace
+
+int krk_launch_upzero(const float* x, float* y, size_t planes, int H, int W, int sh, int sw, int Ho, int Wo, hipStream_t s) {
+    const size_t total = planes * Ho * Wo;
+    if (!total) return 0;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(upzero_kernel, dim3(blocks), dim3(256), 0, s, x, y, H, W, sh, sw, Ho, Wo, total);
+    return last_ok();
+}
+
 int krk_launch_chunk_sum(const float* x, float* y, size_t outer, size_t inner, int nk, size_t in_stride, hipStream_t s) {
     const size_t total = outer * inner;
     if (!total) return 0;

@@ -118,14 +118,19 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
     n, c, h, w = shape
     p: dict[str, Any] = {}
     if kind == 'conv':
-        if g['trans']:
-            raise NotImplementedError('transposed convolutions are not supported by the HIP executor')
         ky, kx, out = int(g['ky']), int(g['kx']), int(g['out'])
         sy, sx = (int(g['sy']), int(g['sx'])) if g['sx'] else (1, 1)
         dy, dx = (int(g['dy']), int(g['dx'])) if g['dx'] else (1, 1)
         p = dict(kernel=(ky, kx), out=out, stride=(sy, sx), dilation=(dy, dx), nl=g['nl'],
                  padding=((dy * (ky - 1)) // 2, (dx * (kx - 1)) // 2))
-        oshape = (n, out, _floor_out(h, ky, sy, dy, p['padding'][0]), _floor_out(w, kx, sx, dx, p['padding'][1]))
+        if g['trans']:
+            # ActConv2D(transposed=True) (layers.py:826-834): ConvTranspose2d with the same padding rule; its smallest output size
+            # (get_shape, layers.py:864-880, no target shape): (in - 1) s - 2 p + d (k - 1) + 1, 0 for a variable axis
+            p['transposed'] = True
+            up = lambda v, k, s_, d, pd: (v - 1) * s_ - 2 * pd + d * (k - 1) + 1 if v else 0     # noqa: E731
+            oshape = (n, out, up(h, ky, sy, dy, p['padding'][0]), up(w, kx, sx, dx, p['padding'][1]))
+        else:
+            oshape = (n, out, _floor_out(h, ky, sy, dy, p['padding'][0]), _floor_out(w, kx, sx, dx, p['padding'][1]))
     elif kind == 'maxpool':
         ky, kx = int(g['ky']), int(g['kx'])
         sy, sx = (int(g['sy']), int(g['sx'])) if g['sx'] else (ky, kx)
@@ -144,9 +149,9 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
         if dim > 3:
             raise ValueError(f'Invalid dimension {dim} in addition block')
         axis = {0: 0, 1: 2, 2: 3, 3: 1}[dim]
-        if axis in (0, 3):
-            raise NotImplementedError(f'addition "{block}" over the {"batch" if axis == 0 else "width"} axis is not supported '
-                                      'by the HIP executor (channels and height are)')
+        if axis == 0:
+            raise NotImplementedError(f'addition "{block}" over the batch axis is not supported by the HIP executor (channels, height '
+                                      'and width are): it changes the number of lines of a batch, which no seq_lens survive')
         if chunk < 1 or (shape[axis] and chunk > shape[axis]):
             raise ValueError(f'addition "{block}": chunk size {chunk} does not fit an axis of {shape[axis]} entries')
         p = dict(axis=axis, chunk=chunk)
@@ -333,8 +338,8 @@ class _ConvHolder(nn.Module):
     def __init__(self, spec: LayerSpec):
         super().__init__()
         p = spec.params
-        self.co = nn.Conv2d(spec.in_shape[1], p['out'], p['kernel'], stride=p['stride'],
-                            padding=p['padding'], dilation=p['dilation'])
+        conv = nn.ConvTranspose2d if p.get('transposed') else nn.Conv2d
+        self.co = conv(spec.in_shape[1], p['out'], p['kernel'], stride=p['stride'], padding=p['padding'], dilation=p['dilation'])
 
 
 class _GroupNormHolder(nn.Module):
@@ -430,6 +435,9 @@ class _Plan:
                 d.dh, d.dw = p['dilation']
                 d.act = _ACTS[p['nl']]
                 arrays = [_f32(mod.co.weight), _f32(mod.co.bias)]
+                if p.get('transposed'):       # the kernel of the equivalent convolution: (in, out) swapped, both spatial axes flipped
+                    d.op = _lib.OP_CONVT
+                    arrays[0] = np.ascontiguousarray(arrays[0].transpose(1, 0, 2, 3)[:, :, ::-1, ::-1])
             elif spec.kind == 'maxpool':
                 d.op = _lib.OP_MAXPOOL
                 d.kh, d.kw = p['kernel']
@@ -442,7 +450,7 @@ class _Plan:
                 d.op = _lib.OP_RESHAPE_HC
             elif spec.kind == 'add':
                 d.op = _lib.OP_ADD
-                d.kh = 1 if p['axis'] == 2 else 0              # include/kraken_amd.h: 0 = channels, 1 = height
+                d.kh = {1: 0, 2: 1, 3: 2}[p['axis']]           # include/kraken_amd.h: 0 = channels, 1 = height, 2 = width
                 d.cout = p['chunk']
             elif spec.kind == 'rnn':
                 d.op = _lib.OP_LSTM

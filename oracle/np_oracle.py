@@ -45,6 +45,46 @@ def _extent(size, k, s, d=1, p=0):
 
 
 # ------------------------------------------------------------------------------ layers
+def _activate(out, act):
+    """The non-linearity of ActConv2D (layers.py:808-825); 's' (sigmoid) is skipped in forward (:850-852)."""
+    if act == 'r':
+        out = np.maximum(out, 0)
+    elif act == 't':
+        out = np.tanh(out)
+    elif act == 'lr':
+        out = np.where(out > 0, out, F32(0.01) * out)
+    elif act == 'm':                                   # torch.nn.Softmax(dim=1), layers.py:814-816
+        e = np.exp(out - out.max(axis=1, keepdims=True)).astype(F32)
+        out = e / e.sum(axis=1, keepdims=True, dtype=F32)
+    elif act not in ('l', 's'):
+        raise NotImplementedError(act)
+    return out.astype(F32)
+
+
+def conv_transpose2d(x, w, b, stride=(1, 1), dilation=(1, 1), act='l'):
+    """
+    ActConv2D(transposed=True).forward, kraken/lib/vgsl/layers.py:826-834, 842-846: torch.nn.ConvTranspose2d with padding
+    ((dh*(kh-1))//2, (dw*(kw-1))//2), no output_size.  Restated as its definition -- every input pixel scatters w * x into the output
+    at (y*sh - ph + dy*dh, x*sw - pw + dx*dw) -- not as the zero-insertion + convolution the device runs.
+    x (N,Cin,H,W), w (Cin,Cout,kh,kw) -> (N,Cout,(H-1)sh - 2ph + dh(kh-1) + 1, ...).
+    """
+    x = np.asarray(x, F32)
+    w = np.asarray(w, F32)
+    N, Cin, H, W = x.shape
+    _, Cout, kh, kw = w.shape
+    sh, sw = stride
+    dh, dw = dilation
+    ph, pw = (dh * (kh - 1)) // 2, (dw * (kw - 1)) // 2
+    Hf, Wf = (H - 1) * sh + dh * (kh - 1) + 1, (W - 1) * sw + dw * (kw - 1) + 1        # before the padding is cut off
+    full = np.zeros((N, Cout, Hf, Wf), F32)
+    for dy in range(kh):
+        for dx in range(kw):
+            full[:, :, dy * dh: dy * dh + (H - 1) * sh + 1: sh, dx * dw: dx * dw + (W - 1) * sw + 1: sw] += \
+                np.einsum('co,nchw->nohw', w[:, :, dy, dx], x, optimize=True).astype(F32)
+    out = full[:, :, ph:Hf - ph, pw:Wf - pw] + np.asarray(b, F32)[None, :, None, None]
+    return _activate(out.astype(F32), act)
+
+
 def conv2d(x, w, b, stride=(1, 1), dilation=(1, 1), act='l'):
     """
     ActConv2D.forward, kraken/lib/vgsl/layers.py:842-860: torch.nn.Conv2d (cross-correlation) with
@@ -67,18 +107,7 @@ def conv2d(x, w, b, stride=(1, 1), dilation=(1, 1), act='l'):
             patch = xp[:, :, dy * dh: dy * dh + (Ho - 1) * sh + 1: sh, dx * dw: dx * dw + (Wo - 1) * sw + 1: sw]
             out += np.einsum('oc,nchw->nohw', wmat[:, :, dy * kw + dx], patch, optimize=True).astype(F32)
     out += np.asarray(b, F32)[None, :, None, None]
-    if act == 'r':
-        out = np.maximum(out, 0)
-    elif act == 't':
-        out = np.tanh(out)
-    elif act == 'lr':
-        out = np.where(out > 0, out, F32(0.01) * out)
-    elif act == 'm':                                   # torch.nn.Softmax(dim=1), layers.py:814-816
-        e = np.exp(out - out.max(axis=1, keepdims=True)).astype(F32)
-        out = e / e.sum(axis=1, keepdims=True, dtype=F32)
-    elif act not in ('l', 's'):
-        raise NotImplementedError(act)
-    return out.astype(F32)
+    return _activate(out, act)
 
 
 def maxpool2d(x, kernel, stride):
@@ -236,7 +265,11 @@ def forward(specs, sd, x, lens=None):
                 acc = (acc + piece).astype(F32)
             x = acc
             continue
-        if k == 'conv':
+        if k == 'conv' and p.get('transposed'):
+            x = conv_transpose2d(x, sd[f'nn.{nm}.co.weight'], sd[f'nn.{nm}.co.bias'], p['stride'], p['dilation'], p['nl'])
+            if cur is not None:       # layers.py:855: (seq_len - 1) stride - 2 padding + dilation (kernel - 1) + 1
+                cur = [(L - 1) * p['stride'][1] - 2 * p['padding'][1] + p['dilation'][1] * (p['kernel'][1] - 1) + 1 for L in cur]
+        elif k == 'conv':
             x = conv2d(x, sd[f'nn.{nm}.co.weight'], sd[f'nn.{nm}.co.bias'], p['stride'], p['dilation'], p['nl'])
             if cur is not None:
                 cur = [conv_out_len(L, p['kernel'][1], p['stride'][1], p['dilation'][1], p['padding'][1]) for L in cur]

@@ -110,7 +110,12 @@ class CpuRecognizer:
                 o = x.unfold(p['axis'], p['chunk'], p['chunk']).sum(p['axis'], keepdim=True)
                 x = o.transpose(-1, p['axis']).squeeze(-1)
                 continue
-            if s.kind == 'conv':        # layers.py:842-860
+            if s.kind == 'conv' and p.get('transposed'):     # layers.py:826-834, 842-846, 855
+                x = _ACT[p['nl']](F.conv_transpose2d(x, self.sd[f'nn.{nm}.co.weight'], self.sd[f'nn.{nm}.co.bias'],
+                                                     p['stride'], p['padding'], 0, 1, p['dilation']))
+                if cur is not None:
+                    cur = ((cur - 1) * p['stride'][1] - 2 * p['padding'][1] + p['dilation'][1] * (p['kernel'][1] - 1) + 1).int()
+            elif s.kind == 'conv':        # layers.py:842-860
                 x = _ACT[p['nl']](F.conv2d(x, self.sd[f'nn.{nm}.co.weight'], self.sd[f'nn.{nm}.co.bias'],
                                            p['stride'], p['padding'], p['dilation']))
                 if cur is not None:

@@ -237,6 +237,16 @@ FORMS_R5_CASES = {
     'peep_stack':  ('[1,8,0,1 Cr3,3,4 S1(1x0)1,3 Lbxo8 Lbx6 O1c5]', 3, 23, [23, 15, 8]),
     'peep_y':      ('[1,6,0,2 Lbyo4]', 2, 9, None),
     'peep_h40':    ('[1,1,0,20 Lbxo40 O1c7]', 2, 30, None),
+    # transposed convolutions (ActConv2D(transposed=True), layers.py:826-834; model.py:701-712): up-sampling strides, an even kernel
+    # (padding (k - 1) // 2 is one short of "same"), dilation, and inside a recogniser
+    'ct_up2':      ('[1,10,0,2 CTr3,3,6,2,2]', 2, 19, [19, 11]),
+    'ct_even':     ('[1,8,0,3 CTl4,2,5,2,3]', 2, 13, None),
+    'ct_dil':      ('[1,9,0,2 CTt3,3,4,1,2,2,1]', 1, 15, None),
+    'ct_net':      ('[1,12,0,1 Cr3,3,8 Mp2,2 CTr3,3,8,2,2 Cr3,3,4 S1(1x0)1,3 Lbx8 O1c5]', 3, 30, [30, 21, 8]),
+    # Addition over the width (layers.py:188-223): 17 columns in pieces of 5, the remainder dropped; seq_lens do not survive it in the
+    # reference either (they are handed through unchanged and exceed the new width)
+    'add_w':       ('[1,6,0,3 Cr3,3,4 A2,5]', 2, 17, None),
+    'add_w_seq':   ('[1,1,0,6 A2,8 Lfx5 O1c4]', 2, 27, None),
 }
 
 GROUP_CASES = {
