@@ -378,8 +378,15 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
     barrier()
     dt = time.perf_counter() - t0
     gather_ms = sr.gather_ms if use_dist else 0.0
+    per_rank = None
     if use_dist:
-        t = torch.tensor([dt, gather_ms], dtype=torch.float64, device=dev)
+        # every rank's own clock and gather time (tools/scale_preflight.sh logs them per rank), then the MAX over ranks for the line
+        mine = torch.tensor([dt, gather_ms], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size())]
+        torch.distributed.all_gather(every, mine)
+        per_rank = {'lines_per_s': [round(N * args.steps / float(e[0].item()), 1) for e in every],
+                    'gather_ms': [round(float(e[1].item()), 3) for e in every]}
+        t = mine.clone()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, gather_ms = float(t[0].item()), float(t[1].item())
     lines = N * args.steps * world
@@ -403,6 +410,8 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
         'chars_per_line': round(n_chars[0] / max(1, N * args.steps), 2),
         'host_us_per_line': {'codec_strings': round(1e6 * host_s[0] / max(1, N * args.steps), 3)},
     }
+    if per_rank:
+        out['per_rank'] = per_rank
     out['_first_strings'] = first[0] if first else []
     if not stub and done:
         # the host side at this text density, outside the timed region: label tuples -> LineResult (text + cut positions +
@@ -763,23 +772,6 @@ def launch_ranks(args) -> int:
     return rc
 
 
-def pin_rank_to_cpus(local_rank: int, local_world: int) -> int:
-    """
-    One rank per GPU must not mean N ranks x (intra-op threads + worker pools) on every core: rank r keeps the r-th contiguous
-    block of the CPUs this process may run on (`os.sched_setaffinity`) and caps torch's intra-op threads to it.  Returns the
-    number of CPUs the rank keeps.
-    """
-    try:
-        cpus = sorted(os.sched_getaffinity(0))
-        per = max(1, len(cpus) // max(1, local_world))
-        mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
-        os.sched_setaffinity(0, mine)
-    except (AttributeError, OSError):
-        mine = list(range(os.cpu_count() or 1))
-    torch.set_num_threads(max(1, min(8, len(mine))))
-    return len(mine)
-
-
 def main():
     args = parse()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -791,11 +783,13 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if args.share_device and (args.mode != 'engine' or args.stub_engine):
         raise SystemExit('--share-device is a plumbing run of the default mode on a real device')
-    cpus_kept = pin_rank_to_cpus(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1 else (os.cpu_count() or 1)
-    if args.share_device:
-        local_rank = 0                      # every rank on HIP device 0
     import kraken_amd
     from kraken_amd import _lib, dist as kdist
+    # rank r keeps the CPUs of its GPU's NUMA node, shared with the other ranks on that node (kraken_amd/dist.py: rank_cpu_block)
+    cpus_kept = (kdist.pin_rank_to_cpus(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1
+                 else {'cpus': os.cpu_count() or 1, 'numa_node': None, 'first_cpu': 0})
+    if args.share_device:
+        local_rank = 0                      # every rank on HIP device 0
     from kraken_amd.specs import BENCH_A, bench_codec
 
     stub = args.stub_engine

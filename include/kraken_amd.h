@@ -69,10 +69,14 @@ extern "C" {
 #define KRK_OP_PAR_BEGIN  7
 #define KRK_OP_PAR_NEXT   8
 #define KRK_OP_PAR_END    9
-#define KRK_OP_ADD        10  /* Addition layers.py:188-223: cout = chunk size, kh = 0 channels / 1 height / 2 width */
+#define KRK_OP_ADD        10  /* Addition layers.py:188-223: cout = chunk size, kh = 0 channels / 1 height / 2 width / 3 batch */
 #define KRK_OP_CONVT      11  /* ActConv2D(transposed=True) layers.py:826-834: fields as KRK_OP_CONV (sh, sw = the up-sampling
                                * factors); w[0] = the kernel of the EQUIVALENT convolution, (cout, cin, kh, kw) with both spatial
                                * axes flipped -- torch's ConvTranspose2d weight (cin, cout, kh, kw) transposed and flipped */
+#define KRK_OP_RESHAPE    12  /* Reshape layers.py:285-335 (model.py:739-777), every form other than the fused RESHAPE_HC: axes in
+                               * NCHW numbering (0 batch, 1 channels, 2 height, 3 width); kh = the axis that is split, kw x sh = its
+                               * two parts (one of them may be -1), sw = `high`, dh = `low` (one of them == kh); cout, dw = the
+                               * channels and height the layers behind it were built for (checked at the call) */
 
 /* activations of ActConv2D (layers.py:808-825).  'sigmoid' is skipped in the
  * reference's forward (layers.py:850-852) and is therefore identical to LINEAR. */
@@ -125,7 +129,10 @@ typedef struct krk_plan krk_plan;
  *            agree (KRK_E_INVALID otherwise); their widths must agree for the width of the call (checked in krk_forward, as
  *            torch.cat would); valid widths behind the group are those of its LAST member (layers.py:64-66).  Exact-f32
  *            arithmetic up to the group's end (the split-bf16 kernels may take over behind it).
- *  ADD       cout = chunk, kh = axis (0 channels, 1 height): out[j] = sum_k in[k*chunk + j], k < floor(size / chunk)
+ *  ADD       cout = chunk, kh = axis (0 channels, 1 height, 2 width, 3 batch): out[j] = sum_k in[k*chunk + j], k < floor(size / chunk)
+ *  RESHAPE   see KRK_OP_RESHAPE.  A layer that changes the batch size (ADD with kh = 3, RESHAPE touching axis 0) leaves the valid
+ *            widths as they are (one per INPUT line, like the reference's seq_lens): layers behind it see full-width lines, and the
+ *            ones the reference fails in with such seq_lens (packed LSTMs, a masked GroupNorm) fail at the call here too.
  */
 typedef struct krk_layer {
     int op;
@@ -170,9 +177,15 @@ void krk_plan_destroy(krk_plan* plan);
 /* Output geometry for an input batch of width W: channels, height, width of the
  * final layer's (N, C, H, W') output.  For a recogniser H == 1. */
 int krk_plan_out_shape(const krk_plan* plan, int W, int* C, int* H, int* Wout);
+/* ... for a batch of N lines, with the number of lines of the output (networks with a batch-changing ADD / RESHAPE layer; for
+ * every other network Nout == N and the rest is krk_plan_out_shape's).  KRK_E_INVALID when a RESHAPE does not divide (N, W). */
+int krk_plan_out_dims(const krk_plan* plan, int N, int W, int* Nout, int* C, int* H, int* Wout);
 
 /* Host-side length propagation: olens_host[n] = valid output width of line n. */
 int krk_plan_olens(const krk_plan* plan, const int* lens_host, int N, int* olens_host);
+/* ... for a batch of width W: Reshape.forward scales seq_lens by (width in front) / (width behind) OF THE BATCH (layers.py:331-332),
+ * so networks with a KRK_OP_RESHAPE layer need W (krk_plan_olens fails for them); identical to krk_plan_olens otherwise. */
+int krk_plan_olens_w(const krk_plan* plan, const int* lens_host, int N, int W, int* olens_host);
 
 /*
  * nn(x, lens): x_dev is (N, in_channels, in_height, W) f32 NCHW, right-padded;

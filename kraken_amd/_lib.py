@@ -17,7 +17,7 @@ KRK_OK = 0
 KRK_E_INVALID, KRK_E_HIP, KRK_E_NOMEM, KRK_E_UNSUPPORTED = -1, -2, -3, -4
 
 OP_CONV, OP_MAXPOOL, OP_GROUPNORM, OP_RESHAPE_HC, OP_LSTM, OP_LINEAR = 1, 2, 3, 4, 5, 6
-OP_PAR_BEGIN, OP_PAR_NEXT, OP_PAR_END, OP_ADD, OP_CONVT = 7, 8, 9, 10, 11
+OP_PAR_BEGIN, OP_PAR_NEXT, OP_PAR_END, OP_ADD, OP_CONVT, OP_RESHAPE = 7, 8, 9, 10, 11, 12
 ACT_LINEAR, ACT_RELU, ACT_TANH, ACT_LEAKY, ACT_SIGMOID, ACT_SOFTMAX = 0, 1, 2, 3, 4, 5
 DIR_FWD, DIR_REV, DIR_BIDI = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
@@ -29,7 +29,7 @@ EXPORTS = ['krk_abi_version', 'krk_last_error', 'krk_device_count', 'krk_plan_cr
            'krk_plan_layer_flops', 'krk_plan_num_steps', 'krk_plan_front_event', 'krk_plan_wait_front',
            'krk_plan_status', 'krk_prep_lines', 'krk_prep_crops', 'krk_upsample_sigmoid', 'krk_dewarp_measure', 'krk_dewarp_apply',
            'krk_prep_lines_fmt', 'krk_dewarp_measure_page', 'krk_dewarp_apply_page', 'krk_plan_has_exchange',
-           'krk_plan_set_recurrence']
+           'krk_plan_set_recurrence', 'krk_plan_out_dims', 'krk_plan_olens_w']
 
 
 class KrkLayer(C.Structure):
@@ -128,6 +128,10 @@ def load():
         lib.krk_plan_out_shape.restype = i32
         lib.krk_plan_olens.argtypes = [vp, vp, i32, vp]
         lib.krk_plan_olens.restype = i32
+        lib.krk_plan_out_dims.argtypes = [vp, i32, i32] + [C.POINTER(i32)] * 4
+        lib.krk_plan_out_dims.restype = i32
+        lib.krk_plan_olens_w.argtypes = [vp, vp, i32, i32, vp]
+        lib.krk_plan_olens_w.restype = i32
         lib.krk_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp]
         lib.krk_forward.restype = i32
         lib.krk_greedy_decode.argtypes = [vp, lng, lng, lng, i32, i32, i32, vp, i32, f32, vp, vp,

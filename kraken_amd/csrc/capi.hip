@@ -42,8 +42,8 @@ int fail(int code, const std::string& msg) {
             return fail(KRK_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
-enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG, S_UNSPLIT, S_ALIAS, S_CONCAT, S_ADD, S_SOFTMAXC, S_UPZERO };
-const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img", "unsplit", "alias", "concat", "add", "softmax", "zero_insert"};
+enum StepKind { S_CONV = 0, S_MAXPOOL, S_GN, S_TOSEQ, S_LSTM, S_LINEAR, S_IMG2ROWS, S_ROWS2IMG, S_UNSPLIT, S_ALIAS, S_CONCAT, S_ADD, S_SOFTMAXC, S_UPZERO, S_PERMUTE };
+const char* kStepNames[] = {"conv", "maxpool", "groupnorm", "to_seq", "lstm", "linear", "img2rows", "rows2img", "unsplit", "alias", "concat", "add", "softmax", "zero_insert", "reshape"};
 
 
 
@@ -485,7 +485,9 @@ struct Step {
     int src = -1;
     struct Member { int step, C, stage; };
     std::vector<Member> srcs;
-    int add_axis = 0, chunk = 0, nk = 0;
+    int add_axis = 0, chunk = 0, nk = 0;   // (add_axis 2: the width, 3: the batch -- the pieces are counted per call)
+    int reshape = -1;           // S_PERMUTE: index into krk_plan::reshapes; in_seq: the input arrives as sequence rows (N, T, C)
+    bool in_seq = false;
     int last_only = 0;          // ROWS2IMG: keep the last step of every column (summarising LSTM): output height 1; LSTM step: time steps of the rows
     // output description
     bool out_is_seq = false;
@@ -509,7 +511,15 @@ struct krk_plan {
     std::vector<Step> steps;
     int nstages = 1;  // length-table rows: 0 = input widths
     // how lengths evolve: stage s+1 = f(stage s) for the steps that change the width
-    struct LenOp { int kind; int k, s, d, p; int from; };  // kind 0: conv (clamp min 1), 1: pool, 2: one column (L?xs), 3: zero insertion of a transposed convolution ((L - 1) s + 1), 4: k columns (Addition over the width)
+    // kind 0: conv (clamp min 1), 1: pool, 2: one column (L?xs), 3: zero insertion of a transposed convolution ((L - 1) s + 1),
+    // 4: k columns (Addition over the width), 5: general Reshape number k of `reshapes` (lines AND width of the batch may change),
+    // 6: k lines (Addition over the batch)
+    struct LenOp { int kind; int k, s, d, p; int from; };
+    // Reshape (reference layers.py:285-335), axes in NCHW numbering: axis `src` is split into a x b (one of them may be -1), the part
+    // that is not kept moves in front of axis `high` / `low` and merges with it.  C, H: the static dims in front of the layer
+    struct ReshapeOp { int src, a, b, high, low, C, H; };
+    std::vector<ReshapeOp> reshapes;
+    bool batch_ops = false;                        // some layer changes the number of lines (Addition / Reshape on the batch axis)
     std::vector<LenOp> lenops;                     // lenops[i] produces stage i+1 from stage `from` <= i (a tree: parallel groups)
     int out_stage = 0;                             // the stage of the plan's output
     DevBuf d_lens;
@@ -535,29 +545,86 @@ struct krk_plan {
 
 namespace {
 
-int width_after(const krk_plan::LenOp& op, int L) {
+// Reshape.forward (reference layers.py:313-333) on shapes: `in` = (N, C, H, W) -> the 5-D view `d5`, the reference's rotation of the
+// permutation list `perm`, and the merged 4-D result `out`.  False when the parts do not divide the axis (torch's reshape raises).
+bool reshape_dims(const krk_plan::ReshapeOp& r, const int in[4], int d5[5], int perm[5], int out[4], int* dest_out = nullptr) {
+    int a = r.a, b = r.b;
+    const int size = in[r.src];
+    if (a == -1) { if (b <= 0 || size % b) return false; a = size / b; }
+    else if (b == -1) { if (a <= 0 || size % a) return false; b = size / a; }
+    if (a <= 0 || b <= 0 || (long)a * b != size) return false;
+    for (int i = 0, j = 0; i < 4; ++i) {
+        if (i == r.src) { d5[j++] = a; d5[j++] = b; }
+        else d5[j++] = in[i];
+    }
+    // "dest = low; if high != src_dim: dest = high; else: src_dim += 1", then the element at src_dim is swapped step by step to dest
+    int dest = r.low, sd = r.src;
+    if (r.high != r.src) dest = r.high; else sd += 1;
+    for (int i = 0; i < 5; ++i) perm[i] = i;
+    const int step = dest > sd ? 1 : -1;
+    for (int x = sd; x != dest; x += step) std::swap(perm[x], perm[x + step]);
+    int pd[5];
+    for (int i = 0; i < 5; ++i) pd[i] = d5[perm[i]];
+    for (int i = 0, j = 0; i < 5; ++i) {
+        if (i == dest) { out[j++] = pd[i] * pd[i + 1]; ++i; }
+        else out[j++] = pd[i];
+    }
+    if (dest_out) *dest_out = dest;
+    return true;
+}
+
+// valid width of a line behind a length-changing layer; Win / Wout: the BATCH's widths in front of / behind it (Reshape only)
+int width_after(const krk_plan& p, const krk_plan::LenOp& op, int L, int Win, int Wout) {
     if (op.kind == 2) return std::min(L, 1);
     if (op.kind == 3) return L > 0 ? (L - 1) * op.s + 1 : 0;
-    if (op.kind == 4) return L;               // Addition.forward hands the seq_lens through untouched (reference layers.py:205-210)
+    if (op.kind == 4 || op.kind == 6) return L;   // Addition.forward hands the seq_lens through untouched (reference layers.py:205-210)
+    // Reshape.forward, layers.py:331-332: (seq_len * (float(initial_len) / o.shape[3])).int() -- an int tensor times a Python float
+    // is a float32 product (the double ratio rounded to float32 first), .int() truncates
+    if (op.kind == 5) return (int)((float)L * (float)((double)Win / (double)Wout));
     if (op.kind == 0) return std::max(conv_out(L, op.k, op.s, op.d, op.p), 1);
     return floordiv(L - (op.k - 1) - 1, op.s) + 1;
 }
-// tensor width (not clamped: shapes follow torch's conv/pool arithmetic)
-int shape_after(const krk_plan::LenOp& op, int W) {
-    if (op.kind == 2) return std::min(W, 1);
-    if (op.kind == 3) return W > 0 ? (W - 1) * op.s + 1 : 0;
-    if (op.kind == 4) return op.k;
-    if (op.kind == 0) return conv_out(W, op.k, op.s, op.d, op.p);
-    return floordiv(W - (op.k - 1) - 1, op.s) + 1;
+
+// lines and width of the batch at every length stage (not clamped: shapes follow torch's conv/pool arithmetic; stage s+1 derives
+// from stage lenops[s].from <= s).  Returns the first stage that cannot be formed (a Reshape that does not divide, an Addition
+// over more lines than there are) or 0
+int stage_dims(const krk_plan& p, int N, int W, std::vector<int>& Ns, std::vector<int>& Ws) {
+    const size_t n = p.lenops.size() + 1;
+    Ns.assign(n, N);
+    Ws.assign(n, 0);
+    Ws[0] = W;
+    for (size_t s = 0; s + 1 < n; ++s) {
+        const krk_plan::LenOp& op = p.lenops[s];
+        const int w = Ws[op.from];
+        Ns[s + 1] = Ns[op.from];
+        if (op.kind == 2) Ws[s + 1] = std::min(w, 1);
+        else if (op.kind == 3) Ws[s + 1] = w > 0 ? (w - 1) * op.s + 1 : 0;
+        else if (op.kind == 4) Ws[s + 1] = op.k;
+        else if (op.kind == 5) {
+            const krk_plan::ReshapeOp& r = p.reshapes[op.k];
+            const int in[4] = {Ns[op.from], r.C, r.H, w};
+            int d5[5], perm[5], out[4];
+            if (!reshape_dims(r, in, d5, perm, out)) return (int)s + 1;
+            Ns[s + 1] = out[0];
+            Ws[s + 1] = out[3];
+        } else if (op.kind == 6) {
+            if (Ns[op.from] < op.k) return (int)s + 1;
+            Ns[s + 1] = op.k;
+            Ws[s + 1] = w;
+        } else if (op.kind == 0) Ws[s + 1] = conv_out(w, op.k, op.s, op.d, op.p);
+        else Ws[s + 1] = floordiv(w - (op.k - 1) - 1, op.s) + 1;
+    }
+    return 0;
 }
 
-// value of length stage `stage` for an input width/length v0 (stage s+1 derives from stage lenops[s].from <= s)
-template <typename F>
-int stage_value(const krk_plan& p, int v0, int stage, F step, std::vector<int>& v) {
+// valid widths of one line at every stage, before the clamp to the tensor width
+void line_widths(const krk_plan& p, int L, const std::vector<int>& Ws, std::vector<int>& v) {
     v.resize(p.lenops.size() + 1);
-    v[0] = v0;
-    for (int s = 0; s < stage; ++s) v[s + 1] = step(p.lenops[s], v[p.lenops[s].from]);
-    return v[stage];
+    v[0] = L;
+    for (size_t s = 0; s + 1 < v.size(); ++s) {
+        const krk_plan::LenOp& op = p.lenops[s];
+        v[s + 1] = width_after(p, op, v[op.from], Ws[op.from], Ws[s + 1]);
+    }
 }
 
 // kg_force > 0: the K-group size the kernel expects whatever the block count (lstm_big_kernel: 4)
@@ -825,6 +892,7 @@ struct PlanBuilder {
     int maxpool(const krk_layer& L, const std::string& where);
     int groupnorm(const krk_layer& L, const std::string& where);
     int reshape(const krk_layer& L, const std::string& where);
+    int reshape_general(const krk_layer& L, const std::string& where);
     int recurrent_or_linear(const krk_layer& L, const std::string& where);
     int linear(const krk_layer& L, const std::string& where, Step& s);
     int lstm(const krk_layer& L, const std::string& where, Step& s);
@@ -1045,6 +1113,35 @@ int PlanBuilder::reshape(const krk_layer& L, const std::string& where) {
         p->steps.back().split_rows = true;
         split_fmt = true;
     }
+    return KRK_OK;
+}
+
+// Reshape in general (reference layers.py:285-335; model.py:739-777): one axis is split in two, one part moves in front of another
+// axis and merges with it -- a permuted copy of the fp32 tensor (permute5_kernel).  Channels and height behind it are static (the
+// caller computed them like the reference's get_shape does, from the spec's input shape); lines and width follow the call.
+int PlanBuilder::reshape_general(const krk_layer& L, const std::string& where) {
+    if (split_fmt) return fail(KRK_E_UNSUPPORTED, where + ": reshape on split-bf16 planes");
+    if (L.kh < 0 || L.kh > 3 || L.sw < 0 || L.sw > 3 || L.dh < 0 || L.dh > 3 || (L.sw != L.kh && L.dh != L.kh))
+        return fail(KRK_E_INVALID, where + ": reshape: either high or low must be the source dimension");
+    if ((L.kw < 1 && L.kw != -1) || (L.sh < 1 && L.sh != -1) || (L.kw == -1 && L.sh == -1))
+        return fail(KRK_E_INVALID, where + ": reshape: part sizes");
+    if (L.cout < 1 || L.dw < 1) return fail(KRK_E_INVALID, where + ": reshape: output channels / height missing");
+    krk_plan::ReshapeOp r{L.kh, L.kw, L.sh, L.sw, L.dh, C, H};
+    Step s;
+    s.kind = S_PERMUTE;
+    s.C = C; s.H = H;
+    s.in_seq = seq;
+    s.reshape = (int)p->reshapes.size();
+    s.outC = L.cout; s.outH = L.dw;
+    s.out_is_seq = false;
+    s.len_in = stage;
+    new_stage(5, s.reshape, 1, 1, 0);
+    s.len_out = stage;
+    if (L.kh == 0 || L.sw == 0 || L.dh == 0) p->batch_ops = true;
+    p->reshapes.push_back(r);
+    p->steps.push_back(std::move(s));
+    C = L.cout; H = L.dw;
+    seq = false;
     return KRK_OK;
 }
 
@@ -1301,6 +1398,21 @@ int PlanBuilder::addition(const krk_layer& L, const std::string& where) {
         p->steps.push_back(std::move(a));
         return KRK_OK;
     }
+    if (L.kh == 3) {     // over the batch: `chunk` lines from here on; the valid widths stay those of the call's lines (krk_layer doc)
+        if (L.cout < 1) return fail(KRK_E_INVALID, where + ": addition with chunk " + std::to_string(L.cout));
+        Step a;
+        a.kind = S_ADD;
+        a.C = C; a.H = H;
+        a.add_axis = 3; a.chunk = L.cout; a.nk = 0;
+        a.out_is_seq = seq;
+        a.outC = C; a.outH = H;
+        a.len_in = stage;
+        new_stage(6, L.cout, 1, 1, 0);
+        a.len_out = stage;
+        p->batch_ops = true;
+        p->steps.push_back(std::move(a));
+        return KRK_OK;
+    }
     const int size = L.kh == 0 ? C : H;
     if (L.kh < 0 || L.kh > 1 || L.cout < 1 || L.cout > size)
         return fail(KRK_E_INVALID, where + ": addition with chunk " + std::to_string(L.cout) + " on an axis of " + std::to_string(size));
@@ -1330,7 +1442,7 @@ int PlanBuilder::build() {
         if (layers[k].op == KRK_OP_GROUPNORM) last_gn = k;
         // parallel groups and additions work on fp32 tensors: like the GroupNorm part, everything up to the last of them runs on
         // the exact-f32 kernels and the split-bf16 ones take over behind it
-        if (layers[k].op == KRK_OP_GROUPNORM || (layers[k].op >= KRK_OP_PAR_BEGIN && layers[k].op <= KRK_OP_CONVT) ||
+        if (layers[k].op == KRK_OP_GROUPNORM || (layers[k].op >= KRK_OP_PAR_BEGIN && layers[k].op <= KRK_OP_RESHAPE) ||
             (layers[k].op == KRK_OP_LSTM && layers[k].kh == 1 && layers[k].kw == 0) ||
             (layers[k].op == KRK_OP_CONV && layers[k].act == KRK_ACT_SOFTMAX))
             last_f32_only = k;
@@ -1359,6 +1471,7 @@ int PlanBuilder::build() {
             case KRK_OP_PAR_END: rc = par_end(where); break;
             case KRK_OP_ADD: rc = addition(L, where); break;
             case KRK_OP_CONVT: rc = conv_transposed(L, where); break;
+            case KRK_OP_RESHAPE: rc = reshape_general(L, where); break;
             default: rc = fail(KRK_E_UNSUPPORTED, where + ": unknown op " + std::to_string(L.op));
         }
         if (rc) return rc;
@@ -1414,24 +1527,47 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
     return KRK_OK;
 }
 
-int krk_plan_out_shape(const krk_plan* plan, int W, int* C, int* H, int* Wout) {
-    if (!plan || plan->steps.empty()) return fail(KRK_E_INVALID, "krk_plan_out_shape: null plan");
-    std::vector<int> tmp;
-    const int w = stage_value(*plan, W, plan->out_stage, shape_after, tmp);
+int krk_plan_out_dims(const krk_plan* plan, int N, int W, int* Nout, int* C, int* H, int* Wout) {
+    if (!plan || plan->steps.empty()) return fail(KRK_E_INVALID, "krk_plan_out_dims: null plan");
+    std::vector<int> Ns, Ws;
+    if (const int bad = stage_dims(*plan, N, W, Ns, Ws))
+        return fail(KRK_E_INVALID, "krk_plan_out_dims: a batch of " + std::to_string(N) + " lines of width " + std::to_string(W) +
+                                   " does not fit the " + (plan->lenops[bad - 1].kind == 6 ? "addition" : "reshape") + " of length stage " +
+                                   std::to_string(bad));
     const Step& last = plan->steps.back();
+    if (Nout) *Nout = Ns[plan->out_stage];
     if (C) *C = last.outC;
     if (H) *H = last.outH;
-    if (Wout) *Wout = w;
+    if (Wout) *Wout = Ws[plan->out_stage];
+    return KRK_OK;
+}
+
+int krk_plan_out_shape(const krk_plan* plan, int W, int* C, int* H, int* Wout) {
+    if (!plan || plan->steps.empty()) return fail(KRK_E_INVALID, "krk_plan_out_shape: null plan");
+    if (plan->batch_ops) return fail(KRK_E_INVALID, "krk_plan_out_shape: the network changes the batch size: krk_plan_out_dims");
+    return krk_plan_out_dims(plan, 1, W, nullptr, C, H, Wout);
+}
+
+int krk_plan_olens_w(const krk_plan* plan, const int* lens_host, int N, int W, int* olens_host) {
+    if (!plan || !lens_host || !olens_host || N < 0) return fail(KRK_E_INVALID, "krk_plan_olens: bad argument");
+    std::vector<int> Ns, Ws, v;
+    if (plan->reshapes.empty() && W <= 0) {
+        Ws.assign(plan->lenops.size() + 1, 0);         // no layer reads the batch's widths
+    } else if (stage_dims(*plan, N, W, Ns, Ws)) {
+        return fail(KRK_E_INVALID, "krk_plan_olens: a batch of " + std::to_string(N) + " lines of width " + std::to_string(W) +
+                                   " does not fit this network");
+    }
+    for (int n = 0; n < N; ++n) {
+        line_widths(*plan, lens_host[n], Ws, v);
+        olens_host[n] = v[plan->out_stage];
+    }
     return KRK_OK;
 }
 
 int krk_plan_olens(const krk_plan* plan, const int* lens_host, int N, int* olens_host) {
-    if (!plan || !lens_host || !olens_host || N < 0) return fail(KRK_E_INVALID, "krk_plan_olens: bad argument");
-    std::vector<int> tmp;
-    for (int n = 0; n < N; ++n) {
-        olens_host[n] = stage_value(*plan, lens_host[n], plan->out_stage, width_after, tmp);
-    }
-    return KRK_OK;
+    if (plan && !plan->reshapes.empty())
+        return fail(KRK_E_INVALID, "krk_plan_olens: a Reshape layer scales seq_lens by the batch's widths: krk_plan_olens_w");
+    return krk_plan_olens_w(plan, lens_host, N, 0, olens_host);
 }
 
 long krk_plan_workspace_bytes(const krk_plan* plan) {
@@ -1605,12 +1741,17 @@ struct Pass {
     const int* lens_host;
     bool one;                         // plain-bf16 plan: the _b1 launchers (cross terms compiled out)
     Probes probe;
-    std::vector<int> Ws;              // tensor width per length stage
-    const int* d_lens = nullptr;      // [stage][N] valid widths on the device (null: every line is full width)
+    std::vector<int> Ws, Ns;          // tensor width and lines per length stage
+    const int* d_lens = nullptr;      // [stage][N0] valid widths on the device (null: every line is full width)
+    int N0 = 0;                       // lines of the call's input (N: lines of the running step's input)
+    // stages behind a layer that changed the number of lines: the reference's seq_lens still count the INPUT's lines there
+    // (Addition / Reshape hand them through), so the kernels see full-width lines ...
+    std::vector<char> detached;
+    std::vector<char> any_short;      // ... and this says whether the reference's GroupNorm would have met a short line
     bool front_done = false;
     int err = KRK_OK;
 
-    const int* lens_at(int stage) const { return d_lens ? d_lens + (size_t)stage * N : nullptr; }
+    const int* lens_at(int stage) const { return (d_lens && !detached[stage]) ? d_lens + (size_t)stage * N0 : nullptr; }
     int hard(int code, const std::string& msg) { err = fail(code, msg); return kFailed; }
     int nomem() { return hard(KRK_E_NOMEM, "forward: workspace allocation failed"); }
     int hip(hipError_t e, const char* what) {
@@ -1639,13 +1780,22 @@ struct Pass {
     int recurrence_f32(Step& s, float* outp, int N, int T, int G);
 };
 
-// per-stage tensor widths
+// per-stage tensor widths and line counts
 int Pass::widths(int W) {
-    Ws.assign(p->nstages, 0);
-    Ws[0] = W;
+    N0 = N;
+    if (const int bad = stage_dims(*p, N, W, Ns, Ws)) {
+        const auto& op = p->lenops[bad - 1];
+        if (op.kind == 6)
+            return hard(KRK_E_INVALID, "forward: addition over the batch with chunk " + std::to_string(op.k) + " on " +
+                                       std::to_string(Ns[op.from]) + " lines");
+        return hard(KRK_E_INVALID, "forward: reshape does not divide a tensor of " + std::to_string(Ns[op.from]) + " lines of width " +
+                                   std::to_string(Ws[op.from]));
+    }
+    detached.assign(p->nstages, 0);
+    any_short.assign(p->nstages, 0);
     for (int s = 0; s + 1 < p->nstages; ++s) {
-        Ws[s + 1] = shape_after(p->lenops[s], Ws[p->lenops[s].from]);
         if (Ws[s + 1] <= 0) return hard(KRK_E_INVALID, "forward: input width " + std::to_string(W) + " too small for this network");
+        detached[s + 1] = detached[p->lenops[s].from] || Ns[s + 1] != Ns[p->lenops[s].from];
     }
     return 0;
 }
@@ -1665,14 +1815,16 @@ int Pass::upload_lens(int W) {
     // the pinned staging buffer may still be in flight from the previous call
     if (p->lens_ev_pending) { if (int r = hip(hipEventSynchronize(p->lens_ev), "hipEventSynchronize")) return r; p->lens_ev_pending = false; }
     int* hl = p->h_lens_pinned;
-    std::vector<int> raw(p->nstages);      // a line's lengths per stage before the clamp to the tensor width
+    std::vector<int> raw;                  // a line's lengths per stage before the clamp to the tensor width
     for (int n = 0; n < N; ++n) {
         const int l = lens_host[n];
         if (l < 1 || l > W) return hard(KRK_E_INVALID, "forward: lens[" + std::to_string(n) + "] outside [1, W]");
-        hl[n] = raw[0] = l;
+        line_widths(*p, l, Ws, raw);
+        hl[n] = l;
+        if (l < W) any_short[0] = 1;
         for (int s = 0; s + 1 < p->nstages; ++s) {
-            raw[s + 1] = width_after(p->lenops[s], raw[p->lenops[s].from]);
             hl[(size_t)(s + 1) * N + n] = std::max(0, std::min(raw[s + 1], Ws[s + 1]));
+            if (raw[s + 1] < Ws[s + 1]) any_short[s + 1] = 1;
         }
     }
     if (int r = hip(hipMemcpyAsync(p->d_lens.p, hl, cnt * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync")) return r;
@@ -1838,6 +1990,10 @@ int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int W
             if (mark("add", 0)) return kFailed;
             // channels of an image: N blocks of C*H*W, pieces of chunk*H*W; channels of sequence rows: N*T rows of C, pieces of
             // chunk; height: N*C planes of H*W, pieces of chunk*W
+            if (s.add_axis == 3) {      // lines: one block of N * (C H W), pieces of chunk lines (image or sequence rows alike)
+                const size_t line = (size_t)s.C * s.H * Win;
+                return krk_launch_chunk_sum(cur, outp, 1, (size_t)s.chunk * line, N / s.chunk, (size_t)N * line, stream);
+            }
             if (s.add_axis == 2) {
                 if (Win < s.chunk) return hard(KRK_E_INVALID, "forward: addition over the width with chunk " + std::to_string(s.chunk) +
                                                               " on a tensor of " + std::to_string(Win) + " columns");
@@ -1848,6 +2004,29 @@ int Pass::layout(Step& s, const float* cur, float* outp, size_t out_elems, int W
             if (s.out_is_seq)
                 return krk_launch_chunk_sum(cur, outp, (size_t)N * Win, (size_t)s.chunk, s.nk, (size_t)s.C, stream);
             return krk_launch_chunk_sum(cur, outp, (size_t)N, (size_t)s.chunk * s.H * Win, s.nk, (size_t)s.C * s.H * Win, stream);
+        }
+        case S_PERMUTE: {
+            if (mark("reshape", 0)) return kFailed;
+            const krk_plan::ReshapeOp& r = p->reshapes[s.reshape];
+            const int in[4] = {N, s.C, s.H, Win};
+            int d5[5], perm[5], out[4];
+            if (!reshape_dims(r, in, d5, perm, out)) return hard(KRK_E_INVALID, "forward: reshape does not divide the tensor");
+            if (out[1] != s.outC || out[2] != s.outH)
+                return hard(KRK_E_INVALID, "forward: reshape gives " + std::to_string(out[1]) + " channels x " + std::to_string(out[2]) +
+                                           " rows for this batch, the layers behind it were built for " + std::to_string(s.outC) + " x " +
+                                           std::to_string(s.outH) + " (the reference derives them from the spec's input shape)");
+            // element strides of the input's four axes: fp32 NCHW, or the rows (N, T, C) of a sequence layer
+            const size_t st4[4] = {(size_t)s.C * s.H * Win, s.in_seq ? (size_t)1 : (size_t)s.H * Win, (size_t)Win,
+                                   s.in_seq ? (size_t)s.C : (size_t)1};
+            size_t st5[5];
+            for (int i = 0, j = 0; i < 4; ++i) {
+                if (i == r.src) { st5[j] = st4[i] * d5[j + 1]; st5[j + 1] = st4[i]; j += 2; }
+                else st5[j++] = st4[i];
+            }
+            int pd[5];
+            size_t ps[5];
+            for (int i = 0; i < 5; ++i) { pd[i] = d5[perm[i]]; ps[i] = st5[perm[i]]; }
+            return krk_launch_permute5(cur, outp, pd, ps, stream);
         }
         default:
             return -4;
@@ -1862,6 +2041,9 @@ int Pass::concat(Step& s, const std::vector<const float*>& outs, float* outp, in
         if (Ws[m.stage] != Wout)       // torch.cat would refuse: the members' widths differ for this input width
             return hard(KRK_E_INVALID, "forward: parallel group members produce different widths (" + std::to_string(Ws[m.stage]) +
                                            " and " + std::to_string(Wout) + ")");
+        if (Ns[m.stage] != N)
+            return hard(KRK_E_INVALID, "forward: parallel group members produce different numbers of lines (" + std::to_string(Ns[m.stage]) +
+                                           " and " + std::to_string(N) + ")");
         const float* src = m.step < 0 ? nullptr : outs[m.step];
         if (!src) return hard(KRK_E_INVALID, "forward: parallel group member without an output");
         // image: N blocks of C_k*H*W floats into blocks of C*H*W; sequence rows (N, T, C): N*T blocks of C_k into rows of C
@@ -2077,9 +2259,21 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         Step& s = p->steps[si];
         const int Win = pass.Ws[s.len_in], Wout = pass.Ws[s.len_out];
         const bool is_last = (si + 1 == nsteps);
-        size_t out_elems = (size_t)N * s.outC * s.outH * Wout;
-        if (s.kind == S_CONV && s.cg.out_nhcw) out_elems = (size_t)N * s.outC * s.outH * nhcw_pitch(Wout);
-        if (s.kind == S_LSTM && s.out_tiled) out_elems = (size_t)((N + 15) / 16 * 16) * s.outC * s.outH * Wout;
+        pass.N = pass.Ns[s.len_in];                 // lines of this step's input (an Addition / Reshape on the batch axis changes them)
+        const int Nout = pass.Ns[s.len_out];
+        size_t out_elems = (size_t)Nout * s.outC * s.outH * Wout;
+        if (s.kind == S_CONV && s.cg.out_nhcw) out_elems = (size_t)Nout * s.outC * s.outH * nhcw_pitch(Wout);
+        if (s.kind == S_LSTM && s.out_tiled) out_elems = (size_t)((Nout + 15) / 16 * 16) * s.outC * s.outH * Wout;
+        // behind a layer that changed the number of lines the reference's seq_lens no longer match the tensor: its packed LSTM
+        // (pack_padded_sequence) and its masked GroupNorm (layers.py:977-984, unless every line is full width) raise
+        if (lens_host && pass.detached[s.len_in]) {
+            if (s.kind == S_LSTM && !s.img_axis)
+                return fail(KRK_E_INVALID, "forward: seq_lens of " + std::to_string(pass.N0) + " lines reach a recurrent layer behind a "
+                                           "batch-changing layer (" + std::to_string(pass.N) + " lines): the reference raises here too");
+            if (s.kind == S_GN && pass.any_short[s.len_in])
+                return fail(KRK_E_INVALID, "forward: seq_lens of " + std::to_string(pass.N0) + " lines with padding reach a GroupNorm behind "
+                                           "a batch-changing layer (" + std::to_string(pass.N) + " lines): the reference raises here too");
+        }
         if (s.kind == S_ALIAS) {      // a parallel member starts from the tensor in front of its group
             cur = s.src < 0 ? x_dev : outs[s.src];
             outs[si] = cur;
@@ -2279,6 +2473,9 @@ int krk_recognize(krk_plan* plan, const float* x_dev, const int* lens_host, int 
     if (!plan || plan->steps.empty()) return fail(KRK_E_INVALID, "krk_recognize: null plan");
     const Step& last = plan->steps.back();
     if (last.kind != S_LINEAR) return fail(KRK_E_UNSUPPORTED, "krk_recognize: the network must end in a linear (O1) layer");
+    if (plan->batch_ops)
+        return fail(KRK_E_UNSUPPORTED, "krk_recognize: the network changes the number of lines (Addition / Reshape on the batch axis): "
+                                       "its output lines are not the caller's lines; krk_forward + krk_greedy_decode");
     hipStream_t s = (hipStream_t)stream;
     const float* logits = nullptr;
     const int* d_olens = nullptr;

@@ -354,6 +354,8 @@ int krk_launch_rows2img(const float* x, float* y, int N, int C, int H, int W, in
 // torch.cat on the channel axis, one source at a time, and Addition's sum over pieces of an axis (parallel groups, `A` layers)
 int krk_launch_concat(const float* x, float* y, size_t outer, size_t inner, size_t stride, size_t off, hipStream_t s);
 int krk_launch_chunk_sum(const float* x, float* y, size_t outer, size_t inner, int nk, size_t in_stride, hipStream_t s);
+// general Reshape: y contiguous over the 5-D dims, y[c0..c4] = x[sum_i c_i * strides[i]]
+int krk_launch_permute5(const float* x, float* y, const int dims[5], const size_t strides[5], hipStream_t s);
 // zero insertion in front of a transposed convolution: y[p][y * sh][x * sw] = x[p][y][x], zeros elsewhere; planes = N * C
 int krk_launch_upzero(const float* x, float* y, size_t planes, int H, int W, int sh, int sw, int Ho, int Wo, hipStream_t s);
 // Softmax over the channels of an NCHW tensor (channel-softmax convolutions, the softmax heatmap head)

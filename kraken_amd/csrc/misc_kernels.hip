@@ -666,6 +666,35 @@ int krk_launch_upzero(const float* x, float* y, size_t planes, int H, int W, int
     return last_ok();
 }
 
+namespace {
+// Reshape in general (reference layers.py:313-330: reshape, permute, reshape): the output is contiguous over the permuted 5-D
+// dims `d`, an element comes from sum_i coord_i * st[i] of the input.  HBM-bound; consecutive threads write consecutive floats,
+// the reads are as scattered as the permutation makes them (a layer nothing in kraken's recognisers uses: correctness, not speed)
+struct Permute5 { int d[5]; size_t st[5]; };
+__global__ void __launch_bounds__(256) permute5_kernel(const float* __restrict__ x, float* __restrict__ y, Permute5 q, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        size_t r = e, off = 0;
+#pragma unroll
+        for (int i = 4; i >= 0; --i) {
+            const size_t c = r % (size_t)q.d[i];
+            r /= (size_t)q.d[i];
+            off += c * q.st[i];
+        }
+        y[e] = x[off];
+    }
+}
+}  // namespace
+
+int krk_launch_permute5(const float* x, float* y, const int dims[5], const size_t strides[5], hipStream_t s) {
+    Permute5 q;
+    size_t total = 1;
+    for (int i = 0; i < 5; ++i) { q.d[i] = dims[i]; q.st[i] = strides[i]; total *= (size_t)dims[i]; }
+    if (!total) return 0;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(permute5_kernel, dim3(blocks), dim3(256), 0, s, x, y, q, total);
+    return last_ok();
+}
+
 int krk_launch_chunk_sum(const float* x, float* y, size_t outer, size_t inner, int nk, size_t in_stride, hipStream_t s) {
     const size_t total = outer * inner;
     if (!total) return 0;

@@ -24,7 +24,7 @@ import torch.distributed as td
 from .vgsl import DecodedBatch
 
 __all__ = ['init', 'shard_bounds', 'shard_indices', 'gather_decoded', 'pack_decoded', 'unpack_decoded', 'concat_decoded',
-           'ShardedRecognizer', 'recognize_lines']
+           'ShardedRecognizer', 'recognize_lines', 'parse_cpulist', 'device_numa_nodes', 'rank_cpu_block', 'pin_rank_to_cpus']
 
 
 def init(backend: Optional[str] = None):
@@ -40,6 +40,92 @@ def init(backend: Optional[str] = None):
     # the host driver only supports dmabuf IPC (see the environment notes)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     td.init_process_group(backend=backend, init_method='env://')
+
+
+def parse_cpulist(text: str) -> list[int]:
+    """'0-3,8,10-11' (the kernel's cpulist format) -> [0, 1, 2, 3, 8, 10, 11]."""
+    cpus: list[int] = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def device_numa_nodes(pci_ids: Sequence[Optional[str]], sysfs: str = '/sys') -> list[Optional[int]]:
+    """NUMA node of every device from /sys/bus/pci/devices/<dddd:bb:dd.f>/numa_node (None: unknown, -1 in sysfs, or no such file)."""
+    nodes: list[Optional[int]] = []
+    for pid in pci_ids:
+        node = None
+        if pid:
+            try:
+                with open(os.path.join(sysfs, 'bus/pci/devices', pid.lower(), 'numa_node')) as fh:
+                    v = int(fh.read().strip())
+                node = v if v >= 0 else None
+            except (OSError, ValueError):
+                node = None
+        nodes.append(node)
+    return nodes
+
+
+def rank_cpu_block(local_rank: int, local_world: int, allowed: Sequence[int], nodes: Optional[Sequence[Optional[int]]] = None,
+                   sysfs: str = '/sys') -> list[int]:
+    """
+    The CPUs rank `local_rank` (one process per GPU) keeps for its host side (the codec, record assembly, worker pools): the CPUs of
+    ITS GPU's NUMA node -- the pinned tuple buffers and the launch path stay on the socket the device hangs on --, divided between
+    the ranks whose GPUs share that node in rank order.  `nodes[r]` = NUMA node of rank r's device (device_numa_nodes); where it is
+    unknown, or a node's cpulist holds none of the `allowed` CPUs, the rank falls back to the r-th contiguous block of `allowed`.
+    Every rank computes the same partition, so blocks never overlap between ranks of one kind (NUMA blocks / fallback blocks).
+    """
+    allowed = sorted(allowed)
+    per = max(1, len(allowed) // max(1, local_world))
+    fallback = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+    node = nodes[local_rank] if nodes is not None and local_rank < len(nodes) else None
+    if node is None:
+        return fallback
+    try:
+        with open(os.path.join(sysfs, f'devices/system/node/node{node}/cpulist')) as fh:
+            node_cpus = [c for c in parse_cpulist(fh.read()) if c in set(allowed)]
+    except (OSError, ValueError):
+        return fallback
+    peers = [r for r in range(local_world) if r < len(nodes) and nodes[r] == node]
+    share = len(node_cpus) // max(1, len(peers))
+    if share < 1:
+        return fallback
+    k = peers.index(local_rank)
+    return node_cpus[k * share:(k + 1) * share]
+
+
+def _device_pci_ids(n: int) -> list[Optional[str]]:
+    ids: list[Optional[str]] = []
+    for i in range(n):
+        try:
+            p = torch.cuda.get_device_properties(i)
+            ids.append(f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0')
+        except Exception:       # no device i / a torch without the PCI fields
+            ids.append(None)
+    return ids
+
+
+def pin_rank_to_cpus(local_rank: int, local_world: int, sysfs: str = '/sys') -> dict:
+    """
+    One rank per GPU must not mean N ranks x (intra-op threads + worker pools) on every core: the rank keeps rank_cpu_block's CPUs
+    (`os.sched_setaffinity`) and caps torch's intra-op threads to them.  Returns {'cpus': count, 'numa_node': node or None,
+    'first_cpu': ..}.
+    """
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = list(range(os.cpu_count() or 1))
+    nodes = device_numa_nodes(_device_pci_ids(local_world), sysfs) if torch.cuda.is_available() else [None] * local_world
+    mine = rank_cpu_block(local_rank, local_world, allowed, nodes, sysfs)
+    try:
+        os.sched_setaffinity(0, mine)
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(max(1, min(8, len(mine))))
+    return {'cpus': len(mine), 'numa_node': nodes[local_rank] if local_rank < len(nodes) else None, 'first_cpu': mine[0] if mine else None}
 
 
 def shard_bounds(n_items: int, world: int, rank: int) -> tuple[int, int]:

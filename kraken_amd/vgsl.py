@@ -80,6 +80,35 @@ _TYPE_TAG = {'conv': 'C', 'maxpool': 'Mp', 'groupnorm': 'Gn', 'dropout': 'Do', '
              'add': 'A'}
 
 
+def reshape_shape(shape: Sequence[int], p: dict) -> tuple:
+    """
+    Reshape.forward (reference layers.py:313-330) on a shape: axis p['src'] is split into a x b (one may be -1), the reference's
+    rotation moves one part in front of axis `high` / `low`, the two merge.  Raises like torch's reshape when the parts do not
+    divide the axis.
+    """
+    src, a, b = p['src'], p['a'], p['b']
+    size = shape[src]
+    if (a == -1 and (b < 1 or size % b)) or (b == -1 and (a < 1 or size % a)) or (a > 0 and b > 0 and a * b != size):
+        want = list(shape[:src]) + [a, b] + list(shape[src + 1:])
+        raise RuntimeError(f"shape '{want}' is invalid for input of size {int(np.prod(shape))}")
+    if a == -1:
+        a = size // b
+    elif b == -1:
+        b = size // a
+    d5 = list(shape[:src]) + [a, b] + list(shape[src + 1:])
+    dest, s_ = p['low'], src
+    if p['high'] != src:
+        dest = p['high']
+    else:
+        s_ += 1
+    perm = list(range(5))
+    step = 1 if dest > s_ else -1
+    for x in range(s_, dest, step):
+        perm[x], perm[x + step] = perm[x + step], perm[x]
+    pd = [d5[i] for i in perm]
+    return tuple(pd[:dest] + [pd[dest] * pd[dest + 1]] + pd[dest + 2:])
+
+
 def _floor_out(size: int, k: int, s: int, d: int = 1, p: int = 0) -> int:
     """Output extent of a conv / pool window along one axis (0 stays variable)."""
     if size == 0:
@@ -149,10 +178,8 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
         if dim > 3:
             raise ValueError(f'Invalid dimension {dim} in addition block')
         axis = {0: 0, 1: 2, 2: 3, 3: 1}[dim]
-        if axis == 0:
-            raise NotImplementedError(f'addition "{block}" over the batch axis is not supported by the HIP executor (channels, height '
-                                      'and width are): it changes the number of lines of a batch, which no seq_lens survive')
-        if chunk < 1 or (shape[axis] and chunk > shape[axis]):
+        # (over the batch axis the output has `chunk` lines and the seq_lens, handed through, still count the input's lines)
+        if chunk < 1 or (axis and shape[axis] and chunk > shape[axis]):     # (the spec's batch size is not the call's)
             raise ValueError(f'addition "{block}": chunk size {chunk} does not fit an axis of {shape[axis]} entries')
         p = dict(axis=axis, chunk=chunk)
         oshape = tuple(chunk if a == axis else v for a, v in enumerate(shape))
@@ -164,14 +191,22 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
             raise ValueError(f'Either high ({high}) or low ({low}) must be source dimension ({src})')
         if a == 0 and b == 0:
             raise ValueError('Only one size may be -1')
-        # the only form on the recognition path: fold height into channels, S1(1x0)1,3
-        # (feature index h*C + c)
-        if not (src == 1 and high == 1 and low == 3 and b == 0 and a == 1) or h == 0:
-            raise NotImplementedError(f'reshape "{block}" is not supported by the HIP executor '
-                                      '(only the height->channel collapse S1(1x0)1,3)')
-        p = dict(src=src, a=a, b=b, high=high, low=low)
-        # the reference derives this shape from a dummy tensor with variable dims set to 1
-        oshape = (n or 1, c * h, 1, w or 1)
+        if a == 0:
+            a = -1
+        elif b == 0:
+            b = -1
+        if src == 1 and high == 1 and low == 3 and a == 1 and b == -1 and h != 0:
+            # the form on the recognition path: fold height into channels, S1(1x0)1,3 (feature index h*C + c): fused into the
+            # convolution in front of it / one pass into sequence rows
+            p = dict(src=src, a=a, b=b, high=high, low=low)
+            # the reference derives this shape from a dummy tensor with variable dims set to 1
+            oshape = (n or 1, c * h, 1, w or 1)
+        else:
+            # every other form (Reshape.forward, layers.py:313-333; build_reshape, model.py:739-777): a permuted copy.  Axes in NCHW
+            # numbering from here on; the output shape like get_shape's: the forward arithmetic on a tensor whose variable dims are 1
+            dim_map = {0: 0, 1: 2, 2: 3, 3: 1}
+            p = dict(general=True, src=dim_map[src], a=a, b=b, high=dim_map[high], low=dim_map[low])
+            oshape = reshape_shape(tuple(v or 1 for v in shape), p)
     elif kind == 'rnn':
         # 'G' parses as a GRU but the reference builds the same torch.nn.LSTM for it (layers.py:504-511, model.py:579-593):
         # an alias, layer name G_<idx>
@@ -446,11 +481,15 @@ class _Plan:
                 d.op = _lib.OP_GROUPNORM
                 d.cout = p['groups']
                 arrays = [_f32(mod.layer.weight), _f32(mod.layer.bias)]
+            elif spec.kind == 'reshape' and p.get('general'):
+                d.op = _lib.OP_RESHAPE                         # include/kraken_amd.h: axes in NCHW numbering
+                d.kh, d.kw, d.sh, d.sw, d.dh = p['src'], p['a'], p['b'], p['high'], p['low']
+                d.cout, d.dw = spec.out_shape[1], spec.out_shape[2]
             elif spec.kind == 'reshape':
                 d.op = _lib.OP_RESHAPE_HC
             elif spec.kind == 'add':
                 d.op = _lib.OP_ADD
-                d.kh = {1: 0, 2: 1, 3: 2}[p['axis']]           # include/kraken_amd.h: 0 = channels, 1 = height, 2 = width
+                d.kh = {1: 0, 2: 1, 3: 2, 0: 3}[p['axis']]     # include/kraken_amd.h: 0 = channels, 1 = height, 2 = width, 3 = batch
                 d.cout = p['chunk']
             elif spec.kind == 'rnn':
                 d.op = _lib.OP_LSTM
@@ -477,6 +516,13 @@ class _Plan:
                 if p.get('aug'):       # y = W[:, 0] * 1 + W[:, 1:] x + b
                     w, b = np.ascontiguousarray(w[:, 1:]), (b + w[:, 0]).astype(np.float32)
                 arrays = [w, b]
+                if spec.in_shape[2] != 1:
+                    # LinSoftmax on an image of more than one row (layers.py:710-722: the features of every pixel through the same
+                    # Linear): a 1x1 convolution without activation, an image again
+                    d.op = _lib.OP_CONV
+                    d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1
+                    d.act = _lib.ACT_LINEAR
+                    arrays[0] = np.ascontiguousarray(w.reshape(w.shape[0], w.shape[1], 1, 1))
             else:
                 raise NotImplementedError(f'layer kind {spec.kind} is not supported by the HIP executor')
             for i, a in enumerate(arrays):
@@ -498,9 +544,17 @@ class _Plan:
         _lib.check(self._lib.krk_plan_out_shape(self.handle, W, C.byref(c), C.byref(h), C.byref(w)))
         return c.value, h.value, w.value
 
-    def olens(self, lens: np.ndarray) -> np.ndarray:
+    def out_dims(self, N: int, W: int):
+        """(lines, channels, height, width) of the output for a batch of N lines of width W (an Addition / Reshape on the batch axis
+        changes the number of lines)."""
+        n, c, h, w = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._lib.krk_plan_out_dims(self.handle, N, W, C.byref(n), C.byref(c), C.byref(h), C.byref(w)))
+        return n.value, c.value, h.value, w.value
+
+    def olens(self, lens: np.ndarray, W: int = 0) -> np.ndarray:
+        """seq_lens behind the network; W = the batch's width (a general Reshape scales them by the batch's widths, layers.py:331-332)."""
         out = np.empty_like(lens)
-        _lib.check(self._lib.krk_plan_olens(self.handle, lens.ctypes.data, len(lens), out.ctypes.data))
+        _lib.check(self._lib.krk_plan_olens_w(self.handle, lens.ctypes.data, len(lens), W, out.ctypes.data))
         return out
 
     def close(self):
@@ -730,10 +784,10 @@ class HipSequential(nn.Module):
         self._check_lens(lens)
         plan = self.plan(dev, xd.shape[2])
         N, _, _, W = xd.shape
-        c, h, w = plan.out_shape(W)
+        n_out, c, h, w = plan.out_dims(N, W)
         seq_out = self._specs_out_is_seq()
         with torch.cuda.device(dev):
-            out = torch.empty((N, w, c) if seq_out else (N, c, h, w), dtype=torch.float32, device=xd.device)
+            out = torch.empty((n_out, w, c) if seq_out else (n_out, c, h, w), dtype=torch.float32, device=xd.device)
             stream = torch.cuda.current_stream().cuda_stream
 
             def run():
@@ -748,7 +802,7 @@ class HipSequential(nn.Module):
                 run()
         olens = None
         if lens is not None:
-            olens = torch.from_numpy(plan.olens(lens))
+            olens = torch.from_numpy(plan.olens(lens, W))
         if seq_out:
             out = out.permute(0, 2, 1).unsqueeze(2)
         return out, olens
@@ -766,6 +820,10 @@ class HipSequential(nn.Module):
                 forks.append(seq)
             elif spec.kind == 'par_next':
                 seq = forks[-1]
+            elif spec.kind == 'reshape' and spec.params.get('general'):
+                seq = False                        # a permuted copy: an NCHW image again
+            elif spec.kind == 'linear' and spec.in_shape[2] != 1:
+                seq = False                        # ... and so is a linear layer over an image of several rows (a 1x1 convolution)
             elif spec.kind in ('reshape', 'linear'):
                 seq = True
             elif spec.kind == 'rnn':
@@ -792,7 +850,7 @@ class HipSequential(nn.Module):
         self._check_lens(lens)
         plan = self.plan(dev, xd.shape[2])
         N, _, _, W = xd.shape
-        c, h, T = plan.out_shape(W)
+        _, c, h, T = plan.out_dims(N, W)      # (a network that changes the number of lines is refused by krk_recognize below)
         with torch.cuda.device(dev):
             d = xd.device
             i32 = dict(dtype=torch.int32, device=d)

@@ -148,6 +148,31 @@ def reshape_hc(x):
     return np.ascontiguousarray(x.transpose(0, 2, 1, 3).reshape(N, H * C, 1, W))
 
 
+def reshape_general(x, p, lens=None):
+    """
+    Reshape.forward in general, kraken/lib/vgsl/layers.py:313-333 (axes in NCHW numbering, as build_reshape maps them,
+    model.py:758-775): axis `src` is split into part_a x part_b, the list of axes is rotated so that one part lands in front of axis
+    `high` / `low`, the two merge.  seq_lens are scaled by (width in front) / (width behind) -- a float32 product, truncated.
+    """
+    x = np.asarray(x, F32)
+    w0, src = x.shape[3], p['src']
+    x5 = x.reshape(x.shape[:src] + (p['a'], p['b']) + x.shape[src + 1:])      # (numpy takes -1 like torch)
+    dest = p['low']
+    if p['high'] != src:
+        dest = p['high']
+    else:
+        src += 1
+    perm = list(range(5))
+    step = 1 if dest > src else -1
+    for i in range(src, dest, step):
+        perm[i], perm[i + step] = perm[i + step], perm[i]
+    x5 = x5.transpose(perm)
+    o = np.ascontiguousarray(x5.reshape(x5.shape[:dest] + (x5.shape[dest] * x5.shape[dest + 1],) + x5.shape[dest + 2:]))
+    if lens is not None:
+        lens = [int(F32(L) * F32(float(w0) / o.shape[3])) for L in lens]
+    return o, lens
+
+
 def _sigmoid(v):
     return (1.0 / (1.0 + np.exp(-v))).astype(F32)
 
@@ -240,8 +265,18 @@ def forward(specs, sd, x, lens=None):
     cur = None if lens is None else [int(v) for v in lens]
     x = mask_width(x, cur)
     forks = []                                            # parallel groups being evaluated: [input, input lens, member outputs]
+    # Behind a layer that changes the number of lines (Addition / Reshape on the batch axis) the reference's seq_lens still count the
+    # INPUT's lines: nothing is masked any more, and the layers that use seq_lens per line fail in the reference (pack_padded_sequence;
+    # the masked GroupNorm unless every line is full width, layers.py:977-984)
+    n_in = x.shape[0]
+    detached = False
     for sp in specs:
         k, p, nm = sp.kind, sp.params, getattr(sp, 'key', sp.name)
+        if detached and cur is not None:
+            if k == 'rnn' and x.shape[2] == 1 and p.get('axis', 'x') == 'x':
+                raise ValueError('seq_lens of another batch size reach a packed LSTM (the reference raises)')
+            if k == 'groupnorm' and min(cur) < x.shape[3]:
+                raise ValueError('seq_lens of another batch size reach a masked GroupNorm (the reference raises)')
         if k == 'dropout':
             continue                                      # identity in eval, layers.py:433-437
         # MultiParamParallel.forward, layers.py:60-71: every member gets the group's input, the outputs are concatenated on the
@@ -264,6 +299,8 @@ def forward(specs, sd, x, lens=None):
             for piece in pieces[1:]:
                 acc = (acc + piece).astype(F32)
             x = acc
+            if x.shape[0] != n_in:
+                detached = True
             continue
         if k == 'conv' and p.get('transposed'):
             x = conv_transpose2d(x, sd[f'nn.{nm}.co.weight'], sd[f'nn.{nm}.co.bias'], p['stride'], p['dilation'], p['nl'])
@@ -278,7 +315,11 @@ def forward(specs, sd, x, lens=None):
             if cur is not None:
                 cur = [pool_out_len(L, p['kernel'][1], p['stride'][1]) for L in cur]
         elif k == 'groupnorm':
-            x = groupnorm(x, sd[f'nn.{nm}.layer.weight'], sd[f'nn.{nm}.layer.bias'], p['groups'], cur)
+            x = groupnorm(x, sd[f'nn.{nm}.layer.weight'], sd[f'nn.{nm}.layer.bias'], p['groups'], None if detached else cur)
+        elif k == 'reshape' and p.get('general'):
+            n0 = x.shape[0]
+            x, cur = reshape_general(x, p, cur)
+            detached = detached or x.shape[0] != n0
         elif k == 'reshape':
             x = reshape_hc(x)
         elif k == 'rnn':
@@ -303,7 +344,7 @@ def forward(specs, sd, x, lens=None):
                 if p.get('summarize'):                      # o[:, :, -1, :].unsqueeze(2), layers.py:537-539
                     x = x[:, :, -1:, :] if p.get('axis', 'x') == 'y' else x[:, :, :, -1:]
             else:
-                x = lstm(x, ws, p['hidden'], p['direction'], cur, p.get('legacy') == 'ocropy')
+                x = lstm(x, ws, p['hidden'], p['direction'], None if detached else cur, p.get('legacy') == 'ocropy')
                 if p.get('summarize'):
                     # the reference raises when a seq_len exceeds the one column that is left (layers.py:543-545)
                     assert cur is None or max(cur) <= 1, 'Do not use summarizing layer in x-axis with batching/sequences'
@@ -312,7 +353,7 @@ def forward(specs, sd, x, lens=None):
             x = linear(x, sd[f'nn.{nm}.lin.weight'], sd[f'nn.{nm}.lin.bias'])
         else:
             raise NotImplementedError(k)
-        if k not in ('linear',):
+        if k not in ('linear',) and not detached:
             x = mask_width(x, cur)
     return x, cur
 

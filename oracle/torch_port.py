@@ -92,8 +92,11 @@ class CpuRecognizer:
         if masked:
             x = _mask(x, cur)
         forks = []
+        n_in = x.shape[0]
         for s in self.specs:
             p, nm = s.params, getattr(s, 'key', s.name)
+            if x.shape[0] != n_in:
+                masked = False      # behind an Addition / Reshape on the batch axis the seq_lens no longer belong to the tensor's lines
             # MultiParamParallel.forward (layers.py:60-71): members share the input, outputs are concatenated on C, the seq_lens
             # are the last member's; Addition.forward (layers.py:205-210)
             if s.kind == 'par_begin':
@@ -131,10 +134,28 @@ class CpuRecognizer:
                 if cur is None or bool((cur >= W).all()):
                     x = F.group_norm(x, p['groups'], g, b, 1e-5)
                 else:
+                    if len(cur) != x.shape[0]:
+                        raise ValueError('seq_lens of another batch size reach a masked GroupNorm (the reference fails to broadcast)')
                     o = torch.zeros_like(x)
                     for i, L in enumerate(cur.clamp(min=1, max=W).tolist()):
                         o[i, ..., :L] = F.group_norm(x[i:i + 1, ..., :L], p['groups'], g, b, 1e-5)[0]
                     x = o
+            elif s.kind == 'reshape' and p.get('general'):      # Reshape.forward, layers.py:313-333 (axes in NCHW numbering)
+                w0, src = x.shape[3], p['src']
+                x = x.reshape(x.shape[:src] + (p['a'], p['b']) + x.shape[src + 1:])
+                dest = p['low']
+                if p['high'] != src:
+                    dest = p['high']
+                else:
+                    src += 1
+                perm = list(range(5))
+                step = 1 if dest > src else -1
+                for i in range(src, dest, step):
+                    perm[i], perm[i + step] = perm[i + step], perm[i]
+                x = x.permute(perm)
+                x = x.reshape(x.shape[:dest] + (x.shape[dest] * x.shape[dest + 1],) + x.shape[dest + 2:])
+                if cur is not None:
+                    cur = (cur * (float(w0) / x.shape[3])).int()
             elif s.kind == 'reshape':   # layers.py:313-335, S1(1x0)1,3
                 n, c, h, w = x.shape
                 x = x.permute(0, 2, 1, 3).reshape(n, h * c, 1, w)

@@ -247,6 +247,28 @@ FORMS_R5_CASES = {
     # reference either (they are handed through unchanged and exceed the new width)
     'add_w':       ('[1,6,0,3 Cr3,3,4 A2,5]', 2, 17, None),
     'add_w_seq':   ('[1,1,0,6 A2,8 Lfx5 O1c4]', 2, 27, None),
+    # Reshape in general (layers.py:285-335; build_reshape, model.py:739-777): an axis split in two, one part rotated in front of
+    # another axis and merged with it.  Fifth entry: seq_lens whose values behind the network are recorded from the reference's batched
+    # call (Reshape scales them by the ratio of the BATCH's widths; the tensors are compared without seq_lens)
+    'rs_c_b2h':    ('[1,6,0,4 S3(2x2)3,1]', 2, 7, None, [7, 5]),              # channels (2 x 2): the minor part in front of the height
+    'rs_c_a2h':    ('[1,6,0,4 S3(2x2)1,3]', 2, 7, None, [7, 5]),              # ... the major part
+    'rs_h_b2w':    ('[1,6,0,4 S1(2x3)1,2]', 2, 7, None, [7, 5]),              # height (2 x 3) into the width: three times as wide
+    'rs_h_a2w':    ('[1,6,0,4 S1(2x3)2,1]', 2, 7, None, [7, 5]),
+    'rs_w_b2c':    ('[1,6,12,4 S2(3x4)2,3]', 2, 12, None, [12, 10]),          # a fixed width (3 x 4) into the channels
+    'rs_w_a2h':    ('[1,6,12,4 S2(0x4)1,2]', 2, 12, None, [12, 10]),          # ... with one part left to the tensor (-1)
+    'rs_same':     ('[1,6,0,4 S1(2x3)1,1]', 2, 7, None, [7, 5]),              # high == low: the two parts change places
+    'rs_alt_hc':   ('[1,4,0,2 Cr3,3,3 S1(4x1)3,1 Lbx5 O1c4]', 2, 11, None, [11, 9]),   # the height collapse spelled the other way round
+    'rs_seq':      ('[1,1,0,6 Lbx4 S3(2x4)3,1 Cr3,3,5]', 2, 9, None, [9, 7]),          # behind a sequence layer: an image again
+    'rs_lin_img':  ('[1,8,0,2 Cr3,3,8 S3(2x4)1,3 O1c5]', 2, 11, None, [11, 6]),      # a linear layer over an image of 16 rows (layers.py:710-722)
+    'rs_net':      ('[1,8,0,1 Cr3,3,4 S1(2x4)1,2 Cr3,3,6 Mp2,2 S1(1x0)1,3 Lbx6 O1c5]', 3, 14, None, None),
+    # ... on the batch axis, and Addition over the batch (layers.py:188-223): the number of lines changes, the seq_lens keep
+    # counting the input's lines
+    'rs_n_b2c':    ('[4,6,0,2 S0(2x2)0,3]', 4, 9, None, [9, 7, 6, 5]),
+    'rs_h2n':      ('[1,6,0,2 S1(2x3)0,1]', 3, 9, None, [9, 7, 6]),
+    'rs_n_net':    ('[4,6,0,2 S0(2x2)0,3 Cr3,3,4 Mp2,2]', 4, 9, None, [9, 7, 6, 5]),
+    'add_n':       ('[1,6,0,2 Cr3,3,3 A0,2]', 5, 9, None, [9, 7, 6, 5, 4]),
+    'add_n_seq':   ('[1,1,0,6 Lfx5 A0,2 O1c4]', 4, 9, None, [9, 7, 6, 5]),
+    'add_n_gn':    ('[1,6,0,4 A0,3 Gn2 Cr3,3,2]', 6, 9, None, None),
 }
 
 GROUP_CASES = {
@@ -301,8 +323,9 @@ def layer_fixture(path, cases=None):
         'linear':        ('[1,1,0,20 O1c9]', 2, 13, None),
         'two_linear':    ('[1,1,0,20 O1c16 O1c36]', 2, 13, None),
     }
-    out = {'cases': json.dumps({k: {'spec': v[0], 'n': v[1], 'w': v[2], 'lens': v[3]} for k, v in cases.items()})}
-    for name, (spec, n, w, lens) in cases.items():
+    out = {'cases': json.dumps({k: {'spec': v[0], 'n': v[1], 'w': v[2], 'lens': v[3], **({'lens_probe': v[4]} if len(v) > 4 and v[4] else {})}
+                                for k, v in cases.items()})}
+    for name, (spec, n, w, lens, *probe) in cases.items():
         torch.manual_seed(hash(name) % 1000 if False else sum(map(ord, name)))
         net = ref_vgsl.TorchVGSLModel(vgsl=spec)
         net.eval()
@@ -322,6 +345,9 @@ def layer_fixture(path, cases=None):
         if lens is None:
             y, _ = net.nn(x, None)
             out[f'{name}/y'] = y.numpy()
+            if probe and probe[0]:      # the seq_lens the reference returns for this batch (the output itself is not kept)
+                _, ol = net.nn(x, torch.tensor(probe[0]))
+                out[f'{name}/olens_probe'] = ol.numpy().astype(np.int32)
         else:
             # parity target for ragged batches = each line on its own (batch 1, lens None)
             olens = []

@@ -40,6 +40,8 @@ def layer_cases(fname='layers.npz'):
             entry['vgsl'] = str(z[f'{name}/vgsl'])      # the reference's named spec (user_metadata['vgsl'])
         if meta['lens'] is None:
             entry['y'] = z[f'{name}/y']
+            if f'{name}/olens_probe' in z.files:      # seq_lens behind the network for meta['lens_probe'], from the reference's batched call
+                entry['olens_probe'] = z[f'{name}/olens_probe']
         else:
             entry['ys'] = [z[f'{name}/y{i}'] for i in range(len(meta['lens']))]
             entry['olens'] = z[f'{name}/olens'] if f'{name}/olens' in z.files else None

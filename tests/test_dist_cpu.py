@@ -190,7 +190,10 @@ def test_bench_launches_its_own_ranks_and_refuses_missing_devices():
     assert out['n_gpus'] == 2 and out['ranks_in_collective'] == 2 and out['gathered_lines'] == 2 * 5 * 8
     assert out['config']['parallelism'] == 'dp2' and 'STUB' in out['data'] and out['gather_ms'] > 0
     # every rank keeps its own block of the host's CPUs (no 8 ranks x all cores)
-    assert 1 <= out['host_cpus_per_rank'] <= max(1, len(os.sched_getaffinity(0)) // 2)
+    assert 1 <= out['host_cpus_per_rank']['cpus'] <= max(1, len(os.sched_getaffinity(0)) // 2)
+    # ... and its own clock in the line (tools/scale_preflight.sh logs them per rank)
+    assert len(out['per_rank']['lines_per_s']) == 2 and all(v > 0 for v in out['per_rank']['lines_per_s'])
+    assert min(out['per_rank']['lines_per_s']) * 2 >= out['value'] * 0.999
     # without the stub there is no device here: the launcher refuses instead of running one rank labelled as two
     import torch
     if not torch.cuda.is_available():
@@ -201,3 +204,74 @@ def test_bench_launches_its_own_ranks_and_refuses_missing_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub-engine'],
                        env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=200)
     assert r.returncode != 0
+
+
+def _fake_sysfs(root, gpu_nodes, node_cpus):
+    """A /sys stand-in: PCI devices 0000:<10+i>:00.0 with numa_node files, NUMA nodes with cpulists."""
+    ids = []
+    for i, node in enumerate(gpu_nodes):
+        pid = f'0000:{0x10 + i:02x}:00.0'
+        d = root / 'bus/pci/devices' / pid
+        d.mkdir(parents=True)
+        (d / 'numa_node').write_text(f'{node}\n')
+        ids.append(pid)
+    for node, text in node_cpus.items():
+        d = root / f'devices/system/node/node{node}'
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(text + '\n')
+    return ids
+
+
+def test_rank_cpu_blocks_follow_the_numa_node_of_the_ranks_gpu(tmp_path):
+    """Eight GPUs on two sockets (the MI355X node's shape: four GPUs per socket, hyper-thread siblings in the second half of the
+    cpulist): every rank keeps CPUs of ITS socket, the four ranks of a socket share them without overlap, all CPUs are dealt."""
+    from kraken_amd import dist as kdist
+    assert kdist.parse_cpulist('0-3,8,10-11') == [0, 1, 2, 3, 8, 10, 11]
+    ids = _fake_sysfs(tmp_path, [0, 0, 0, 0, 1, 1, 1, 1], {0: '0-63,128-191', 1: '64-127,192-255'})
+    nodes = kdist.device_numa_nodes(ids, str(tmp_path))
+    assert nodes == [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = list(range(256))
+    blocks = [kdist.rank_cpu_block(r, 8, allowed, nodes, str(tmp_path)) for r in range(8)]
+    node0 = set(kdist.parse_cpulist('0-63,128-191'))
+    for r, b in enumerate(blocks):
+        assert len(b) == 32 and (set(b) <= node0) == (r < 4)
+    assert sorted(c for b in blocks for c in b) == allowed
+    # a restricted affinity mask (a container that may use half of each socket) is respected
+    half = [c for c in allowed if c % 2 == 0]
+    blocks = [kdist.rank_cpu_block(r, 8, half, nodes, str(tmp_path)) for r in range(8)]
+    assert all(len(b) == 16 and set(b) <= set(half) for b in blocks) and len({c for b in blocks for c in b}) == 128
+    # an interleaved topology (GPU i on socket i % 2) still gives disjoint per-socket blocks
+    ids2 = _fake_sysfs(tmp_path / 'b', [0, 1, 0, 1], {0: '0-7', 1: '8-15'})
+    nodes2 = kdist.device_numa_nodes(ids2, str(tmp_path / 'b'))
+    assert [kdist.rank_cpu_block(r, 4, range(16), nodes2, str(tmp_path / 'b')) for r in range(4)] == \
+        [[0, 1, 2, 3], [8, 9, 10, 11], [4, 5, 6, 7], [12, 13, 14, 15]]
+
+
+def test_rank_cpu_blocks_fall_back_to_contiguous_blocks(tmp_path):
+    """numa_node -1 (a single-socket box, a VM), a missing sysfs entry, a device torch cannot describe: plain contiguous blocks."""
+    from kraken_amd import dist as kdist
+    ids = _fake_sysfs(tmp_path, [-1, -1], {})
+    assert kdist.device_numa_nodes(ids + [None, '0000:ff:00.0'], str(tmp_path)) == [None, None, None, None]
+    assert [kdist.rank_cpu_block(r, 2, range(8), [None, None], str(tmp_path)) for r in range(2)] == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    # a node whose cpulist holds none of the allowed CPUs
+    ids = _fake_sysfs(tmp_path / 'c', [0, 0], {0: '100-103'})
+    nodes = kdist.device_numa_nodes(ids, str(tmp_path / 'c'))
+    assert kdist.rank_cpu_block(1, 2, range(8), nodes, str(tmp_path / 'c')) == [4, 5, 6, 7]
+    info = kdist.pin_rank_to_cpus(0, 1, str(tmp_path))      # this process: one rank keeps everything it may run on
+    assert info['cpus'] == len(os.sched_getaffinity(0))
+
+
+@pytest.mark.timeout(300)
+def test_scale_preflight_script_on_the_host_stub(tmp_path):
+    """tools/scale_preflight.sh (what runs first on a multi-GPU node) with the host stub and gloo: N = 1 and 2 launched the way the
+    driver launches them (torch.distributed.run), every line checked for its rank count and backend, per-rank rates logged."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(PREFLIGHT_STUB='1', PREFLIGHT_RANKS='2', PREFLIGHT_OUT=str(tmp_path), GRAFT_REPO_ROOT=ROOT)
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'scale_preflight.sh'), '3'], env=env, capture_output=True, text=True,
+                       timeout=280)
+    summary = (tmp_path / 'summary.txt').read_text()
+    assert r.returncode == 0, r.stdout + r.stderr + summary
+    assert 'N=1: ok' in summary and 'N=2: ok' in summary and 'preflight passed' in summary
+    import json
+    two = json.loads((tmp_path / 'scale_2.json').read_text().strip().splitlines()[-1])
+    assert two['ranks_in_collective'] == 2 and two['collective_backend'] == 'gloo' and len(two['per_rank']['gather_ms']) == 2

@@ -64,6 +64,9 @@ def test_layers_against_reference_golden(name):
         assert olens is None
         assert tuple(y.shape) == c['y'].shape
         np.testing.assert_allclose(y.cpu().numpy(), c['y'], atol=2e-5, rtol=1e-4)
+        if 'olens_probe' in c:     # the seq_lens the reference's batched call returns (Reshape's width ratio, batch-changing layers)
+            _, olens = m.nn(x.cuda(), torch.tensor(c['lens_probe']))
+            assert olens.tolist() == c['olens_probe'].tolist()
     else:
         for i, L in enumerate(c['lens']):
             x[i, ..., L:] = 0
@@ -227,6 +230,34 @@ def test_parallel_members_of_different_width_fail_like_torch_cat():
     m = build_model('[1,8,0,1 (Cr3,3,4 Cr3,4,4) Mp2,2]', seed=0).to('cuda')
     with pytest.raises(kraken_amd._lib.KrakenAmdError, match='different widths'):
         m.nn(torch.rand(1, 1, 8, 20).cuda())
+
+
+def test_seq_lens_behind_a_batch_changing_layer_fail_where_the_reference_fails():
+    """Addition / Reshape on the batch axis hand the seq_lens through (layers.py:205-210, 331-333): they still count the INPUT's lines.
+    The reference's packed LSTM (pack_padded_sequence) and its masked GroupNorm (layers.py:977-984, unless every line is full width)
+    raise on them; convolutions and pools only do arithmetic.  Same here: KRK_E_INVALID at the call, the tensors without seq_lens run."""
+    import kraken_amd
+    m = build_model('[1,1,0,6 A0,2 Lfx5 O1c4]', seed=0).to('cuda')
+    x = torch.rand(4, 6, 1, 9).cuda()
+    y, _ = m.nn(x)
+    assert tuple(y.shape) == (2, 4, 1, 9)
+    with pytest.raises(kraken_amd._lib.KrakenAmdError, match='recurrent layer behind a batch-changing layer'):
+        m.nn(x, torch.tensor([9, 7, 6, 5]))
+    c = CASES['add_n_gn']
+    g = build_model(c['spec'], c['sd']).to('cuda')
+    xg = torch.from_numpy(c['x']).cuda()
+    y, olens = g.nn(xg, torch.tensor([9] * 6))             # every line full width: the reference's GroupNorm does not look at them
+    np.testing.assert_allclose(y.cpu().numpy(), c['y'], atol=2e-5, rtol=1e-4)
+    assert olens.tolist() == [9] * 6
+    with pytest.raises(kraken_amd._lib.KrakenAmdError, match='GroupNorm behind a batch-changing layer'):
+        g.nn(xg, torch.tensor([9, 7, 6, 5, 4, 3]))
+    with pytest.raises(kraken_amd._lib.KrakenAmdError, match='changes the number of lines'):
+        m.nn.recognize(x)
+    # a reshape whose channel count depends on the batch: the layers behind it were built for the spec's batch size
+    r = build_model('[4,6,0,2 S0(2x2)0,3 Cr3,3,4]', seed=0).to('cuda')
+    assert tuple(r.nn(torch.rand(4, 2, 6, 9).cuda())[0].shape) == (2, 4, 6, 9)
+    with pytest.raises(kraken_amd._lib.KrakenAmdError, match='reshape'):
+        r.nn(torch.rand(6, 2, 6, 9).cuda())
 
 
 # ------------------------------------------------------------- (1) golden: benchmark networks

@@ -38,6 +38,9 @@ def test_np_oracle_layers(name):
         y, _ = np_oracle.forward(specs, c['sd'], c['x'])
         assert y.shape == c['y'].shape
         np.testing.assert_allclose(y, c['y'], atol=LAYER_TOL, rtol=1e-4)
+        if 'olens_probe' in c:     # the seq_lens the reference's batched call returns (Reshape's width ratio, batch-changing layers)
+            _, olens = np_oracle.forward(specs, c['sd'], c['x'], c['lens_probe'])
+            assert list(olens) == c['olens_probe'].tolist()
     else:
         y, olens = np_oracle.forward(specs, c['sd'], _zero_pad_x(c['x'], c['lens']), c['lens'])
         for i, want in enumerate(c['ys']):
@@ -59,6 +62,9 @@ def test_torch_port_layers(name):
     if c['lens'] is None:
         y, _ = ref.forward(c['x'])
         np.testing.assert_allclose(y.numpy(), c['y'], atol=2e-6, rtol=1e-5)
+        if 'olens_probe' in c:
+            _, olens = ref.forward(c['x'], c['lens_probe'], reference_batched=True)
+            assert olens.tolist() == c['olens_probe'].tolist()
     else:
         y, olens = ref.forward(_zero_pad_x(c['x'], c['lens']), c['lens'])
         for i, want in enumerate(c['ys']):
