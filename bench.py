@@ -251,7 +251,10 @@ def roofline_of(engine, precision):
         cands = [c for c in cands if 'solo' not in c] or cands
         summary = cands[-1]
         tag = os.path.basename(summary)
-        pmc = json.load(open(summary))['kernels']
+        whole = json.load(open(summary))
+        pmc = whole['kernels']
+        # the clock the committed profile ran at (tools/clock_sample.py; the MFMA-busy fractions are of ACTUAL cycles)
+        sclk = ((whole.get('clock') or {}).get('sclk_mhz') or {}).get('median')
         steps_profiled = max(1, max((v.get('calls', 0) for k, v in pmc.items() if k.startswith('rowmax_rows_kernel')), default=1))
 
         def entry(kname):
@@ -273,6 +276,8 @@ def roofline_of(engine, precision):
             if v.get('mfma_util_chip') is not None:
                 e['mfma_busy_chip'] = v['mfma_util_chip']
                 e['mfma_busy_on_its_CUs'] = round(v['mfma_util_chip'] * 256.0 / cus_of(kname, v), 4)
+                if v.get('mfma_util_of_nominal_peak') is not None:
+                    e['mfma_busy_of_nominal_peak'] = v['mfma_util_of_nominal_peak']
             pmc_groups[gname] = e
         # HBM bytes of one step = sum over all profiled kernels of calls x bytes / profiled steps (one rowmax launch per step)
         tot = sum(v.get('calls', 0) * (v.get('hbm_read_MB_x2', v.get('hbm_read_MB_per_launch', 0.0)) + v.get('hbm_write_MB_per_launch', 0.0))
@@ -289,6 +294,10 @@ def roofline_of(engine, precision):
             if 'mfma_busy_chip' in d:
                 roofline['mfma_busy_chip'] = d['mfma_busy_chip']
                 roofline['mfma_busy_on_its_CUs'] = d['mfma_busy_on_its_CUs']
+            if sclk:
+                roofline['profile_sclk_mhz'] = sclk
+                roofline['profile_sclk_note'] = ('shader clock under this load in the committed profile (rocm-smi, power-capped; nominal 2400 MHz): '
+                                                 'busy fractions are of actual cycles, x sclk/2400 gives them against the nominal peak')
     except Exception:
         pass
     roofline['step_traffic'] = step_traffic
@@ -493,8 +502,9 @@ def mode_api(args, rank, local_rank):
             R.DEVICE_PREP = dev_prep
             best, reps = 0.0, []
             # the first pass creates plans, pinned buffers and the allocator's blocks; a pass is 50..100 ms of wall time, so single
-            # passes scatter (collector pauses, thread start-up): best AND median of the warm passes are reported
-            for rep in range(8 if dev_prep else 3):
+            # passes scatter (collector pauses, thread start-up): the MEDIAN of the warm passes is the number reported (what a caller of
+            # rpred sees), the best pass next to it; both preparations get the same eight passes and the same collector treatment
+            for rep in range(8):
                 with warnings.catch_warnings():
                     warnings.simplefilter('ignore')
                     t0 = time.perf_counter()
@@ -506,7 +516,7 @@ def mode_api(args, rank, local_rank):
                 assert len(recs) == n and all(r.prediction for r in recs)
                 best = max(best, n / dt)
                 reps.append(round(n / dt, 1))
-                if rep == 0 and dev_prep and not os.environ.get('KRK_API_NOFREEZE'):
+                if rep == 0 and not os.environ.get('KRK_API_NOFREEZE'):
                     # what a long-running service does once its models are loaded (gc.freeze: everything allocated so far leaves
                     # the collector's generations): without it every other 60 ms pass pays a ~55 ms full collection of the
                     # interpreter's heap (torch's modules), triggered by the ~15 container objects a record consists of
@@ -515,8 +525,8 @@ def mode_api(args, rank, local_rank):
                     gc.collect()
                     gc.freeze()
                     res['gc'] = 'gc.freeze() after the first pass'
-            res[label + '_lines_per_s'] = round(best, 1)
-            res[label + '_median_warm_pass'] = round(float(np.median(reps[2:])), 1) if len(reps) > 3 else None
+            res[label + '_lines_per_s'] = round(float(np.median(reps[2:])), 1)
+            res[label + '_best_pass'] = round(best, 1)
             res[label + '_all_passes'] = reps
         R.DEVICE_PREP = True
         # the same model with inputs resident in HBM (what the default mode measures)

@@ -16,7 +16,11 @@ crashes on images of more than one block), so it is read from the `Imaging` stru
 is private: its layout is not assumed but PROBED -- every known layout is tried and accepted only if all of xsize, ysize,
 bands, pixelsize and linesize read back as this image's, the row pointers are non-null and `linesize` apart inside a block,
 and sampled pixels equal `Image.getpixel`.  Anything else -> `None`, and the caller keeps the `np.asarray` path.
-`tests/test_host_cpu.py::test_pillow_rows_*` pin both outcomes.
+Three guards in front of the first dereference of anything the probe found (a layout whose five ints line up by accident must not
+make this module read foreign memory): Pillow's major version is one the offsets were checked against (`_TESTED_MAJORS`); the row
+table pointer `image` equals `image8` (1-byte pixels) or `image32` (4-byte pixels) -- Pillow keeps those three consistent in every
+layout -- before the table is read; and once per process and pixel size a band of rows read through the table is compared byte for
+byte with `Image.tobytes()` of the same band (`_first_use_check`).  `tests/test_host_cpu.py::test_pillow_rows_*` pin every outcome.
 """
 import ctypes
 from typing import NamedTuple, Optional
@@ -34,6 +38,10 @@ _BANDS = {'1': 1, 'L': 1, 'RGB': 3, 'RGBX': 4, 'RGBA': 4}
 #                   int pixelsize, linesize
 #   Pillow <= 11.2: char mode[6 + 1] (+ 1 byte of padding) in front of the same fields
 _LAYOUTS = ((12, 16, 20, 48, 72, 76), (16, 20, 24, 56, 80, 84))
+# Pillow major versions these offsets were checked against (9.x-12.x: the struct's head has not moved apart from the mode field);
+# any other version keeps the np.asarray path until someone has looked at its Imaging.h
+_TESTED_MAJORS = frozenset(range(9, 13))
+_VERIFIED: set = set()     # pixel sizes whose first-use band check has passed in this process
 
 
 class RowTable(NamedTuple):
@@ -66,6 +74,9 @@ def image_rows(im) -> Optional[RowTable]:
     try:
         if im.mode not in _PIXELSIZE or ctypes.sizeof(ctypes.c_void_p) != 8:
             return None
+        import PIL
+        if int(PIL.__version__.split('.')[0]) not in _TESTED_MAJORS:
+            return None
         im.load()                                                  # files are read lazily
         w, h = im.size
         if w <= 0 or h <= 0:
@@ -84,6 +95,12 @@ def image_rows(im) -> Optional[RowTable]:
             table = ctypes.c_void_p.from_address(base + o_image).value
             if not table:
                 continue
+            # char **image8, **image32, **image sit side by side; `image` is a copy of the one that fits the pixel size and the
+            # other one is NULL (libImaging/Storage.c).  Checked BEFORE the table is dereferenced
+            image8 = ctypes.c_void_p.from_address(base + o_image - 16).value
+            image32 = ctypes.c_void_p.from_address(base + o_image - 8).value
+            if (px == 1 and (image8 != table or image32)) or (px == 4 and (image32 != table or image8)):
+                continue
             rows = np.frombuffer((ctypes.c_uint64 * h).from_address(table), dtype=np.uint64).astype(np.int64)
             if (rows == 0).any():
                 continue
@@ -92,7 +109,7 @@ def image_rows(im) -> Optional[RowTable]:
             if h > 1 and (step != w * px).sum() > max(4, h // 64):
                 continue
             t = RowTable(rows, w * px, px, w, h, (im, capsule))
-            if _samples_agree(im, t):
+            if _samples_agree(im, t) and _first_use_check(im, t):
                 return t
         return None
     except Exception:
@@ -114,6 +131,28 @@ def _samples_agree(im, t: RowTable) -> bool:
         want = (want,) if isinstance(want, int) else tuple(want)
         if tuple(raw[:nb]) != want[:nb]:
             return False
+    return True
+
+
+def _first_use_check(im, t: RowTable) -> bool:
+    """
+    Once per process and pixel size: up to 64 rows from the middle of the image, read through the table, equal `Image.tobytes()` of
+    the same band (the public, slow path this module replaces) in every byte Pillow defines (the X of R, G, B, X is padding).
+    """
+    if t.pixelsize in _VERIFIED:
+        return True
+    y0 = max(0, t.height // 2 - 32)
+    y1 = min(t.height, y0 + 64)
+    got = np.empty((y1 - y0) * t.linesize, np.uint8)
+    copy_rows(t, y0, y1, got)
+    band = im.crop((0, y0, t.width, y1))
+    nb = _BANDS[im.mode]
+    if im.mode == '1':
+        band = band.convert('L')
+    want = np.frombuffer(band.tobytes(), np.uint8).reshape(y1 - y0, t.width, nb)
+    if not np.array_equal(got.reshape(y1 - y0, t.width, t.pixelsize)[:, :, :nb], want):
+        return False
+    _VERIFIED.add(t.pixelsize)
     return True
 
 

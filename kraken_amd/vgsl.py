@@ -443,6 +443,94 @@ def _f32(t: torch.Tensor) -> np.ndarray:
     return np.ascontiguousarray(t.detach().to('cpu', torch.float32).numpy())
 
 
+def layer_table(specs: Sequence[LayerSpec], modules: 'HipSequential'):
+    """
+    The `krk_layer` table of a network (include/kraken_amd.h) and the host arrays its weight pointers refer to (keep them alive until
+    krk_plan_create has returned).  No device needed: INTEGRATION.md section 3's in-tree binding builds the same table from the
+    reference's own modules, and a CPU test compares the two.
+    """
+    descs, keep = [], []
+    for spec in specs:
+        if spec.kind == 'dropout':
+            continue   # identity in eval mode (reference layers.py:433-437)
+        d = _lib.KrkLayer()
+        if spec.structural:
+            d.op = {'par_begin': _lib.OP_PAR_BEGIN, 'par_next': _lib.OP_PAR_NEXT, 'par_end': _lib.OP_PAR_END}[spec.kind]
+            descs.append(d)
+            continue
+        mod = modules.holder(spec)
+        arrays: list[np.ndarray] = []
+        p = spec.params
+        if spec.kind == 'conv':
+            d.op = _lib.OP_CONV
+            d.cout = p['out']
+            d.kh, d.kw = p['kernel']
+            d.sh, d.sw = p['stride']
+            d.dh, d.dw = p['dilation']
+            d.act = _ACTS[p['nl']]
+            arrays = [_f32(mod.co.weight), _f32(mod.co.bias)]
+            if p.get('transposed'):       # the kernel of the equivalent convolution: (in, out) swapped, both spatial axes flipped
+                d.op = _lib.OP_CONVT
+                arrays[0] = np.ascontiguousarray(arrays[0].transpose(1, 0, 2, 3)[:, :, ::-1, ::-1])
+        elif spec.kind == 'maxpool':
+            d.op = _lib.OP_MAXPOOL
+            d.kh, d.kw = p['kernel']
+            d.sh, d.sw = p['stride']
+        elif spec.kind == 'groupnorm':
+            d.op = _lib.OP_GROUPNORM
+            d.cout = p['groups']
+            arrays = [_f32(mod.layer.weight), _f32(mod.layer.bias)]
+        elif spec.kind == 'reshape' and p.get('general'):
+            d.op = _lib.OP_RESHAPE                         # include/kraken_amd.h: axes in NCHW numbering
+            d.kh, d.kw, d.sh, d.sw, d.dh = p['src'], p['a'], p['b'], p['high'], p['low']
+            d.cout, d.dw = spec.out_shape[1], spec.out_shape[2]
+        elif spec.kind == 'reshape':
+            d.op = _lib.OP_RESHAPE_HC
+        elif spec.kind == 'add':
+            d.op = _lib.OP_ADD
+            d.kh = {1: 0, 2: 1, 3: 2, 0: 3}[p['axis']]     # include/kraken_amd.h: 0 = channels, 1 = height, 2 = width, 3 = batch
+            d.cout = p['chunk']
+        elif spec.kind == 'rnn':
+            d.op = _lib.OP_LSTM
+            d.cout = p['hidden']
+            d.direction = _DIRS[p['direction']]
+            d.kw = 1 if p.get('axis', 'x') == 'y' else 0   # include/kraken_amd.h: time axis of an LSTM layer
+            d.kh = 1 if p.get('summarize') else 0          # include/kraken_amd.h: keep only the last step (L?ys / L?xs)
+            sfx = [''] + (['_reverse'] if p['direction'] == 'b' else [])
+            for s in sfx:
+                w_ih, w_hh = _f32(getattr(mod.layer, f'weight_ih_l0{s}')), _f32(getattr(mod.layer, f'weight_hh_l0{s}'))
+                if p.get('legacy') == 'ocropy':   # the same folded 1, and the peephole vectors (i, f, o) in the slot of b_hh
+                    d.act = 1                     # include/kraken_amd.h: an LSTM layer with act = 1 is the ocropy peephole cell
+                    arrays += [np.ascontiguousarray(w_ih[:, 1:]), w_hh, np.ascontiguousarray(w_ih[:, 0]),
+                               np.concatenate([_f32(getattr(mod.layer, f'weight_{g_}p_l0{s}')) for g_ in 'ifo'])]
+                elif p.get('legacy'):    # x' = [1, x], no biases: gates = W[:, 0] + W[:, 1:] x + W_hh h
+                    arrays += [np.ascontiguousarray(w_ih[:, 1:]), w_hh, np.ascontiguousarray(w_ih[:, 0]),
+                               np.zeros(w_ih.shape[0], np.float32)]
+                else:
+                    arrays += [w_ih, w_hh, _f32(getattr(mod.layer, f'bias_ih_l0{s}')), _f32(getattr(mod.layer, f'bias_hh_l0{s}'))]
+        elif spec.kind == 'linear':
+            d.op = _lib.OP_LINEAR
+            d.cout = p['out']
+            w, b = _f32(mod.lin.weight), _f32(mod.lin.bias)
+            if p.get('aug'):       # y = W[:, 0] * 1 + W[:, 1:] x + b
+                w, b = np.ascontiguousarray(w[:, 1:]), (b + w[:, 0]).astype(np.float32)
+            arrays = [w, b]
+            if spec.in_shape[2] != 1:
+                # LinSoftmax on an image of more than one row (layers.py:710-722: the features of every pixel through the same
+                # Linear): a 1x1 convolution without activation, an image again
+                d.op = _lib.OP_CONV
+                d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1
+                d.act = _lib.ACT_LINEAR
+                arrays[0] = np.ascontiguousarray(w.reshape(w.shape[0], w.shape[1], 1, 1))
+        else:
+            raise NotImplementedError(f'layer kind {spec.kind} is not supported by the HIP executor')
+        for i, a in enumerate(arrays):
+            d.w[i] = a.ctypes.data
+        keep.append(arrays)
+        descs.append(d)
+    return descs, keep
+
+
 class _Plan:
     """Owns one ``krk_plan`` handle (weights repacked + uploaded by the C library)."""
 
@@ -450,85 +538,7 @@ class _Plan:
                  device: int, precision: int = _lib.PREC_F32):
         lib = _lib.load()
         _lib.require_gpu()
-        descs, keep = [], []
-        for spec in specs:
-            if spec.kind == 'dropout':
-                continue   # identity in eval mode (reference layers.py:433-437)
-            d = _lib.KrkLayer()
-            if spec.structural:
-                d.op = {'par_begin': _lib.OP_PAR_BEGIN, 'par_next': _lib.OP_PAR_NEXT, 'par_end': _lib.OP_PAR_END}[spec.kind]
-                descs.append(d)
-                continue
-            mod = modules.holder(spec)
-            arrays: list[np.ndarray] = []
-            p = spec.params
-            if spec.kind == 'conv':
-                d.op = _lib.OP_CONV
-                d.cout = p['out']
-                d.kh, d.kw = p['kernel']
-                d.sh, d.sw = p['stride']
-                d.dh, d.dw = p['dilation']
-                d.act = _ACTS[p['nl']]
-                arrays = [_f32(mod.co.weight), _f32(mod.co.bias)]
-                if p.get('transposed'):       # the kernel of the equivalent convolution: (in, out) swapped, both spatial axes flipped
-                    d.op = _lib.OP_CONVT
-                    arrays[0] = np.ascontiguousarray(arrays[0].transpose(1, 0, 2, 3)[:, :, ::-1, ::-1])
-            elif spec.kind == 'maxpool':
-                d.op = _lib.OP_MAXPOOL
-                d.kh, d.kw = p['kernel']
-                d.sh, d.sw = p['stride']
-            elif spec.kind == 'groupnorm':
-                d.op = _lib.OP_GROUPNORM
-                d.cout = p['groups']
-                arrays = [_f32(mod.layer.weight), _f32(mod.layer.bias)]
-            elif spec.kind == 'reshape' and p.get('general'):
-                d.op = _lib.OP_RESHAPE                         # include/kraken_amd.h: axes in NCHW numbering
-                d.kh, d.kw, d.sh, d.sw, d.dh = p['src'], p['a'], p['b'], p['high'], p['low']
-                d.cout, d.dw = spec.out_shape[1], spec.out_shape[2]
-            elif spec.kind == 'reshape':
-                d.op = _lib.OP_RESHAPE_HC
-            elif spec.kind == 'add':
-                d.op = _lib.OP_ADD
-                d.kh = {1: 0, 2: 1, 3: 2, 0: 3}[p['axis']]     # include/kraken_amd.h: 0 = channels, 1 = height, 2 = width, 3 = batch
-                d.cout = p['chunk']
-            elif spec.kind == 'rnn':
-                d.op = _lib.OP_LSTM
-                d.cout = p['hidden']
-                d.direction = _DIRS[p['direction']]
-                d.kw = 1 if p.get('axis', 'x') == 'y' else 0   # include/kraken_amd.h: time axis of an LSTM layer
-                d.kh = 1 if p.get('summarize') else 0          # include/kraken_amd.h: keep only the last step (L?ys / L?xs)
-                sfx = [''] + (['_reverse'] if p['direction'] == 'b' else [])
-                for s in sfx:
-                    w_ih, w_hh = _f32(getattr(mod.layer, f'weight_ih_l0{s}')), _f32(getattr(mod.layer, f'weight_hh_l0{s}'))
-                    if p.get('legacy') == 'ocropy':   # the same folded 1, and the peephole vectors (i, f, o) in the slot of b_hh
-                        d.act = 1                     # include/kraken_amd.h: an LSTM layer with act = 1 is the ocropy peephole cell
-                        arrays += [np.ascontiguousarray(w_ih[:, 1:]), w_hh, np.ascontiguousarray(w_ih[:, 0]),
-                                   np.concatenate([_f32(getattr(mod.layer, f'weight_{g_}p_l0{s}')) for g_ in 'ifo'])]
-                    elif p.get('legacy'):    # x' = [1, x], no biases: gates = W[:, 0] + W[:, 1:] x + W_hh h
-                        arrays += [np.ascontiguousarray(w_ih[:, 1:]), w_hh, np.ascontiguousarray(w_ih[:, 0]),
-                                   np.zeros(w_ih.shape[0], np.float32)]
-                    else:
-                        arrays += [w_ih, w_hh, _f32(getattr(mod.layer, f'bias_ih_l0{s}')), _f32(getattr(mod.layer, f'bias_hh_l0{s}'))]
-            elif spec.kind == 'linear':
-                d.op = _lib.OP_LINEAR
-                d.cout = p['out']
-                w, b = _f32(mod.lin.weight), _f32(mod.lin.bias)
-                if p.get('aug'):       # y = W[:, 0] * 1 + W[:, 1:] x + b
-                    w, b = np.ascontiguousarray(w[:, 1:]), (b + w[:, 0]).astype(np.float32)
-                arrays = [w, b]
-                if spec.in_shape[2] != 1:
-                    # LinSoftmax on an image of more than one row (layers.py:710-722: the features of every pixel through the same
-                    # Linear): a 1x1 convolution without activation, an image again
-                    d.op = _lib.OP_CONV
-                    d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1
-                    d.act = _lib.ACT_LINEAR
-                    arrays[0] = np.ascontiguousarray(w.reshape(w.shape[0], w.shape[1], 1, 1))
-            else:
-                raise NotImplementedError(f'layer kind {spec.kind} is not supported by the HIP executor')
-            for i, a in enumerate(arrays):
-                d.w[i] = a.ctypes.data
-            keep.append(arrays)
-            descs.append(d)
+        descs, keep = layer_table(specs, modules)
         arr = (_lib.KrkLayer * len(descs))(*descs)
         handle = C.c_void_p()
         _lib.check(lib.krk_plan_create(arr, len(descs), in_channels, in_height, precision, device, C.byref(handle)))

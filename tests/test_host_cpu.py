@@ -555,6 +555,35 @@ def test_pillow_rows_refuse_what_they_cannot_verify(monkeypatch):
     monkeypatch.setattr(pilmem, '_samples_agree', lambda im_, t: False)      # pixels that do not read back: refused as well
     assert pilmem.image_rows(im) is None
     monkeypatch.undo()
+    # a Pillow version nobody has checked the struct of
+    import PIL
+    monkeypatch.setattr(PIL, '__version__', '99.0.0')
+    assert pilmem.image_rows(im) is None
+    monkeypatch.undo()
+    # the first use per process and pixel size compares a band with Image.tobytes(): a table that passes the pixel samples but not
+    # that comparison is refused (and nothing is marked verified)
+    monkeypatch.setattr(pilmem, '_VERIFIED', set())
+    seen = []
+    real = pilmem.copy_rows
+
+    def corrupt(t, y0, y1, dst, *a, **k):
+        real(t, y0, y1, dst, *a, **k)
+        seen.append((y0, y1))
+        dst[5] ^= 0xff
+    monkeypatch.setattr(pilmem, 'copy_rows', corrupt)
+    assert pilmem.image_rows(im) is None and seen == [(0, 40)] and not pilmem._VERIFIED
+    monkeypatch.setattr(pilmem, 'copy_rows', real)
+    assert pilmem.image_rows(im) is not None and pilmem._VERIFIED == {4}
+    assert pilmem.image_rows(Image.new('L', (7, 200), 9)) is not None and pilmem._VERIFIED == {1, 4}
+    monkeypatch.undo()
+    # `image` must be the copy of image8 / image32 that fits the pixel size -- checked before the table is dereferenced
+    calls = []
+    real_from = np.frombuffer
+    monkeypatch.setattr(pilmem, '_PIXELSIZE', dict(pilmem._PIXELSIZE, RGB=1))     # claims 1-byte pixels for an image stored in image32
+    monkeypatch.setattr(pilmem, '_int_at', lambda a, f=pilmem._int_at: 1 if f(a) == 4 else (64 if f(a) == 256 else f(a)))
+    monkeypatch.setattr(pilmem.np, 'frombuffer', lambda *a, **k: (calls.append(1), real_from(*a, **k))[1])
+    assert pilmem.image_rows(im) is None and not calls      # refused without reading a single row pointer
+    monkeypatch.undo()
     # a file that is decoded lazily
     buf = io.BytesIO()
     Image.fromarray(np.random.default_rng(0).integers(0, 256, (30, 20, 3), dtype=np.uint8), 'RGB').save(buf, 'PNG')
@@ -612,3 +641,18 @@ def test_bench_cpu_leg_is_kraken_itself_when_kraken_imports():
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stderr[-2000:]
     assert json.loads(out.stdout.strip().splitlines()[-1]) == ['port', 'reference', True, 3, True, False]
+
+
+def test_integration_stub_builds_the_same_layer_table():
+    """INTEGRATION.md section 3's in-tree binding is executed: its `layer_table`, cut out of the markdown and run
+    over the reference's own modules, gives the krk_layer table kraken_amd.vgsl.layer_table builds -- field by field, weight array by
+    weight array -- for every golden network (tests/integration_stub_check.py, in a process of its own: it imports the reference)."""
+    import subprocess
+    import sys
+    from tests.golden import _refshim
+    if not _refshim.available():
+        pytest.skip('no reference checkout on this box')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'integration_stub_check.py')], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and 'integration stub ok' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
