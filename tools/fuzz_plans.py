@@ -30,6 +30,11 @@ SPECS = [
     # (streaming kernel) and a clstm cell
     '[1,24,0,1 Cr3,3,16 (I [Cr3,3,16 Cl3,3,16]) A3,16 Mp2,2 Cr3,7,32 Mp2,2 Cr3,3,32 S1(1x0)1,3 Lbx48 Lbx32 O1c19]',
     '[1,16,0,1 (Cr3,3,8 Cr5,9,8 [Cr1,1,4 Cr3,13,16]) Mp2,2 Cr3,5,32 Cr3,3,16 S1(1x0)1,3 Lfxc48 Lbx64 O1c23]',
+    # round 5: a transposed convolution, a general reshape (channels 2 x 8, the major part in front of the height) and the ocropy
+    # peephole cell in front of the split-bf16 part
+    '[1,16,0,1 Cr3,3,8 Mp2,2 CTr3,3,8,2,2 Cr3,5,16 S1(1x0)1,3 Lbx24 O1c9]',
+    '[1,12,0,1 Cr3,3,16 S3(2x8)1,3 Cr3,3,16 Mp2,2 S1(1x0)1,3 Lbx32 Lbx16 O1c11]',
+    '[1,16,0,1 Cr3,7,16 Mp2,2 Cr3,3,8 S1(1x0)1,3 Lbxo12 Lbx24 O1c13]',
 ]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()) if '--time-seed' in sys.argv else 0)
