@@ -338,19 +338,22 @@ int upload_x6_weights(ConvGeom& g, const float* w) {
     return KRK_OK;
 }
 
-// conv1_x3.hip weight order: [kernel row dy][plane][lane][8]; lane = filter + 32*half holds taps 8*half..+7.  `w` is (Cout, 1, kh, kw).
+// conv1_x3.hip weight order: [channel][kernel row dy][plane][lane][8]; lane = filter + 32*half holds taps 8*half..+7.  `w` is
+// (Cout, Cin, kh, kw), Cin = 1 or 3.
 int upload_conv1_x3_weights(ConvGeom& g, const float* w) {
-    std::vector<uint16_t> pack((size_t)g.kh * 2 * 64 * 8, 0);
-    for (int dy = 0; dy < g.kh; ++dy)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 8; ++e) {
-                const int f = lane & 31, dx = 8 * (lane >> 5) + e;
-                if (f >= g.Cout || dx >= g.kw) continue;
-                const float v = w[((size_t)f * g.kh + dy) * g.kw + dx];
-                const uint16_t hi = f2bf(v);
-                pack[((size_t)(dy * 2 + 0) * 64 + lane) * 8 + e] = hi;
-                pack[((size_t)(dy * 2 + 1) * 64 + lane) * 8 + e] = f2bf(v - bf2f(hi));
-            }
+    std::vector<uint16_t> pack((size_t)g.Cin * g.kh * 2 * 64 * 8, 0);
+    for (int ch = 0; ch < g.Cin; ++ch)
+        for (int dy = 0; dy < g.kh; ++dy)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int f = lane & 31, dx = 8 * (lane >> 5) + e;
+                    if (f >= g.Cout || dx >= g.kw) continue;
+                    const float v = w[(((size_t)f * g.Cin + ch) * g.kh + dy) * g.kw + dx];
+                    const uint16_t hi = f2bf(v);
+                    const size_t row = (size_t)(ch * g.kh + dy) * 2;
+                    pack[((row + 0) * 64 + lane) * 8 + e] = hi;
+                    pack[((row + 1) * 64 + lane) * 8 + e] = f2bf(v - bf2f(hi));
+                }
     HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return KRK_OK;
@@ -1880,6 +1883,7 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         a.y = (__bf16*)outp; a.y_plane = out_elems;
         a.len_in = lens_at(s.len_in); a.len_out = lens_at(s.len_out);
         a.N = N; a.H = g.H; a.W = Win; a.Cout = g.Cout; a.kh = g.kh; a.kw = g.kw; a.ph = g.ph; a.pw = g.pw;
+        a.Cin = g.Cin;
         a.Ho = g.Ho; a.Wo = conv_out(Win, g.kw, g.sw, g.dw, g.pw);
         a.Hy = g.Hy; a.Wy = g.pool ? floordiv(a.Wo - 2, 2) + 1 : a.Wo;
         a.act = g.act;
@@ -1888,7 +1892,7 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         a.y_pitch = g.out_nhcw ? nhcw_pitch(a.Wy) : 0;
         a.y_f32 = 0;
         a.dbg = probe.x3_dbg;
-        s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.kh * g.kw;
+        s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
         if (mark("conv1_x3", s.flops)) return kFailed;
         return one ? krk_launch_conv1_x3_b1(a, g.pool, stream) : krk_launch_conv1_x3(a, g.pool, stream);
     }

@@ -148,8 +148,8 @@ struct X3Args {
 
 // first convolution of a one-channel image on the bf16 cores (conv1_x3.hip)
 struct Conv1Args {
-    const float* x;       // [N][1][H][W] fp32
-    const __bf16* wpack;  // [kh][plane][64 lanes][8]: lane (filter, half) holds taps 8*half..+7 of kernel row dy
+    const float* x;       // [N][Cin][H][W] fp32, Cin = 1 or 3
+    const __bf16* wpack;  // [Cin][kh][plane][64 lanes][8]: lane (filter, half) holds taps 8*half..+7 of kernel row dy of a channel
     const float* bias;    // [32]
     __bf16* y;            // hi plane of the split channels-last output; lo plane at + y_plane
     size_t y_plane;
@@ -162,6 +162,7 @@ struct Conv1Args {
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no K loop, 2 no staging loads, 4 no stores
     int y_f32;            // 1: write fp32 NHWC instead of split planes (GroupNorm consumer)
     int y_pitch;          // > 0: write "NHCW" planes [N][Hy][Cout][y_pitch] (for conv_taps_x3.hip) instead of NHWC
+    int Cin = 1;
 };
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw);
 int krk_launch_conv1_x3(const Conv1Args& a, bool pool, hipStream_t s);

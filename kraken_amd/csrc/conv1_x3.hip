@@ -1,4 +1,4 @@
-// First convolution of a grayscale line (Cin = 1) on the gfx950 bf16 matrix cores with split operands
+// First convolution of a grayscale (Cin = 1) or colour (Cin = 3, round 5) line on the gfx950 bf16 matrix cores with split operands
 // ("bf16x3", see conv_x3.hip).  Reference: kraken/lib/vgsl/layers.py ActConv2D.forward :842-860 applied to
 // the (N, 1, H, W) input, with the following 2x2 MaxPool (:381-388) fused.
 //
@@ -12,7 +12,10 @@
 //             aligned ds_read_b64 give the 12-pixel window and v_alignbyte shifts produce the four segments
 //   tile      4 waves x (2 output rows x 128 columns); an input row fetched once serves both output rows
 //             (kernel rows dy and dy-1) and all four segments: 6 LDS reads per 24 MFMAs
-//   weights   kh x (hi, lo) A fragments = kh*8 VGPRs, resident for the whole kernel
+//   weights   kh x (hi, lo) A fragments = kh*8 VGPRs, resident for the whole kernel (Cin = 1); with three input channels the
+//             3 kh fragment pairs live in LDS (18 KB at kh = 3; 72 more VGPRs would halve the occupancy) and a lane re-reads
+//             its 16 bytes per (channel, kernel row): 4 ds_read_b128 against 24 MFMAs.  The K axis then runs over
+//             (channel, dy, dx): the tile holds the window of every channel, staged from the (N, 3, H, W) fp32 planes
 //   staging   fp32 input -> (hi, lo) bf16 rows in LDS (6 KB per tile), register-prefetched one column
 //             tile ahead; a workgroup walks all column tiles of its 8 output rows
 //   epilogue  2x2 max-pool inside a lane (segments s, s+1 and the two rows), bias + activation, length
@@ -31,12 +34,14 @@ constexpr int TW = 128;     // output columns per tile
 constexpr int TH = 8;       // output rows per tile (2 per wave)
 
 // RELU: the activation is ReLU (every kraken recogniser): chosen at launch, so the epilogue is straight-line code
-template <int KH, bool POOL, bool NHCW, bool RELU>
+template <int KH, bool POOL, bool NHCW, bool RELU, int CIN>
 __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
     constexpr int IH = TH + KH - 1;
     constexpr int NST = (IH * LW + 255) / 256;
-    __shared__ __attribute__((aligned(16))) __bf16 tile[2][2][IH][LW];   // [buffer][plane][row][column]
+    __shared__ __attribute__((aligned(16))) __bf16 tile[2][2][CIN][IH][LW];   // [buffer][plane][channel][row][column]
     __shared__ __attribute__((aligned(16))) float bias_s[32];
+    // CIN > 1: the A fragments [channel][kernel row][plane][lane][8] (the order of a.wpack) in LDS
+    __shared__ __attribute__((aligned(16))) __bf16 wlds[CIN > 1 ? CIN * KH * 2 * 64 * 8 : 8];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -51,14 +56,19 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
 
     // resident weights: A fragment of kernel row dy = 32 filters x 16 taps, lane (filter, half) holds taps 8*half..+7
     bf16x8 wh[KH], wl[KH];
+    if constexpr (CIN == 1) {
 #pragma unroll
-    for (int dy = 0; dy < KH; ++dy) {
-        wh[dy] = *reinterpret_cast<const bf16x8*>(a.wpack + ((size_t)(dy * 2 + 0) * 64 + lane) * 8);
-        wl[dy] = *reinterpret_cast<const bf16x8*>(a.wpack + ((size_t)(dy * 2 + 1) * 64 + lane) * 8);
+        for (int dy = 0; dy < KH; ++dy) {
+            wh[dy] = *reinterpret_cast<const bf16x8*>(a.wpack + ((size_t)(dy * 2 + 0) * 64 + lane) * 8);
+            wl[dy] = *reinterpret_cast<const bf16x8*>(a.wpack + ((size_t)(dy * 2 + 1) * 64 + lane) * 8);
+        }
+    } else {
+        for (int e = tid; e < CIN * KH * 2 * 64; e += 256)
+            *reinterpret_cast<bf16x8*>(wlds + (size_t)e * 8) = *reinterpret_cast<const bf16x8*>(a.wpack + (size_t)e * 8);
     }
     // staging: element e = tid + 256*i of the IH x LW input window
     int s_off[NST], s_iw[NST];   // s_iw = column relative to w0, or a large negative number for a row outside the image
-    const float* xin = a.x + (size_t)n * a.H * a.W;
+    const float* xin = a.x + (size_t)n * CIN * a.H * a.W;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const int e = tid + 256 * i;
@@ -72,25 +82,31 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
     // with loads and stores under exec-mask branches the compiler cannot count what is in flight and waits with vmcnt(0) --
     // which, vmcnt retiring in order INCLUDING stores, holds the next tile until this tile's stores are acknowledged.
     constexpr unsigned kOOB = 0x7FFFF000u;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, a.H * a.W * (int)sizeof(float), 0x00020000);
-    float st[NST];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, CIN * a.H * a.W * (int)sizeof(float), 0x00020000);
+    const unsigned chan_b = (unsigned)(a.H * a.W) * 4u;      // bytes between the channel planes of a line
+    float st[CIN][NST];
     auto gload = [&](int w0) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int gw = w0 + s_iw[i];
             const bool ok = gw >= 0 && gw < len_in && !KRK_DBGBIT(a, 2);
-            st[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? (unsigned)(s_off[i] + w0) * 4u : kOOB, 0, 0));
+#pragma unroll
+            for (int ch = 0; ch < CIN; ++ch)
+                st[ch][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? (unsigned)(s_off[i] + w0) * 4u + ch * chan_b : kOOB, 0, 0));
         }
     };
     auto lstore = [&](int buf) {
-        __bf16* t = &tile[buf][0][0][0];
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int e = tid + 256 * i;
-            if (e < IH * LW) {
-                const __bf16 h = (__bf16)st[i];
-                t[e] = h;
-                t[IH * LW + e] = (__bf16)(st[i] - (float)h);
+        for (int ch = 0; ch < CIN; ++ch) {
+            __bf16* t = &tile[buf][0][ch][0][0];
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int e = tid + 256 * i;
+                if (e < IH * LW) {
+                    const __bf16 h = (__bf16)st[ch][i];
+                    t[e] = h;
+                    t[CIN * IH * LW + e] = (__bf16)(st[ch][i] - (float)h);
+                }
             }
         }
     };
@@ -119,11 +135,20 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
 
         if (w0 < wlim && !KRK_DBGBIT(a, 1)) {
 #pragma unroll
+          for (int ch = 0; ch < CIN; ++ch) {
+#pragma unroll
             for (int i = 0; i < KH + 1; ++i) {
+                if constexpr (CIN > 1) {
+                    // this channel's fragments of kernel rows i and i - 1 (the two output rows of the wave), from LDS
+                    if (i < KH) {
+                        wh[i] = *reinterpret_cast<const bf16x8*>(wlds + ((size_t)((ch * KH + i) * 2 + 0) * 64 + lane) * 8);
+                        wl[i] = *reinterpret_cast<const bf16x8*>(wlds + ((size_t)((ch * KH + i) * 2 + 1) * 64 + lane) * 8);
+                    }
+                }
                 bf16x8 f[2][4];   // [plane][segment]
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const u32x2* src = reinterpret_cast<const u32x2*>(&tile[buf][p][2 * wave + i][4 * c + 8 * half]);
+                    const u32x2* src = reinterpret_cast<const u32x2*>(&tile[buf][p][ch][2 * wave + i][4 * c + 8 * half]);
                     const u32x2 q0 = src[0], q1 = src[1], q2 = src[2];
                     const unsigned d0 = q0[0], d1 = q0[1], d2 = q1[0], d3 = q1[1], d4 = q2[0], d5 = q2[1];
                     f[p][0] = __builtin_bit_cast(bf16x8, u32x4{d0, d1, d2, d3});
@@ -145,6 +170,7 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
                     }
                 }
             }
+          }
         }
 
         // ---- epilogue: lane = pixels w0 + 4c + s of rows h0 + 2*wave + o; register 4j+i = filter 8j + 4*half + i
@@ -287,17 +313,17 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
     }
 }
 
-template <int KH>
+template <int KH, int CIN>
 int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
     dim3 grid((unsigned)(a.N * a.tiles_h));
     const bool nhcw = a.y_pitch > 0;
     const bool relu = a.act == ACT_RELU;
-    if (pool && nhcw && relu) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true, true>), grid, dim3(256), 0, s, a);
-    else if (pool && nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true, false>), grid, dim3(256), 0, s, a);
-    else if (pool) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, false, false>), grid, dim3(256), 0, s, a);
-    else if (nhcw && relu) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true, true>), grid, dim3(256), 0, s, a);
-    else if (nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv1_x3_kernel<KH, false, false, false>), grid, dim3(256), 0, s, a);
+    if (pool && nhcw && relu) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true, true, CIN>), grid, dim3(256), 0, s, a);
+    else if (pool && nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true, false, CIN>), grid, dim3(256), 0, s, a);
+    else if (pool) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, false, false, CIN>), grid, dim3(256), 0, s, a);
+    else if (nhcw && relu) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true, true, CIN>), grid, dim3(256), 0, s, a);
+    else if (nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true, false, CIN>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv1_x3_kernel<KH, false, false, false, CIN>), grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -305,18 +331,26 @@ int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
 
 #ifndef KRK_BF16_ONE
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw) {
-    return Cin == 1 && Cout <= 32 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5) && kw >= 1 && kw <= 16 && sh == 1 &&
-           sw == 1 && dh == 1 && dw == 1;
+    // three channels (colour models): kernel rows 1 and 3 (tile + fragments of kh = 5 would not fit the 64 KB of static LDS)
+    return (Cin == 1 || (Cin == 3 && kh <= 3)) && Cout <= 32 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5) && kw >= 1 &&
+           kw <= 16 && sh == 1 && sw == 1 && dh == 1 && dw == 1;
 }
 
 #endif
 
 int KRK_FN(krk_launch_conv1_x3)(const Conv1Args& a, bool pool, hipStream_t s) {
     if (a.N <= 0) return 0;
+    if (a.Cin == 3) {
+        switch (a.kh) {
+            case 1: return launch_kh<1, 3>(a, pool, s);
+            case 3: return launch_kh<3, 3>(a, pool, s);
+            default: return -1;
+        }
+    }
     switch (a.kh) {
-        case 1: return launch_kh<1>(a, pool, s);
-        case 3: return launch_kh<3>(a, pool, s);
-        case 5: return launch_kh<5>(a, pool, s);
+        case 1: return launch_kh<1, 1>(a, pool, s);
+        case 3: return launch_kh<3, 1>(a, pool, s);
+        case 5: return launch_kh<5, 1>(a, pool, s);
         default: return -1;
     }
 }

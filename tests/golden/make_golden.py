@@ -215,6 +215,12 @@ X3_NETWORK_CASES = {
     'x3_taps12_gn': ('[1,12,0,1 Cr3,12,16 Cr3,12,32 Gn8 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lbx16 Lfx32 O1c8]', 2, 133, [133, 70]),
     'x3_taps15':    ('[1,8,0,1 Ct1,3,4 Cs3,15,16 Cl3,3,16 S1(1x0)1,3 Lfx16 O1c5]', 2, 96, None),
     'x3_c32_taps':  ('[1,24,0,1 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,32 S1(1x0)1,3 Lbx56 Lbx24 O1c50]', 2, 400, [400, 233]),
+    # round 5: colour lines (3 input channels) through the first-layer kernel: pooled + tap kernel behind it (the RGB recogniser's
+    # shape), an unpooled first layer, kernel height 1, fewer than 32 filters, a first layer whose consumer is not the tap kernel
+    'x3_rgb_pool':  ('[1,16,0,3 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,32 S1(1x0)1,3 Lbx40 O1c30]', 3, 300, [300, 171, 64]),
+    'x3_rgb_flat':  ('[1,12,0,3 Ct3,11,28 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx24 O1c9]', 2, 150, [150, 77]),
+    'x3_rgb_kh1':   ('[1,8,0,3 Cl1,9,16 Cr3,3,16 S1(1x0)1,3 Lbx16 O1c8]', 2, 131, None),
+    'x3_rgb_strid': ('[1,16,0,3 Ct3,3,16 Cr3,7,48,1,2 Cl1,1,32 S1(1x0)1,3 Lbx8 O1c7]', 2, 97, [97, 50]),
 }
 
 
@@ -634,8 +640,76 @@ def spec_names_fixture(path, n=80, seed=7):
     print('wrote', path, len(out), 'specs,', sum(r['ok'] for r in out), 'accepted by the reference')
 
 
+def reshape_random_fixture(path, n=240, seed=11):
+    """Random Reshape / Addition layers through the reference (layers.py:188-223, 285-335; build_reshape / build_addition,
+    model.py:616-635, 739-777): every axis as the split axis, every target, fixed parts and `-1` parts, fixed and variable widths, the
+    batch axis.  Per case: the spec, the call's (N, W), whether the reference builds it (else the exception type), the output of an
+    arange tensor (a reshape only moves values: exact integers) and the seq_lens it returns for a ragged length vector.
+    tests compare the parser (construction errors, static shape), both oracles and -- on the GPU -- the permuted-copy kernel."""
+    import random
+    rng = random.Random(seed)
+    meta, arrays = [], {}
+
+    def factor(v):
+        cands = [(a, v // a) for a in range(1, v + 1) if v % a == 0]
+        a, b = rng.choice(cands)
+        r = rng.random()
+        if r < 0.25:
+            return 0, b             # the first part left to the tensor
+        if r < 0.5:
+            return a, 0
+        if r < 0.58:
+            return a + 1, b         # does not divide: torch's reshape raises
+        return a, b
+
+    for i in range(n):
+        N, C, H, W = rng.choice([1, 2, 4, 6]), rng.choice([2, 3, 4, 6, 8]), rng.choice([1, 2, 3, 4, 6]), rng.choice([4, 6, 8, 12])
+        var_w = rng.random() < 0.4
+        if rng.random() < 0.2:        # Addition, incl. the batch axis
+            dim = rng.choice([0, 1, 2, 3])
+            size = {0: N, 1: H, 2: W, 3: C}[dim]
+            chunk = rng.choice([c for c in range(1, size + 1)] + [size + 1])
+            block = f'A{dim},{chunk}'
+        else:
+            src = rng.choice([0, 1, 2, 3])
+            size = {0: N, 1: H, 2: W, 3: C}[src]
+            a, b = factor(size)
+            other = rng.choice([0, 1, 2, 3])
+            high, low = (src, other) if rng.random() < 0.5 else (other, src)
+            if rng.random() < 0.05:
+                high = (src + 1) % 4
+                low = (src + 2) % 4  # neither is the source: ValueError
+            block = f'S{src}({a}x{b}){high},{low}'
+        spec = f'[{N},{H},{0 if var_w else W},{C} {block}]'
+        rec = {'spec': spec, 'n': N, 'w': W, 'i': i}
+        try:
+            net = ref_vgsl.TorchVGSLModel(vgsl=spec)
+        except Exception as e:
+            rec.update(ok=False, error=type(e).__name__)
+            meta.append(rec)
+            continue
+        net.eval()
+        x = torch.arange(N * C * H * W, dtype=torch.float32).reshape(N, C, H, W)
+        rec.update(ok=True, static=list(net.nn[-1].output_shape))
+        try:
+            with torch.no_grad():
+                y, _ = net.nn(x, None)
+            rec['runs'] = True
+            arrays[f'y{i}'] = y.numpy().astype(np.int32)
+            lens = [W] + [rng.randint(1, W) for _ in range(N - 1)]
+            with torch.no_grad():
+                _, ol = net.nn(x, torch.tensor(lens))
+            rec.update(lens=lens, olens=[int(v) for v in ol.tolist()])
+        except Exception as e:
+            rec.update(runs=False, run_error=type(e).__name__)
+        meta.append(rec)
+    arrays['cases'] = np.array(json.dumps(meta))
+    np.savez_compressed(path, **arrays)
+    print('wrote', path, len(meta), 'cases,', sum(r['ok'] for r in meta), 'built,', sum(bool(r.get('runs')) for r in meta), 'ran')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms', 'bench_lines', 'forms_r5']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms', 'bench_lines', 'forms_r5', 'reshape_random']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -663,6 +737,8 @@ if __name__ == '__main__':
         layer_fixture(os.path.join(HERE, 'groups_random.npz'), random_group_cases())
     if 'spec_names' in which:
         spec_names_fixture(os.path.join(HERE, 'spec_names.json'))
+    if 'reshape_random' in which:
+        reshape_random_fixture(os.path.join(HERE, 'reshape_random.npz'))
     if 'codec' in which:
         codec_fixture(os.path.join(HERE, 'codec.npz'))
     if 'transforms' in which:

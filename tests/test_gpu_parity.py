@@ -260,6 +260,40 @@ def test_seq_lens_behind_a_batch_changing_layer_fail_where_the_reference_fails()
         r.nn(torch.rand(6, 2, 6, 9).cuda())
 
 
+def test_random_reshapes_and_additions_on_the_device_like_the_reference():
+    """The 240 random `S…` / `A…` layers of tests/golden/reshape_random.npz (made by the reference) through krk_forward: an arange
+    tensor lands exactly where the reference puts it (a reshape only moves values; Addition sums small integers: exact in fp32), the
+    output has the reference's shape -- lines included -- and nn(x, lens) returns its seq_lens; where the reference's forward raises
+    (an Addition over more entries than the call's tensor has), the call raises here."""
+    import kraken_amd
+    z = load_golden('reshape_random.npz')
+    ran = refused = 0
+    for c in json.loads(str(z['cases'])):
+        if not c['ok']:
+            continue
+        try:
+            m = kraken_amd.TorchVGSLModel(vgsl=c['spec']).to('cuda')
+        except ValueError:
+            assert not c.get('runs'), c['spec']         # refused at construction where the reference fails at the call
+            refused += 1
+            continue
+        n, ch, h, w = c['n'], m.input[1], m.input[2], c['w']
+        x = torch.arange(n * ch * h * w, dtype=torch.float32).reshape(n, ch, h, w).cuda()
+        if not c.get('runs'):
+            with pytest.raises(kraken_amd._lib.KrakenAmdError):
+                m.nn(x)
+            refused += 1
+            continue
+        want = z[f"y{c['i']}"]
+        y, _ = m.nn(x)
+        assert tuple(y.shape) == want.shape, (c['spec'], tuple(y.shape), want.shape)
+        assert np.array_equal(y.cpu().numpy().astype(np.int32), want), c['spec']
+        _, olens = m.nn(x, torch.tensor(c['lens']))
+        assert olens.tolist() == c['olens'], (c['spec'], c['lens'], olens.tolist(), c['olens'])
+        ran += 1
+    assert ran >= 150 and refused >= 10, (ran, refused)
+
+
 # ------------------------------------------------------------- (1) golden: benchmark networks
 @pytest.mark.parametrize('which', ['a', 'b'])
 def test_bench_networks_against_reference_golden(which, bench_a, bench_b):

@@ -261,3 +261,46 @@ def test_dewarp_restatement_is_bit_exact_against_scipy_and_the_reference_fixture
     off, r0, r1, r2 = index[60]
     w1, rr = _gauss_weights(60 * 1.0)
     assert rr == r1 and np.array_equal(tab[off + 2 * r0 + 1:off + 2 * r0 + 1 + 2 * r1 + 1], w1)
+
+
+def _reshape_cases():
+    z = load_golden('reshape_random.npz')
+    return z, json.loads(str(z['cases']))
+
+
+def test_random_reshapes_and_additions_like_the_reference():
+    """240 random `S…` / `A…` layers made by the reference (tests/golden/make_golden.py: reshape_random_fixture): every split axis and
+    target, `-1` parts, parts that do not divide, fixed and variable widths, the batch axis.  The parser refuses what the reference
+    refuses with the same exception type (and, earlier than the reference, an Addition whose chunk exceeds a fixed axis: there the
+    reference's forward raises), derives the same static output shape, and both oracles move an arange tensor to exactly the same
+    places and return the same seq_lens."""
+    z, cases = _reshape_cases()
+    ran = 0
+    for c in cases:
+        try:
+            _, specs = parse_vgsl(c['spec'])
+            err = None
+        except Exception as e:      # noqa: BLE001
+            specs, err = None, type(e).__name__
+        if not c['ok']:
+            assert err == c['error'], (c['spec'], err, c['error'])
+            continue
+        if specs is None:
+            assert err == 'ValueError' and ' A' in c['spec'] and not c.get('runs'), (c['spec'], err)
+            continue
+        assert list(specs[-1].out_shape) == c['static'], (c['spec'], specs[-1].out_shape, c['static'])
+        if not c.get('runs'):
+            continue
+        n, ch, h, w = c['n'], specs[0].in_shape[1], specs[0].in_shape[2], c['w']
+        x = np.arange(n * ch * h * w, dtype=np.float32).reshape(n, ch, h, w)
+        want = z[f"y{c['i']}"]
+        y, _ = np_oracle.forward(specs, {}, x)
+        assert y.shape == want.shape and np.array_equal(y.astype(np.int32), want), c['spec']
+        yt, _ = CpuRecognizer(specs, {}).forward(x)
+        assert np.array_equal(yt.numpy().astype(np.int32), want), c['spec']
+        _, ol = np_oracle.forward(specs, {}, x, c['lens'])
+        assert list(ol) == c['olens'], (c['spec'], c['lens'], ol, c['olens'])
+        _, olt = CpuRecognizer(specs, {}).forward(x, c['lens'], reference_batched=True)
+        assert olt.tolist() == c['olens'], c['spec']
+        ran += 1
+    assert ran >= 150
