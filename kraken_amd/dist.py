@@ -24,7 +24,7 @@ import torch.distributed as td
 from .vgsl import DecodedBatch
 
 __all__ = ['init', 'shard_bounds', 'shard_indices', 'gather_decoded', 'pack_decoded', 'unpack_decoded', 'concat_decoded',
-           'ShardedRecognizer', 'recognize_lines', 'parse_cpulist', 'device_numa_nodes', 'rank_cpu_block', 'pin_rank_to_cpus']
+           'ShardedRecognizer', 'recognize_lines', 'GatheredBatch', 'parse_cpulist', 'device_numa_nodes', 'rank_cpu_block', 'pin_rank_to_cpus']
 
 
 def init(backend: Optional[str] = None):
@@ -145,29 +145,64 @@ def shard_indices(widths: Sequence[int], world: int, rank: int) -> np.ndarray:
     return np.sort(order[rank::world])
 
 
+def _tuple_index(counts: np.ndarray, t: int) -> np.ndarray:
+    """Flat index (row * t + column) of every existing tuple of a padded (n, t) result, line by line: O(tuples), not O(n * t)."""
+    c = counts.astype(np.int64)
+    k = int(c.sum())
+    first = np.cumsum(c) - c                                   # position of a line's first tuple in the compact order
+    return np.arange(k, dtype=np.int64) + np.repeat(np.arange(len(c), dtype=np.int64) * t - first, c)
+
+
 def pack_decoded(batch: DecodedBatch, olens) -> np.ndarray:
     """DecodedBatch -> flat int32 [counts | olens | labels | starts | ends | conf bits] (compacted)."""
     counts = np.asarray(batch.counts, dtype=np.int32)
     n = len(counts)
     t = batch.labels.shape[1] if n else 0
-    keep = (np.arange(t)[None, :] < counts[:, None]) if n else np.zeros((0, 0), bool)
-    parts = [counts, np.asarray(olens, dtype=np.int32).reshape(-1)]
-    for arr in (batch.labels, batch.starts, batch.ends, batch.confs.view(np.int32)):
-        parts.append(np.asarray(arr, dtype=np.int32)[keep])
-    return np.concatenate(parts).astype(np.int32)
+    lin = _tuple_index(counts, t) if n else np.zeros(0, np.int64)
+    k = len(lin)
+    flat = np.empty(2 * n + 4 * k, dtype=np.int32)
+    flat[:n] = counts
+    flat[n:2 * n] = np.asarray(olens, dtype=np.int32).reshape(-1)
+    for a, arr in enumerate((batch.labels, batch.starts, batch.ends, np.asarray(batch.confs).view(np.int32))):
+        np.take(np.ascontiguousarray(arr).reshape(-1), lin, out=flat[2 * n + a * k:2 * n + (a + 1) * k])
+    return flat
 
 
 def unpack_decoded(flat: np.ndarray, n: int, k: int) -> tuple[DecodedBatch, np.ndarray]:
     """Inverse of pack_decoded for n lines / k tuples; rows are padded to the longest line."""
-    counts = flat[:n]
+    counts = np.asarray(flat[:n], dtype=np.int32)
     olens = flat[n:2 * n]
     body = flat[2 * n:2 * n + 4 * k].reshape(4, k)
-    t = int(counts.max()) if n else 0
-    out = np.zeros((4, n, max(t, 1)), dtype=np.int32)
-    keep = np.arange(max(t, 1))[None, :] < counts[:, None]
-    for a in range(4):
-        out[a][keep] = body[a]
+    t = max(int(counts.max()) if n else 0, 1)
+    out = np.zeros((4, n * t), dtype=np.int32)
+    if k:
+        out[:, _tuple_index(counts, t)] = body
+    out = out.reshape(4, n, t)
     return DecodedBatch(out[0], out[1], out[2], out[3].view(np.float32), counts.copy()), olens.copy()
+
+
+class GatheredBatch(DecodedBatch):
+    """
+    One rank's lines as they arrived in the exchange: the compact int32 message (`pack_decoded`'s layout) plus `counts` and `olens`,
+    which are slices of it.  The padded `(n, t)` arrays of a `DecodedBatch` -- `labels`, `starts`, `ends`, `confs` -- are built from
+    the message on first access (`unpack_decoded`): a consumer that only routes or counts lines never pays for them, and on an N-rank
+    job every rank would otherwise unpack N ranks' lines inside the exchange.
+    """
+
+    def __init__(self, flat: np.ndarray, n: int, k: int):
+        self._flat, self._n, self._k, self._full = flat, int(n), int(k), None
+        self.counts = np.asarray(flat[:n], dtype=np.int32).copy()
+        self.olens = np.asarray(flat[n:2 * n], dtype=np.int32).copy()
+
+    def _unpacked(self) -> DecodedBatch:
+        if self._full is None:
+            self._full = unpack_decoded(self._flat, self._n, self._k)[0]
+        return self._full
+
+    labels = property(lambda self: self._unpacked().labels)
+    starts = property(lambda self: self._unpacked().starts)
+    ends = property(lambda self: self._unpacked().ends)
+    confs = property(lambda self: self._unpacked().confs)
 
 
 def concat_decoded(batches) -> tuple[DecodedBatch, np.ndarray]:
@@ -202,7 +237,8 @@ def gather_decoded(batch, olens=None, group=None, force: bool = False) -> list[D
     dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
     # [counts | olens | labels | starts | ends | conf bits] of all parts, field by field
     counts = np.concatenate([np.asarray(b.counts, dtype=np.int32) for b, _ in parts])
-    packs = [pack_decoded(b, o) for b, o in parts]
+    # (ShardedRecognizer.stream packs a batch the moment it is collected, while the device works on the next ones)
+    packs = [getattr(b, '_packed', None) if getattr(b, '_packed', None) is not None else pack_decoded(b, o) for b, o in parts]
     ns = [len(b.counts) for b, _ in parts]
     ks = [int(np.sum(b.counts)) for b, _ in parts]
     n, k = int(sum(ns)), int(sum(ks))
@@ -222,12 +258,10 @@ def gather_decoded(batch, olens=None, group=None, force: bool = False) -> list[D
     buf[:flat.size] = torch.from_numpy(flat).to(dev)
     bufs = [torch.empty_like(buf) for _ in range(world)]
     td.all_gather(bufs, buf, group=group)
-    out = []
-    for b, (a, c) in zip(bufs, sizes):
-        batch, ol = unpack_decoded(b.cpu().numpy(), a, c)
-        batch.olens = ol                       # valid output steps per line travel with the tuples
-        out.append(batch)
-    return out
+    # every rank's message is on this rank's host now; the padded arrays are built when a consumer asks for them (GatheredBatch);
+    # the valid output steps per line travel with the tuples (`.olens`)
+    host = torch.stack(bufs).cpu().numpy()
+    return [GatheredBatch(host[r], a, c) for r, (a, c) in enumerate(sizes)]
 
 
 class ShardedRecognizer:
@@ -267,9 +301,13 @@ class ShardedRecognizer:
         """
         eng, done = self.engine, []
 
+        prepack = td.is_initialized()          # an exchange will follow: pack now, under the device's work on the next batches
+
         def finish(item):
             if on_batch is not None:
                 on_batch(*item)
+            if prepack and item[1] is not None:
+                item[0]._packed = pack_decoded(item[0], item[1])
             done.append(item)
 
         for b in batches:

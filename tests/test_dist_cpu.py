@@ -275,3 +275,33 @@ def test_scale_preflight_script_on_the_host_stub(tmp_path):
     import json
     two = json.loads((tmp_path / 'scale_2.json').read_text().strip().splitlines()[-1])
     assert two['ranks_in_collective'] == 2 and two['collective_backend'] == 'gloo' and len(two['per_rank']['gather_ms']) == 2
+
+
+def test_gathered_batches_unpack_lazily_and_prepacked_batches_are_reused():
+    """The exchange hands every rank's lines over as the compact message (`GatheredBatch`): counts and olens at once, the padded
+    arrays on first access -- equal to what was packed; a batch `ShardedRecognizer.stream` packed while the device worked is not
+    packed again in the exchange."""
+    from kraken_amd import dist as kdist
+    parts = [_fake_batch(r, n) for r, n in enumerate((5, 1, 17))]
+    flat = [kdist.pack_decoded(b, o) for b, o in parts]
+    for (b, o), f in zip(parts, flat):
+        g = kdist.GatheredBatch(f, len(b.counts), int(np.sum(b.counts)))
+        assert g._full is None and g.counts.tolist() == list(b.counts) and g.olens.tolist() == list(o)
+        assert g._full is None                      # counting lines did not build the padded arrays
+        assert g.tuples() == b.tuples() and g._full is not None
+        for i, c in enumerate(b.counts):
+            assert np.array_equal(g.labels[i, :c], b.labels[i, :c]) and np.array_equal(g.confs[i, :c], b.confs[i, :c])
+    # a pre-packed batch: gather_decoded must take the stored message (a poisoned one shows up in the result)
+    b, o = parts[0]
+    b._packed = flat[0].copy()
+    b._packed[len(b.counts):2 * len(b.counts)] = 77                       # olens of the stored message
+    import torch.distributed as td
+    if not td.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29641')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        kdist.init('gloo')
+    out = kdist.gather_decoded([(b, o)], force=True)
+    assert out[0].olens.tolist() == [77] * len(b.counts) and out[0].tuples() == b.tuples()
+    td.destroy_process_group()
