@@ -277,6 +277,9 @@ def roofline_of(engine, precision):
             wr = v['hbm_write_MB_per_launch']
             e = {'kernel': kname, 'rocprof_avg_launch_ms': round(v['avg_us'] / 1e3, 4), 'hbm_read_MB': rd, 'hbm_write_MB': wr,
                  'hbm_GBps': round((rd + wr) / v['avg_us'] * 1e3, 1) if v.get('avg_us') else None}
+            sharers = [g for g in groups if g != gname and KERNEL_OF.get(g, g) == kname]
+            if sharers:       # rocprofv3 cannot tell the launches of one kernel apart: the figures are the average over ALL of them
+                e['averaged_with'] = sharers
             if v.get('mfma_util_chip') is not None:
                 e['mfma_busy_chip'] = v['mfma_util_chip']
                 e['mfma_busy_on_its_CUs'] = round(v['mfma_util_chip'] * 256.0 / cus_of(kname, v), 4)
