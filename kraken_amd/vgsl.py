@@ -179,7 +179,9 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
             raise ValueError(f'Invalid dimension {dim} in addition block')
         axis = {0: 0, 1: 2, 2: 3, 3: 1}[dim]
         # (over the batch axis the output has `chunk` lines and the seq_lens, handed through, still count the input's lines)
-        if chunk < 1 or (axis and shape[axis] and chunk > shape[axis]):     # (the spec's batch size is not the call's)
+        # (checked against channels and height only: the spec's batch size is not the call's, and a width in the shape arithmetic
+        # may be the 1 the reference's get_shape puts in for a variable dim behind a Reshape -- the call's tensor decides there)
+        if chunk < 1 or (axis in (1, 2) and shape[axis] and chunk > shape[axis]):
             raise ValueError(f'addition "{block}": chunk size {chunk} does not fit an axis of {shape[axis]} entries')
         p = dict(axis=axis, chunk=chunk)
         oshape = tuple(chunk if a == axis else v for a, v in enumerate(shape))

@@ -601,6 +601,74 @@ def random_group_cases(n=14, seed=11):
     return cases
 
 
+def random_forms_cases(n=32, seed=23):
+    """Random sequential networks mixing the round-5 forms -- general reshapes, Additions over every axis but the batch, transposed
+    convolutions -- with convolutions, pools, GroupNorm and, where the height ends at 1, a recurrent tail: whatever the reference
+    builds AND runs becomes a golden (tensors compared without seq_lens: a reshape's seq_lens rule is pinned elsewhere)."""
+    import random
+    rng = random.Random(seed)
+
+    def dims(spec):
+        m = ref_vgsl.TorchVGSLModel(vgsl=spec + ']')
+        return m.output[1], m.output[2]
+
+    def divisors(v):
+        return [a for a in range(1, v + 1) if v % a == 0]
+
+    cases, tries = {}, 0
+    while len(cases) < n and tries < 4000:
+        tries += 1
+        spec = f'[1,{rng.choice([8, 12])},0,{rng.choice([1, 2, 3])} C{rng.choice("rtl")}3,3,{rng.choice([4, 6, 8])}'
+        used = set()
+        try:
+            for _ in range(rng.randint(2, 5)):
+                c, h = dims(spec)
+                kind = rng.choice(['conv', 'conv', 'pool', 'ct', 'sc2h', 'sh2c', 'sh2w', 'add', 'gn'])
+                if kind == 'conv':
+                    blk = f'C{rng.choice("rtl")}{rng.choice([1, 3])},{rng.choice([3, 5])},{rng.choice([4, 6, 8])}'
+                elif kind == 'pool':
+                    blk = 'Mp2,2'
+                elif kind == 'ct':
+                    blk = rng.choice([f'CTr3,3,{rng.choice([4, 8])},2,2', f'CTl2,2,{rng.choice([4, 6])},2,2', f'CTt3,3,{rng.choice([4, 6])}'])
+                elif kind == 'sc2h':
+                    a = rng.choice(divisors(c))
+                    blk = rng.choice([f'S3({a}x{c // a})1,3', f'S3({a}x{c // a})3,1', f'S3({a}x0)1,3'])
+                elif kind == 'sh2c':
+                    a = rng.choice(divisors(h))
+                    blk = rng.choice([f'S1({a}x{h // a})1,3', f'S1({a}x{h // a})3,1', f'S1(0x{h // a})3,1'])
+                elif kind == 'sh2w':
+                    a = rng.choice(divisors(h))
+                    blk = rng.choice([f'S1({a}x{h // a})1,2', f'S1({a}x{h // a})2,1'])
+                elif kind == 'add':
+                    ax = rng.choice([1, 3, 2])
+                    size = {1: h, 3: c, 2: 9}[ax]
+                    blk = f'A{ax},{rng.randint(1, size)}'
+                else:
+                    g = rng.choice(divisors(c))
+                    blk = f'Gn{g}'
+                used.add(kind)
+                spec += ' ' + blk
+            c, h = dims(spec)
+            if h == 1 and rng.random() < 0.7:
+                spec += rng.choice([' Lbx8 O1c5', ' Lfx6', ' O1c4'])
+            elif rng.random() < 0.4 and h <= 16:
+                spec += ' S1(1x0)1,3 Lbx8 O1c5'
+            spec += ']'
+            if not used & {'ct', 'sc2h', 'sh2c', 'sh2w', 'add'}:
+                continue
+            net = ref_vgsl.TorchVGSLModel(vgsl=spec)
+            net.eval()
+            w = rng.choice([17, 24, 31])
+            with torch.no_grad():
+                y, _ = net.nn(torch.randn(2, net.input[1], net.input[2], w), None)
+            if y.numel() == 0 or y.numel() > 200000:
+                continue
+        except Exception:
+            continue
+        cases[f'rf{len(cases):02d}'] = (spec, 2, w, None)
+    return cases
+
+
 def spec_names_fixture(path, n=80, seed=7):
     """Randomly nested specs (serial / parallel groups to depth 3, Addition-free leaves that keep H and W) through the reference's
     parser: the state-dict keys + shapes, the named spec and the output shape it derives -- or the fact that it refuses the spec.
@@ -709,7 +777,7 @@ def reshape_random_fixture(path, n=240, seed=11):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms', 'bench_lines', 'forms_r5', 'reshape_random']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms', 'bench_lines', 'forms_r5', 'reshape_random', 'forms_random']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -739,6 +807,8 @@ if __name__ == '__main__':
         spec_names_fixture(os.path.join(HERE, 'spec_names.json'))
     if 'reshape_random' in which:
         reshape_random_fixture(os.path.join(HERE, 'reshape_random.npz'))
+    if 'forms_random' in which:
+        layer_fixture(os.path.join(HERE, 'forms_random.npz'), random_forms_cases())
     if 'codec' in which:
         codec_fixture(os.path.join(HERE, 'codec.npz'))
     if 'transforms' in which:

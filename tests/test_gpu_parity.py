@@ -28,6 +28,7 @@ CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes
 CASES.update(layer_cases('groups.npz'))       # round 4: nested [ ] / ( ) groups, Addition, x-axis summarising LSTMs
 CASES.update(layer_cases('groups_random.npz'))   # ... and 14 randomly nested networks (identity members, groups inside groups inside groups)
 CASES.update(layer_cases('forms_r5.npz'))        # round 5: the forms that were still refused (ocropy peephole cell, ...)
+CASES.update(layer_cases('forms_random.npz'))    # ... and 32 random networks mixing them with convolutions, pools, GroupNorm, recurrent tails
 
 
 def _sha(t) -> str:
@@ -113,6 +114,7 @@ def test_x3_kernels_against_reference_golden(name, prec):
 GROUP_NETS = layer_cases('groups.npz')
 GROUP_NETS.update(layer_cases('groups_random.npz'))
 GROUP_NETS.update(layer_cases('forms_r5.npz'))       # round 5: the ocropy peephole cell, ... (exact-f32 kernels inside a bf16x3 plan)
+GROUP_NETS.update(layer_cases('forms_random.npz'))
 
 
 @pytest.mark.parametrize('name', sorted(GROUP_NETS))

@@ -21,6 +21,7 @@ CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes
 CASES.update(layer_cases('groups.npz'))       # round 4: nested [ ] / ( ) groups, Addition, x-axis summarising LSTMs
 CASES.update(layer_cases('groups_random.npz'))   # ... and 14 randomly nested networks (identity members, groups inside groups inside groups)
 CASES.update(layer_cases('forms_r5.npz'))        # round 5: the forms that were still refused (ocropy peephole cell, ...)
+CASES.update(layer_cases('forms_random.npz'))    # ... and 32 random networks mixing them with convolutions, pools, GroupNorm, recurrent tails
 
 
 def _zero_pad_x(x, lens):
