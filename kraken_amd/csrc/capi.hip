@@ -563,9 +563,10 @@ bool reshape_dims(const krk_plan::ReshapeOp& r, const int in[4], int d5[5], int 
     // "dest = low; if high != src_dim: dest = high; else: src_dim += 1", then the element at src_dim is swapped step by step to dest
     int dest = r.low, sd = r.src;
     if (r.high != r.src) dest = r.high; else sd += 1;
+    // ... i.e. position sd of the 5-D view travels to position dest and the positions in between close the gap: a rotation
     for (int i = 0; i < 5; ++i) perm[i] = i;
-    const int step = dest > sd ? 1 : -1;
-    for (int x = sd; x != dest; x += step) std::swap(perm[x], perm[x + step]);
+    if (dest > sd) std::rotate(perm + sd, perm + sd + 1, perm + dest + 1);
+    else std::rotate(perm + dest, perm + sd, perm + sd + 1);
     int pd[5];
     for (int i = 0; i < 5; ++i) pd[i] = d5[perm[i]];
     for (int i = 0, j = 0; i < 5; ++i) {

@@ -101,11 +101,10 @@ def reshape_shape(shape: Sequence[int], p: dict) -> tuple:
         dest = p['high']
     else:
         s_ += 1
-    perm = list(range(5))
-    step = 1 if dest > s_ else -1
-    for x in range(s_, dest, step):
-        perm[x], perm[x + step] = perm[x + step], perm[x]
-    pd = [d5[i] for i in perm]
+    # the part at position s_ of the 5-D view travels to position `dest`, the axes in between close the gap (the reference bubbles
+    # it there by adjacent swaps: the same rotation), then positions dest and dest + 1 merge
+    pd = list(d5)
+    pd.insert(dest, pd.pop(s_))
     return tuple(pd[:dest] + [pd[dest] * pd[dest + 1]] + pd[dest + 2:])
 
 

@@ -163,9 +163,7 @@ def reshape_general(x, p, lens=None):
     else:
         src += 1
     perm = list(range(5))
-    step = 1 if dest > src else -1
-    for i in range(src, dest, step):
-        perm[i], perm[i + step] = perm[i + step], perm[i]
+    perm.insert(dest, perm.pop(src))                      # layers.py:323-327 bubbles axis `src` to `dest` by adjacent swaps: this rotation
     x5 = x5.transpose(perm)
     o = np.ascontiguousarray(x5.reshape(x5.shape[:dest] + (x5.shape[dest] * x5.shape[dest + 1],) + x5.shape[dest + 2:]))
     if lens is not None:
