@@ -10,7 +10,11 @@
  *   krk_plan_create   <- TorchVGSLModel._parse / build_* (kraken/lib/vgsl/model.py:202-243,
  *                        570-817): the parsed layer list + state-dict tensors
  *   krk_plan_olens    <- per-layer seq_len arithmetic (kraken/lib/vgsl/layers.py:387,
- *                        858-859, 334)
+ *   krk_plan_olens_w     858-859, 334); _w: with the batch's width, which Reshape.forward scales
+ *                        seq_lens by (layers.py:331-332)
+ *   krk_plan_out_shape <- the shape arithmetic of get_shape() on the call's tensor (layers.py:337-345 and
+ *   krk_plan_out_dims     each layer's own); _dims: with the number of lines, which an Addition / Reshape
+ *                        on the batch axis changes (layers.py:205-210, 313-330)
  *   krk_forward       <- MultiParamSequential.forward, i.e. `nn(x, seq_lens)`
  *                        (kraken/lib/vgsl/layers.py:44-53; model.py:488-489)
  *   krk_greedy_decode <- greedy_decoder (kraken/lib/ctc_decoder.py:35-72), optionally
