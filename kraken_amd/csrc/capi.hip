@@ -584,7 +584,7 @@ int width_after(const krk_plan& p, const krk_plan::LenOp& op, int L, int Win, in
     if (op.kind == 4 || op.kind == 6) return L;   // Addition.forward hands the seq_lens through untouched (reference layers.py:205-210)
     // Reshape.forward, layers.py:331-332: (seq_len * (float(initial_len) / o.shape[3])).int() -- an int tensor times a Python float
     // is a float32 product (the double ratio rounded to float32 first), .int() truncates
-    if (op.kind == 5) return (int)((float)L * (float)((double)Win / (double)Wout));
+    if (op.kind == 5) return Wout > 0 ? (int)((float)L * (float)((double)Win / (double)Wout)) : 0;
     if (op.kind == 0) return std::max(conv_out(L, op.k, op.s, op.d, op.p), 1);
     return floordiv(L - (op.k - 1) - 1, op.s) + 1;
 }
