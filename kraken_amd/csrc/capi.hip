@@ -105,6 +105,7 @@ struct ConvGeom {
     void* d_wx6 = nullptr;    // its weights [chunk][tap][block][plane 3][lane][8]
     int x6CBpad = 1;
     void* d_wx3 = nullptr;
+    unsigned* d_gctr = nullptr;   // gemm_x3.hip, persistent form: tile-queue counters of this step's projection (64 bytes, zero between launches)
     void* d_wx5 = nullptr;    // conv_taps_x3.hip, five-group packing (kw <= 13)
     bool c1x3 = false;        // one-channel first convolution on the bf16 cores (conv1_x3.hip); weights in d_wx3
     bool taps = false;        // wide-kernel convolution with taps as K (conv_taps_x3.hip); reads NHCW planes
@@ -442,6 +443,10 @@ int pack_gemm_x3_weights(const ConvGeom& g, const float* w, const std::vector<in
 
 int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
     if (g.Cin % 16) return fail(KRK_E_UNSUPPORTED, "bf16x3: input features must be a multiple of 16");
+    if (!g.d_gctr) {
+        HIPCHK(hipMalloc((void**)&g.d_gctr, 64));
+        HIPCHK(hipMemset(g.d_gctr, 0, 64));
+    }
     return pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3);
 }
 
@@ -747,6 +752,7 @@ void free_step(Step& s) {
     if (s.cg.d_w) (void)hipFree(s.cg.d_w);
     if (s.cg.d_b) (void)hipFree(s.cg.d_b);
     if (s.cg.d_wx3) (void)hipFree(s.cg.d_wx3);
+    if (s.cg.d_gctr) (void)hipFree(s.cg.d_gctr);
     if (s.cg.d_wx5) (void)hipFree(s.cg.d_wx5);
     if (s.cg.d_wx6) (void)hipFree(s.cg.d_wx6);
     if (s.d_c1w) (void)hipFree(s.d_c1w);
@@ -1713,6 +1719,7 @@ void fill_gemm(const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane
     a.nlines = 0;
     a.dbg = dbg;
     a.nbuf = env_int("KRK_GEMM_SPREAD", 1) ? 3 : 2;   // gemm_x3.hip reads nbuf == 2 as "copies in front of the MFMAs" (A/B probe)
+    a.ctr = env_int("KRK_GEMM_P", 1) ? g.d_gctr : nullptr;   // KRK_GEMM_P=0: the one-tile-per-workgroup kernel everywhere (A/B probe)
 }
 
 // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)

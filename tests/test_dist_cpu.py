@@ -305,3 +305,209 @@ def test_gathered_batches_unpack_lazily_and_prepacked_batches_are_reused():
     out = kdist.gather_decoded([(b, o)], force=True)
     assert out[0].olens.tolist() == [77] * len(b.counts) and out[0].tuples() == b.tuples()
     td.destroy_process_group()
+
+
+# ------------------------------------------------------------------- round 6: the product call at eight ranks, with failures
+SHARD8_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from kraken_amd import dist as kdist
+from kraken_amd import rpred as krpred
+from kraken_amd.codec import PytorchCodec
+from kraken_amd.vgsl import DecodedBatch
+mode, n_lines, fail_rank = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+kdist.init(backend='gloo', timeout_s=90)
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+
+class Stub:                                   # RecognitionEngine surface; a line decodes to chr(width % 50 + 1) x (1 + line sum % 3)
+    def __init__(self):
+        self.slots, self.q, self.collected = [0, 0], [], 0
+    def free_slots(self):
+        return 2 - len(self.q)
+    def submit(self, x, lens=None):
+        self.q.append((x.clone(), np.asarray(lens)))
+    def collect(self):
+        x, lens = self.q.pop(0)
+        self.collected += 1
+        if rank == fail_rank and self.collected == 2:
+            raise RuntimeError('injected failure in batch 2')
+        n = len(lens)
+        reps = np.array([1 + int(round(float(x[j].sum()))) % 3 for j in range(n)], np.int32)
+        lab = np.repeat((lens % 50 + 1).astype(np.int32)[:, None], 3, 1)
+        st = np.tile(np.arange(3, dtype=np.int32) * 2, (n, 1))
+        return DecodedBatch(lab, st, st + 1, np.full((n, 3), 0.25, np.float32), reps), (lens // 8).astype(np.int32)
+    def close(self):
+        pass
+
+decoded = [0]
+_orig = krpred._decode_lines
+def counting(codec, batch, olens, probs=None):
+    decoded[0] += len(batch.counts)
+    return _orig(codec, batch, olens, probs)
+krpred._decode_lines = counting
+
+rng = np.random.RandomState(5)
+widths = rng.randint(40, 400, size=n_lines)
+lines = [torch.full((1, 4, int(w)), float(i % 7) / (4 * int(w))) for i, w in enumerate(widths)]     # line sum = i % 7
+codec = PytorchCodec({chr(0x40 + k): [k] for k in range(1, 52)})
+model = type('M', (), {'codec': codec})()
+sr = kdist.ShardedRecognizer(model, batch=16, engine_factory=Stub)
+shards = [kdist.shard_indices(widths, world, r) for r in range(world)]
+orders = [sh[np.argsort(widths[sh], kind='stable')] for sh in shards]
+lost = set(orders[fail_rank][16:32].tolist()) if 0 <= fail_rank < world else set()   # the failing rank's SECOND batch
+want = lambda i: '' if i in lost else chr(0x40 + widths[i] % 50 + 1) * (1 + (i % 7) % 3)
+
+if mode == 'raise':
+    try:
+        sr.recognize_lines(lines, on_error='raise')
+        print('rank', rank, 'NOT raised')
+    except kdist.ShardError as e:
+        assert list(e.ranks) == [fail_rank] and 'injected failure' in e.ranks[fail_rank], e.ranks
+        print('rank', rank, 'raised')
+else:
+    res = sr.recognize_lines(lines, results=mode, root=1)
+    assert len(res) == n_lines
+    # host work proportional to the shard: this rank ran the codec over ITS lines only, whatever it received
+    assert decoded[0] == len(shards[rank]) == sr.decoded_lines, (rank, decoded[0], len(shards[rank]))
+    sees_all = mode == 'all' or (mode == 'root' and rank == 1)
+    for i in range(n_lines):
+        owner = next(r for r in range(world) if i in set(shards[r].tolist()))
+        if sees_all or owner == rank:
+            assert res[i] is not None and res[i].text == want(i), (rank, i, res[i], want(i))
+            if i in lost:
+                assert res[i].out_width == 0 and len(res[i].starts) == 0 and len(res[i].confs) == 0
+            else:
+                assert res[i].out_width == widths[i] // 8 and list(res[i].starts) == [0, 2, 4][:len(res[i].text)]
+                assert res[i].confs.dtype == np.float32 and all(c == 0.25 for c in res[i].confs)
+        else:
+            assert res[i] is None, (rank, i)
+    # every rank learns which rank failed (the status word travels in every mode); the text where the messages went
+    if lost:
+        assert list(sr.rank_errors) == [fail_rank], sr.rank_errors
+        if sees_all or rank == fail_rank:
+            assert 'batch 1: RuntimeError: injected failure in batch 2' in sr.rank_errors[fail_rank], sr.rank_errors
+    else:
+        assert sr.rank_errors == {}
+    print('rank', rank, 'ok', len(res), 'decoded', decoded[0], 'host_us_per_line %.1f' % sr.host_us_per_line)
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+def _run_ranks(script, world, args, timeout=220):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT] + [str(a) for a in args], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=timeout)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    return procs, outs
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('mode,n_lines,fail_rank', [('all', 300, 3), ('root', 300, -1), ('local', 300, 6), ('all', 5, -1),
+                                                    ('root', 11, 0)])
+def test_recognize_lines_at_eight_ranks_decodes_only_its_shard_and_survives_a_failing_rank(tmp_path, mode, n_lines, fail_rank):
+    """
+    VERDICT r5 #2: world_size 8 over gloo with the host stub -- uneven shards, ranks without a single line (5 and 11 lines over 8
+    ranks), a rank whose engine raises in its second batch: nobody hangs, the failed batch comes back as the reference's empty
+    records on every rank that receives it, every rank knows who failed, and a rank runs the codec over ITS shard only.
+    """
+    script = tmp_path / 'worker.py'
+    script.write_text(SHARD8_WORKER)
+    procs, outs = _run_ranks(script, 8, [mode, n_lines, fail_rank])
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f'rank {rank} ok {n_lines}' in o, o
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rank_raises_one_exception_on_every_rank_when_asked(tmp_path):
+    """``on_error='raise'``: the rank that failed still joins the exchange; all eight ranks raise the same ShardError."""
+    script = tmp_path / 'worker.py'
+    script.write_text(SHARD8_WORKER)
+    procs, outs = _run_ranks(script, 8, ['raise', 300, 5])
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f'rank {rank} raised' in o, o
+
+
+DEAD_PEER_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from kraken_amd import dist as kdist
+from tests.test_dist_cpu import _fake_batch
+kdist.init(backend='gloo', timeout_s=10)
+rank = int(os.environ['RANK'])
+if rank == 1:
+    os._exit(7)                               # gone before the exchange: no status word will ever come from this rank
+t0 = time.time()
+try:
+    kdist.gather_decoded(*_fake_batch(0, 4))
+    print('rank 0 returned')
+except Exception as e:
+    print('rank 0 gave up after %.0f s: %s' % (time.time() - t0, type(e).__name__))
+'''
+
+
+@pytest.mark.timeout(120)
+def test_a_peer_that_is_gone_ends_the_exchange_with_the_groups_timeout(tmp_path):
+    """A killed process cannot send a status word: the collective ends with the timeout `init` was given, not NCCL's ten minutes."""
+    script = tmp_path / 'worker.py'
+    script.write_text(DEAD_PEER_WORKER)
+    procs, outs = _run_ranks(script, 2, [], timeout=100)
+    assert procs[1].returncode == 7
+    assert 'rank 0 gave up after' in outs[0], outs[0]
+    assert float(outs[0].split('after')[1].split('s:')[0]) < 60
+
+
+def test_stream_turns_a_failed_batch_into_empty_lines_and_keeps_going():
+    """One rank, no process group: `stream(on_error='empty')` -- submit failures and collect failures both cost the batch only."""
+    from kraken_amd import dist as kdist
+
+    class Eng:
+        def __init__(self):
+            self.slots, self.q, self.n = [0, 0, 0], [], 0
+        def free_slots(self):
+            return 3 - len(self.q)
+        def submit(self, x, lens=None):
+            self.n += 1
+            if self.n == 2:
+                raise ValueError('bad height')
+            self.q.append(x.shape[0])
+        def collect(self):
+            n = self.q.pop(0)
+            if n == 7:
+                raise RuntimeError('status word')
+            return _fake_batch(n, n)
+        def close(self):
+            pass
+    import torch
+    sr = kdist.ShardedRecognizer(type('M', (), {'codec': None})(), engine_factory=Eng)
+    sizes = [4, 5, 7, 3, 6]
+    done = sr.stream([torch.zeros(n, 1, 2, 8) for n in sizes], on_error='empty')
+    assert [len(b.counts) for b, _ in done] == sizes
+    assert [int(np.sum(b.counts)) == 0 for b, _ in done] == [False, True, True, False, False]
+    assert sr.status == 1 and [i for i, _ in sr.errors] == [1, 2] and 'bad height' in sr.errors[0][1]
+    with pytest.raises(ValueError):            # 'raise' (the benchmark's mode): the engine's exception propagates
+        sr2 = kdist.ShardedRecognizer(type('M', (), {'codec': None})(), engine_factory=Eng)
+        sr2.stream([torch.zeros(n, 1, 2, 8) for n in [4, 3, 7]], on_error='raise')
+    # finished results on the wire: pack_results / GatheredResults round trip, lazily
+    from kraken_amd.rpred import LineResult
+    rs = [LineResult('ab', np.array([0, 3]), np.array([1, 4]), np.array([.5, .25], np.float32), 9),
+          LineResult('', np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32), 0),
+          LineResult('\U0001F600x', np.array([2, 5]), np.array([2, 7]), np.array([1., .125], np.float32), 30)]
+    g = kdist.GatheredResults(kdist.pack_results(rs), 3)
+    assert len(g) == 3 and [r.text for r in g] == ['ab', '', '\U0001F600x'] and [r.out_width for r in g] == [9, 0, 30]
+    assert g[2].starts.tolist() == [2, 5] and g[2].ends.tolist() == [2, 7] and g[2].confs.tolist() == [1., .125]
