@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define KRK_ABI_VERSION 1
+#define KRK_ABI_VERSION 2   /* 2 (round 6): + krk_plan_get_recurrence; round 5 had added CONVT / RESHAPE ops, krk_plan_out_dims, krk_plan_olens_w, krk_plan_set_recurrence under version 1 */
 
 /* error codes */
 #define KRK_OK            0
@@ -346,6 +346,9 @@ int krk_plan_has_exchange(const krk_plan* plan);
 #define KRK_RECURRENCE_AUTO 0
 #define KRK_RECURRENCE_STREAMING 1
 int krk_plan_set_recurrence(krk_plan* plan, int variant);
+/* The plan's current setting (KRK_RECURRENCE_*; negative = error): lets a caller that switches a plan for one retry put back
+ * what was there instead of assuming KRK_RECURRENCE_AUTO. */
+int krk_plan_get_recurrence(const krk_plan* plan);
 
 /* Cross-batch scheduling for callers that keep several plans in flight on separate streams
  * (kraken_amd/engine.py; no reference analogue -- the reference runs one batch at a time,

@@ -29,7 +29,7 @@ EXPORTS = ['krk_abi_version', 'krk_last_error', 'krk_device_count', 'krk_plan_cr
            'krk_plan_layer_flops', 'krk_plan_num_steps', 'krk_plan_front_event', 'krk_plan_wait_front',
            'krk_plan_status', 'krk_prep_lines', 'krk_prep_crops', 'krk_upsample_sigmoid', 'krk_dewarp_measure', 'krk_dewarp_apply',
            'krk_prep_lines_fmt', 'krk_dewarp_measure_page', 'krk_dewarp_apply_page', 'krk_plan_has_exchange',
-           'krk_plan_set_recurrence', 'krk_plan_out_dims', 'krk_plan_olens_w']
+           'krk_plan_set_recurrence', 'krk_plan_out_dims', 'krk_plan_olens_w', 'krk_plan_get_recurrence']
 
 
 class KrkLayer(C.Structure):
@@ -58,6 +58,7 @@ def is_exchange_timeout(e: Exception) -> bool:
 
 
 RECURRENCE_AUTO, RECURRENCE_STREAMING = 0, 1
+ABI_VERSION = 2          # include/kraken_amd.h: KRK_ABI_VERSION
 
 
 class streaming_recurrence:
@@ -67,19 +68,25 @@ class streaming_recurrence:
     environment (KRK_LSTM_V stays what it is: a debugging probe)."""
 
     def __init__(self, plan_handle):
-        self.handle = plan_handle
+        self.handle, self.before = plan_handle, RECURRENCE_AUTO
 
     def __enter__(self):
-        check(load().krk_plan_set_recurrence(self.handle, RECURRENCE_STREAMING))
+        lib = load()
+        before = lib.krk_plan_get_recurrence(self.handle)
+        if before < 0:
+            check(before)
+        self.before = before                     # a plan its owner had set to STREAMING stays there after the retry (ADVICE r5)
+        check(lib.krk_plan_set_recurrence(self.handle, RECURRENCE_STREAMING))
 
     def __exit__(self, *exc):
-        load().krk_plan_set_recurrence(self.handle, RECURRENCE_AUTO)
+        check(load().krk_plan_set_recurrence(self.handle, self.before))
 
 
 def checked_run(plan_handle, run, wait, log=None):
     """
-    The one policy for a batch whose recurrent cluster kernel gave up waiting for its peers, shared by ``nn(x)``,
-    ``nn.recognize`` and ``RecognitionEngine.collect``: ``run()`` enqueues the batch, ``wait()`` blocks until it has completed;
+    The one policy for a batch whose recurrent cluster kernel gave up waiting for its peers, used by ``nn(x)`` and
+    ``nn.recognize`` (``RecognitionEngine.collect`` applies the same rule to a batch that is ALREADY enqueued on a slot's stream --
+    it re-launches through its own slot bookkeeping, with the same ``streaming_recurrence`` switch): ``run()`` enqueues the batch, ``wait()`` blocks until it has completed;
     the plan's status word is read then, and an exchange timeout re-runs THIS batch once on the streaming kernel (a warning, not
     a lost page).  Anything else -- and a second failure -- raises.
     """
@@ -118,6 +125,10 @@ def load():
         lib = C.CDLL(LIB_PATH)
         vp, i32, f32, lng = C.c_void_p, C.c_int, C.c_float, C.c_long
         lib.krk_abi_version.restype = i32
+        # the version FIRST: a stale library must say "rebuild", not die of an AttributeError on an export it lacks
+        if lib.krk_abi_version() != ABI_VERSION:
+            raise ImportError(f'{LIB_PATH}: ABI version {lib.krk_abi_version()}, this package needs {ABI_VERSION}; '
+                              'rebuild the extension (python -m kraken_amd.build)')
         lib.krk_last_error.restype = C.c_char_p
         lib.krk_device_count.restype = i32
         lib.krk_plan_create.argtypes = [C.POINTER(KrkLayer), i32, i32, i32, i32, i32, C.POINTER(vp)]
@@ -161,6 +172,8 @@ def load():
         lib.krk_plan_has_exchange.restype = i32
         lib.krk_plan_set_recurrence.argtypes = [vp, i32]
         lib.krk_plan_set_recurrence.restype = i32
+        lib.krk_plan_get_recurrence.argtypes = [vp]
+        lib.krk_plan_get_recurrence.restype = i32
         lib.krk_prep_lines.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
         lib.krk_prep_lines.restype = i32
         lib.krk_prep_crops.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
@@ -178,8 +191,6 @@ def load():
         lib.krk_dewarp_measure_page.restype = i32
         lib.krk_dewarp_apply_page.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp]
         lib.krk_dewarp_apply_page.restype = i32
-        if lib.krk_abi_version() != 1:
-            raise ImportError('libkraken_amd.so ABI version mismatch; rebuild the extension')
         _lib = lib
     return _lib
 

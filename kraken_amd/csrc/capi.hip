@@ -105,7 +105,6 @@ struct ConvGeom {
     void* d_wx6 = nullptr;    // its weights [chunk][tap][block][plane 3][lane][8]
     int x6CBpad = 1;
     void* d_wx3 = nullptr;
-    unsigned* d_gctr = nullptr;   // gemm_x3.hip, persistent form: tile-queue counters of this step's projection (64 bytes, zero between launches)
     void* d_wx5 = nullptr;    // conv_taps_x3.hip, five-group packing (kw <= 13)
     bool c1x3 = false;        // one-channel first convolution on the bf16 cores (conv1_x3.hip); weights in d_wx3
     bool taps = false;        // wide-kernel convolution with taps as K (conv_taps_x3.hip); reads NHCW planes
@@ -443,10 +442,6 @@ int pack_gemm_x3_weights(const ConvGeom& g, const float* w, const std::vector<in
 
 int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
     if (g.Cin % 16) return fail(KRK_E_UNSUPPORTED, "bf16x3: input features must be a multiple of 16");
-    if (!g.d_gctr) {
-        HIPCHK(hipMalloc((void**)&g.d_gctr, 64));
-        HIPCHK(hipMemset(g.d_gctr, 0, 64));
-    }
     return pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3);
 }
 
@@ -752,7 +747,6 @@ void free_step(Step& s) {
     if (s.cg.d_w) (void)hipFree(s.cg.d_w);
     if (s.cg.d_b) (void)hipFree(s.cg.d_b);
     if (s.cg.d_wx3) (void)hipFree(s.cg.d_wx3);
-    if (s.cg.d_gctr) (void)hipFree(s.cg.d_gctr);
     if (s.cg.d_wx5) (void)hipFree(s.cg.d_wx5);
     if (s.cg.d_wx6) (void)hipFree(s.cg.d_wx6);
     if (s.d_c1w) (void)hipFree(s.d_c1w);
@@ -1628,6 +1622,11 @@ int krk_plan_set_recurrence(krk_plan* plan, int variant) {
     return KRK_OK;
 }
 
+int krk_plan_get_recurrence(const krk_plan* plan) {
+    if (!plan) return fail(KRK_E_INVALID, "krk_plan_get_recurrence: null plan");
+    return plan->recurrence;
+}
+
 void* krk_plan_front_event(krk_plan* plan) { return plan ? (void*)plan->front_ev : nullptr; }
 
 int krk_plan_wait_front(krk_plan* plan, void* event) {
@@ -1719,7 +1718,6 @@ void fill_gemm(const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane
     a.nlines = 0;
     a.dbg = dbg;
     a.nbuf = env_int("KRK_GEMM_SPREAD", 1) ? 3 : 2;   // gemm_x3.hip reads nbuf == 2 as "copies in front of the MFMAs" (A/B probe)
-    a.ctr = env_int("KRK_GEMM_P", 1) ? g.d_gctr : nullptr;   // KRK_GEMM_P=0: the one-tile-per-workgroup kernel everywhere (A/B probe)
 }
 
 // strides of a split channels-last output (NHWC, or sequence rows when the reshape is fused)
@@ -2502,8 +2500,11 @@ int krk_recognize(krk_plan* plan, const float* x_dev, const int* lens_host, int 
                           (int*)plan->d_labels.p, (float*)plan->d_confs.p, s, out);
     if (rc) return rc;
     if (olens_host) {
-        if (lens_host) krk_plan_olens(plan, lens_host, N, olens_host);
-        else for (int n = 0; n < N; ++n) olens_host[n] = T;
+        // with the batch's width: a general Reshape scales seq_lens by it (krk_plan_olens refuses such plans and writes nothing)
+        if (lens_host) {
+            if ((rc = krk_plan_olens_w(plan, lens_host, N, W, olens_host))) return rc;
+        } else
+            for (int n = 0; n < N; ++n) olens_host[n] = T;
     }
     return KRK_OK;
 }

@@ -205,7 +205,6 @@ struct GemmX3Args {
     int act;
     int dbg;              // probe bits (env KRK_X3_DBG): 1 no MFMA, 2 no copies, 4 no stores, 8 no LDS reads
     int nbuf;             // 3; 2 = probe (KRK_GEMM_SPREAD=0): all six copies of a K step in front of its MFMAs
-    unsigned* ctr = nullptr;   // persistent form (round 6): [0..7] per-XCD tile queues, [8] workgroups that left; zero between launches (the last workgroup out resets them); null = the one-tile-per-workgroup kernel
 };
 int krk_launch_gemm_x3(const GemmX3Args& a, hipStream_t s);
 int krk_launch_gemm_x3_b1(const GemmX3Args& a, hipStream_t s);

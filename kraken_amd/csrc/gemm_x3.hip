@@ -23,7 +23,6 @@
 //   epilogue  = + bias, transposed through the (now free) LDS buffers so that each store instruction writes
 //               two full 512-byte row runs of the fp32 rows [row][Cout] the recurrent kernel / decoder read
 #include "common.h"
-#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -228,377 +227,18 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(const GemmX3Args a) {
 
 }  // namespace
 
-// ------------------------------------------------------------------------------------------------------------------------
-// Round 6: the PERSISTENT form (gemm_x3p_kernel).  What the one-tile-per-workgroup kernel above cannot do: overlap a tile's
-// 128 KB of fp32 row stores with matrix work.  Its two co-resident workgroups start together, and they STAY in phase -- a
-// workgroup that lags finds the matrix pipe to itself while its neighbour stores and catches up, so every stagger decays by
-// half per tile (which is why round 2's staggered start measured nothing) -- and the kernel paid 0.160 ms where its K loops
-// take 0.123.  Here ONE workgroup of eight waves owns a CU for the whole launch:
-//   tile      = the same 256 rows x 128 columns, the same LDS stages, the same MFMA order per accumulator (bit-identical
-//               results), but a wave holds 64 x 64 of it (64 accumulator registers), so that the FINISHED tile fits next to
-//               the running one: at a tile's end the accumulators move to `prev`, and `prev` is drained -- + bias, transposed
-//               through a per-wave LDS scratch into whole 256-byte row runs, stored -- in seventeen slices that ride on K steps
-//               1..17 of the NEXT tile.  The stores are raw-buffer stores that are ALWAYS issued (out-of-range offset = dropped):
-//               every hand-counted vmcnt below knows exactly how many are in flight.
-//   tiles     = claimed at run time from eight queues (one per XCD: the column groups of a row tile run back to back on one
-//               L2, as before; an XCD that runs dry steals from the next).  The claim for tile i+1 is an atomic issued at the end
-//               of tile i's K step 0 and read at the end of step 2; its tile's first copies are needed at step nkb-3.
-//   pipeline  = the three LDS stages run straight through the tile boundaries (a tile's last K steps already copy the next
-//               tile's first ones): no drain and refill per tile.
-//   grid      = one workgroup per CU (or per tile if there are fewer); workgroups that start late -- their CU was busy with
-//               another batch's recurrence -- find the queues empty and leave.
-namespace {
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int P_STAGE = (A_Q + B_Q) * 16;            // bytes per pipeline stage: 24 KB (16 KB of X, 8 KB of W)
-constexpr int P_SCR_ROW = (64 + 4) * 4;              // bytes per scratch row: 64 columns + 16 B (conflict-free column writes)
-constexpr int P_SCR_WAVE = 32 * P_SCR_ROW;           // 8704 bytes per wave
-constexpr int P_OFF_SCR = 3 * P_STAGE;
-constexpr int P_OFF_BIAS = P_OFF_SCR + 8 * P_SCR_WAVE;
-constexpr int P_BIAS_MAX = 2048;                     // floats: Cout rounded up to 128 must fit
-constexpr int P_OFF_CLAIM = P_OFF_BIAS + P_BIAS_MAX * 4;
-constexpr int P_LDS = P_OFF_CLAIM + 64;              // 151 616 bytes: one workgroup per CU
-constexpr int P_UNROLL = 20;                         // K steps of a tile written out (the drain rides on steps 1..17)
-constexpr unsigned P_OOB = 0x80000000u;              // voffset beyond the descriptor (outputs < 2 GiB): the store is dropped
-
-// stores issued by the drain slice that rides on K step j (see drain()): two in each read slice but the first, two in the flush
-constexpr int p_stores(int j) { return ((j >= 6 && j <= 9) || (j >= 14 && j <= 17)) ? 2 : 0; }
-// vmcnt at the top of K step kb: its stage's three copies were issued in step kb-2; behind them in the queue are that step's
-// stores, the three copies of step kb-1 and its stores
-constexpr int p_wait(int kb) { return 3 + p_stores(kb - 2) + p_stores(kb - 1); }
-
-template <int N>
-__device__ __forceinline__ void p_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
-
-template <int V> struct PTag { static constexpr int value = V; };
-struct PFrag { bf16x8 xh[2], xl[2], wh[2], wl[2]; };
-
-// MODE: the row order of the output (GemmX3Args::tileT): 0 plain, 1 line-major in -> tile-time-major out, -1 the reverse
-template <int MODE>
-__global__ void __launch_bounds__(512, 1) gemm_x3p_kernel(const GemmX3Args a) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];   // dynamic LDS starts at address 0 (no static LDS in this kernel)
-    char* const ldsb = reinterpret_cast<char*>(lds);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, px = lane & 31;
-    const int rq = wave & 3, ch = wave >> 2;          // the wave's 64 rows and 64 columns of the tile
-    const int nkb = a.K >> 4;
-    const int xcd = blockIdx.x & 7;
-    float* const biasL = reinterpret_cast<float*>(ldsb + P_OFF_BIAS);
-    int* const claimL = reinterpret_cast<int*>(ldsb + P_OFF_CLAIM);   // [0] the claimed tile, [1] thread 0's queue scan position (plain LDS: every reader sits behind a wait with a memory clobber)
-    for (int i = tid; i < a.ncg * TN; i += 512) biasL[i] = i < a.Cout ? a.bias[i] : 0.f;
-
-    // ---- tile queues (thread 0).  Queue x holds the row tiles x, x+8, ... times all column groups, column group fastest.
-    // claimL[1] ("scan"): queues (xcd + scan) & 7 and later may still hold tiles
-    auto queue_len = [&](int x) { return ((a.ntiles - x + 7) >> 3) * a.ncg; };
-    auto tile_id = [&](int x, int q) { const int r = q / a.ncg; return (r * 8 + x) * a.ncg + (q - r * a.ncg); };   // row tile * ncg + column group
-    auto claim_now = [&](int& scan) -> int {
-        while (scan < 8) {
-            const int x = (xcd + scan) & 7;
-            const int q = (int)atomicAdd(a.ctr + x, 1u);
-            if (q < queue_len(x)) return tile_id(x, q);
-            ++scan;
-        }
-        return -1;
-    };
-    if (tid == 0) { int sc = 0; claimL[0] = claim_now(sc); claimL[1] = sc; }
-    __syncthreads();
-    int cur_id = __builtin_amdgcn_readfirstlane(claimL[0]);
-    __builtin_amdgcn_s_barrier();                     // claimL[0] is rewritten during the first tile
-
-    // ---- copy sources: a 64-bit wave-uniform base (SGPRs) + a 32-bit lane offset.  X piece (plane, k-half = ch) of row chunk rq:
-    // only the lane offset (the row) depends on the tile; W chunk `wave`: only the base (the column group) does.
-    const size_t xstep = (size_t)a.M * 32;            // bytes between K steps of one k-half (two 8-element K blocks)
-    const char* const xb0 = reinterpret_cast<const char*>(a.x) + (size_t)ch * a.M * 16;
-    const char* const xb1 = xb0 + a.x_plane * 2;
-    const char* const wb0 = reinterpret_cast<const char*>(a.w) + wave * 1024;
-    const unsigned wo = (unsigned)lane * 16;
-    auto x_off = [&](int id) -> unsigned { return (unsigned)min((id / a.ncg) * TM + rq * 64 + lane, a.M - 1) * 16u; };
-    const unsigned dX0 = (unsigned)(((0 + ch) * TM + rq * 64) * 16), dX1 = (unsigned)(((2 + ch) * TM + rq * 64) * 16);
-    const unsigned dW = (unsigned)((A_Q + wave * 64) * 16);
-    auto p_copy = [&](const char* sbase, unsigned voff, unsigned lds_off) {      // 64 lanes x 16 B -> LDS [lds_off, +1 KB)
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
-    };
-    // the three copies of K step `kb` of the tile (row offset xo, column group cg) into stage b
-    auto copy3 = [&](unsigned xo, int cg, int kb, int b) {
-        const unsigned st = (unsigned)(b * P_STAGE);
-        p_copy(xb0 + (size_t)kb * xstep, xo, st + dX0);
-        p_copy(xb1 + (size_t)kb * xstep, xo, st + dX1);
-        p_copy(wb0 + ((size_t)cg * nkb + kb) * (B_Q * 16), wo, st + dW);
-    };
-
-    f32x16 acc[2][2], prev[2][2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[cb][s][r] = 0.f; prev[cb][s][r] = 0.f; }
-
-    if (cur_id >= 0) {
-        unsigned cu_xo = x_off(cur_id), nx_xo = cu_xo;
-        int cu_cg = cur_id % a.ncg, nx_cg = cu_cg;
-        int nxt_id = -1;
-        int prev_rt = 0, prev_cg = 0;
-        bool prev_valid = false;
-        int qv = 0;                                    // thread 0: the claim in flight
-
-        // ---- drain state: output descriptor, scratch, row iterator of the segment being stored
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0x7FFFFFFF, 0x00020000);
-        char* const scr = ldsb + P_OFF_SCR + wave * P_SCR_WAVE;
-        const bool nostore = KRK_DBGBIT(a, 4);
-        const int T = __builtin_amdgcn_readfirstlane(MODE < 0 ? -a.tileT : a.tileT);     // steps per line (MODE != 0)
-        const int lim = MODE > 0 ? T : 16 * T;
-        int ia = 0, ib = 0, irow = 0;                  // row iterator: (line, step) / (16-line tile, row in it) / plain; irow = the input row
-        f32x4 pend[2];
-        unsigned pend_off[2] = {P_OOB, P_OOB};
-        pend[0] = pend[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto row_init = [&](int R) {
-            irow = R;
-            if constexpr (MODE != 0) { ia = R / lim; ib = R - ia * lim; }
-        };
-        auto row_adv4 = [&]() {
-            irow += 4;
-            if constexpr (MODE != 0) {                 // four corrections cover every T >= 1
-                ib += 4;
-                bool w;
-                w = ib >= lim; ib -= w ? lim : 0; ia += w ? 1 : 0;
-                w = ib >= lim; ib -= w ? lim : 0; ia += w ? 1 : 0;
-                w = ib >= lim; ib -= w ? lim : 0; ia += w ? 1 : 0;
-                w = ib >= lim; ib -= w ? lim : 0; ia += w ? 1 : 0;
-            }
-        };
-        auto row_off = [&](int col) -> unsigned {
-            bool keep = prev_valid && irow < a.M && col < a.Cout && !nostore;
-            unsigned orow = (unsigned)irow;            // the launcher admits outputs below 2 GiB only: 32-bit row arithmetic
-            if constexpr (MODE > 0) orow = ((unsigned)(ia >> 4) * (unsigned)T + (unsigned)ib) * 16u + (unsigned)(ia & 15);
-            else if constexpr (MODE < 0) {
-                const int n = ia * 16 + (ib & 15);
-                keep = keep && n < a.nlines;
-                orow = (unsigned)n * (unsigned)T + (unsigned)(ib >> 4);
-            }
-            const unsigned off = (orow * (unsigned)a.Cout + (unsigned)col) * 4u;
-            return keep ? off : P_OOB;
-        };
-        // slice D (0..16) of the drain of `prev`: per 32-row segment s four WRITE slices (two (column block, j) quads each: + bias,
-        // column order -> scratch rows), then four READ slices (two row quads each: 4 rows x 256 B per instruction); what a read
-        // slice fetched is stored by the NEXT slice, so no slice waits for its own LDS reads
-        auto drain = [&](auto dtag) {
-            constexpr int D = decltype(dtag)::value;
-            if constexpr (D >= 0 && D <= 16) {
-                constexpr int s = (D >> 3) & 1, ph = D & 7;
-                if constexpr (D == 16 || ph >= 5 || D == 8) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[e]), yrs, (int)pend_off[e], 0, 0);
-                }
-                if constexpr (D < 16 && ph < 4) {
-                    if constexpr (ph == 0) row_init(prev_rt * TM + rq * 64 + s * 32 + (lane >> 4));
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        constexpr int u = 2 * ph;
-                        const int cb = (u + e) >> 2, j = (u + e) & 3;
-                        const int c = cb * 32 + 8 * j + 4 * half;
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(biasL + prev_cg * TN + ch * 64 + c);
-                        f32x4 v;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = prev[cb][s][4 * j + i] + bv[i];
-                        *reinterpret_cast<f32x4*>(scr + px * P_SCR_ROW + c * 4) = v;
-                    }
-                } else if constexpr (D < 16) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int i2 = (ph - 4) * 2 + e;
-                        pend[e] = *reinterpret_cast<const f32x4*>(scr + (4 * i2 + (lane >> 4)) * P_SCR_ROW + (lane & 15) * 16);
-                        pend_off[e] = row_off(prev_cg * TN + ch * 64 + 4 * (lane & 15));
-                        row_adv4();
-                    }
-                }
-            }
-        };
-
-        // ---- fragments and MFMAs of one K step
-        const int arow = rq * 64 + px;
-        auto read = [&](int b, PFrag& f) {
-            const f32x4* L = reinterpret_cast<const f32x4*>(ldsb + b * P_STAGE);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f.xh[s] = __builtin_bit_cast(bf16x8, L[(0 + half) * TM + arow + 32 * s]);
-                f.xl[s] = __builtin_bit_cast(bf16x8, L[(2 + half) * TM + arow + 32 * s]);
-            }
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                f.wh[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (0 + half) * TN + ch * 64 + cb * 32 + px]);
-                f.wl[cb] = __builtin_bit_cast(bf16x8, L[A_Q + (2 + half) * TN + ch * 64 + cb * 32 + px]);
-            }
-        };
-        int b = 0;                                     // stage of the step about to run
-        // one K step.  NW = vmcnt that proves the NEXT step's stage has landed; D = drain slice riding on this step
-        auto step = [&](auto wtag, auto dtag, int kb, const PFrag& cur, PFrag& nxt) {
-            p_vmwait<decltype(wtag)::value>();
-            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0) through the builtin: the compiler's own wait counting must see it
-            __builtin_amdgcn_s_barrier();
-            const int bn = b == 2 ? 0 : b + 1;
-            read(bn, nxt);
-            // the copies of step kb+3 go to the stage this step's fragments came from (every wave is past reading it)
-            const int k3 = kb + 3;
-            const bool own = k3 < nkb;
-            const unsigned xo = own ? cu_xo : nx_xo;
-            const int cgc = own ? cu_cg : nx_cg;
-            const int kc = own ? k3 : k3 - nkb;
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh[cb], cur.xh[s], acc[cb][s], 0, 0, 0);
-                    KRK_CROSS(acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh[cb], cur.xl[s], acc[cb][s], 0, 0, 0);
-                              acc[cb][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wl[cb], cur.xh[s], acc[cb][s], 0, 0, 0);)
-                }
-                if (cb == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    copy3(xo, cgc, kc, b);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            drain(dtag);
-            b = bn;
-        };
-
-        // ---- prologue: the first tile's K steps 0..2 into the three stages
-#pragma unroll
-        for (int k = 0; k < 3; ++k) copy3(cu_xo, cu_cg, k, k);
-        PFrag fa = {}, fb = {};
-        p_vmwait<6>();
-        __builtin_amdgcn_s_barrier();
-        read(0, fa);
-
-        while (true) {
-            // K steps 0..19 written out: the previous tile's drain rides on steps 1..17, the claim of the next tile on 0..4
-            step(PTag<p_wait(0)>{}, PTag<-1>{}, 0, fa, fb);
-            if (tid == 0) {
-                // The claim of the next tile, in flight during steps 1 and 2.  By hand: hipcc's atomic optimizer turns atomicAdd into
-                // "one lane adds, s_waitcnt vmcnt(0), v_readfirstlane" on the spot -- a full round trip to L2 in front of every
-                // wave of the workgroup.  The result register must not be touched before the wait at the end of step 2.
-                const int sc = claimL[1];
-                const unsigned qoff = sc < 8 ? (unsigned)((xcd + sc) & 7) * 4u : 36u, one = 1u;     // [9]: a counter nobody reads
-                asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(qv) : "v"(qoff), "v"(one), "s"(a.ctr) : "memory");
-            }
-            step(PTag<p_wait(1)>{}, PTag<0>{}, 1, fb, fa);
-            step(PTag<p_wait(2)>{}, PTag<1>{}, 2, fa, fb);
-            if (tid == 0) {
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(qv) : : "memory");     // wave 0 only: the claim (and this wave's copies so far)
-                int sc = claimL[1];
-                const int qx = (xcd + sc) & 7;
-                int id;
-                if (sc < 8 && qv < queue_len(qx)) id = tile_id(qx, qv);
-                else { if (sc < 8) ++sc; id = claim_now(sc); claimL[1] = sc; }
-                claimL[0] = id;
-            }
-            step(PTag<p_wait(3)>{}, PTag<2>{}, 3, fb, fa);
-            step(PTag<p_wait(4)>{}, PTag<3>{}, 4, fa, fb);
-            nxt_id = __builtin_amdgcn_readfirstlane(claimL[0]);      // written before the barrier of step 4
-            if (nxt_id >= 0) { nx_xo = x_off(nxt_id); nx_cg = nxt_id % a.ncg; }
-            else { nx_xo = cu_xo; nx_cg = cu_cg; }                  // no next tile: the last steps copy (harmlessly) from this one
-            step(PTag<p_wait(5)>{}, PTag<4>{}, 5, fb, fa);
-            step(PTag<p_wait(6)>{}, PTag<5>{}, 6, fa, fb);
-            step(PTag<p_wait(7)>{}, PTag<6>{}, 7, fb, fa);
-            step(PTag<p_wait(8)>{}, PTag<7>{}, 8, fa, fb);
-            step(PTag<p_wait(9)>{}, PTag<8>{}, 9, fb, fa);
-            step(PTag<p_wait(10)>{}, PTag<9>{}, 10, fa, fb);
-            step(PTag<p_wait(11)>{}, PTag<10>{}, 11, fb, fa);
-            step(PTag<p_wait(12)>{}, PTag<11>{}, 12, fa, fb);
-            step(PTag<p_wait(13)>{}, PTag<12>{}, 13, fb, fa);
-            step(PTag<p_wait(14)>{}, PTag<13>{}, 14, fa, fb);
-            step(PTag<p_wait(15)>{}, PTag<14>{}, 15, fb, fa);
-            step(PTag<p_wait(16)>{}, PTag<15>{}, 16, fa, fb);
-            step(PTag<p_wait(17)>{}, PTag<16>{}, 17, fb, fa);
-            step(PTag<p_wait(18)>{}, PTag<-1>{}, 18, fa, fb);
-            step(PTag<p_wait(19)>{}, PTag<-1>{}, 19, fb, fa);
-            static_assert(P_UNROLL == 20 && p_wait(20) == 3 && p_wait(21) == 3, "the run-time K loop below waits vmcnt(3)");
-            int kb = P_UNROLL;
-            for (; kb + 1 < nkb; kb += 2) {
-                step(PTag<3>{}, PTag<-1>{}, kb, fa, fb);
-                step(PTag<3>{}, PTag<-1>{}, kb + 1, fb, fa);
-            }
-            if (kb < nkb) {
-                step(PTag<3>{}, PTag<-1>{}, kb, fa, fb);
-                fa = fb;
-            }
-            // the tile is complete: park it, start the next one
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    prev[cb][s] = acc[cb][s];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[cb][s][r] = 0.f;
-                }
-            prev_rt = cur_id / a.ncg;
-            prev_cg = cur_id - prev_rt * a.ncg;
-            prev_valid = true;
-            if (nxt_id < 0) break;
-            cur_id = nxt_id;
-            cu_xo = nx_xo;
-            cu_cg = nx_cg;
-        }
-        // the last tile's drain has nothing to ride on (the dummy copies of the last three steps may still be landing: the
-        // scratch region is not theirs)
-        drain(PTag<0>{}); drain(PTag<1>{}); drain(PTag<2>{}); drain(PTag<3>{}); drain(PTag<4>{}); drain(PTag<5>{});
-        drain(PTag<6>{}); drain(PTag<7>{}); drain(PTag<8>{}); drain(PTag<9>{}); drain(PTag<10>{}); drain(PTag<11>{});
-        drain(PTag<12>{}); drain(PTag<13>{}); drain(PTag<14>{}); drain(PTag<15>{}); drain(PTag<16>{});
-        p_vmwait<0>();                                 // LDS-DMA copies must not land in a successor workgroup's LDS
-    }
-    // the last workgroup out zeroes the queues for the next launch on this stream
-    if (tid == 0) {
-        const unsigned gone = atomicAdd(a.ctr + 8, 1u);
-        if (gone == gridDim.x - 1) {
-#pragma unroll
-            for (int x = 0; x < 10; ++x) atomicExch(a.ctr + x, 0u);
-        }
-    }
-}
-
-}  // namespace
-
 int KRK_FN(krk_launch_gemm_x3)(const GemmX3Args& a, hipStream_t s) {
     if (a.K % 16 || a.M <= 0) return a.M == 0 ? 0 : -1;
-    static bool attr_set[64] = {false};
-    static int ncu[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const bool known = dev >= 0 && dev < 64;
-    // the attribute belongs to the function object of the CURRENT device: once per device, not once per process
-    if (!known || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * (A_Q + B_Q) * 16));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3p_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3p_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        int n = 0;
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, known ? dev : 0);
-        if (known) { attr_set[dev] = true; ncu[dev] = n; }
-    }
-    // persistent form: enough K steps to carry a tile's drain, 16-byte row pieces, bias and output inside its LDS / descriptor
-    const int nkb = a.K >> 4;
-    const size_t out_rows = (size_t)a.M + 16 * (size_t)(a.tileT < 0 ? -a.tileT : a.tileT);
-    int cus = known && ncu[dev] > 0 ? ncu[dev] : 256;
-    static const int grid_probe = [] { const char* e = getenv("KRK_GEMM_PGRID"); return e ? atoi(e) : 0; }();   // A/B probe: workgroups of the persistent grid
-    if (grid_probe > 0) cus = grid_probe;
-    const long tiles = (long)a.ntiles * a.ncg;
-    // at least four tiles per workgroup: below that the dynamic queue's tail (one tile = 1/4 of the launch) costs more than the
-    // overlapped stores save (LinSoftmax with 256 classes: 300 tiles -- 0.20 ms here against 0.065 ms one tile per workgroup)
-    if (a.ctr && nkb >= P_UNROLL && (a.Cout & 3) == 0 && a.ncg * TN <= P_BIAS_MAX && out_rows * a.Cout * 4 < 0x7FFFFFFFull &&
-        tiles >= 4L * cus && !(KRK_DBGBIT(a, 1) || KRK_DBGBIT(a, 2) || KRK_DBGBIT(a, 8))) {
-        if (a.tileT > 0) hipLaunchKernelGGL(gemm_x3p_kernel<1>, dim3((unsigned)cus), dim3(512), P_LDS, s, a);
-        else if (a.tileT < 0) hipLaunchKernelGGL(gemm_x3p_kernel<-1>, dim3((unsigned)cus), dim3(512), P_LDS, s, a);
-        else hipLaunchKernelGGL(gemm_x3p_kernel<0>, dim3((unsigned)cus), dim3(512), P_LDS, s, a);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
     const int slots = (a.ntiles + 7) / 8 * 8;
     const size_t lds = (size_t)3 * (A_Q + B_Q) * 16;
+    // the attribute belongs to the function object of the CURRENT device: once per device, not once per process
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
     hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)(slots * a.ncg)), dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -521,7 +521,6 @@ class RecognitionEngine:
             finally:
                 self._inflight, self._next, self.chain_fronts = deque(inflight), keep_next, chain
                 self._fronts[:] = fronts
-            slot.event.synchronize()
             slot.busy, slot.keep, slot.keep_lens = False, None, None
             _lib.check(self.lib.krk_plan_status(slot.plan.handle))
         nt = slot.cap_n * slot.cap_t

@@ -210,6 +210,13 @@ def _fused_ok(net) -> bool:
     hs = getattr(vgsl, 'nn', None)
     if hs is None or not hasattr(hs, 'recognize'):
         return False
+    # The engine sizes its slots for ONE line of the widest width (krk_plan_out_dims with N = 1): a general Reshape must divide
+    # every batch's (lines, width), not that probe's, and a network that changes the number of lines has no per-line output at all
+    # (krk_recognize refuses it) -- such recognisers take the synchronous path
+    if any(sp.kind == 'reshape' and sp.params.get('general') for sp in getattr(vgsl, 'layer_specs', ())):
+        return False
+    if any(sp.kind == 'add' and sp.params.get('axis') == 0 for sp in getattr(vgsl, 'layer_specs', ())):
+        return False
     return getattr(net, 'decoder', _ctc.greedy_decoder) is _ctc.greedy_decoder
 
 

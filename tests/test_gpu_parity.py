@@ -262,6 +262,25 @@ def test_seq_lens_behind_a_batch_changing_layer_fail_where_the_reference_fails()
         r.nn(torch.rand(6, 2, 6, 9).cuda())
 
 
+def test_recognize_reports_the_seq_lens_of_a_network_with_a_general_reshape():
+    """krk_recognize filled olens_host through krk_plan_olens, which refuses plans with a general Reshape and writes
+    nothing -- `recognize(x, lens)` returned uninitialised olens for such recognisers.  The fused call and forward() must agree,
+    and both must be the seq_lens the reference returns (`olens_probe` of the golden)."""
+    c = CASES['rs_alt_hc']                                 # [1,4,0,2 Cr3,3,3 S1(4x1)3,1 Lbx5 O1c4]
+    m = build_model(c['spec'], c['sd']).to('cuda')
+    x = torch.from_numpy(c['x']).clone()
+    lens = [int(v) for v in c['lens_probe']]
+    for i, L in enumerate(lens):
+        x[i, ..., L:] = 0
+    _, want = m.nn(x.cuda(), torch.tensor(lens))
+    for prec in ('f32', 'bf16x3'):
+        m.nn.set_precision(prec)
+        batch, olens, _, _ = m.nn.recognize(x.cuda(), torch.tensor(lens))
+        torch.cuda.synchronize()
+        assert olens.tolist() == want.tolist() == c['olens_probe'].tolist()
+        assert len(batch.tuples()) == len(lens)
+
+
 def test_random_reshapes_and_additions_on_the_device_like_the_reference():
     """The 240 random `S…` / `A…` layers of tests/golden/reshape_random.npz (made by the reference) through krk_forward: an arange
     tensor lands exactly where the reference puts it (a reshape only moves values; Addition sums small integers: exact in fp32), the
