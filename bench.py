@@ -69,6 +69,10 @@ def parse():
                          "rescaled LSTM input projections and recalibrated output biases, so that a line decodes to ~70 characters (the "
                          "host codec / record side at real text density)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-self-profile', action='store_true',
+                    help='skip the rocprofv3 passes bench.py runs on itself after the timed region (kernel trace + three --pmc passes '
+                         'of a 6-step run); roofline.traffic / rocprof_* then come from the newest committed summary under profiles/')
+    ap.add_argument('--no-config4-check', action='store_true', help='skip the 1024 config-4 golden lines after the timed region')
     ap.add_argument('--host-input', action='store_true',
                     help='hand every batch over as a pinned HOST tensor (PCIe-inclusive rate; DESIGN.md quotes it, `value` never does)')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the gather even with one rank (smoke test)')
@@ -212,7 +216,7 @@ KERNEL_OF = {'conv': 'conv_f32_kernel', 'lstm_xproj': 'conv_f32_kernel<1,1,0,4>'
              'lstm_rec_x3': 'lstm_ws_kernel'}
 
 
-def roofline_of(engine, precision):
+def roofline_of(engine, precision, fresh=None):
     """Per-launch timing from the HIP events recorded inside the timed region (last batch of each slot, on its own stream)."""
     per_launch = {}
     for slot_times in engine.layer_times():
@@ -237,7 +241,7 @@ def roofline_of(engine, precision):
                 'gflop_per_launch': round(dom['gflop'] / dom['n'], 3),
                 'achieved': round(ach, 2), 'peak': peak_of(dom_name), 'unit': 'TFLOP/s',
                 'frac': round(ach / peak_of(dom_name), 4), 'traffic': None,
-                'clock': 'HIP events on the stream the kernels ran on (the rocprofv3 average of the same command is in profiles/)',
+                'clock': 'HIP events on the stream the kernels ran on (rocprofv3: rocprof_avg_launch_ms / frac_rocprof, from the passes named in traffic.source)',
                 'note': ('algorithmic FLOPs of the launch group / its HIP-event time with the other batches in flight; the '
                          'split-operand kernels issue 3 bf16 MFMAs per algorithmic product'
                          if dom_name.endswith('_x3') else 'exact f32 MFMA')}
@@ -253,10 +257,17 @@ def roofline_of(engine, precision):
         cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)) or
                        ([] if precision != 'f32' else glob.glob(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json'))))
         cands = [c for c in cands if 'solo' not in c] or cands
-        summary = cands[-1]
-        tag = os.path.basename(summary)
-        whole = json.load(open(summary))
+        if fresh and fresh.get('summary'):
+            whole, tag = fresh['summary'], 'THIS RUN'
+            src = ('this run: rocprofv3 passes bench.py launched on its own command after the timed region (' + fresh['command'] + '; '
+                   '--kernel-trace --stats, then --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, one pass each)')
+        else:
+            summary = cands[-1]
+            tag = os.path.basename(summary)
+            whole = json.load(open(summary))
+            src = f'profiles/{tag} (COMMITTED file, not this run' + (': ' + fresh['why'] if fresh and fresh.get('why') else '') + ')'
         pmc = whole['kernels']
+        by_grid = (fresh or {}).get('by_grid') or {}
         # the clock the committed profile ran at (tools/clock_sample.py; the MFMA-busy fractions are of ACTUAL cycles)
         sclk = ((whole.get('clock') or {}).get('sclk_mhz') or {}).get('median')
         steps_profiled = max(1, max((v.get('calls', 0) for k, v in pmc.items() if k.startswith('rowmax_rows_kernel')), default=1))
@@ -278,8 +289,18 @@ def roofline_of(engine, precision):
             e = {'kernel': kname, 'rocprof_avg_launch_ms': round(v['avg_us'] / 1e3, 4), 'hbm_read_MB': rd, 'hbm_write_MB': wr,
                  'hbm_GBps': round((rd + wr) / v['avg_us'] * 1e3, 1) if v.get('avg_us') else None}
             sharers = [g for g in groups if g != gname and KERNEL_OF.get(g, g) == kname]
-            if sharers:       # rocprofv3 cannot tell the launches of one kernel apart: the figures are the average over ALL of them
-                e['averaged_with'] = sharers
+            if sharers:
+                # rocprofv3's stats average over ALL launches of a kernel; the kernel trace tells them apart by grid size, and a launch
+                # group is the grid that occurs groups[g]['n'] times per step (three projections, one linear layer)
+                mine = [g_ for g_ in by_grid.get(kname.split('<')[0], []) if g_['per_step'] == groups[gname]['n']]
+                others = {groups[o]['n'] for o in sharers}
+                if len(mine) == 1 and groups[gname]['n'] not in others:
+                    e['rocprof_avg_launch_ms'] = round(mine[0]['avg_us'] / 1e3, 4)
+                    e['grid'] = mine[0]['grid']
+                    e['counters_averaged_with'] = sharers      # the --pmc passes still average the kernel's launches
+                    e['hbm_GBps'] = None                       # (bytes of the average launch over this grid's duration would mean nothing)
+                else:
+                    e['averaged_with'] = sharers
             if v.get('mfma_util_chip') is not None:
                 e['mfma_busy_chip'] = v['mfma_util_chip']
                 e['mfma_busy_on_its_CUs'] = round(v['mfma_util_chip'] * 256.0 / cus_of(kname, v), 4)
@@ -289,11 +310,11 @@ def roofline_of(engine, precision):
         # HBM bytes of one step = sum over all profiled kernels of calls x bytes / profiled steps (one rowmax launch per step)
         tot = sum(v.get('calls', 0) * (v.get('hbm_read_MB_x2', v.get('hbm_read_MB_per_launch', 0.0)) + v.get('hbm_write_MB_per_launch', 0.0))
                   for v in pmc.values())
-        step_traffic = {'GB': round(tot / steps_profiled / 1e3, 3), 'steps_profiled': steps_profiled, 'source': f'profiles/{tag}'}
+        step_traffic = {'GB': round(tot / steps_profiled / 1e3, 3), 'steps_profiled': steps_profiled, 'source': src}
         d = pmc_groups.get(dom_name)
         if d:
             roofline['traffic'] = {'read_MB': d['hbm_read_MB'], 'write_MB': d['hbm_write_MB'], 'per': 'launch', 'hbm_GBps': d['hbm_GBps'],
-                                   'source': f'profiles/{tag} (FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the guide for the wide streaming reads)'}
+                                   'source': src + ' -- FETCH_SIZE doubled per the guide for the wide streaming reads'}
             # the same fraction on the profiler's clock: rocprofv3's average duration of the kernel in the committed run
             roofline['frac_hip_events'] = roofline['frac']
             roofline['frac_rocprof'] = round(dom['gflop'] / dom['n'] / d['rocprof_avg_launch_ms'] / peak_of(dom_name), 4)
@@ -303,7 +324,7 @@ def roofline_of(engine, precision):
                 roofline['mfma_busy_on_its_CUs'] = d['mfma_busy_on_its_CUs']
             if sclk:
                 roofline['profile_sclk_mhz'] = sclk
-                roofline['profile_sclk_note'] = ('shader clock under this load in the committed profile (rocm-smi, power-capped; nominal 2400 MHz): '
+                roofline['profile_sclk_note'] = ('shader clock under this load in the profile named in traffic.source (rocm-smi, power-capped; nominal 2400 MHz): '
                                                  'busy fractions are of actual cycles, x sclk/2400 gives them against the nominal peak')
     except Exception:
         pass
@@ -314,6 +335,106 @@ def roofline_of(engine, precision):
                                     'frac_of_peak': round(v['gflop'] / v['ms'] / peak_of(k), 4) if v['ms'] > 0 else 0,
                                     'rocprof': v.get('pmc')}
                                 for k, v in groups.items()}
+
+
+def self_profile(args):
+    """
+    VERDICT r5 item 6: the rocprofv3 figures of the line measured in THIS invocation.  After the timed region rank 0 runs its own
+    command again for 6 steps under rocprofv3 -- one --kernel-trace --stats pass and three --pmc passes (FETCH_SIZE, WRITE_SIZE,
+    SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; counters never together with a trace, MI355X_MICROARCH.md) -- and condenses them with
+    tools/summarize_pmc.py.  Returns {'summary', 'by_grid', 'command', 'seconds'} or {'why': reason} (no rocprofv3 on PATH, already
+    under a profiler, a pass failed or timed out): the caller then falls back to the committed summary and says so in `source`.
+    """
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    t_start = time.perf_counter()
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return {'why': 'rocprofv3 is not on PATH'}
+    if any(k.startswith(('ROCPROF', 'ROCP_', 'ROCTRACER')) for k in os.environ):
+        return {'why': 'this process already runs under a profiler'}
+    tmp = tempfile.mkdtemp(prefix='krk_selfprof_', dir='/tmp')
+    cmd = [sys.executable, os.path.abspath(__file__), '--precision', args.precision, '--slots', str(args.slots), '--batch', str(args.batch),
+           '--width', str(args.width), '--data', args.data, '--steps', '6', '--warmup', '2', '--preheat-ms', '0', '--no-cpu-baseline',
+           '--no-self-profile', '--no-config4-check']
+    env = dict(os.environ, TMPDIR='/tmp')
+    passes = [('stats', ['--kernel-trace', '--stats']), ('fetch', ['--pmc', 'FETCH_SIZE']), ('write', ['--pmc', 'WRITE_SIZE']),
+              ('mfma', ['--pmc', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'])]
+    try:
+        for tag, flags in passes:
+            r = subprocess.run([exe, *flags, '--output-format', 'csv', '-d', os.path.join(tmp, tag), '--', *cmd], cwd='/tmp', env=env,
+                               capture_output=True, text=True, timeout=240)
+            if r.returncode:
+                return {'why': f'rocprofv3 pass "{tag}" exited {r.returncode}: {(r.stderr or r.stdout)[-200:]!r}'}
+
+        def newest(tag, suffix):
+            hits = glob.glob(os.path.join(tmp, tag, '**', '*' + suffix), recursive=True)
+            return max(hits, key=os.path.getmtime) if hits else None
+        files = [newest('stats', 'kernel_stats.csv'), newest('fetch', 'counter_collection.csv'), newest('write', 'counter_collection.csv'),
+                 newest('mfma', 'counter_collection.csv')]
+        if not all(files):
+            return {'why': 'a rocprofv3 pass wrote no csv'}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'summarize_pmc.py'), 'self', *files], capture_output=True, text=True,
+                           timeout=60)
+        if r.returncode:
+            return {'why': 'tools/summarize_pmc.py failed: ' + r.stderr[-200:]}
+        summary = json.loads(r.stdout)
+        # per (kernel, grid size): the launches of one kernel that belong to different launch groups (gemm_x3: projections / linear)
+        by_grid, steps = {}, 6
+        trace = newest('stats', 'kernel_trace.csv')
+        if trace:
+            acc = {}
+            for row in csv.DictReader(open(trace)):
+                m = re.search(r'(\w+_kernel)', row.get('Kernel_Name', ''))
+                if not m:
+                    continue
+                grid = int(row.get('Grid_Size_X', row.get('Grid_Size', 0)) or 0)
+                a = acc.setdefault((m.group(1), grid), [0, 0.0])
+                a[0] += 1
+                a[1] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
+            steps = max(1, max((n for (k, _), (n, _) in acc.items() if k == 'rowmax_rows_kernel'), default=6))
+            for (k, grid), (n, ns) in acc.items():
+                by_grid.setdefault(k, []).append({'grid': grid, 'calls': n, 'per_step': n // steps if n % steps == 0 else -1,
+                                                  'avg_us': round(ns / n / 1e3, 1)})
+        return {'summary': summary, 'by_grid': by_grid, 'command': 'bench.py ' + ' '.join(cmd[2:]),
+                'seconds': round(time.perf_counter() - t_start, 1)}
+    except subprocess.TimeoutExpired as e:
+        return {'why': f'a rocprofv3 pass did not finish in {e.timeout:.0f} s'}
+    except Exception as e:                               # the bench line must come out whatever the profiler does
+        return {'why': f'{type(e).__name__}: {e}'[:200]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def config4_golden_check(model, precision):
+    """
+    BASELINE config 4's 1024 DISTINCT ragged lines (tests/golden/bench_lines.npz: cfg4, kraken's batch-1 strings and top-2 margins)
+    through the plan that was just timed, width-bucketed batches of 128 with masked padding: how many strings are identical, and
+    whether every differing line lies inside the plan's tie window (4 x its measured logit error).  Outside the timed region.
+    """
+    try:
+        z = np.load(os.path.join(ROOT, 'tests', 'golden', 'bench_lines.npz'), allow_pickle=False)
+        want, margin, widths = json.loads(str(z['cfg4_strings'])), z['cfg4_margin'], z['cfg4_widths'].tolist()
+    except Exception:
+        return None
+    tie = 1e-5 if precision == 'f32' else 1e-4
+    got = []
+    for lo in range(0, len(widths), 128):
+        ws = widths[lo:lo + 128]
+        xb = torch.zeros(len(ws), 1, 48, max(ws))
+        for i, w in enumerate(ws):
+            xb[i, ..., :w] = torch.rand(1, 1, 48, w, generator=torch.Generator().manual_seed(50000 + lo + i))[0]
+        b, _, _, _ = model.nn.recognize(xb.cuda(), torch.tensor(ws))
+        got += model.codec.decode_strings(b)
+    diff = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+    return {'lines': len(want), 'identical': len(want) - len(diff), 'differ_inside_tie_window': sum(1 for i in diff if margin[i] < tie),
+            'differ_outside_tie_window': sum(1 for i in diff if margin[i] >= tie), 'tie_window': tie,
+            'source': 'tests/golden/bench_lines.npz: cfg4_strings / cfg4_margin, made by the unmodified reference at batch 1; here '
+                      'width-sorted batches of 128, masked padding, after the timed region'}
 
 
 class _StubEngine:
@@ -433,6 +554,7 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
     }
     if per_rank:
         out['per_rank'] = per_rank
+    out['warmup_effective'] = args.warmup + preheat_steps      # every untimed step in front of the timed region
     out['preheat'] = {'steps': preheat_steps, 'ms': args.preheat_ms,
                       'note': 'untimed steps in front of the W warm-up steps (clock governor out of its idle state); --preheat-ms 0 switches it off'}
     out['_first_strings'] = first[0] if first else []
@@ -452,7 +574,14 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
         out['data'] = 'STUB ENGINE -- plumbing test without a GPU, no device work: `value` is meaningless'
         out['dtype'] = 'none (stub)'
         return out
-    roofline, launches, groups = roofline_of(engine, args.precision)
+    fresh = None
+    if rank == 0 and world == 1 and not args.no_self_profile:
+        fresh = self_profile(args)           # (the parent keeps its engine: it is idle, and 288 GB hold both)
+    elif rank == 0:
+        fresh = {'why': '--no-self-profile' if args.no_self_profile else 'multi-rank run'}
+    roofline, launches, groups = roofline_of(engine, args.precision, fresh)
+    if fresh and fresh.get('seconds'):
+        roofline['self_profile_s'] = fresh['seconds']
     out.update({
         'roofline': roofline,
         'launches': [{'name': l['name'], 'ms': round(l['ms'], 3), 'tflops': round(l['gflop'] / l['ms'], 1) if l['ms'] > 0 else 0}
@@ -852,6 +981,11 @@ def main():
             out.setdefault('parity_checked', {})['kraken_golden'] = {
                 'lines': len(g), 'identical': sum(a == b for a, b in zip(first_strings, g)),
                 'source': 'tests/golden/bench_lines.npz: cfg2_strings, made by the unmodified reference (tests/golden/make_golden.py)'}
+    if rank == 0 and world == 1 and args.mode == 'engine' and not stub and not args.no_config4_check and golden_strings(args) is not None \
+            and args.precision in ('f32', 'bf16x3'):
+        c4 = config4_golden_check(model, args.precision)
+        if c4 is not None:
+            out.setdefault('parity_checked', {})['kraken_golden_config4'] = c4
     if world > 1:
         out['host_cpus_per_rank'] = cpus_kept
     if args.share_device:

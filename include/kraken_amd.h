@@ -9,6 +9,7 @@
  *
  *   krk_plan_create   <- TorchVGSLModel._parse / build_* (kraken/lib/vgsl/model.py:202-243,
  *                        570-817): the parsed layer list + state-dict tensors
+ *   krk_plan_clone    <- (none) one more execution context over the same weights: kraken shares its modules between callers
  *   krk_plan_olens    <- per-layer seq_len arithmetic (kraken/lib/vgsl/layers.py:387,
  *   krk_plan_olens_w     858-859, 334); _w: with the batch's width, which Reshape.forward scales
  *                        seq_lens by (layers.py:331-332)
@@ -49,7 +50,7 @@
 extern "C" {
 #endif
 
-#define KRK_ABI_VERSION 2   /* 2 (round 6): + krk_plan_get_recurrence; round 5 had added CONVT / RESHAPE ops, krk_plan_out_dims, krk_plan_olens_w, krk_plan_set_recurrence under version 1 */
+#define KRK_ABI_VERSION 3   /* 3 (round 6): + krk_plan_clone; 2 (round 6): + krk_plan_get_recurrence; round 5 had added CONVT / RESHAPE ops, krk_plan_out_dims, krk_plan_olens_w, krk_plan_set_recurrence under version 1 */
 
 /* error codes */
 #define KRK_OK            0
@@ -177,6 +178,14 @@ int krk_plan_create(const krk_layer* layers, int n_layers,
                     int in_channels, int in_height,
                     int precision, int device, krk_plan** out);
 void krk_plan_destroy(krk_plan* plan);
+/*
+ * A second plan over the SAME packed weights (no reference analogue: the reference's modules are shared by every caller of
+ * `nn`, kraken/lib/models.py:96-117; here a plan also owns per-call workspace, so concurrent batches need a plan each).  The clone
+ * has its own workspace (grown on first use), events, status word, profiling and recurrence switch state; the weights are freed
+ * when the last plan sharing them is destroyed, in any order.  Costs two small allocations instead of the repack + upload of
+ * krk_plan_create (7 ms per plan for kraken's default recogniser: a third of an engine's start-up).
+ */
+int krk_plan_clone(const krk_plan* src, krk_plan** out);
 
 /* Output geometry for an input batch of width W: channels, height, width of the
  * final layer's (N, C, H, W') output.  For a recogniser H == 1. */

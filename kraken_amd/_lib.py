@@ -29,7 +29,7 @@ EXPORTS = ['krk_abi_version', 'krk_last_error', 'krk_device_count', 'krk_plan_cr
            'krk_plan_layer_flops', 'krk_plan_num_steps', 'krk_plan_front_event', 'krk_plan_wait_front',
            'krk_plan_status', 'krk_prep_lines', 'krk_prep_crops', 'krk_upsample_sigmoid', 'krk_dewarp_measure', 'krk_dewarp_apply',
            'krk_prep_lines_fmt', 'krk_dewarp_measure_page', 'krk_dewarp_apply_page', 'krk_plan_has_exchange',
-           'krk_plan_set_recurrence', 'krk_plan_out_dims', 'krk_plan_olens_w', 'krk_plan_get_recurrence']
+           'krk_plan_set_recurrence', 'krk_plan_out_dims', 'krk_plan_olens_w', 'krk_plan_get_recurrence', 'krk_plan_clone']
 
 
 class KrkLayer(C.Structure):
@@ -58,7 +58,7 @@ def is_exchange_timeout(e: Exception) -> bool:
 
 
 RECURRENCE_AUTO, RECURRENCE_STREAMING = 0, 1
-ABI_VERSION = 2          # include/kraken_amd.h: KRK_ABI_VERSION
+ABI_VERSION = 3          # include/kraken_amd.h: KRK_ABI_VERSION
 
 
 class streaming_recurrence:
@@ -133,6 +133,8 @@ def load():
         lib.krk_device_count.restype = i32
         lib.krk_plan_create.argtypes = [C.POINTER(KrkLayer), i32, i32, i32, i32, i32, C.POINTER(vp)]
         lib.krk_plan_create.restype = i32
+        lib.krk_plan_clone.argtypes = [vp, C.POINTER(vp)]
+        lib.krk_plan_clone.restype = i32
         lib.krk_plan_destroy.argtypes = [vp]
         lib.krk_plan_destroy.restype = None
         lib.krk_plan_out_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]

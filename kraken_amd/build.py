@@ -18,6 +18,8 @@ LIB = os.path.join(HERE, 'libkraken_amd.so')
 SOURCES = ['conv_mfma.hip', 'conv_x3.hip', 'conv_x3p.hip', 'conv_x6.hip', 'conv1_x3.hip', 'conv_taps_x3.hip', 'gemm_x3.hip', 'norm_x3.hip', 'lstm_rec.hip', 'lstm_small.hip', 'lstm_x3.hip', 'lstm_ws.hip', 'misc_kernels.hip', 'c1gn.hip', 'prep_lines.hip', 'dewarp.hip', 'capi.hip']
 # sources compiled a second time with -DKRK_BF16_ONE: the plain-bf16 plan's launchers (name_b1), see csrc/common.h
 ONE_TERM = ['conv1_x3.hip', 'conv_taps_x3.hip', 'conv_x3.hip', 'conv_x3p.hip', 'gemm_x3.hip', 'lstm_ws.hip']
+# further compiles of one source under a define (kernel experiments selected by a probe switch at run time): {source: [(suffix, -D...)]}
+VARIANTS = {}
 HEADERS = [os.path.join(CSRC, 'common.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'kraken_amd.h')]
 ARCH = 'gfx950'
@@ -59,6 +61,11 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
         objs.append(obj)
         if force or _stale(obj, [sp] + HEADERS + [os.path.abspath(__file__)]):
             jobs.append([hipcc, *flags, '-c', sp, '-o', obj])
+        for suffix, define in VARIANTS.get(src, ()):
+            objv = os.path.join(bdir, src.replace('.hip', f'_{suffix}.o'))
+            objs.append(objv)
+            if force or _stale(objv, [sp] + HEADERS + [os.path.abspath(__file__)]):
+                jobs.append([hipcc, *flags, define, '-c', sp, '-o', objv])
         if src in ONE_TERM:
             obj1 = os.path.join(bdir, src.replace('.hip', '_b1.o'))
             objs.append(obj1)

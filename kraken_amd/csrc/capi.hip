@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 // phase cycle counters of the instrumented kernel (common.h KRK_PHASES): conv_x3p; returns the count
@@ -537,6 +538,9 @@ struct krk_plan {
     // device-side failure word (mapped host memory): set by a kernel that gave up waiting (lstm_ws.hip exchange timeout)
     unsigned* err_host = nullptr;
     unsigned* err_dev = nullptr;
+    // the packed weights (every d_w* / d_gamma / ... pointer of `steps`) belong to this set, shared by the plan krk_plan_create built
+    // and its krk_plan_clone copies; freed when the last of them is destroyed.  Null only while a plan is being built.
+    std::shared_ptr<std::vector<void*>> weights;
     int recurrence = KRK_RECURRENCE_AUTO;   // krk_plan_set_recurrence: which recurrent kernel the split-bf16 layers of THIS plan take
     bool profiling = false;
     std::vector<hipEvent_t> events;          // one per profiled launch + 1
@@ -743,23 +747,17 @@ int upload(float** dst, const std::vector<float>& v) {
     return KRK_OK;
 }
 
-void free_step(Step& s) {
-    if (s.cg.d_w) (void)hipFree(s.cg.d_w);
-    if (s.cg.d_b) (void)hipFree(s.cg.d_b);
-    if (s.cg.d_wx3) (void)hipFree(s.cg.d_wx3);
-    if (s.cg.d_wx5) (void)hipFree(s.cg.d_wx5);
-    if (s.cg.d_wx6) (void)hipFree(s.cg.d_wx6);
-    if (s.d_c1w) (void)hipFree(s.d_c1w);
-    if (s.d_c1b) (void)hipFree(s.d_c1b);
-    if (s.d_wrecsm) (void)hipFree(s.d_wrecsm);
-    if (s.d_peep) (void)hipFree(s.d_peep);
-    if (s.d_wrecsmx) (void)hipFree(s.d_wrecsmx);
-    if (s.d_gamma) (void)hipFree(s.d_gamma);
-    if (s.d_beta) (void)hipFree(s.d_beta);
-    if (s.d_wrec32) (void)hipFree(s.d_wrec32);
-    if (s.d_wrec16) (void)hipFree(s.d_wrec16);
-    if (s.d_wrecx3) (void)hipFree(s.d_wrecx3);
-    if (s.d_wrecws) (void)hipFree(s.d_wrecws);
+// every pointer of a step into the packed weights (krk_plan::weights)
+std::vector<void*> step_weights(const Step& s) {
+    return {s.cg.d_w, s.cg.d_b, s.cg.d_wx3, s.cg.d_wx5, s.cg.d_wx6, s.d_c1w, s.d_c1b, s.d_wrecsm, s.d_peep, s.d_wrecsmx, s.d_gamma,
+            s.d_beta, s.d_wrec32, s.d_wrec16, s.d_wrecx3, s.d_wrecws};
+}
+
+// `weights`: false for a plan whose weights are owned by krk_plan::weights (shared with its clones)
+void free_step(Step& s, bool weights) {
+    if (weights)
+        for (void* q : step_weights(s))
+            if (q) (void)hipFree(q);
     if (s.ws_ctrl) (void)hipFree(s.ws_ctrl);
     s.ws_gran.release();
     s.out.release();
@@ -792,7 +790,8 @@ void krk_plan_destroy(krk_plan* plan) {
     if (!plan) return;
     (void)hipSetDevice(plan->device);
     (void)hipDeviceSynchronize();
-    for (auto& s : plan->steps) free_step(s);
+    for (auto& s : plan->steps) free_step(s, plan->weights == nullptr);
+    plan->weights.reset();                      // the last plan that shares them frees the packed weights
     plan->d_lens.release();
     plan->d_labels.release();
     plan->d_confs.release();
@@ -1180,8 +1179,6 @@ int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
     for (int k = 0; k < 4 * s.ndir; ++k)
         if (!L.w[k]) return fail(KRK_E_INVALID, where + ": LSTM weights missing");
     s.Hp = (s.hidden + 7) / 8 * 8;
-    if (s.Hp > 768)
-        return fail(KRK_E_UNSUPPORTED, where + ": hidden size > 768 not implemented by the recurrent kernels");
     // act = 1 on an LSTM layer: the legacy ocropy peephole cell (reference layers.py:72-186): w[4d + 3] holds the peephole vectors
     // (i, f, o: 3 x hidden) instead of a second bias; the generic-width f32 kernel runs it
     if (L.act != 0 && L.act != 1) return fail(KRK_E_INVALID, where + ": LSTM cell variant");
@@ -1490,7 +1487,60 @@ int PlanBuilder::build() {
 
 }  // namespace
 
+namespace {
+
+// what every plan has for itself, whether built or cloned: events, the mapped status word.  Returns what failed, or null.
+const char* plan_private_state(krk_plan* p) {
+    if (hipEventCreateWithFlags(&p->lens_ev, hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+    if (hipEventCreateWithFlags(&p->front_ev, hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+    if (hipHostMalloc((void**)&p->err_host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&p->err_dev, p->err_host, 0) != hipSuccess)
+        return "hipHostMalloc (status word) failed";
+    *p->err_host = 0;
+    return nullptr;
+}
+
+}  // namespace
+
 extern "C" {
+
+int krk_plan_clone(const krk_plan* src, krk_plan** out) {
+    if (!src || !out) return fail(KRK_E_INVALID, "krk_plan_clone: null plan");
+    if (!src->weights) return fail(KRK_E_INVALID, "krk_plan_clone: the source plan is not complete");
+    HIPCHK(hipSetDevice(src->device));
+    krk_plan* p = new krk_plan(*src);            // schedule, geometry, length rules and the weight POINTERS (the set is shared)
+    // ... and nothing of the source's per-call state: workspaces grow on first use, events and the status word are its own
+    for (auto& st : p->steps) {
+        st.out = st.aux = st.aux2 = st.ws_gran = DevBuf{};
+        st.ws_tickets = st.ws_epoch = 0;
+        st.ws_ctrl = nullptr;
+    }
+    p->d_lens = p->d_labels = p->d_confs = p->d_final = DevBuf{};
+    p->h_lens_pinned = nullptr;
+    p->h_lens_cap = 0;
+    p->lens_ev = p->front_ev = p->front_wait = nullptr;
+    p->lens_ev_pending = false;
+    p->err_host = p->err_dev = nullptr;
+    p->profiling = false;
+    p->events.clear();
+    p->prof_names.clear();
+    p->prof_flops.clear();
+    p->prof_n = 0;
+    p->last_N = p->last_W = 0;
+    auto bail = [&](const std::string& msg) {
+        krk_plan_destroy(p);
+        return fail(KRK_E_HIP, msg);
+    };
+    for (size_t i = 0; i < p->steps.size(); ++i)
+        if (src->steps[i].ws_ctrl) {             // the cluster kernel's ticket counter is written by every launch
+            if (hipMalloc((void**)&p->steps[i].ws_ctrl, 64) != hipSuccess || hipMemset(p->steps[i].ws_ctrl, 0, 64) != hipSuccess)
+                return bail("krk_plan_clone: hipMalloc (ticket counter) failed");
+        }
+    if (const char* what = plan_private_state(p)) return bail(what);
+    HIPCHK(hipDeviceSynchronize());
+    *out = p;
+    return KRK_OK;
+}
 
 int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int in_height, int precision,
                     int device, krk_plan** out) {
@@ -1518,14 +1568,22 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
         krk_plan_destroy(p);
         return rc;
     }
-    if (hipEventCreateWithFlags(&p->lens_ev, hipEventDisableTiming) != hipSuccess)
-        return bail(KRK_E_HIP, "hipEventCreate failed");
-    if (hipEventCreateWithFlags(&p->front_ev, hipEventDisableTiming) != hipSuccess)
-        return bail(KRK_E_HIP, "hipEventCreate failed");
-    if (hipHostMalloc((void**)&p->err_host, 64, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&p->err_dev, p->err_host, 0) != hipSuccess)
-        return bail(KRK_E_HIP, "hipHostMalloc (status word) failed");
-    *p->err_host = 0;
+    {
+        const int dev = device;
+        auto* set = new std::vector<void*>();
+        for (const auto& st : p->steps)
+            for (void* q : step_weights(st))
+                if (q) set->push_back(q);
+        p->weights = std::shared_ptr<std::vector<void*>>(set, [dev](std::vector<void*>* v) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            (void)hipSetDevice(dev);
+            for (void* q : *v) (void)hipFree(q);
+            (void)hipSetDevice(cur);
+            delete v;
+        });
+    }
+    if (const char* what = plan_private_state(p)) return bail(KRK_E_HIP, what);
     HIPCHK(hipDeviceSynchronize());
     *out = p;
     return KRK_OK;
@@ -2226,6 +2284,16 @@ int Pass::recurrence_f32(Step& s, float* outp, int Ns, int T, int G) {
         l.wp = s.d_wrec16;
         l.NB = G / 16;
         l.NG = (s.Hp / 4 + 3) / 4;
+        // above the widths LDS holds (768 / 1152): the workgroups' cell state, then h too, in this step's scratch (lstm_rec.hip)
+        const size_t cfl = krk_lstm_big_cstate_floats(Ns, s.ndir, s.Hp), hfl = krk_lstm_big_hstate_floats(Ns, s.ndir, s.Hp);
+        if (cfl + hfl) {
+            if (s.ws_gran.ensure((cfl + hfl) * sizeof(float))) return nomem();      // (the cluster kernel's buffer: never both on one step)
+            l.cstate = (float*)s.ws_gran.p;
+            if (hfl) {
+                l.hstate = (float*)s.ws_gran.p + cfl;
+                if (int r = hip(hipMemsetAsync(l.hstate, 0, hfl * sizeof(float), stream), "hipMemsetAsync")) return r;
+            }
+        }
         return krk_launch_lstm_big(l, stream);
     }
     // 32-line tiles once they fill most of the 256 CUs, 16-line tiles below that

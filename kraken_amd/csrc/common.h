@@ -221,6 +221,10 @@ struct LstmArgs {
     int xstride, ostride;
     int dbg;              // probe bits (env KRK_LSTM_DBG): 1 no GEMM, 2 no gate math, 4 no output pass, 8 no x prefetch
     const float* peep = nullptr;   // lstm_big_kernel: [ndir][3][Hp] peephole weights of the ocropy cell (i, f, o), else null
+    // lstm_big_kernel above the widths LDS holds (round 6): the cell state of a workgroup in HBM ([ndir][tiles][Hp][16 lines], Hp > 768)
+    // and, above 1152, h as well ([ndir][tiles][parity 2][K rows][16 lines], zeroed by the host before the launch)
+    float* cstate = nullptr;
+    float* hstate = nullptr;
 };
 
 // small hidden sizes (Hp <= 32, lstm_small.hip): wp = [ndir][Hp/4 blocks][Hp/4 K steps][64 lanes]
@@ -297,7 +301,9 @@ int krk_launch_dewarp_apply(const unsigned char* crops, size_t rs, int ps, const
 // host-side launchers (implemented in the .hip files)
 int krk_launch_conv(const ConvArgs& a, bool in_seq, bool out_seq, bool pool, hipStream_t s);
 int krk_launch_lstm(const LstmArgs& a, int M, hipStream_t s);
-int krk_launch_lstm_big(const LstmArgs& a, hipStream_t s);   // 256 < Hp <= 768 (lstm_rec.hip)
+int krk_launch_lstm_big(const LstmArgs& a, hipStream_t s);   // Hp > 256 (lstm_rec.hip); a.cstate above 768, a.hstate above 1152
+size_t krk_lstm_big_cstate_floats(int N, int ndir, int Hp);   // 0: the cell state fits LDS
+size_t krk_lstm_big_hstate_floats(int N, int ndir, int Hp);   // 0: h fits LDS
 int krk_launch_conv_x3(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
 int krk_launch_conv_x3_b1(const X3Args& a, bool out_f32, bool pool, hipStream_t s);
 // three-plane ("bf16x6") convolution in front of a GroupNorm (conv_x6.hip): fp32-class products on the bf16 cores, fp32 NCHW out

@@ -251,13 +251,22 @@ __global__ void __launch_bounds__(256, 1) lstm_f32_kernel(const LstmArgs a) {
 // KG = 4 fragment order), but the gate-column blocks of a wave are a RUN-TIME loop -- each block runs its whole K loop, then its
 // gate math -- and the cell state lives in LDS, so nothing is sized by the hidden width except LDS (h twice + c: 12 bytes x 17 per
 // unit: Hp <= 768).  A correctness path: W_hh streams from L2 every step (4 Hp^2 floats per workgroup), no prefetch pipelining.
+// Round 6 (the reference accepts any size): above 768 the CELL STATE lives in HBM (CST: only the gate-0 lane of a
+// unit's quad reads and writes it -- a thread sees its own stores -- and broadcasts it where the peephole cell needs it; LDS then
+// holds h twice: Hp <= 1152); above that h lives in HBM as well (HST: [parity][K row][16 lines] per workgroup, written with plain
+// stores -- write-through to L2, completed by the barrier's vmcnt(0) -- and read with agent-scope loads that bypass the CU's L1):
+// no LDS limit at all.  The arithmetic and its order are those of the LDS form (same MFMA sequence per block).
+template <bool CST, bool HST>
 __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
-    constexpr int M = 16, KG = 4, KPI = 4, LS = M + 1;
+    constexpr int M = 16, KG = 4, KPI = 4;
+    constexpr int LS = HST ? M : M + 1;                // row stride of h (LDS rows are padded to 17 banks; HBM rows are not)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int hrows = a.NG * KG * KPI;                 // K rows incl. the zero padding of the last group
-    float* hs = smem;                                  // [2][hrows][LS]
-    float* cs = smem + 2 * hrows * LS;                 // [Hp][LS] cell state of (unit, line)
-    int* lens_s = reinterpret_cast<int*>(cs + a.Hp * LS);
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    float* hs = HST ? a.hstate + wg * 2 * hrows * LS : smem;                       // [2][hrows][LS]
+    float* cs = CST ? a.cstate + wg * (size_t)a.Hp * M : smem + 2 * hrows * LS;    // [Hp][CLS] cell state of (unit, line)
+    constexpr int CLS = CST ? M : M + 1;
+    int* lens_s = reinterpret_cast<int*>(smem + (HST ? 0 : 2 * hrows * LS) + (CST ? 0 : a.Hp * CLS));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -271,7 +280,7 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
         if (n < a.N) l = a.lens ? min(max(a.lens[n], 0), a.T) : a.T;
         lens_s[tid] = l;
     }
-    for (int e = tid; e < 2 * hrows * LS + a.Hp * LS; e += 256) smem[e] = 0.f;
+    for (int e = tid; e < (HST ? 0 : 2 * hrows * LS) + (CST ? 0 : a.Hp * CLS); e += 256) smem[e] = 0.f;
     __syncthreads();
     int Lmax = 0;
     for (int i = 0; i < M; ++i) Lmax = max(Lmax, lens_s[i]);
@@ -286,6 +295,10 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
     const float* wbase = a.wp + ((size_t)dir * a.NG * a.NB * 64 + lane) * KG;
     const size_t gstride = (size_t)a.NB * 64 * KG;
     const float gscale = (gate == 2) ? 2.f : 1.f;
+    auto h_at = [&](const float* hb, int idx) -> float {       // h of the previous step: LDS, or HBM past this CU's L1
+        if constexpr (HST) return __hip_atomic_load(hb + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return hb[idx];
+    };
     int cur = 0;
     for (int s = 0; s < Lmax; ++s) {
         const float* hcur = hs + cur * hrows * LS;
@@ -303,9 +316,14 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(wbase + (size_t)g * gstride + (size_t)b * 64 * KG);
 #pragma unroll
                 for (int e = 0; e < KG; ++e)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hcur[(KPI * (g * KG + e) + khalf) * LS + arow], w[e], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h_at(hcur, (KPI * (g * KG + e) + khalf) * LS + arow), w[e], acc, 0, 0, 0);
             }
             const int unit = b * 4 + ul;
+            // the cell state in front of this step: LDS (every lane of the quad reads it), or HBM through the quad's gate-0 lane
+            auto c_prev = [&](int r) -> float {
+                if constexpr (CST) return quad_bcast<0x00>((gate == 0 && s > 0) ? cs[unit * CLS + irow[r]] : 0.f);
+                else return cs[unit * CLS + irow[r]];
+            };
             if (a.peep) {
                 // ocropy's peephole cell (reference layers.py:72-103): i and f look at c, the output gate at the NEW c and is not
                 // squashed: c' = sig(f + w_f c) c + sig(i + w_i c) tanh(g); h = (o + w_o c') tanh(c')
@@ -313,7 +331,7 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
                 const float wp = gate < 2 ? pw[gate * a.Hp + unit] : 0.f, wo = pw[2 * a.Hp + unit];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float cp = cs[unit * LS + irow[r]];
+                    const float cp = c_prev(r);
                     const float z = acc[r] + wp * cp;
                     float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * z));
                     gv = (gate == 2) ? (2.f * gv - 1.f) : (gate == 3 ? z : gv);
@@ -324,7 +342,7 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
                     const float c = gf * cp + gi * gg;
                     const float h = (zo + wo * c) * krk_tanh(c);
                     if (gate == 0) {
-                        cs[unit * LS + irow[r]] = c;
+                        cs[unit * CLS + irow[r]] = c;
                         hnext[unit * LS + irow[r]] = h;
                     }
                 }
@@ -338,21 +356,21 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
                 const float gf = quad_bcast<0x55>(gv);
                 const float gg = quad_bcast<0xAA>(gv);
                 const float go = quad_bcast<0xFF>(gv);
-                const float c = gf * cs[unit * LS + irow[r]] + gi * gg;
+                const float c = gf * c_prev(r) + gi * gg;
                 const float h = go * krk_tanh(c);
                 if (gate == 0) {
-                    cs[unit * LS + irow[r]] = c;
+                    cs[unit * CLS + irow[r]] = c;
                     hnext[unit * LS + irow[r]] = h;
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();                // (HST: s_waitcnt vmcnt(0) in front of the barrier -- every wave's h stores have reached L2)
         for (int i = wave; i < M; i += 4) {
             const int li = lens_s[i];
             if (s < li) {
                 const int t = rev ? (li - 1 - s) : s;
                 float* o = a.out + ((size_t)(n0 + i) * a.T + t) * a.ostride + (size_t)dir * a.H;
-                for (int k = lane; k < a.H; k += 64) o[k] = hnext[k * LS + i];
+                for (int k = lane; k < a.H; k += 64) o[k] = h_at(hnext, k * LS + i);
             }
         }
         cur ^= 1;
@@ -382,13 +400,31 @@ int krk_lstm_kg(int M, int per_wave) {
     return per_wave <= 13 ? 8 : 4;
 }
 
-// hidden sizes 256 < Hp <= 768: a.NB = Hp / 4 blocks of 16 gate columns, a.NG = K groups of 4 steps (weights: the M = 16 pack)
+// LDS holds h twice and the cell state up to Hp = 768; the cell state moves to HBM above that, h above 1152 (see lstm_big_kernel)
+constexpr int kBigCellInLds = 768, kBigHInLds = 1152;
+size_t krk_lstm_big_cstate_floats(int N, int ndir, int Hp) {
+    return Hp > kBigCellInLds ? (size_t)((N + 15) / 16) * ndir * Hp * 16 : 0;
+}
+size_t krk_lstm_big_hstate_floats(int N, int ndir, int Hp) {
+    const int hrows = (Hp / 4 + 3) / 4 * 16;
+    return Hp > kBigHInLds ? (size_t)((N + 15) / 16) * ndir * 2 * hrows * 16 : 0;
+}
+
+// hidden sizes Hp > 256 (or the peephole cell at any width): a.NB = Hp / 4 blocks of 16 gate columns, a.NG = K groups of 4 steps
+// (weights: the M = 16 pack).  The caller provides a.cstate / a.hstate (sizes above; hstate ZEROED) when they are non-zero.
 int krk_launch_lstm_big(const LstmArgs& a, hipStream_t s) {
-    if (a.Hp > 768 || a.N <= 0) return a.N <= 0 ? 0 : -4;
+    if (a.N <= 0) return 0;
+    const bool cst = a.Hp > kBigCellInLds, hst = a.Hp > kBigHInLds;
+    if ((cst && !a.cstate) || (hst && !a.hstate)) return -4;
     dim3 grid((unsigned)((a.N + 15) / 16), (unsigned)a.ndir);
-    const size_t lds = ((size_t)2 * a.NG * 16 * 17 + (size_t)a.Hp * 17 + 16) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(lstm_big_kernel, grid, dim3(256), lds, s, a);
+    const size_t lds = ((hst ? 0 : (size_t)2 * a.NG * 16 * 17) + (cst ? 0 : (size_t)a.Hp * 17) + 16) * sizeof(float);
+    auto launch = [&](auto kfn) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
+    };
+    if (hst) launch(lstm_big_kernel<true, true>);
+    else if (cst) launch(lstm_big_kernel<true, false>);
+    else launch(lstm_big_kernel<false, false>);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

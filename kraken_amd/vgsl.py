@@ -219,8 +219,6 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
         if g['legacy'] == 'o' and g['dir'] != 'b':
             # the reference builds PeepholeBidiLSTM whatever the direction letter and then fails to reshape its 2 x hidden outputs
             raise ValueError(f'RNN variant "{block}": the ocropy peephole cell is bidirectional (the reference fails on any other direction)')
-        if hidden > 768:
-            raise NotImplementedError(f'recurrent layer "{block}": hidden sizes above 768 are not supported by the HIP recurrent kernels')
         # axis 'y' = the reference's `transpose`: image columns are the sequences (layers.py:521-523);
         # 's' keeps only the last step of every column (:537-539): (N, C, H, W) -> (N, O, 1, W)
         # on the x axis 's' keeps the last COLUMN: (N, C, H, W) -> (N, O, H, 1) (get_shape, :549-561)
@@ -549,6 +547,15 @@ class _Plan:
         # plans with a wide recurrent layer on the split-bf16 kernels run the cluster kernel (lstm_ws), whose only failure signal
         # is the status word (krk_plan_status); the others have nothing to report and nn(x) need not synchronise for it
         self.has_status = bool(lib.krk_plan_has_exchange(handle))
+
+    def clone(self) -> '_Plan':
+        """A plan of its own over the SAME packed device weights (krk_plan_clone): own workspace, events and status word, no repack,
+        no upload -- what the engine's further slots take."""
+        handle = C.c_void_p()
+        _lib.check(self._lib.krk_plan_clone(self.handle, C.byref(handle)))
+        twin = object.__new__(_Plan)
+        twin.handle, twin.device, twin._lib, twin.has_status = handle, self.device, self._lib, self.has_status
+        return twin
 
     def out_shape(self, W: int):
         c, h, w = C.c_int(), C.c_int(), C.c_int()

@@ -24,6 +24,9 @@ Nothing here runs on the GPU box; the fixtures travel instead.  What is pinned:
                    floor cases, masked GroupNorm, the S1(1x0)1,3 reshape, f/r/b LSTMs with ragged lens.
   bench_lines.npz  BASELINE configs 2 and 4 line by line: kraken's tuples, strings and top-2 margins for all 256 lines of
                    the benchmark tensor and for 1024 distinct ragged lines (batch 1 each).
+  bench_lines_r6.npz  BASELINE config 3's rank shard line by line (2048 DISTINCT lines 1x48x1200) and 64 lines 1x120x1200 through
+                   kraken's default height-120 spec (kraken/configs/vgsl.py:102): tuples, strings, margins (+ logits of 4 lines).
+  big_lstm.npz     recurrent layers above 768 hidden units (1024 bidirectional, 1280 forward, 832 peephole), ragged lengths.
   codec.npz        PytorchCodec.decode / encode known answers incl. multi-label codes.
   transforms.npz   ImageInputTransforms outputs (dewarp + fixed-height paths) for synthetic line images.
 """
@@ -51,6 +54,7 @@ from kraken.lib.ctc_decoder import greedy_decoder as ref_greedy  # noqa: E402
 from kraken.lib.models import TorchSeqRecognizer as RefRecognizer  # noqa: E402
 
 from tests.specs import BENCH_A, BENCH_B, bench_codec  # noqa: E402
+from kraken_amd.specs import DEFAULT_H120  # noqa: E402
 
 RES = os.path.join(_refshim.REFERENCE_ROOT, 'tests', 'resources')
 
@@ -301,6 +305,88 @@ GROUP_CASES = {
     'clstm_stack':  ('[1,8,0,1 Cr3,3,4 S1(1x0)1,3 Lfxc8 Lbxc6 O1c5]', 3, 23, [23, 15, 8]),
     'clstm_y':      ('[1,6,0,2 Lfyc4]', 2, 9, None),
 }
+
+
+@torch.inference_mode()
+def bench_lines_r6_fixture(path, seed=0, only=None):
+    """
+    VERDICT r5 item 7.  cfg3: one rank's shard of BASELINE config 3 -- 2048 DISTINCT lines 1x48x1200, line i = row i % 16 of
+    synth_input(16, 1200, seed=30000 + i // 16) -- through the unmodified reference in batches of 16 (equal widths: the batched result
+    is the per-line result).  h120: 64 lines 1x120x1200 (synth_input(64, 1200, seed=1200, h=120)) through kraken's DEFAULT
+    recognition spec (kraken/configs/vgsl.py:102, height 120) with a 256-class output layer and portable weights; logits of its first
+    4 lines.  R6_ONLY=h120 (or cfg3) recomputes one of the two and keeps the other from the existing file.
+    """
+    from tests.helpers import portable_weights
+    out = {}
+    if only and os.path.exists(path):
+        out = {k: v for k, v in np.load(path, allow_pickle=False).items()}
+    for tag, spec, nlines, h in (('cfg3', BENCH_A, 2048, 48), ('h120', DEFAULT_H120, 64, 120)):
+        if only and tag not in only:
+            continue
+        torch.manual_seed(seed)
+        net = ref_vgsl.TorchVGSLModel(vgsl=spec, codec=bench_codec())
+        if tag == 'h120':
+            # kraken's orthogonal LSTM init is a LAPACK QR: for the 800 x 960 input weights of this spec its bits differ between
+            # machines, so this case draws its weights element-wise (tests/helpers.py: portable_weights)
+            portable_weights(net, seed=120)
+        net.eval()
+        rec = RefRecognizer(net, device='cpu')
+        out[f'{tag}_spec'] = spec
+        out[f'{tag}_state_digest'] = json.dumps({k: digest(v) for k, v in net.state_dict().items()})
+        dec, mar, strs, dig = [], [], [], hashlib.sha256()
+        for lo in range(0, nlines, 16):
+            x = synth_input(16, 1200, seed=30000 + lo // 16, h=h) if tag == 'cfg3' else synth_input(64, 1200, seed=1200, h=h)[lo:lo + 16]
+            dig.update(np.ascontiguousarray(x.numpy()).tobytes())
+            lens = torch.tensor([1200] * 16)
+            logits, olens = net.nn(x, lens)
+            dec += ref_greedy(logits.softmax(1).squeeze(2), olens)
+            top2 = logits.squeeze(2).topk(2, dim=1).values
+            mar.append((top2[:, 0] - top2[:, 1]).min(dim=1).values)
+            strs += rec.predict_string(x, lens)
+            if tag == 'h120' and lo == 0:
+                out['h120_logits4'] = logits[:4].numpy().astype(np.float32)
+        flat, counts = tuples_to_arr(dec)
+        out[f'{tag}_xdigest'] = dig.hexdigest()
+        out[f'{tag}_tuples'] = flat.astype(np.float32)
+        out[f'{tag}_counts'] = counts
+        out[f'{tag}_margin'] = torch.cat(mar).numpy()
+        out[f'{tag}_strings'] = json.dumps(strs)
+        print(tag, 'tuples', out[f'{tag}_tuples'].shape, 'min margin', float(out[f'{tag}_margin'].min()), flush=True)
+    np.savez_compressed(path, **out)
+    print('wrote', path)
+
+
+@torch.inference_mode()
+def big_lstm_fixture(path):
+    """
+    Hidden sizes above 768 (the reference builds any size, model.py:570-597): three one-layer recognisers through
+    the unmodified reference with ragged seq_lens -- 1024 bidirectional (cell state in HBM), 1280 forward (h in HBM too), 832 with
+    the ocropy peephole cell.  The weights are `portable_weights` (tests/helpers.py: 33 MB per case otherwise); inputs and logits.
+    """
+    from tests.helpers import portable_weights
+    out = {}
+    cases = {'bidi1024': '[1,1,0,16 Lbx1024 O1c8]', 'fwd1280': '[1,1,0,16 Lfx1280 O1c8]', 'peep832': '[1,1,0,16 Lbxo832 O1c8]'}
+    for k, (tag, spec) in enumerate(cases.items()):
+        net = ref_vgsl.TorchVGSLModel(vgsl=spec)
+        portable_weights(net, seed=900 + k)
+        net.eval()
+        x = synth_input(5, 23, seed=7000 + k, h=1, c=16)
+        # (the reference's peephole cell does not take packed sequences, layers.py:176: that case runs full-width lines, no seq_lens)
+        lens = torch.tensor([23, 9, 17, 1, 23] if 'peep' not in tag else [23] * 5)
+        for i, l in enumerate(lens.tolist()):
+            x[i, ..., l:] = 0
+        y, olens = net.nn(x, lens if 'peep' not in tag else None)
+        olens = lens if olens is None else olens
+        out[f'{tag}_spec'] = spec
+        out[f'{tag}_seed'] = 900 + k
+        out[f'{tag}_x'] = x.numpy()
+        out[f'{tag}_lens'] = lens.numpy()
+        out[f'{tag}_y'] = y.numpy()
+        out[f'{tag}_olens'] = olens.numpy()
+        out[f'{tag}_state_digest'] = json.dumps({n: digest(v) for n, v in net.state_dict().items()})
+        print(tag, tuple(y.shape), float(y.abs().max()))
+    np.savez_compressed(path, **out)
+    print('wrote', path)
 
 
 @torch.inference_mode()
@@ -777,7 +863,7 @@ def reshape_random_fixture(path, n=240, seed=11):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms', 'bench_lines', 'forms_r5', 'reshape_random', 'forms_random']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms', 'bench_lines', 'bench_lines_r6', 'big_lstm', 'forms_r5', 'reshape_random', 'forms_random']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -789,6 +875,10 @@ if __name__ == '__main__':
                       cases=(('n4w400', 4, 400, [0, 3]), ('n16w800', 16, 800, [7])))
     if 'bench_lines' in which:
         bench_lines_fixture(os.path.join(HERE, 'bench_lines.npz'))
+    if 'big_lstm' in which:
+        big_lstm_fixture(os.path.join(HERE, 'big_lstm.npz'))
+    if 'bench_lines_r6' in which:
+        bench_lines_r6_fixture(os.path.join(HERE, 'bench_lines_r6.npz'), only=os.environ.get('R6_ONLY', '').split(',') if os.environ.get('R6_ONLY') else None)
     if 'layers' in which:
         layer_fixture(os.path.join(HERE, 'layers.npz'))
     if 'image_lstm' in which:

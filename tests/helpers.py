@@ -70,3 +70,35 @@ def wavy_line(rng, h, w):
             hi = min(yc[x] + rng.randint(2, max(h // 3, 3)), h)
             arr[lo:hi, x:x + 2] = rng.randint(0, 90)
     return arr
+
+
+def portable_weights(model, seed: int = 0) -> None:
+    """
+    Overwrites every parameter of a VGSL model (the reference's or ours: same state-dict names) with values that are the same bits on
+    every machine: element-wise uniform draws, torch's default bounds (convolutions U(+-0.1) like kraken's init_weights, LSTMs
+    U(+-1/sqrt(hidden)), linear layers Xavier-uniform, forget-gate biases 1).  kraken's own init is orthogonal for the LSTMs
+    (model.py:465-475) -- a LAPACK QR whose bits depend on the CPU and thread count once a matrix is wide enough (the 800 x 960 input
+    weights of the height-120 spec differed between the authoring container and the GPU box), so a fixture made with it does not travel.
+    """
+    import math
+    sd = model.state_dict()
+    for k, name in enumerate(sorted(sd)):
+        p = sd[name]
+        g = torch.Generator().manual_seed(seed * 1000 + k)
+        if '.co.' in name:
+            bound = 0.1
+        elif 'weight_ih' in name or 'weight_hh' in name or 'bias_ih' in name or 'bias_hh' in name:
+            bound = 1.0 / math.sqrt(p.shape[0] // 4)
+        elif 'weight_ip' in name or 'weight_fp' in name or 'weight_op' in name:      # ocropy peephole weights (layers.py:60-70)
+            bound = 0.5
+        elif p.dim() == 2:
+            bound = math.sqrt(6.0 / (p.shape[0] + p.shape[1]))
+        else:
+            bound = 0.0
+        v = (torch.rand(p.shape, generator=g) * 2 - 1) * bound
+        if 'bias_ih' in name or 'bias_hh' in name:
+            h = p.shape[0] // 4
+            v[h:2 * h] = 1.0
+        with torch.no_grad():
+            p.copy_(v.to(p.device))
+

@@ -79,12 +79,12 @@ def test_bad_or_unsupported_specs_raise(spec, exc):
 # forward call.  (Table in DESIGN.md section 7.)
 UNSUPPORTED_FORMS = [
     ('[1,48,0,1 W0.5,10 S1(1x0)1,3 O1c10]', 'W0.5,10', 'model.py:677 (wav2vec mask)'),
-    ('[1,48,0,1 Cr3,3,32 S1(1x0)1,3 Lbx800 O1c10]', 'Lbx800', 'hidden size above 768'),
 ]
 
 
 @pytest.mark.parametrize('spec,token,what', UNSUPPORTED_FORMS)
 def test_unsupported_vgsl_forms_are_refused_at_construction_naming_the_block(spec, token, what):
+    # (round 6: hidden sizes above 768 left this table -- lstm_big_kernel keeps the cell state, then h, in HBM: tests/golden/big_lstm.npz)
     with pytest.raises(NotImplementedError) as e:
         kraken_amd.TorchVGSLModel(vgsl=spec)
     assert token in str(e.value), (what, str(e.value))

@@ -73,6 +73,11 @@ def test_torch_port_layers(name):
             np.testing.assert_allclose(y[i:i + 1, ..., :w].numpy(), want, atol=LAYER_TOL, rtol=1e-4)
 
 
+def _sha(t) -> str:
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()
+
+
 def _bench_model(spec):
     import kraken_amd
     torch.manual_seed(0)
@@ -131,6 +136,55 @@ def test_port_on_the_line_by_line_fixture_of_configs_2_and_4():
     got = ref.predict_labels(xb, [widths[i] for i in pick])
     assert [[t[:3] for t in l] for l in got] == [[t[:3] for t in want[i]] for i in pick]
     assert [''.join(c for c, *_ in codec.decode(l)) for l in got] == [strs[i] for i in pick]
+
+
+def test_port_on_config3_shard_and_the_height_120_default_spec():
+    """oracle/torch_port.py against kraken's tuples / strings of bench_lines_r6.npz: sixteen lines of config 3's 2048-line shard and
+    eight lines (+ the logits of four) of kraken's default height-120 recogniser (kraken/configs/vgsl.py:102)."""
+    from kraken_amd.codec import PytorchCodec
+    from kraken_amd.specs import DEFAULT_H120
+    from tests.specs import bench_codec
+    z = load_golden('bench_lines_r6.npz')
+    codec = PytorchCodec(bench_codec())
+    for tag, spec, h, rows in (('cfg3', BENCH_A, 48, [5 * 16 + k for k in range(16)]), ('h120', DEFAULT_H120, 120, list(range(8)))):
+        assert str(z[f'{tag}_spec']) == spec
+        m = _bench_model(spec)
+        if tag == 'h120':
+            from tests.helpers import portable_weights
+            portable_weights(m, seed=120)
+        assert {k: _sha(v) for k, v in m.state_dict().items()} == json.loads(str(z[f'{tag}_state_digest']))
+        _, specs = parse_vgsl(spec)
+        ref = CpuRecognizer(specs, {k: v.numpy() for k, v in m.state_dict().items()})
+        want = arr_to_tuples(z[f'{tag}_tuples'], z[f'{tag}_counts'])
+        strs = json.loads(str(z[f'{tag}_strings']))
+        x = synth_input(16, 1200, seed=30000 + 5, h=h) if tag == 'cfg3' else synth_input(64, 1200, seed=1200, h=h)[:8]
+        keep = [k for k, i in enumerate(rows) if z[f'{tag}_margin'][i] > 1e-5]
+        got = ref.predict_labels(x, [1200] * len(x))
+        assert [[t[:3] for t in got[k]] for k in keep] == [[t[:3] for t in want[rows[k]]] for k in keep]
+        assert [''.join(c for c, *_ in codec.decode(got[k])) for k in keep] == [strs[rows[k]] for k in keep]
+        if tag == 'h120':
+            logits, _ = ref.forward(x[:4], [1200] * 4)
+            assert float((torch.as_tensor(logits) - torch.from_numpy(z['h120_logits4'])).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('tag', ['bidi1024', 'fwd1280', 'peep832'])
+def test_port_on_hidden_sizes_above_768(tag):
+    """The oracle (torch port) against the reference's logits of big_lstm.npz -- the checker of the GPU test of the same name."""
+    import kraken_amd
+    from tests.helpers import portable_weights
+    z = load_golden('big_lstm.npz')
+    spec = str(z[f'{tag}_spec'])
+    m = kraken_amd.TorchVGSLModel(vgsl=spec)
+    portable_weights(m, seed=int(z[f'{tag}_seed']))
+    assert {k: _sha(v) for k, v in m.state_dict().items()} == json.loads(str(z[f'{tag}_state_digest']))
+    _, specs = parse_vgsl(spec)
+    ref = CpuRecognizer(specs, {k: v.numpy() for k, v in m.state_dict().items()})
+    lens = z[f'{tag}_lens'].tolist()
+    y, olens = ref.forward(torch.from_numpy(z[f'{tag}_x']), lens if 'peep' not in tag else None)
+    assert olens is None or list(olens) == z[f'{tag}_olens'].tolist()
+    want = torch.from_numpy(z[f'{tag}_y'])
+    for i, l in enumerate(lens):
+        assert float((torch.as_tensor(y)[i, ..., :l] - want[i, ..., :l]).abs().max()) < 1e-5
 
 
 def test_oracles_ragged_equals_per_line_reference():
