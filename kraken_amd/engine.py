@@ -105,6 +105,12 @@ class RecognitionEngine:
             self.classes, _, max_t = self.slots[0].plan.out_shape(max_width)
             for s in self.slots:
                 s.ensure_results(max_batch, max_t)
+        # (round 6, measured and not kept: a helper thread that pays the ~13 ms first copy of every stream -- the runtime builds a
+        # stream's copy queue on first use, profiles/r06_h2d_first_copy.txt -- while the caller prepares its first lines: first passes
+        # of 119-160 ms with it against 167-169 without on the 2048-line page, 53 against 50 ms on the 40-line page: inside the
+        # run-to-run spread of a fresh process, profiles/r06_cold_start.txt)
+        self._pg_host, self._pg_ev, self._pg_i = [None, None], [None, None], 0
+        self._pg_stream = torch.cuda.Stream(device=device)
         self._next = 0
         self._inflight = deque()
         self.in_use = False          # held by a LinePipeline (rpred.py: one consumer per engine at a time)
