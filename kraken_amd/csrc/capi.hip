@@ -53,6 +53,43 @@ static int env_int(const char* name, int dflt = 0) {
     return v ? atoi(v) : dflt;
 }
 
+// roctx ranges around a call and its launch groups ("roctx ranges around submit / forward / decode").  The marker
+// library is NOT a link dependency: it is looked up once -- already in the process (rocprofv3 --marker-trace preloads
+// librocprofiler-sdk-roctx.so) or, with KRK_ROCTX=1, opened by name (then libroctx64.so for the older tools) -- and without it
+// every call below is one predictable branch.
+#include <dlfcn.h>
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+        const bool want = env_int("KRK_ROCTX") != 0;
+        void* h = nullptr;
+        for (const char* n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!h && want)
+            for (const char* n : names)
+                if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h || getenv("KRK_NO_ROCTX")) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+    bool on() const { return push != nullptr; }
+};
+static const Roctx& roctx() {
+    static Roctx r;
+    return r;
+}
+// one range, closed when it goes out of scope
+struct RoctxRange {
+    bool open = false;
+    explicit RoctxRange(const std::string& name) {
+        if (roctx().on()) { roctx().push(name.c_str()); open = true; }
+    }
+    ~RoctxRange() { if (open) roctx().pop(); }
+};
+
 // Python-style floor division (the reference does float division + floor).
 inline int floordiv(int a, int b) {
     int q = a / b, r = a % b;
@@ -1825,7 +1862,18 @@ struct Pass {
         return e == hipSuccess ? 0 : hard(KRK_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
     }
     // marks the start of a profiled launch group (HIP event on the caller's stream)
+    ~Pass() { end_groups(); }         // whatever path the call leaves by
+    bool group_open = false;          // a roctx range of the running launch group is open (closed by the next mark / end_groups)
+    void end_groups() {
+        if (group_open) roctx().pop();
+        group_open = false;
+    }
     int mark(const char* name, double flops) {
+        if (roctx().on()) {           // host-side span of the group's launches; the kernels carry the names rocprofv3 lists
+            end_groups();
+            roctx().push(name);
+            group_open = true;
+        }
         if (!p->profiling || p->prof_n + 1 >= p->events.size()) return 0;
         if (hipEventRecord(p->events[p->prof_n], stream) != hipSuccess) return hard(KRK_E_HIP, "hipEventRecord failed");
         p->prof_names[p->prof_n] = name;
@@ -2322,6 +2370,7 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         HIPCHK(hipStreamWaitEvent(stream, p->front_wait, 0));
         p->front_wait = nullptr;
     }
+    RoctxRange whole(roctx().on() ? "krk_forward N=" + std::to_string(N) + " W=" + std::to_string(W) : std::string());
     Pass pass{p, N, stream, lens_host, p->precision == KRK_PREC_BF16};
     if (pass.widths(W) || pass.upload_lens(W)) return pass.err;
 
@@ -2555,11 +2604,13 @@ int krk_recognize(krk_plan* plan, const float* x_dev, const int* lens_host, int 
         return fail(KRK_E_UNSUPPORTED, "krk_recognize: the network changes the number of lines (Addition / Reshape on the batch axis): "
                                        "its output lines are not the caller's lines; krk_forward + krk_greedy_decode");
     hipStream_t s = (hipStream_t)stream;
+    RoctxRange whole(roctx().on() ? "krk_recognize N=" + std::to_string(N) + " W=" + std::to_string(W) : std::string());
     const float* logits = nullptr;
     const int* d_olens = nullptr;
     int T = 0;
     int rc = run_plan(plan, x_dev, lens_host, N, W, s, logits_dev, &logits, &d_olens, &T);
     if (rc) return rc;
+    RoctxRange dec("softmax + greedy decode");
     const int C = last.outC;
     const size_t rows = (size_t)N * T;
     if (plan->d_labels.ensure(rows * sizeof(int)) || plan->d_confs.ensure(rows * sizeof(float)))
