@@ -41,7 +41,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, ablate: bool = False, asan: bool = False) -> str:
     """
     Compiles every HIP source for gfx950 and links the C-ABI library. Returns its path.
 
@@ -49,9 +49,16 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
     branches (``KRK_DBGBIT``, common.h) compiled in -- a measuring tool (tools/lstm_probe.py), selected with
     ``KRAKEN_AMD_LIB``; the release library has no probe code in its hot loops.
     """
-    bdir = BUILD + ('_ablate' if ablate else '')
-    lib_path = LIB.replace('.so', '_ablate.so') if ablate else LIB
-    flags = FLAGS + (['-DKRK_ABLATE'] if ablate else [])
+    if asan:
+        # HOST AddressSanitizer of the C++ side (plan compiler, weight packing, length arithmetic, the C ABI's argument handling): the
+        # device code is compiled as always (-fno-gpu-sanitize: GPU ASan needs xnack+ code objects, which this pool does not run).
+        # Run through tools/asan_run.sh, which preloads clang's ASan runtime into the (uninstrumented) python.
+        bdir, lib_path = BUILD + '_asan', LIB.replace('.so', '_asan.so')
+        flags = [f for f in FLAGS if f != '-O3'] + ['-O1', '-g', '-fsanitize=address', '-fno-gpu-sanitize', '-fno-omit-frame-pointer']
+    else:
+        bdir = BUILD + ('_ablate' if ablate else '')
+        lib_path = LIB.replace('.so', '_ablate.so') if ablate else LIB
+        flags = FLAGS + (['-DKRK_ABLATE'] if ablate else [])
     os.makedirs(bdir, exist_ok=True)
     hipcc = _hipcc()
     objs, jobs = [], []
@@ -83,13 +90,59 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(lib_path, objs):
-        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', lib_path])
+        run([hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *(['-fsanitize=address', '-fno-gpu-sanitize', '-shared-libsan'] if asan else []),
+             *objs, '-o', lib_path])
     return lib_path
+
+
+def build_asan_host(verbose: bool = False) -> str:
+    """
+    ``kraken_amd/libkraken_amd_asanhost.so``: the library's HOST code under AddressSanitizer, linked against a host stand-in for the
+    HIP runtime (tools/asan/fake_hip.cpp: device memory = malloc, launches = no-ops) instead of libamdhip64 -- runs WITHOUT a GPU
+    (tests/test_asan_host.py, tools/asan_host_driver.py).  capi.hip (the plan compiler, the packers, the C ABI) is instrumented; the
+    other sources' launch stubs come from the regular objects.  Nothing is computed: a checker of host memory safety only.
+    """
+    build()
+    bdir = BUILD + '_asan'
+    os.makedirs(bdir, exist_ok=True)
+    hipcc = _hipcc()
+    clangxx = os.path.join(os.path.dirname(os.path.realpath(hipcc)), '..', 'lib', 'llvm', 'bin', 'clang++')
+    if not os.path.exists(clangxx):
+        clangxx = '/opt/rocm/lib/llvm/bin/clang++'
+    san = ['-O1', '-g', '-fsanitize=address', '-fno-omit-frame-pointer']
+    lib_path = LIB.replace('.so', '_asanhost.so')
+    capi, fake = os.path.join(bdir, 'capi.o'), os.path.join(bdir, 'fake_hip.o')
+    fake_src = os.path.join(os.path.dirname(HERE), 'tools', 'asan', 'fake_hip.cpp')
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f'failed: {" ".join(cmd)}\n{r.stdout}\n{r.stderr}')
+    if _stale(capi, [os.path.join(CSRC, 'capi.hip')] + HEADERS + [os.path.abspath(__file__)]):
+        run([hipcc, *[f for f in FLAGS if f != '-O3'], *san, '-fno-gpu-sanitize', '-c', os.path.join(CSRC, 'capi.hip'), '-o', capi])
+    if _stale(fake, [fake_src]):
+        run([clangxx, '-std=c++17', '-fPIC', *san, '-c', fake_src, '-o', fake])
+    objs = [capi, fake] + [os.path.join(BUILD, src.replace('.hip', '.o')) for src in SOURCES if src != 'capi.hip'] + \
+           [os.path.join(BUILD, src.replace('.hip', '_b1.o')) for src in ONE_TERM]
+    if _stale(lib_path, objs):
+        run([clangxx, '-shared', '-fPIC', '-fsanitize=address', '-shared-libsan', *objs, '-ldl', '-o', lib_path])
+    return lib_path
+
+
+def asan_runtime() -> str:
+    """clang's shared ASan runtime, to preload into an uninstrumented python."""
+    r = subprocess.run(['/opt/rocm/lib/llvm/bin/clang', '-print-file-name=libclang_rt.asan-x86_64.so'], capture_output=True, text=True)
+    return r.stdout.strip()
 
 
 if __name__ == '__main__':
     try:
-        print(build(force='--force' in sys.argv, verbose=True, ablate='--ablate' in sys.argv))
+        if '--asan-host' in sys.argv:
+            print(build_asan_host(verbose=True))
+        else:
+            print(build(force='--force' in sys.argv, verbose=True, ablate='--ablate' in sys.argv, asan='--asan' in sys.argv))
     except Exception as e:                      # a failed build must be the LAST thing on the screen, not a stale .so
         print(str(e)[-3000:], file=sys.stderr)
         print('BUILD FAILED', flush=True)

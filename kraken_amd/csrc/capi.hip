@@ -802,6 +802,15 @@ void free_step(Step& s, bool weights) {
     s.aux2.release();
 }
 
+// A step under construction owns what it has uploaded until it joins the plan: a layer the plan's arithmetic refuses half-way (the
+// caller then falls back to the exact-f32 plan) must not leave its packed weights behind (found by the host-ASan harness, round 6:
+// two allocations per refused plan).  `keep` is set right in front of the push_back.
+struct StepGuard {
+    Step& s;
+    bool keep = false;
+    ~StepGuard() { if (!keep) free_step(s, true); }
+};
+
 bool monotone_act(int act) { return act >= 0 && act <= KRK_ACT_SIGMOID; }
 
 int map_act(int act) { return act == KRK_ACT_SIGMOID ? ACT_LINEAR : act; }
@@ -965,6 +974,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where, int ph_force
         if (!taps_ok) leave_x3();
     }
     Step s;
+    StepGuard guard{s};
     s.kind = S_CONV;
     s.C = C;
     s.H = H;
@@ -1043,6 +1053,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where, int ph_force
         C = g.Cout;
         H = g.Hy;
     }
+    guard.keep = true;
     p->steps.push_back(std::move(s));
     if (softmax) {
         Step m;
@@ -1087,6 +1098,7 @@ int PlanBuilder::groupnorm(const krk_layer& L, const std::string& where) {
     if (!L.w[0] || !L.w[1]) return fail(KRK_E_INVALID, where + ": group norm weights missing");
     const int gn_at = i;          // (i moves on when the MaxPool behind is taken in)
     Step s;
+    StepGuard guard{s};
     s.kind = S_GN;
     s.C = C;
     s.H = H;
@@ -1132,6 +1144,7 @@ int PlanBuilder::groupnorm(const krk_layer& L, const std::string& where) {
             cs.skip = true;
         }
     }
+    guard.keep = true;
     p->steps.push_back(std::move(s));
     return KRK_OK;
 }
@@ -1301,6 +1314,7 @@ int PlanBuilder::recurrent_or_linear(const krk_layer& L, const std::string& wher
         push_toseq();
     }
     Step s;
+    StepGuard guard{s};
     s.C = C;
     s.H = 1;
     s.out_is_seq = !img_lstm;
@@ -1318,6 +1332,7 @@ int PlanBuilder::recurrent_or_linear(const krk_layer& L, const std::string& wher
         s.in_tiled = true;
     }
     if (int rc = (L.op == KRK_OP_LINEAR) ? linear(L, where, s) : lstm(L, where, s)) return rc;
+    guard.keep = true;
     p->steps.push_back(std::move(s));
     if (img_lstm || sum_x) {
         // sum_x on a plain sequence: rows (N, W, C) -> (N, 1, C), the same pick with one row per line
