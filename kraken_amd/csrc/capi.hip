@@ -1846,6 +1846,7 @@ struct Probes {
     int lstm_m = env_int("KRK_LSTM_M");          // f32 plan: force 16- or 32-line tiles
     int conv_x6 = env_int("KRK_CONV_X6", 1);     // 0: the exact-f32 kernel also where the three-plane kernel (conv_x6.hip) is planned
     int taps_dma = env_int("KRK_TAPS_DMA", 1);   // conv_taps_x3.hip: input tile through raw-buffer -> LDS copies (0: register staging)
+    int x3p_sb = env_int("KRK_X3P_SB", 1);       // 0: conv_x3p.hip with TWO tile buffers (80 instead of 52 KB of LDS: two workgroups per CU instead of three)
     int conv_x3p = env_int("KRK_CONV_X3P", 1);   // 0: conv_x3.hip also where the pipelined kernel (conv_x3p.hip) covers the geometry
 };
 
@@ -2000,6 +2001,7 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         if (mark("conv_x3", s.flops)) return kFailed;
         if (g.xtps > 0 && probe.conv_x3p && (size_t)g.H * Win * g.Cin * 2 < 0x7fffffffull) {
             a.tps = g.xtps;
+            a.single_buf = probe.x3p_sb;
             return one ? krk_launch_conv_x3p_b1(a, g.pool, stream) : krk_launch_conv_x3p(a, g.pool, stream);
         }
         return one ? krk_launch_conv_x3_b1(a, false, g.pool, stream) : krk_launch_conv_x3(a, false, g.pool, stream);

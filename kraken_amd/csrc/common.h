@@ -143,6 +143,7 @@ struct X3Args {
     int y_f32;                   // 1: write fp32 NHWC (same element index as the hi plane) for a GroupNorm consumer
     int y_blkM, y_cols;          // > 0: sequence output in K-blocked order, y_blkM rows of y_cols per line (see gemm_x3.hip)
     int tps;                     // conv_x3p.hip: tile copies per weight-stage boundary (0: not eligible)
+    int single_buf = 0;          // conv_x3p.hip: one tile buffer (three workgroups per CU), copies at the chunk boundaries
     int SR, tiles_h, tiles_w;    int dbg;                            // probe bits (env KRK_X3_DBG): 1 skip K loop, 2 skip staging loads, 4 skip stores
 };
 

@@ -44,7 +44,10 @@ __device__ __forceinline__ void vmwait_n(int n) {   // n is wave-uniform
 __device__ unsigned long long g_x3p_phases[8];
 #endif
 
-template <int POOL, int CB>
+// SB (round 6): ONE tile buffer instead of two -- 4 x NB + 24 KB of LDS (52 KB for BENCH-A's two layers) so that THREE workgroups share a
+// CU where two did (80 KB each): the next chunk's tile is copied at the chunk boundary itself (barrier, NB copies per wave, wait, barrier)
+// and the other two workgroups' MFMAs cover that wait.  98-112 registers per wave: twelve waves fit.
+template <int POOL, int CB, bool SB>
 __global__ void __launch_bounds__(256, 2) conv_x3p_kernel(const X3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -90,7 +93,8 @@ __global__ void __launch_bounds__(256, 2) conv_x3p_kernel(const X3Args a) {
     const int npix = a.IH * a.IW;
     const int NB = (npix + 63) >> 6;
     const int PPL = NB * 1024;                           // bytes per (plane, piece) of a tile buffer
-    unsigned char* wring = smem8 + 8 * PPL;              // weight ring: 3 stages x 8 KB
+    constexpr int NTB = SB ? 1 : 2;                      // tile buffers
+    unsigned char* wring = smem8 + NTB * 4 * PPL;        // weight ring: 3 stages x 8 KB
 
     // ---- tile copies.  Lane l of pixel block b owns tile pixel p = 64 b + l; its global byte offset inside the line is recomputed
     // per copy (a register table indexed by the run-time block number ends up in scratch memory): ih = p / IW by a 16-bit
@@ -106,7 +110,7 @@ __global__ void __launch_bounds__(256, 2) conv_x3p_kernel(const X3Args a) {
     const int q16 = (wave & 1) * 16;
     // copy pixel block b of chunk c into tile buffer c & 1
     auto tile_copy = [&](int c, int b) {
-        unsigned char* dst = smem8 + (c & 1) * 4 * PPL + my_pp + b * 1024;
+        unsigned char* dst = smem8 + (SB ? 0 : (c & 1)) * 4 * PPL + my_pp + b * 1024;
         const unsigned so = (unsigned)(c * 32 + q16);
         const int p = b * 64 + lane;
         const int ih = (int)(((unsigned)p * iw_rcp) >> 16), iw = p - ih * a.IW;
@@ -168,17 +172,32 @@ __global__ void __launch_bounds__(256, 2) conv_x3p_kernel(const X3Args a) {
         }
         // tile copies of chunk tc (into the buffer chunk tc - 2 used): legal once every wave is past chunk tc - 2, i.e. from the
         // first stage that starts inside chunk tc - 1
-        if (tc < a.nchunks && st * IT >= (tc - 1) * ntaps) {
+        if (!SB && tc < a.nchunks && st * IT >= (tc - 1) * ntaps) {
             for (int k = 0; k < TPS && tb < NB; ++k, ++tb, ++cnt) tile_copy(tc, tb);
             if (tb == NB) { tb = 0; ++tc; }
         }
         last_cnt = cnt;
         KRK_PH(a, 3);
-        if (any_live && !KRK_DBGBIT(a, 1)) {
+        {
             const int nk = min(IT, G - st * IT);
             const unsigned char* wst = wring + slot * 8192 + lane * 16;
             for (int k = 0; k < nk; ++k) {
-                const unsigned char* xt = smem8 + (ci & 1) * 4 * PPL + (dy * a.dh * a.IW + dx * a.dw) * 16;
+                if (SB && dx == 0 && dy == 0 && ci > 0) {
+                    // single tile buffer: chunk ci starts here.  Everyone has read chunk ci - 1 (their MFMAs are issued: the fragment
+                    // reads have returned), so it can be overwritten; whatever else is in flight (weight stages) lands with it
+                    __builtin_amdgcn_s_barrier();
+                    for (int b = 0; b < NB; ++b) tile_copy(ci, b);
+                    vmwait<0>();
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (!any_live || KRK_DBGBIT(a, 1)) {      // (the boundary above is for every wave; the arithmetic only for live ones)
+                    if (++dx == a.kw) {
+                        dx = 0;
+                        if (++dy == a.kh) { dy = 0; ++ci; }
+                    }
+                    continue;
+                }
+                const unsigned char* xt = smem8 + (SB ? 0 : (ci & 1)) * 4 * PPL + (dy * a.dh * a.IW + dx * a.dw) * 16;
                 bf16x8 xh[2], xl[2], wh[CB], wl[CB];
 #pragma unroll
                 for (int sg = 0; sg < 2; ++sg) {
@@ -279,11 +298,11 @@ __global__ void __launch_bounds__(256, 2) conv_x3p_kernel(const X3Args a) {
 #endif
 }
 
-template <int POOL>
+template <int POOL, bool SB>
 int launch_p(const X3Args& a, int cb, dim3 grid, size_t lds, hipStream_t s) {
 #define KRK_LAUNCH(CB_)                                                                         \
     do {                                                                                        \
-        auto kfn = conv_x3p_kernel<POOL, CB_>;                                                  \
+        auto kfn = conv_x3p_kernel<POOL, CB_, SB>;                                              \
         if (lds > 48 * 1024)                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
@@ -327,6 +346,8 @@ int KRK_FN(krk_launch_conv_x3p)(const X3Args& a, bool pool, hipStream_t s) {
     const int cb = krk_x3_cb(a.Cout);
     dim3 grid((unsigned)(a.tiles_w * a.tiles_h * a.N), (unsigned)((CBt + cb - 1) / cb));
     const int nb = (a.IH * a.IW + 63) / 64;
-    const size_t lds = (size_t)8 * nb * 1024 + 3 * 8192;   // two tile buffers (hi, lo) x 2 pieces + weight ring
-    return pool ? launch_p<1>(a, cb, grid, lds, s) : launch_p<0>(a, cb, grid, lds, s);
+    // one (a.single_buf) or two tile buffers of (hi, lo) x 2 pieces + the weight ring
+    const size_t lds = (size_t)(a.single_buf ? 4 : 8) * nb * 1024 + 3 * 8192;
+    if (a.single_buf) return pool ? launch_p<1, true>(a, cb, grid, lds, s) : launch_p<0, true>(a, cb, grid, lds, s);
+    return pool ? launch_p<1, false>(a, cb, grid, lds, s) : launch_p<0, false>(a, cb, grid, lds, s);
 }
