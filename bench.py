@@ -523,11 +523,13 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
     per_rank = None
     if use_dist:
         # every rank's own clock and gather time (tools/scale_preflight.sh logs them per rank), then the MAX over ranks for the line
-        mine = torch.tensor([dt, gather_ms], dtype=torch.float64, device=dev)
+        mine = torch.tensor([dt, gather_ms, 1e6 * host_s[0] / max(1, N * args.steps)], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size())]
         torch.distributed.all_gather(every, mine)
         per_rank = {'lines_per_s': [round(N * args.steps / float(e[0].item()), 1) for e in every],
-                    'gather_ms': [round(float(e[1].item()), 3) for e in every]}
+                    'gather_ms': [round(float(e[1].item()), 3) for e in every],
+                    # each rank's own host work per line it decoded (codec: tuples -> strings): must not grow with the number of ranks
+                    'host_us_per_line': [round(float(e[2].item()), 3) for e in every]}
         t = mine.clone()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, gather_ms = float(t[0].item()), float(t[1].item())

@@ -66,7 +66,8 @@ if d.get('gathered_lines') != n * d['steps'] * d['config']['lines_per_gpu_step']
     bad.append(f"gathered_lines {d.get('gathered_lines')}")
 pr = d.get('per_rank') or {'lines_per_s': [d['value']], 'gather_ms': [d['gather_ms']]}
 print(f"N={n}: {'FAILED: ' + ', '.join(bad) if bad else 'ok'}  {d['value']} lines/s whole job, {d['ms_per_step']} ms/step, "
-      f"per rank {pr['lines_per_s']} lines/s, gather {pr['gather_ms']} ms, cpus per rank {d.get('host_cpus_per_rank')}")
+      f"per rank {pr['lines_per_s']} lines/s, gather {pr['gather_ms']} ms, host us/line per rank {pr.get('host_us_per_line', [d.get('host_us_per_line', {}).get('codec_strings')])}, "
+      f"cpus per rank {d.get('host_cpus_per_rank')}")
 PY
     grep -q "^N=$N: ok" "$O/summary.txt" || FAIL=1
     N=$((N * 2))
