@@ -501,10 +501,20 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
             torch.cuda.synchronize()
 
     # untimed, before the W warm-up steps: bring the clock governor (and the allocator, and RCCL below) to where a running service is
-    preheat_steps, t_pre = 0, time.perf_counter()
-    while not stub and (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+    # ... in chunks of 16 steps, for at least --preheat-ms, and on until two consecutive chunks run at the same rate (2 %) or eight times
+    # that long: on some boxes 400 ms is not enough after an idle period (profiles/r06_preheat_adaptive.txt: the same command gave
+    # 81 k and 118 k lines/s minutes apart on one box, the kernels' own times identical)
+    preheat_steps, t_pre, rates = 0, time.perf_counter(), []
+    while not stub and args.preheat_ms > 0:
+        t_c = time.perf_counter()
         sr.stream((xs[i % len(xs)] for i in range(16)), to_text)
+        torch.cuda.synchronize()
+        rates.append(16 / (time.perf_counter() - t_c))
         preheat_steps += 16
+        spent = (time.perf_counter() - t_pre) * 1e3
+        steady = len(rates) >= 2 and abs(rates[-1] - rates[-2]) <= 0.02 * rates[-1]
+        if (spent >= args.preheat_ms and steady) or spent >= 8 * args.preheat_ms:
+            break
     done = sr.stream((xs[i % len(xs)] for i in range(args.warmup)), to_text)
     if use_dist:
         sr.gather(done[-2:], force=args.force_dist)      # untimed: RCCL builds its communicator on first use
@@ -557,7 +567,7 @@ def mode_engine(args, model, rank, world, local_rank, use_dist, kdist):
     if per_rank:
         out['per_rank'] = per_rank
     out['warmup_effective'] = args.warmup + preheat_steps      # every untimed step in front of the timed region
-    out['preheat'] = {'steps': preheat_steps, 'ms': args.preheat_ms,
+    out['preheat'] = {'steps': preheat_steps, 'ms': args.preheat_ms, 'chunk_rates_steps_per_s': [round(r, 1) for r in rates[-6:]],
                       'note': 'untimed steps in front of the W warm-up steps (clock governor out of its idle state); --preheat-ms 0 switches it off'}
     out['_first_strings'] = first[0] if first else []
     if not stub and done:

@@ -202,44 +202,6 @@ class RecognitionEngine:
         dev._krk_ready = ev
         return dev
 
-    def upload_rows(self, table, y0: int, y1: int, pool=None, piece: int = 8 << 20, ring: int = 4) -> torch.Tensor:
-        """
-        Rows [y0, y1) of an image whose rows lie in Pillow's memory (``pilmem.RowTable``) -> device tensor (rows, width[, 4]), through
-        a RING of ``ring`` pinned pieces of ``piece`` bytes: the rows of piece k + 1 are ``memmove``d (on ``pool``) while piece k is
-        on the PCIe link, and a fresh process touches 32 MB of pinned memory for the first time instead of a whole page's worth
-        (``page_buffer`` + one copy of 118 MB: 69 ms of page faults on the first page, profiles/r06_cold_start.txt).
-        """
-        from . import pilmem
-        ls = table.linesize
-        shape = (y1 - y0, table.width) if table.pixelsize == 1 else (y1 - y0, table.width, table.pixelsize)
-        dev = torch.empty(shape, dtype=torch.uint8, device=f'cuda:{self.device}')
-        if not hasattr(self, '_ring'):
-            self._ring, self._ring_ev, self._ring_i = [None] * ring, [None] * ring, 0
-        if not hasattr(self, '_pg_stream'):
-            self._pg_host, self._pg_ev, self._pg_i = [None, None], [None, None], 0
-            self._pg_stream = torch.cuda.Stream(device=self.device)
-        per = max(1, piece // ls)                                        # rows per piece
-        self._pg_stream.wait_stream(torch.cuda.current_stream(self.device))      # `dev` may recycle a block still in use there
-        flat = dev.view(-1)
-        ev = None
-        for ya in range(y0, y1, per):
-            yb = min(ya + per, y1)
-            i = self._ring_i = (self._ring_i + 1) % len(self._ring)
-            need = (yb - ya) * ls
-            if self._ring_ev[i] is not None:
-                self._ring_ev[i].synchronize()                           # the copy that last read this piece has finished
-            if self._ring[i] is None or self._ring[i].numel() < need:
-                self._ring[i] = torch.empty(max(need, piece), dtype=torch.uint8, pin_memory=True)
-            pilmem.copy_rows(table, ya, yb, self._ring[i].numpy()[:need], pool, piece=1 << 20)
-            with torch.cuda.stream(self._pg_stream):
-                flat[(ya - y0) * ls:(yb - y0) * ls].copy_(self._ring[i][:need], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self._pg_stream)
-            self._ring_ev[i] = ev
-        dev.record_stream(self._pg_stream)
-        dev._krk_ready = ev
-        return dev
-
     def _page_format(self, page_dev: torch.Tensor):
         """
         (rows, width, bytes per pixel) of an uploaded page: (H, W) is an 'L' page, (H, W, 3) packed RGB, (H, W, 4) Pillow's own
