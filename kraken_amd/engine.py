@@ -202,6 +202,34 @@ class RecognitionEngine:
         dev._krk_ready = ev
         return dev
 
+    def upload_rows(self, table, y0: int, y1: int) -> torch.Tensor:
+        """
+        Rows [y0, y1) of an image whose rows lie in Pillow's memory (``pilmem.RowTable``) -> device tensor (rows, width[, 4]), copied
+        STRAIGHT from Pillow's blocks: one pageable host -> device copy per run of rows that are contiguous there (a block holds
+        many rows).  On MI355X hosts a pageable copy runs at the pinned rate (460 MB: 9.8 ms against 4-6 ms of memmove on 8 threads
+        + 8.5 ms of DMA) and, unlike a pinned staging buffer, costs nothing the first time: the FIRST DMA out of a fresh pinned
+        buffer of that size took 159 ms (profiles/r06_h2d_paths.txt) -- most of a page's first pass.
+        """
+        ls = table.linesize
+        shape = (y1 - y0, table.width) if table.pixelsize == 1 else (y1 - y0, table.width, table.pixelsize)
+        dev = torch.empty(shape, dtype=torch.uint8, device=f'cuda:{self.device}')
+        flat = dev.view(-1)
+        rows = table.rows[y0:y1]
+        cuts = np.flatnonzero(np.diff(rows) != ls) + 1
+        starts = np.concatenate(([0], cuts)).tolist()
+        ends = np.concatenate((cuts, [y1 - y0])).tolist()
+        self._pg_stream.wait_stream(torch.cuda.current_stream(self.device))      # `dev` may recycle a block still in use there
+        with torch.cuda.stream(self._pg_stream):
+            for a, b in zip(starts, ends):
+                n = (b - a) * ls
+                src = np.frombuffer((C.c_ubyte * n).from_address(int(rows[a])), dtype=np.uint8)
+                flat[a * ls:b * ls].copy_(torch.from_numpy(src))               # pageable: returns when the bytes have left the host
+            ev = torch.cuda.Event()
+            ev.record(self._pg_stream)
+        dev.record_stream(self._pg_stream)
+        dev._krk_ready = ev
+        return dev
+
     def _page_format(self, page_dev: torch.Tensor):
         """
         (rows, width, bytes per pixel) of an uploaded page: (H, W) is an 'L' page, (H, W, 3) packed RGB, (H, W, 4) Pillow's own

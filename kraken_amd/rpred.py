@@ -679,14 +679,11 @@ class _RecognitionRun:
         rows = self._rows
         if rows is not None and (rows.pixelsize == 1 if mode == 'L' and self.im.mode in ('1', 'L') else
                                  rows.pixelsize == 4 and self.im.mode in ('RGB', 'RGBX', 'RGBA')):
-            # the band's rows as they lie in Pillow's memory: one memmove per block run, in parallel on the pool, into the pinned
-            # upload buffer.  Colour pages travel as R, G, B, X; the kernels take the pixel stride and, for a 1-channel model,
-            # Pillow's 'L' conversion (krk_prep_lines_fmt / krk_dewarp_*_page)
-            # (round 6: a ring of pinned 8-16 MB pieces -- memmove of piece k + 1 under the DMA of piece k -- was measured here and
-            # removed: the first pass of a fresh process did not gain, warm RGB passes lost 10 %, profiles/r06_cold_start.txt)
-            buf = eng.page_buffer((y1 - y0, W) if rows.pixelsize == 1 else (y1 - y0, W, 4))
-            pilmem.copy_rows(rows, y0, y1, buf.reshape(-1), self._pool)
-            dev = eng.upload_page_buffer()
+            # the band's rows as they lie in Pillow's memory.  Colour pages travel as R, G, B, X; the kernels take the pixel stride and,
+            # for a 1-channel model, Pillow's 'L' conversion (krk_prep_lines_fmt / krk_dewarp_*_page).
+            # The band goes up straight from Pillow's blocks, one pageable copy per contiguous run of rows (engine.upload_rows: on these
+            # hosts as fast as memmove + pinned DMA, and a fresh process pays no first-use cost of a pinned page buffer)
+            dev = eng.upload_rows(rows, y0, y1)
             if whole:
                 self._pages[mode] = dev
             return dev, y0

@@ -1555,8 +1555,10 @@ def test_rpred_reads_the_page_from_pillows_rows_and_gives_the_same_records(page_
     seg = Segmentation(type='bbox', imagename='p', text_direction='horizontal-lr', script_detection=False,
                        lines=[BBoxLine(id=f'l{i}', bbox=list(b)) for i, b in enumerate(boxes)])
     moved = []
-    real = pilmem.copy_rows
-    monkeypatch.setattr(pilmem, 'copy_rows', lambda t, y0, y1, *a, **k: (moved.append((y1 - y0) * t.linesize), real(t, y0, y1, *a, **k))[1])
+    from kraken_amd.engine import RecognitionEngine
+    real = RecognitionEngine.upload_rows          # (round 6: the band goes up straight from Pillow's blocks, no staging copy)
+    monkeypatch.setattr(RecognitionEngine, 'upload_rows',
+                        lambda self, t, y0, y1: (moved.append((y1 - y0) * t.linesize), real(self, t, y0, y1))[1])
 
     def records():
         with warnings.catch_warnings():

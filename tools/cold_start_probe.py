@@ -22,6 +22,7 @@ ap.add_argument('--lines', type=int, default=2048)
 ap.add_argument('--mode', default='L')
 ap.add_argument('--passes', type=int, default=3)
 ap.add_argument('--width', type=int, default=1200)
+ap.add_argument('--workers', type=int, default=8, help='num_line_workers (1: everything on the main thread, so that --cprofile sees the line preparation)')
 ap.add_argument('--cprofile', type=int, default=0, help='print the top N functions (cumulative) of every pass')
 a = ap.parse_args()
 print('import %.0f ms' % (1e3 * (time.perf_counter() - t_import)))
@@ -79,7 +80,7 @@ for p in range(a.passes):
             prof = cProfile.Profile()
             prof.enable()
         t0 = time.perf_counter()
-        it = R.rpred(net, page, seg, bidi_reordering=False, num_line_workers=8)
+        it = R.rpred(net, page, seg, bidi_reordering=False, num_line_workers=a.workers)
         first = next(it)
         t_first = time.perf_counter() - t0
         n = 1 + sum(1 for _ in it)
