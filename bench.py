@@ -367,7 +367,7 @@ def self_profile(args):
     try:
         for tag, flags in passes:
             r = subprocess.run([exe, *flags, '--output-format', 'csv', '-d', os.path.join(tmp, tag), '--', *cmd], cwd='/tmp', env=env,
-                               capture_output=True, text=True, timeout=240)
+                               capture_output=True, text=True, timeout=120)          # (a pass takes 3-4 s; a profiler that hangs must not hold the line up)
             if r.returncode:
                 return {'why': f'rocprofv3 pass "{tag}" exited {r.returncode}: {(r.stderr or r.stdout)[-200:]!r}'}
 
