@@ -1105,6 +1105,13 @@ def test_hidden_sizes_above_768_against_reference_golden(tag, prec):
     for i, l in enumerate(lens.tolist()):
         one, _ = m.nn(x[i:i + 1, ..., :l].contiguous().cuda())
         assert float((one.cpu() - want[i:i + 1, ..., :l]).abs().max()) < (2e-5 if prec == 'f32' else X3_TOL), (tag, i)
+    # 37 lines = three 16-line tiles per direction: every workgroup has its own slice of the HBM cell / h state (lstm_rec.hip)
+    big = x.repeat(8, 1, 1, 1)[:37].contiguous()
+    blens = lens.repeat(8)[:37]
+    yb, _ = m.nn(big.cuda(), blens if 'peep' not in tag else None)
+    for i in range(37):
+        l = int(blens[i])
+        assert float((yb[i, ..., :l].cpu() - y[i % 5, ..., :l].cpu()).abs().max()) == 0.0, (tag, i)
 
 
 def test_edge_shapes(bench_a, bench_a_x3):
