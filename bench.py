@@ -91,7 +91,7 @@ def parse():
     ap.add_argument('--api-workers', type=int, default=6, help='--mode api: host threads preparing lines (PIL conversions hold the GIL: more than ~6 threads only contend, 16 cost 40 %%)')
     args = ap.parse_args()
     if args.slots is None:
-        args.slots = 4 if args.mode == 'config4' else 3
+        args.slots = 4 if args.mode == 'config4' or args.precision == 'f32' else 3      # (f32 plan: its recurrences hold 32 CUs for 2 ms each: 4 in flight 31.6 k, 3: 28.7 k)
     return args
 
 

@@ -185,7 +185,9 @@ void plan_conv_geom(ConvGeom& g) {
     }
     const int kk = g.kh * g.kw;
     // largest channel chunk whose LDS tile stays within 64 KiB (= NPT * 256 staged floats per workgroup)
-    constexpr int kTileFloats = 64 * 256;
+    // 48 KB (round 6; was 64): three workgroups of the exact-f32 kernel share a CU where two did (BENCH-A f32 plan: the 32 -> 32, 3 x 13 layer 4.6 -> 3.4 ms
+    // under load; KRK_F32_TILE_KB, read when the plan is built, is the probe: profiles/r06_occupancy_three_workgroups.txt)
+    const int kTileFloats = std::min(64, std::max(8, env_int("KRK_F32_TILE_KB", 48))) * 256;
     int cmax;
     g.vec4 = 0;
     if (g.in_seq && g.Cin % 4 == 0) {
