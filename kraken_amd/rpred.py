@@ -221,25 +221,6 @@ def _fused_ok(net) -> bool:
     return getattr(net, 'decoder', _ctc.greedy_decoder) is _ctc.greedy_decoder
 
 
-_HEAP_FROZEN = False
-
-
-def _freeze_import_heap():
-    """
-    Once per process, when the first engine is built: ``gc.freeze()`` -- the objects that exist by then (torch's, PIL's, numpy's and
-    this package's modules: ~10^6 of them, none of which will ever be garbage) move to the collector's permanent generation.  Without
-    it the FIRST generation-2 pass after a page -- triggered by the page's records and crop descriptors becoming long-lived --
-    walks that whole heap: 55 ms in the middle of the second page of a process (profiles/r06_cold_start.txt), and again whenever the
-    heap has grown by a quarter.  KRK_GC_FREEZE=0 leaves the collector alone.
-    """
-    global _HEAP_FROZEN
-    if _HEAP_FROZEN or os.environ.get('KRK_GC_FREEZE', '1') == '0':
-        return
-    import gc
-    gc.freeze()            # (no gc.collect() in front: that IS the 55 ms pass; whatever garbage is frozen with the heap stays, once)
-    _HEAP_FROZEN = True
-
-
 def _engine_for(net, temperature: float):
     """
     Checks out a RecognitionEngine of a recogniser for ONE consumer (a LinePipeline); None for models the engine does not take
@@ -269,7 +250,6 @@ def _engine_for(net, temperature: float):
     pool = cache.setdefault(key, [])
     eng = next((e for e in pool if not e.in_use and not e.closed), None)
     if eng is None:
-        _freeze_import_heap()
         eng = RecognitionEngine(vgsl, device=dev, max_batch=32, max_width=256, slots=ENGINE_SLOTS, temperature=temperature)
         if hs.precision != key[1]:                    # the engine's plans fell back to exact f32 (new_plan): file it under what it is
             key = (dev, hs.precision, hs._weights_version())
@@ -1206,3 +1186,22 @@ def recognition_pred(model, im, segmentation, config=None):
                 return
     finally:                   # also on GeneratorExit: `next(model.predict(...))`, `break` in the consumer's loop
         run.close()
+
+
+def _freeze_import_heap():
+    """
+    Once per process, at the END OF THIS MODULE'S IMPORT: ``gc.freeze()`` -- the objects that exist by then (torch's, PIL's, numpy's and
+    this package's modules: ~10^6 of them, none of which will ever be garbage) move to the collector's permanent generation.  Without
+    it the first generation-2 pass after a page -- triggered by the page's records and crop descriptors becoming long-lived -- walks
+    that whole heap: 55 ms in the middle of the SECOND page of a process (profiles/r06_cold_start.txt), and again whenever the heap has
+    grown by a quarter.  At import time nothing of a caller's run exists yet: freezing later (when the first engine is built) would make
+    the run that builds it immortal -- an abandoned generator would never hand its engine back
+    (tests/test_rpred_cpu.py::test_an_abandoned_run_hands_back_a_clean_engine).  No gc.collect() in front: that would BE the 55 ms pass.
+    KRK_GC_FREEZE=0 leaves the collector alone.
+    """
+    if os.environ.get('KRK_GC_FREEZE', '1') != '0':
+        import gc
+        gc.freeze()
+
+
+_freeze_import_heap()
