@@ -249,7 +249,7 @@ int krk_recognize(krk_plan* plan, const float* x_dev, const int* lens_host,
  *   x_dev      float (n, channels, out_h, batch_w): line k occupies columns [0, out_w_k + 2*pad), zeros to its right
  *   flags_dev  int32 [n]: 1 if the line holds any non-white pixel (the reference's flat-line rule, kraken/rpred.py:221)
  * max_in_h = tallest crop of the batch.  pad must be > 0 (the inversion `max - x` then has max = 1); KRK_E_UNSUPPORTED
- * for geometry outside the kernel's range (crop taller than 768 rows, > 96 filter taps, out_h > 64).
+ * for geometry outside the kernel's range (crop taller than 768 rows, > 96 filter taps, out_h > 128).
  */
 int krk_prep_lines(const unsigned char* page_dev, int page_h, int page_w, int channels, const int* boxes_dev, int n,
                    int max_in_h, int out_h, int pad, int batch_w, float* x_dev, int* flags_dev, void* stream);

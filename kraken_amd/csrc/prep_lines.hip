@@ -18,7 +18,7 @@
 // 256-line batch would otherwise ship 30 MB of coefficient tables over PCIe for 14 MB of pixels.
 // The float stage: ToDtype(scale=True) is uint8 / 255 in fp32 (a 256-entry table made on the host by the same division),
 // `max - x` with max = 1.0 because the white padding is part of the tensor (pad > 0 is required; pad == 0 stays on the host).
-// One workgroup = 64 output columns of one line.  Kernel is integer/byte work: HBM-bound on the page read.
+// One workgroup = 64 output columns of one line (all out_h <= 128 rows of them).  Kernel is integer/byte work: HBM-bound on the page read.
 #include "common.h"
 
 namespace {
@@ -27,6 +27,7 @@ namespace {
 #pragma clang fp contract(off)
 constexpr int PREC_BITS = 32 - 8 - 2;
 constexpr int COLS = 64;          // output columns per workgroup
+constexpr int MAX_OUT_H = 128;    // model input heights up to 128 (kraken's default recognition spec is 120 high; round 6: was 64)
 constexpr int MAX_K = 96;         // taps per output sample (scale up to ~15)
 constexpr int MAX_ROWS = 768;     // source rows of a line
 
@@ -120,8 +121,8 @@ __global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __
         kvb[2 * tid] = xmin;
         kvb[2 * tid + 1] = xmax;
     }
-    if (tid >= 64 && tid < 64 + COLS) {
-        const int j = tid - 64, xx = col0 + j - pad;
+    if (tid >= MAX_OUT_H && tid < MAX_OUT_H + COLS) {            // (threads 0 .. out_h - 1 make the vertical weights, 128 .. 191 the horizontal ones)
+        const int j = tid - MAX_OUT_H, xx = col0 + j - pad;
         int xmin = 0, xmax = 0;
         if (xx >= 0 && xx < ow) xmax = resample_weights(in_w, ow, xx, &xmin, kh + j * MAX_K);
         khb[2 * j] = xmin;
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(256) prep_lines_kernel(const unsigned char* __
 int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, size_t rs, int ps, int ch, const int* boxes_dev, int n,
                           int max_in_h, const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s) {
     if (n <= 0) return 0;
-    if (out_h < 1 || out_h > 64 || pad < 1 || (ch != 1 && ch != 3) || max_in_h > MAX_ROWS) return -4;
+    if (out_h < 1 || out_h > MAX_OUT_H || pad < 1 || (ch != 1 && ch != 3) || max_in_h > MAX_ROWS) return -4;
     if (ps < ch || ps > 4 || (ch == 1 && ps == 2) || rs < (size_t)page_w * ps) return -4;
     const size_t lds = (size_t)(out_h + COLS) * (MAX_K + 2) * sizeof(int) + (size_t)ch * (max_in_h + 2) * COLS;
     if (lds > 160 * 1024) return -4;
@@ -216,7 +217,7 @@ int krk_launch_prep_lines(const unsigned char* page, int page_h, int page_w, siz
 int krk_launch_prep_crops(const unsigned char* crops, int ch, const int* desc_dev, int n, int max_in_h,
                           const float* lut, int out_h, int pad, int batch_w, float* out, int* flags, hipStream_t s) {
     if (n <= 0) return 0;
-    if (out_h < 1 || out_h > 64 || pad < 1 || (ch != 1 && ch != 3) || max_in_h > MAX_ROWS) return -4;
+    if (out_h < 1 || out_h > MAX_OUT_H || pad < 1 || (ch != 1 && ch != 3) || max_in_h > MAX_ROWS) return -4;
     const size_t lds = (size_t)(out_h + COLS) * (MAX_K + 2) * sizeof(int) + (size_t)ch * (max_in_h + 2) * COLS;
     if (lds > 160 * 1024) return -4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_lines_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -538,8 +538,8 @@ class _RecognitionRun:
             return self._host_path('padding other than (n > 0, 0)')
         if ts._center_norm and (ts._mode != 'L' or not DEVICE_DEWARP):
             return self._host_path('the CenterNormalizer dewarp on the device is switched off (rpred.DEVICE_DEWARP)')
-        if ts._perm != (0, 1, 2) or ts._mode not in ('L', 'RGB') or ts._scale[1] != 0 or not 1 <= ts._scale[0] <= 64:
-            return self._host_path('input spec outside the kernel\'s range (legacy height-in-channels layout, height > 64, fixed width)')
+        if ts._perm != (0, 1, 2) or ts._mode not in ('L', 'RGB') or ts._scale[1] != 0 or not 1 <= ts._scale[0] <= 128:
+            return self._host_path('input spec outside the kernel\'s range (legacy height-in-channels layout, height > 128, fixed width)')
         if not (_fused_ok(net) and net.nn.input[2] > 0):
             return self._host_path('recogniser without the fused engine (custom decoder, variable height)')
         return True                                        # (the engine itself is created on the main thread, _advance)
@@ -654,8 +654,10 @@ class _RecognitionRun:
         if ow <= 0:
             return None                              # Image.resize raises on an empty target: the host path reports it
         taps = lambda n_in, n_out: math.ceil(3.0 * max(1.0, n_in / n_out)) * 2 + 1      # noqa: E731
-        if h > 512 or taps(h, out_h) > 96 or taps(w, ow) > 96:
-            self._host_path('crop geometry outside the kernel\'s range (taller than 512 px or scaled by more than 15)')
+        channels = 3 if ts._mode == 'RGB' else 1
+        max_rows = min(512, (160 * 1024 - (out_h + 64) * 98 * 4) // (channels * 64) - 2)      # (the kernel's LDS budget: _prepare_on_device)
+        if h > max_rows or taps(h, out_h) > 96 or taps(w, ow) > 96:
+            self._host_path(f'crop geometry outside the kernel\'s range (taller than {max_rows} px or scaled by more than 15)')
             return None
         im = box if box.mode == ts._mode else box.convert(ts._mode)
         arr = np.asarray(im, dtype=np.uint8)
@@ -729,7 +731,11 @@ class _RecognitionRun:
             logger.warning(f'Conversion of line {line} failed. Emitting empty record..')
             return self._empty(line)
         taps = lambda n_in, n_out: math.ceil(3.0 * max(1.0, n_in / n_out)) * 2 + 1      # noqa: E731
-        if h > 512 or taps(h, out_h) > 96 or taps(w, ow) > 96:
+        # the kernel keeps the crop's rows of a 64-column tile and its filter tables in LDS (prep_lines.hip: (out_h + 64) x 98 ints +
+        # channels x (rows + 2) x 64 bytes <= 160 KB): 512 rows at height 48, 456 for a colour line of a 120-row model
+        channels = 3 if ts._mode == 'RGB' else 1
+        max_rows = min(512, (160 * 1024 - (out_h + 64) * 98 * 4) // (channels * 64) - 2)
+        if h > max_rows or taps(h, out_h) > 96 or taps(w, ow) > 96:
             return None                              # outside the kernel's range
         pad = int(ts.pad[0])
         return _Pending(idx, line, tag, net, None, (w, h), image=self.im.crop(box) if want_image else None,

@@ -1393,19 +1393,21 @@ def _boxes(n, page, seed=9, hmin=20, hmax=130):
     return out
 
 
-@pytest.mark.parametrize('mode', ['L', 'RGB'])
-def test_device_line_preprocessing_is_bit_exact(mode):
-    """krk_prep_lines == PIL crop + kraken's ImageInputTransforms (itself pinned to the reference in transforms.npz)."""
+@pytest.mark.parametrize('mode,H', [('L', 48), ('RGB', 48), ('L', 120), ('RGB', 120), ('L', 128), ('L', 65)])
+def test_device_line_preprocessing_is_bit_exact(mode, H):
+    """krk_prep_lines == PIL crop + kraken's ImageInputTransforms (itself pinned to the reference in transforms.npz); model heights up
+    to 128 since round 6 (kraken's default recognition spec is 120 high, kraken/configs/vgsl.py:102)."""
     from kraken_amd import _lib
     from kraken_amd.transforms import ImageInputTransforms
     page = _rgb_page().convert(mode)
     ch = 1 if mode == 'L' else 3
-    boxes = _boxes(40, page) + [(0, 0, 900, 48), (5, 5, 400, 29), (850, 1380, 960, 1430), (0, 100, 37, 612), (10, 10, 13, 300)]
-    ts = ImageInputTransforms(1, 48, 0, ch, (16, 0), valid_norm=False)
+    # (the last but one box is 512 rows high: a colour line of a 120-row model keeps 456 rows in LDS at most -- rpred sends taller ones to the host)
+    boxes = _boxes(40, page) + [(0, 0, 900, 48), (5, 5, 400, 29), (850, 1380, 960, 1430), (0, 100, 37, 612 if (ch, H) != (3, 120) else 550), (10, 10, 13, 300)]
+    ts = ImageInputTransforms(1, H, 0, ch, (16, 0), valid_norm=False)
     want, rows = [], []
     for b in boxes:
         w, h = b[2] - b[0], b[3] - b[1]
-        ow = int(w * 48 / h)
+        ow = int(w * H / h)
         if ow <= 0:
             continue
         want.append(ts(page.crop(b)))
@@ -1415,14 +1417,14 @@ def test_device_line_preprocessing_is_bit_exact(mode):
     pg = torch.from_numpy(np.array(page)).to(dev)
     bx = torch.tensor(rows, dtype=torch.int32, device=dev)
     wmax = max(r[4] for r in rows) + 32
-    out = torch.full((len(rows), ch, 48, wmax), -7.0, device=dev)
+    out = torch.full((len(rows), ch, H, wmax), -7.0, device=dev)
     flags = torch.full((len(rows),), -1, dtype=torch.int32, device=dev)
     _lib.check(lib.krk_prep_lines(pg.data_ptr(), page.size[1], page.size[0], ch, bx.data_ptr(), len(rows),
-                                  max(r[3] - r[1] for r in rows), 48, 16, wmax, out.data_ptr(), flags.data_ptr(),
+                                  max(r[3] - r[1] for r in rows), H, 16, wmax, out.data_ptr(), flags.data_ptr(),
                                   torch.cuda.current_stream().cuda_stream))
     got = out.cpu()
     for i, w in enumerate(want):
-        assert tuple(w.shape) == (ch, 48, rows[i][4] + 32)
+        assert tuple(w.shape) == (ch, H, rows[i][4] + 32)
         assert torch.equal(got[i, :, :, :w.shape[2]], w), (i, rows[i], (got[i, :, :, :w.shape[2]] - w).abs().max())
         assert got[i, :, :, w.shape[2]:].abs().sum() == 0
     assert flags.cpu().tolist() == [int(w.max() != w.min()) for w in want]
@@ -1690,7 +1692,9 @@ def test_device_dewarp_is_bit_exact_against_the_reference_transform():
             (48, 16, [_wavy_line(rng, int(rng.randint(20, 121)), int(rng.randint(40, 900))) for _ in range(40)] + [np.full((33, 100), 255, np.uint8)], None),
             # round 3: fused multiply-adds (hipcc's default contraction) moved a few columns' centre on lines 3, 22, 50, 53 of this set
             (48, 16, [_wavy_line(rng9, int(rng9.randint(30, 90)), int(rng9.randint(200, 1000))) for _ in range(60)], None),
-            (36, 8, [_wavy_line(rng9, int(rng9.randint(16, 140)), int(rng9.randint(60, 1400))) for _ in range(60)], None)):
+            (36, 8, [_wavy_line(rng9, int(rng9.randint(16, 140)), int(rng9.randint(60, 1400))) for _ in range(60)], None),
+            # round 6: kraken's default model height (kraken/configs/vgsl.py:102)
+            (120, 16, [_wavy_line(rng9, int(rng9.randint(30, 150)), int(rng9.randint(100, 1200))) for _ in range(40)], None)):
         m = build_model(f'[1,{target},0,1 Cr3,13,32 Mp2,2 Cr3,13,32 S1(1x0)1,3 Lbx16 O1c9]', seed=0).to('cuda')
         m.nn.set_precision('bf16x3')
         eng = RecognitionEngine(m, device=0, max_batch=64, max_width=512, slots=1)
@@ -1813,6 +1817,46 @@ def test_rpred_device_preparation_equals_host_preparation(monkeypatch):
         warnings.simplefilter('ignore')
         sync_recs = list(R.mm_rpred(defaultdict(lambda: net2), page, seg, bidi_reordering=False))
     for a, b in zip(host_recs, sync_recs):
+        assert a.prediction == b.prediction and list(a.cuts) == list(b.cuts)
+        np.testing.assert_allclose(a.confidences, b.confidences, atol=CONF_TOL)
+
+
+@pytest.mark.parametrize('channels', [1, 3])
+def test_rpred_prepares_height_120_models_on_the_device(channels, monkeypatch):
+    """kraken's DEFAULT recognition spec is 120 rows high (kraken/configs/vgsl.py:102); until round 6 the device preparation stopped at
+    64 and such models took the 30x slower host path.  Records with the lines prepared (1 channel: dewarped) on the device == records
+    with PIL / scipy on the host, and the device path must actually have been taken."""
+    import warnings
+    from kraken_amd import rpred as R
+    from kraken_amd.containers import BBoxLine, Segmentation
+    from kraken_amd.engine import RecognitionEngine
+    from kraken_amd.models import TorchSeqRecognizer
+    from kraken_amd.specs import DEFAULT_H120
+    spec = DEFAULT_H120 if channels == 1 else DEFAULT_H120.replace('[1,120,0,1 ', '[1,120,0,3 ')
+    m = build_model(spec, codec=bench_codec(), seed=0)
+    m.seg_type, m.model_type = 'bbox', ['recognition']
+    net = TorchSeqRecognizer(m, device='cuda')
+    page = _rgb_page() if channels == 3 else _rgb_page().convert('L')
+    boxes = _boxes(60, page, seed=4)
+    seg = Segmentation(type='bbox', imagename='p', text_direction='horizontal-lr', script_detection=False,
+                       lines=[BBoxLine(id=f'l{i}', bbox=list(b)) for i, b in enumerate(boxes)])
+    used = []
+    for name in ('submit_boxes', 'submit_dewarped'):
+        real = getattr(RecognitionEngine, name)
+        monkeypatch.setattr(RecognitionEngine, name, (lambda real, name: lambda self, *a, **k: (used.append(name), real(self, *a, **k))[1])(real, name))
+
+    def records():
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return list(R.rpred(net, page, seg, bidi_reordering=False))
+    dev_recs = records()
+    assert used and set(used) == {'submit_boxes' if channels == 3 else 'submit_dewarped'}
+    n_used = len(used)
+    monkeypatch.setattr(R, 'DEVICE_PREP', False)
+    host_recs = records()
+    assert len(used) == n_used
+    assert sum(bool(r.prediction) for r in dev_recs) >= 50
+    for a, b in zip(dev_recs, host_recs):
         assert a.prediction == b.prediction and list(a.cuts) == list(b.cuts)
         np.testing.assert_allclose(a.confidences, b.confidences, atol=CONF_TOL)
 
