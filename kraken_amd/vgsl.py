@@ -196,10 +196,13 @@ def _parse_layer(block: str, shape: tuple, idx: int) -> LayerSpec:
             a = -1
         elif b == 0:
             b = -1
-        if src == 1 and high == 1 and low == 3 and a == 1 and b == -1 and h != 0:
+        if src == 1 and high == 1 and low == 3 and h != 0 and ((a == 1 and b in (-1, h)) or (a == -1 and b == h)):
             # the form on the recognition path: fold height into channels, S1(1x0)1,3 (feature index h*C + c): fused into the
-            # convolution in front of it / one pass into sequence rows
-            p = dict(src=src, a=a, b=b, high=high, low=low)
+            # convolution in front of it / one pass into sequence rows.  Round 6: the same collapse spelled with the height written
+            # out -- S1(1x12)1,3, the form of kraken's classic recognition specs (48 rows, two 2x2 pools) -- is the same operation on
+            # the same tensor and takes the same path (it ran as a general permuted copy, which kept such recognisers off the
+            # pipelined engine and the split-bf16 kernels)
+            p = dict(src=src, a=1, b=-1, high=high, low=low)
             # the reference derives this shape from a dummy tensor with variable dims set to 1
             oshape = (n or 1, c * h, 1, w or 1)
         else:

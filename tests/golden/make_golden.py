@@ -365,18 +365,28 @@ def big_lstm_fixture(path):
     """
     from tests.helpers import portable_weights
     out = {}
-    cases = {'bidi1024': '[1,1,0,16 Lbx1024 O1c8]', 'fwd1280': '[1,1,0,16 Lfx1280 O1c8]', 'peep832': '[1,1,0,16 Lbxo832 O1c8]'}
+    # 'classic': kraken's classic recognition spec (48 rows, two pools, the height collapse written out as S1(1x12)1,3): since round 6
+    # that spelling takes the fused collapse like S1(1x0)1,3 (kraken_amd/vgsl.py)
+    cases = {'bidi1024': '[1,1,0,16 Lbx1024 O1c8]', 'fwd1280': '[1,1,0,16 Lfx1280 O1c8]', 'peep832': '[1,1,0,16 Lbxo832 O1c8]',
+             'classic': '[1,48,0,1 Cr3,3,32 Do0.1,2 Mp2,2 Cr3,3,64 Do0.1,2 Mp2,2 S1(1x12)1,3 Lbx100 Do O1c50]'}
     for k, (tag, spec) in enumerate(cases.items()):
         net = ref_vgsl.TorchVGSLModel(vgsl=spec)
         portable_weights(net, seed=900 + k)
         net.eval()
-        x = synth_input(5, 23, seed=7000 + k, h=1, c=16)
+        x = synth_input(5, 23, seed=7000 + k, h=1, c=16) if tag != 'classic' else synth_input(5, 92, seed=7000 + k, h=48, c=1)
         # (the reference's peephole cell does not take packed sequences, layers.py:176: that case runs full-width lines, no seq_lens)
-        lens = torch.tensor([23, 9, 17, 1, 23] if 'peep' not in tag else [23] * 5)
+        lens = torch.tensor([23, 9, 17, 1, 23] if 'peep' not in tag else [23] * 5) * (4 if tag == 'classic' else 1)
         for i, l in enumerate(lens.tolist()):
             x[i, ..., l:] = 0
         y, olens = net.nn(x, lens if 'peep' not in tag else None)
         olens = lens if olens is None else olens
+        if tag == 'classic':
+            # a convolutional stack: the reference's BATCHED result with padding depends on the batch (the padding bleeds through
+            # bias + ReLU: DESIGN.md section 1); the parity target is its per-line result, line by line at batch 1
+            for i, l in enumerate(lens.tolist()):
+                yi, _ = net.nn(x[i:i + 1, ..., :l].contiguous())
+                y[i] = 0
+                y[i, ..., :yi.shape[3]] = yi[0]
         out[f'{tag}_spec'] = spec
         out[f'{tag}_seed'] = 900 + k
         out[f'{tag}_x'] = x.numpy()

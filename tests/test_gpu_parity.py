@@ -1084,7 +1084,7 @@ def test_height_120_default_spec_against_kraken(prec, default_h120):
 
 # ------------------------------------------------- hidden sizes above 768 (tests/golden/big_lstm.npz, made by the reference)
 @pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
-@pytest.mark.parametrize('tag', ['bidi1024', 'fwd1280', 'peep832'])
+@pytest.mark.parametrize('tag', ['bidi1024', 'fwd1280', 'peep832', 'classic'])
 def test_hidden_sizes_above_768_against_reference_golden(tag, prec):
     """kraken builds nn.LSTM of any width (model.py:570-597); lstm_big_kernel keeps the cell state in HBM above 768 hidden units and
     h as well above 1152 (lstm_rec.hip).  Ragged seq_lens, both plans (the recurrence is exact f32 in either)."""
@@ -1099,18 +1099,28 @@ def test_hidden_sizes_above_768_against_reference_golden(tag, prec):
     y, olens = m.nn(x.cuda(), lens if 'peep' not in tag else None)      # (the reference's peephole cell takes no seq_lens)
     assert olens is None or olens.tolist() == z[f'{tag}_olens'].tolist()
     want = torch.from_numpy(z[f'{tag}_y'])
-    for i, l in enumerate(lens.tolist()):
+    out_lens = z[f'{tag}_olens'].tolist()
+    if tag == 'classic':
+        # ('classic': kraken's classic spec with the height collapse written out, S1(1x12)1,3 -- the fused collapse since round 6, so
+        # such recognisers run on the pipelined engine and, in a bf16x3 plan, on the split-bf16 kernels)
+        from kraken_amd import rpred as R
+        from kraken_amd.codec import PytorchCodec as kraken_amd_codec
+        from kraken_amd.models import TorchSeqRecognizer
+        m.add_codec(kraken_amd_codec({chr(0x61 + i): [i + 1] for i in range(26)}))
+        assert R._fused_ok(TorchSeqRecognizer(m, device='cuda'))
+        assert not any(sp.kind == 'reshape' and sp.params.get('general') for sp in m.layer_specs)
+    for i, l in enumerate(out_lens):
         assert float((y[i, ..., :l].cpu() - want[i, ..., :l]).abs().max()) < (2e-5 if prec == 'f32' else X3_TOL), (tag, i)
     # the same lines one by one (batch 1, no lens): the per-line result the masked batch must reproduce
-    for i, l in enumerate(lens.tolist()):
+    for i, (l, ol) in enumerate(zip(lens.tolist(), out_lens)):
         one, _ = m.nn(x[i:i + 1, ..., :l].contiguous().cuda())
-        assert float((one.cpu() - want[i:i + 1, ..., :l]).abs().max()) < (2e-5 if prec == 'f32' else X3_TOL), (tag, i)
+        assert float((one.cpu() - want[i:i + 1, ..., :ol]).abs().max()) < (2e-5 if prec == 'f32' else X3_TOL), (tag, i)
     # 37 lines = three 16-line tiles per direction: every workgroup has its own slice of the HBM cell / h state (lstm_rec.hip)
     big = x.repeat(8, 1, 1, 1)[:37].contiguous()
     blens = lens.repeat(8)[:37]
     yb, _ = m.nn(big.cuda(), blens if 'peep' not in tag else None)
     for i in range(37):
-        l = int(blens[i])
+        l = out_lens[i % 5]
         assert float((yb[i, ..., :l].cpu() - y[i % 5, ..., :l].cpu()).abs().max()) == 0.0, (tag, i)
 
 
