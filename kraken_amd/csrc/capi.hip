@@ -138,6 +138,7 @@ struct ConvGeom {
     bool x3 = false;          // run on the bf16 matrix cores with split operands
     bool split_out = false;   // write the output as split channels-last bf16 planes
     int xchunk = 16, xnchunks = 1, xKB = 1, xKB_last = 1, xPSTR = 48, xplane = 0;
+    int xK = 0;               // gemm_x3.hip: K of the projection = Cin rounded up to 16 (round 6: the rows' last octet is a zeroed pad when Cin % 16 == 8)
     int xtps = 0;             // > 0: the pipelined kernel (conv_x3p.hip) covers this geometry: tile copies per weight-stage boundary
     bool x6 = false;          // three-plane ("bf16x6") convolution in front of a GroupNorm (conv_x6.hip): fp32 NCHW in and out
     void* d_wx6 = nullptr;    // its weights [chunk][tap][block][plane 3][lane][8]
@@ -480,9 +481,21 @@ int pack_gemm_x3_weights(const ConvGeom& g, const float* w, const std::vector<in
     return KRK_OK;
 }
 
+// Round 6: K % 16 == 8 (2 x 100 hidden units: kraken's classic recognisers) -- the K-blocked rows get one more octet, zeroed per call,
+// and the weights a zero column block; before, such a network lost its whole split-bf16 plan.
 int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
-    if (g.Cin % 16) return fail(KRK_E_UNSUPPORTED, "bf16x3: input features must be a multiple of 16");
-    return pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3);
+    if (g.Cin % 8) return fail(KRK_E_UNSUPPORTED, "bf16x3: input features must be a multiple of 8");
+    g.xK = (g.Cin + 15) / 16 * 16;
+    if (g.xK == g.Cin) return pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3);
+    int nrows = g.Cout;
+    if (rowmap)
+        for (int v : *rowmap) nrows = std::max(nrows, v + 1);
+    std::vector<float> wp((size_t)nrows * g.xK, 0.f);
+    for (int r = 0; r < nrows; ++r) std::memcpy(&wp[(size_t)r * g.xK], w + (size_t)r * g.Cin, (size_t)g.Cin * sizeof(float));
+    ConvGeom gp = g;
+    gp.Cin = g.xK;
+    const int rc = pack_gemm_x3_weights(gp, wp.data(), rowmap, 128, &g.d_wx3);
+    return rc;
 }
 
 struct Step {
@@ -542,6 +555,7 @@ struct Step {
     // split-bf16 LSTM -> LSTM / linear: the rows between them stay tile-time-major (16-line tiles, ceil(N/16)*16*T rows):
     // the recurrent kernel writes whole 256-byte runs and gemm_x3 needs no permutation (the linear layer undoes it)
     bool out_tiled = false, in_tiled = false;
+    int seq_kpad = 0;         // > 0: this step's split sequence rows feed a projection whose K is padded to seq_kpad: the planes are that wide, the last octet zeroed
     double flops = 0.0;
 };
 
@@ -1212,6 +1226,7 @@ int PlanBuilder::linear(const krk_layer& L, const std::string& where, Step& s) {
         g.x3 = true;
         s.in_split = split_fmt;
         if (upload_gemm_x3_weights(g, L.w[0], nullptr) != KRK_OK) return KRK_E_UNSUPPORTED;
+        if (s.in_split && g.xK != g.Cin && !p->steps.empty()) p->steps.back().seq_kpad = g.xK;      // the producer leaves room for the pad octet
         split_fmt = false;   // fp32 rows out
     }
     s.outC = L.cout;
@@ -1256,8 +1271,9 @@ int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
         g.x3 = true;
         s.in_split = split_fmt;
         if (upload_gemm_x3_weights(g, wih.data(), &rowmap) != KRK_OK) return KRK_E_UNSUPPORTED;
+        if (s.in_split && g.xK != g.Cin && !p->steps.empty()) p->steps.back().seq_kpad = g.xK;      // the producer leaves room for the pad octet
         // all but a final LSTM run the recurrence on the bf16 cores and hand over split planes
-        s.rec_x3 = (i + 1 < n_layers) && (s.ndir * s.hidden) % 16 == 0 && !big;
+        s.rec_x3 = (i + 1 < n_layers) && (s.ndir * s.hidden) % 8 == 0 && !big;
         split_fmt = s.rec_x3;
     }
     const float* whh[2] = {L.w[1], s.ndir == 2 ? L.w[5] : nullptr};
@@ -1823,7 +1839,7 @@ void fill_x3(const ConvGeom& g, X3Args& a, const void* xin, size_t x_plane, void
 void fill_gemm(const ConvGeom& g, GemmX3Args& a, const void* xin, size_t x_plane, float* yout, int rows, int dbg) {
     a.x = (const __bf16*)xin; a.x_plane = x_plane;
     a.w = (const __bf16*)g.d_wx3; a.bias = g.d_b; a.y = yout;
-    a.M = rows; a.K = g.Cin; a.Cout = g.Cout;
+    a.M = rows; a.K = g.xK ? g.xK : g.Cin; a.Cout = g.Cout;
     a.ncg = (g.Cout + 127) / 128; a.ntiles = (rows + 255) / 256;
     a.act = g.act;
     a.tileT = 0;
@@ -2196,7 +2212,10 @@ int Pass::split_input(Step& s, const float* cur, size_t in_elems, const void** x
     if (s.in_split) return 0;
     if (s.aux2.ensure(in_elems * sizeof(float))) return nomem();
     if (mark("split", 0)) return kFailed;
-    if (int rc = krk_launch_split_rows(cur, s.aux2.p, (int)(in_elems / s.cg.Cin), s.cg.Cin, stream)) return rc;
+    const int kx = s.cg.xK ? s.cg.xK : s.cg.Cin, rows = (int)(in_elems / kx);
+    if (kx != s.cg.Cin)           // the pad octet of both planes (the kernel writes Cin / 8 octets of kx / 8)
+        if (int r = hip(hipMemset2DAsync((char*)s.aux2.p + (size_t)(s.cg.Cin / 8) * rows * 16, in_elems * 2, 0, (size_t)rows * 16, 2, stream), "hipMemset2DAsync")) return r;
+    if (int rc = krk_launch_split_rows(cur, s.aux2.p, rows, s.cg.Cin, in_elems, stream)) return rc;
     *xin = s.aux2.p;
     return 0;
 }
@@ -2213,7 +2232,7 @@ int Pass::linear(Step& s, const float* cur, float* outp, int Win) {
     s.flops = 2.0 * N * (double)Win * s.cg.Cout * s.cg.Cin;
     if (s.cg.x3) {
         const int Nr = s.in_tiled ? (N + 15) / 16 * 16 : N;      // tile-time-major rows come in whole 16-line tiles
-        const size_t in_elems = (size_t)Nr * Win * s.cg.Cin;
+        const size_t in_elems = (size_t)Nr * Win * (s.cg.xK ? s.cg.xK : s.cg.Cin);      // elements per plane, the pad octet included
         const void* xin;
         if (int rc = split_input(s, cur, in_elems, &xin)) return rc;
         GemmX3Args a;
@@ -2244,7 +2263,7 @@ int Pass::lstm(Step& s, const float* cur, float* outp, size_t out_elems, int Win
     int rc;
     if (s.cg.x3) {
         const int Nr = s.in_tiled ? (Ns + 15) / 16 * 16 : Ns;
-        const size_t in_elems = (size_t)Nr * T * s.cg.Cin;
+        const size_t in_elems = (size_t)Nr * T * (s.cg.xK ? s.cg.xK : s.cg.Cin);
         const void* xin;
         if ((rc = split_input(s, cur, in_elems, &xin))) return rc;
         GemmX3Args a;
@@ -2410,6 +2429,8 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         size_t out_elems = (size_t)Nout * s.outC * s.outH * Wout;
         if (s.kind == S_CONV && s.cg.out_nhcw) out_elems = (size_t)Nout * s.outC * s.outH * nhcw_pitch(Wout);
         if (s.kind == S_LSTM && s.out_tiled) out_elems = (size_t)((Nout + 15) / 16 * 16) * s.outC * s.outH * Wout;
+        const size_t seq_feat = (size_t)s.outC * s.outH;             // features of a sequence row
+        if (s.seq_kpad) out_elems = out_elems / seq_feat * s.seq_kpad;   // planes of seq_kpad features: one zeroed octet behind the real ones
         // behind a layer that changed the number of lines the reference's seq_lens no longer match the tensor: its packed LSTM
         // (pack_padded_sequence) and its masked GroupNorm (layers.py:977-984, unless every line is full width) raise
         if (lens_host && pass.detached[s.len_in]) {
@@ -2430,6 +2451,10 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         else {
             if (s.out.ensure(out_elems * sizeof(float))) return fail(KRK_E_NOMEM, "forward: workspace allocation failed");
             outp = (float*)s.out.p;
+        }
+        if (s.seq_kpad && !s.skip) {
+            const size_t rows = out_elems / s.seq_kpad;
+            HIPCHK(hipMemset2DAsync((char*)outp + (seq_feat / 8) * rows * 16, out_elems * 2, 0, rows * 16, 2, stream));
         }
         if (s.skip) { outs[si] = cur; continue; }   // recomputed inside the next step (c1gn.hip): `cur` stays the step's input
         int rc;

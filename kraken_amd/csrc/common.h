@@ -318,7 +318,7 @@ int krk_launch_conv_x3p(const X3Args& a, bool pool, hipStream_t s);
 int krk_launch_conv_x3p_b1(const X3Args& a, bool pool, hipStream_t s);
 int krk_launch_split(const float* x, void* hi, size_t plane_elems, size_t n, hipStream_t s);
 // fp32 rows [M][K] -> K-blocked split planes [K/8][M][8] (hi, lo at + M*K elements)
-int krk_launch_split_rows(const float* x, void* hi, int M, int K, hipStream_t s);
+int krk_launch_split_rows(const float* x, void* hi, int M, int K, size_t plane, hipStream_t s);
 int krk_x3_cb(int Cout);
 int krk_launch_maxpool(const float* x, float* y, const int* len_out, int N, int C, int H, int W,
                        int kh, int kw, int sh, int sw, int Ho, int Wo, hipStream_t s);

@@ -360,13 +360,14 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
 }  // namespace
 
 #ifndef KRK_BF16_ONE
-int krk_launch_split_rows(const float* x, void* hi, int M, int K, hipStream_t s) {
-    if (K % 8) return -1;
+// `plane`: elements between the hi and the lo plane (M x K, or more when the consumer's K is padded: capi.hip seq_kpad)
+int krk_launch_split_rows(const float* x, void* hi, int M, int K, size_t plane, hipStream_t s) {
+    if (K % 8 || plane < (size_t)M * K) return -1;
     const size_t total = (size_t)M * (K / 8);
     if (!total) return 0;
     const unsigned blocks = (unsigned)min((size_t)8192, (total + 255) / 256);
     hipLaunchKernelGGL(split_rows_kernel, dim3(blocks), dim3(256), 0, s, x, reinterpret_cast<__bf16*>(hi),
-                       reinterpret_cast<__bf16*>(hi) + (size_t)M * K, M, K / 8);
+                       reinterpret_cast<__bf16*>(hi) + plane, M, K / 8);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -333,18 +333,62 @@ __global__ void __launch_bounds__(512) lstm_ws_kernel(const LstmWsArgs a) {
         unsigned sp_vo = kOOBws;
         u32x4 sp_v = u32x4{0u, 0u, 0u, 0u};
         if (!KRK_DBGBIT(a, 16)) sp_v = store_read(g, s - 1, hb, sp_vo);
-        bf16x8 hh[NKB], hl[NKB];
+        // NKB == 8 (hidden sizes 225 ... 256, round 6): 128 registers of resident weights leave no room for all sixteen h fragments
+        // of a slot (the compiler spilled eight registers, and its scratch traffic would sit between the hand-counted vmcnt waits):
+        // the fragments are read K block by K block, each feeding BOTH gate-column blocks of the wave, and the two cell updates
+        // follow the last MFMA.  Per accumulator the K blocks still arrive in ascending order.
+        constexpr bool KMAJOR = NKB >= 8;
+        bf16x8 hh[KMAJOR ? 1 : NKB], hl[KMAJOR ? 1 : NKB];
+        if constexpr (!KMAJOR) {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const unsigned char* hp = hb + us * OS + line * RSO + kb * 16;
             hh[kb] = *reinterpret_cast<const bf16x8*>(hp);
             hl[kb] = *reinterpret_cast<const bf16x8*>(hp + plane);
         }
+        }
         if (!KRK_DBGBIT(a, 16)) vm_store_b128(sp_v, sp_vo, ors);
         // NG > 2: the next slot's h was published NG-1 slots ago -- ask for it now, it lands under this slot's MFMAs
         if ((NG > 2 || KRK_DBGBIT(a, 64)) && nxt && !KRK_DBGBIT(a, 1)) gather_issue(ng, nxt_par);
         const unsigned want = tagbase | ((unsigned)(s + 1) & 0xFFFFu);
         const unsigned pso = (unsigned)(g * 2 + (par ^ 1)) * gp_bytes;
+        if constexpr (KMAJOR) {
+            f32x4 acc0[BPW], acc1[BPW], acc2[BPW];
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                acc0[i] = xv[i];
+                acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const unsigned char* hp = hb + us * OS + line * RSO + kb * 16;
+                const bf16x8 fh = *reinterpret_cast<const bf16x8*>(hp);
+                const bf16x8 fl = *reinterpret_cast<const bf16x8*>(hp + plane);
+#pragma unroll
+                for (int i = 0; i < BPW; ++i) {
+                    acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(whi[i][kb]), fh, acc0[i], 0, 0, 0);
+                    KRK_CROSS(acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(whi[i][kb]), fl, acc1[i], 0, 0, 0);
+                              acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_bf(wlo[i][kb]), fh, acc2[i], 0, 0, 0);)
+                }
+                if (NG == 2 && kb == NKB / 2 - 1 && nxt && !KRK_DBGBIT(a, 1)) gather_issue(ng, nxt_par, acc0[0][0] + acc1[0][0] + acc2[0][0]);
+            }
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                const f32x4 z = acc0[i] + (acc1[i] + acc2[i]);
+                const float h = krk_lstm_cell(z, cst[g][i]);
+                const __bf16 hb16 = (__bf16)h;
+                const __bf16 lb16 = (__bf16)(h - (float)hb16);
+                const unsigned short hbits = __builtin_bit_cast(unsigned short, hb16), lbits = __builtin_bit_cast(unsigned short, lb16);
+                unsigned char* dst = (own_lds[i] == dump_off) ? smem8 + dump_off : hn + own_lds[i];
+                *reinterpret_cast<unsigned short*>(dst) = hbits;
+                *reinterpret_cast<unsigned short*>(dst + ((own_lds[i] == dump_off) ? 2 : plane)) = lbits;
+                u32x2 gran;
+                gran[0] = (unsigned)hbits | ((unsigned)lbits << 16);
+                gran[1] = want;
+                vm_store_b64_sc1(gran, pub_vo[i], grs, pso);
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
             f32x4 acc0 = xv[i], acc1 = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -421,7 +465,7 @@ int launch_ws(const LstmWsArgs& a, hipStream_t s) {
 #ifndef KRK_BF16_ONE
 bool krk_lstm_ws_supported(int H, int Hp) {
     const int NKB = (Hp + 31) / 32, NB = Hp / 4;
-    return (H % 8) == 0 && NKB >= 1 && NKB <= 7 && NB <= 64 && (NB + 3) / 4 <= 16;
+    return (H % 8) == 0 && NKB >= 1 && NKB <= 8 && NB <= 64 && (NB + 3) / 4 <= 16;
 }
 
 int krk_lstm_ws_clusters(int N, int ndir, int groups) { return (N + 16 * groups - 1) / (16 * groups) * ndir; }
@@ -442,7 +486,7 @@ int KRK_FN(krk_launch_lstm_ws)(const LstmWsArgs& a, int groups, hipStream_t s) {
     const int bpw = (a.BPC + 7) / 8;
 #define KRK_WS(NKB_, BPW_) if (a.NKB == NKB_ && bpw == BPW_) return groups == 4 ? launch_ws<NKB_, BPW_, 4>(a, s) : launch_ws<NKB_, BPW_, 2>(a, s)
     // NB = Hp/4 in (8(NKB-1), 8 NKB]; BPC = ceil(NB/4) in {2 NKB - 1, 2 NKB}; BPW = ceil(BPC/8)
-    KRK_WS(1, 1); KRK_WS(2, 1); KRK_WS(3, 1); KRK_WS(4, 1); KRK_WS(5, 2); KRK_WS(6, 2); KRK_WS(7, 2);
+    KRK_WS(1, 1); KRK_WS(2, 1); KRK_WS(3, 1); KRK_WS(4, 1); KRK_WS(5, 2); KRK_WS(6, 2); KRK_WS(7, 2); KRK_WS(8, 2);
 #undef KRK_WS
     return -4;
 }

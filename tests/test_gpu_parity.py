@@ -1201,6 +1201,35 @@ def test_recurrent_kernel_variants_agree(bench_a_x3, monkeypatch):
         assert _max_conf_diff(got, base) < 1e-5, env
 
 
+@pytest.mark.parametrize('hidden', [232, 256])
+def test_cluster_kernel_at_hidden_sizes_up_to_256(hidden, monkeypatch):
+    """Round 6: lstm_ws.hip covers eight K blocks (hidden sizes 225 ... 256; Lbx256 is a common size and took the streaming kernel: 3.3 ms
+    per layer where the cluster kernel needs 0.6).  Its K-major instantiation against the streaming kernel (same arithmetic per
+    accumulator: identical tuples) and against the CPU oracle, ragged batch, and the kernel must be the one that ran."""
+    import kraken_amd
+    spec = f'[1,48,0,1 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,64 Mp2,2 Cr3,9,64 S1(1x0)1,3 Lbx{hidden} Lfx{hidden} O1c40]'
+    torch.manual_seed(0)
+    m = kraken_amd.TorchVGSLModel(vgsl=spec, codec={chr(0x100 + i): [i + 1] for i in range(39)})
+    m.nn.set_precision('bf16x3')
+    m.to('cuda')
+    x = synth_input(40, 320).cuda()
+    lens = torch.tensor([320 - 5 * i for i in range(40)])
+    y, _ = m.nn(x, lens)
+    base = m.nn.recognize(x, lens)[0].tuples()
+    from kraken_amd import _lib as _lib_mod
+    assert _lib_mod.load().krk_plan_has_exchange(m.nn.plan(0).handle)              # the cluster kernel is planned for these layers
+    monkeypatch.setenv('KRK_LSTM_V', '1')
+    ys, _ = m.nn(x, lens)
+    got = m.nn.recognize(x, lens)[0].tuples()
+    monkeypatch.delenv('KRK_LSTM_V')
+    assert _keys(got) == _keys(base)
+    assert float((y - ys).abs().max()) < 2e-5
+    ref = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()})
+    want, _ = ref.forward(x.cpu(), lens.tolist())
+    for i, l in enumerate((lens // 8).tolist()):
+        assert float((y[i, ..., :l].cpu() - torch.as_tensor(want)[i, ..., :l]).abs().max()) < X3_TOL, i
+
+
 @pytest.mark.parametrize('forced', [None, '3'])
 def test_narrow_recurrent_layers_never_hit_the_exchange_timeout(forced, monkeypatch):
     """
