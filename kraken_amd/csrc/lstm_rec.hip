@@ -303,21 +303,59 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
     for (int s = 0; s < Lmax; ++s) {
         const float* hcur = hs + cur * hrows * LS;
         float* hnext = hs + (cur ^ 1) * hrows * LS;
-        for (int b = wave; b < a.NB; b += 4) {
-            f32x4 acc;
+        // FOUR gate-column blocks of a wave advance together (round 6): four independent accumulator chains share every h operand
+        // (one wave per SIMD: a single chain of dependent 16x16x4 MFMAs left the matrix pipe idle between them), and the weight
+        // fragments of four K groups x four blocks are requested before the first is used (one load at a time, each waited for in
+        // front of its MFMAs, made a step of H = 512 a chain of 1024 L2 latencies: 53 ms per layer).  Per accumulator the K
+        // order is unchanged.
+        constexpr int NA = 4, PF = 4;
+        for (int b0 = wave; b0 < a.NB; b0 += 4 * NA) {
+            f32x4 acc[NA];
+            const float* wb[NA];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool on = s < ilen[r];
-                const int t = rev ? (ilen[r] - 1 - s) : s;
-                const float* xr = a.xp + ((size_t)(n0 + irow[r]) * a.T + (on ? t : 0)) * a.xstride + (size_t)dir * a.G + cl;
-                acc[r] = on ? xr[(size_t)b * M] : 0.f;
-            }
-            for (int g = 0; g < a.NG; ++g) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wbase + (size_t)g * gstride + (size_t)b * 64 * KG);
+            for (int j = 0; j < NA; ++j) {
+                const int b = min(b0 + 4 * j, a.NB - 1);            // (blocks past the end recompute the last one; never stored)
+                wb[j] = wbase + (size_t)b * 64 * KG;
 #pragma unroll
-                for (int e = 0; e < KG; ++e)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h_at(hcur, (KPI * (g * KG + e) + khalf) * LS + arow), w[e], acc, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    const bool on = s < ilen[r];
+                    const int t = rev ? (ilen[r] - 1 - s) : s;
+                    const float* xr = a.xp + ((size_t)(n0 + irow[r]) * a.T + (on ? t : 0)) * a.xstride + (size_t)dir * a.G + cl;
+                    acc[j][r] = on ? xr[(size_t)b * M] : 0.f;
+                }
             }
+            int g = 0;
+            for (; g + PF <= a.NG; g += PF) {
+                f32x4 w[NA][PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) w[j][u] = *reinterpret_cast<const f32x4*>(wb[j] + (size_t)(g + u) * gstride);
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+#pragma unroll
+                    for (int e = 0; e < KG; ++e) {
+                        const float hv = h_at(hcur, (KPI * ((g + u) * KG + e) + khalf) * LS + arow);
+#pragma unroll
+                        for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv, w[j][u][e], acc[j], 0, 0, 0);
+                    }
+            }
+            for (; g < a.NG; ++g) {
+                f32x4 w[NA];
+#pragma unroll
+                for (int j = 0; j < NA; ++j) w[j] = *reinterpret_cast<const f32x4*>(wb[j] + (size_t)g * gstride);
+#pragma unroll
+                for (int e = 0; e < KG; ++e) {
+                    const float hv = h_at(hcur, (KPI * (g * KG + e) + khalf) * LS + arow);
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv, w[j][e], acc[j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+            const int b = b0 + 4 * j;
+            if (b >= a.NB) break;
+            const f32x4 accb = acc[j];
             const int unit = b * 4 + ul;
             // the cell state in front of this step: LDS (every lane of the quad reads it), or HBM through the quad's gate-0 lane
             auto c_prev = [&](int r) -> float {
@@ -332,7 +370,7 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float cp = c_prev(r);
-                    const float z = acc[r] + wp * cp;
+                    const float z = accb[r] + wp * cp;
                     float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * z));
                     gv = (gate == 2) ? (2.f * gv - 1.f) : (gate == 3 ? z : gv);
                     const float gi = quad_bcast<0x00>(gv);
@@ -350,7 +388,7 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * acc[r]));
+                float gv = __builtin_amdgcn_rcpf(1.0f + __expf(-gscale * accb[r]));
                 gv = (gate == 2) ? (2.f * gv - 1.f) : gv;
                 const float gi = quad_bcast<0x00>(gv);
                 const float gf = quad_bcast<0x55>(gv);
@@ -362,6 +400,7 @@ __global__ void __launch_bounds__(256, 1) lstm_big_kernel(const LstmArgs a) {
                     cs[unit * CLS + irow[r]] = c;
                     hnext[unit * LS + irow[r]] = h;
                 }
+            }
             }
         }
         __syncthreads();                // (HST: s_waitcnt vmcnt(0) in front of the barrier -- every wave's h stores have reached L2)
