@@ -15,13 +15,14 @@ import bench  # noqa: E402
 import kraken_amd  # noqa: E402
 from kraken_amd import _lib, engine as E, rpred as R, vgsl as V  # noqa: E402
 from kraken_amd.models import TorchSeqRecognizer  # noqa: E402
-from kraken_amd.specs import BENCH_A, BENCH_A_RGB, bench_codec  # noqa: E402
+from kraken_amd.specs import BENCH_A, BENCH_A_RGB, DEFAULT_H120, bench_codec  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--lines', type=int, default=2048)
 ap.add_argument('--mode', default='L')
 ap.add_argument('--passes', type=int, default=3)
 ap.add_argument('--width', type=int, default=1200)
+ap.add_argument('--height', type=int, default=48, help='48: BENCH-A; 120: kraken\'s default recognition spec')
 ap.add_argument('--workers', type=int, default=8, help='num_line_workers (1: everything on the main thread, so that --cprofile sees the line preparation)')
 ap.add_argument('--cprofile', type=int, default=0, help='print the top N functions (cumulative) of every pass')
 a = ap.parse_args()
@@ -63,13 +64,15 @@ timed(V.HipSequential, 'plan', 'HipSequential.plan (krk_plan_create per slot)')
 torch.manual_seed(0)
 t0 = time.perf_counter()
 spec = BENCH_A if a.mode == 'L' else BENCH_A_RGB
+if a.height == 120:
+    spec = DEFAULT_H120 if a.mode == 'L' else DEFAULT_H120.replace('[1,120,0,1 ', '[1,120,0,3 ')
 m = kraken_amd.TorchVGSLModel(vgsl=spec, codec=bench_codec())
 m.seg_type, m.model_type = 'bbox', ['recognition']
 m.to('cuda:0')
 net = TorchSeqRecognizer(m, device='cuda:0')
 torch.cuda.synchronize()
 print('model build + to(cuda) %.0f ms' % (1e3 * (time.perf_counter() - t0)))
-page, seg = bench._page_of_lines(a.lines, a.width - 32, 48, a.mode)
+page, seg = bench._page_of_lines(a.lines, a.width - 32, a.height, a.mode)
 for p in range(a.passes):
     acc.clear()
     with warnings.catch_warnings():
