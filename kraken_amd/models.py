@@ -68,6 +68,15 @@ class TorchSeqRecognizer(object):
         self.device = None
         self._probs = None
         self._out_shape = None
+        # The legacy recogniser has no config to carry a precision (kraken/lib/models.py:29-79 runs whatever torch's default is: fp32).
+        # A model nobody chose an arithmetic for gets what kraken's default precision string '32-true' maps to in
+        # prepare_for_inference: the fp32-CLASS split-bf16 plan (|d logit| 2e-5, strings identical on the pinned lines) -- not the
+        # exact-f32 plan, which is a quarter as fast (round 6: rpred() on a freshly loaded model ran on it).  set_precision('f32')
+        # on the model keeps the exact plan.
+        hs = getattr(nn, 'nn', None)
+        if hs is not None and hasattr(hs, 'set_precision') and not getattr(hs, 'precision_chosen', True):
+            hs.set_precision('32-true')
+            hs.precision_chosen = False            # (still nobody's explicit choice: a later prepare_for_inference decides again)
         if device:
             self.to(device)
 

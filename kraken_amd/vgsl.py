@@ -634,6 +634,7 @@ class HipSequential(nn.Module):
         self._plans: dict = {}          # (device, precision, weights version, height) -> _Plan, a few heights at most
         self._sum_x = any(s.kind == 'rnn' and s.params.get('summarize') and s.params.get('axis') == 'x' for s in specs)
         self.precision = _lib.PREC_F32
+        self.precision_chosen = False      # set_precision() was called (by the caller or by prepare_for_inference): nobody picks another default
 
     # -- plan management -------------------------------------------------------------
     def set_precision(self, precision) -> None:
@@ -651,6 +652,7 @@ class HipSequential(nn.Module):
         if precision not in table:
             raise ValueError(f'unknown precision {precision!r}; choose "f32", "bf16x3" or one of kraken\'s precision '
                              f'strings {sorted(PRECISION_OF_CONFIG)}')
+        self.precision_chosen = True
         if table[precision] != self.precision:
             self.precision = table[precision]
             self.invalidate()

@@ -1900,6 +1900,26 @@ def test_rpred_prepares_height_120_models_on_the_device(channels, monkeypatch):
         np.testing.assert_allclose(a.confidences, b.confidences, atol=CONF_TOL)
 
 
+def test_legacy_recogniser_runs_the_32_true_plan_unless_told_otherwise():
+    """kraken's legacy API (TorchSeqRecognizer + rpred) has no config to carry a precision: a model nobody chose an arithmetic for runs
+    what kraken's default '32-true' maps to (the fp32-class split-bf16 plan), not the exact-f32 plan that is a quarter as fast; an
+    explicit choice on the model is kept, and prepare_for_inference still decides for the task API."""
+    import kraken_amd
+    from kraken_amd.models import TorchSeqRecognizer
+    fresh = build_model(BENCH_A, codec=bench_codec(), seed=0)
+    assert fresh.nn.precision == kraken_amd._lib.PREC_F32 and not fresh.nn.precision_chosen
+    TorchSeqRecognizer(fresh, device='cuda')
+    assert fresh.nn.precision == kraken_amd._lib.PREC_BF16X3
+    exact = build_model(BENCH_A, codec=bench_codec(), seed=0)
+    exact.nn.set_precision('f32')
+    TorchSeqRecognizer(exact, device='cuda')
+    assert exact.nn.precision == kraken_amd._lib.PREC_F32
+    odd = build_model('[1,48,0,1 Cr3,3,12 Mp2,2 S1(1x0)1,3 Lbx6 O1c5]', codec={'a': [1], 'b': [2], 'c': [3], 'd': [4]}, seed=0)
+    net = TorchSeqRecognizer(odd, device='cuda')            # a network the split kernels do not cover keeps the exact plan (with a warning)
+    net.predict_labels(synth_input(2, 64).cuda())
+    assert odd.nn.precision == kraken_amd._lib.PREC_F32
+
+
 def test_mm_rpred_tag_routing_on_the_engine(bench_b):
     """reference tests/test_rpred.py:388-440 with two real models: per-tag routing, tags_ignore, default factory."""
     import warnings
