@@ -963,6 +963,8 @@ class TorchVGSLModel(nn.Module):
             dev = 'cuda'                      # this implementation has no CPU path
         self.to(dev)
         precision = getattr(config, 'precision', None)
+        if precision is None and not self.nn.precision_chosen:
+            precision = '32-true'             # kraken's own default (configs/base.py:65) for a config that does not carry one
         if precision is not None:
             # kraken's strings and 'f32' / 'bf16x3' (reference: Fabric(precision=...), model.py:518-523).  A network the
             # split-bf16 kernels do not cover (odd channel counts ...) keeps the exact-f32 plan instead of failing later.
