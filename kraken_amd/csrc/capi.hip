@@ -1273,7 +1273,10 @@ int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
         if (upload_gemm_x3_weights(g, wih.data(), &rowmap) != KRK_OK) return KRK_E_UNSUPPORTED;
         if (s.in_split && g.xK != g.Cin && !p->steps.empty()) p->steps.back().seq_kpad = g.xK;      // the producer leaves room for the pad octet
         // all but a final LSTM run the recurrence on the bf16 cores and hand over split planes
-        s.rec_x3 = (i + 1 < n_layers) && (s.ndir * s.hidden) % 8 == 0 && !big;
+        // ... up to 256 hidden units on the cluster / streaming kernels, 257 ... 512 on the block-major streaming kernel (lstm_x3.hip,
+        // round 6: they fell to the exact-f32 lstm_big_kernel, 30 ms per layer at 512); the peephole cell and wider layers stay there
+        const bool big_x3 = big && !peep && s.Hp <= 512 && !getenv("KRK_NO_LSTM_X3B");
+        s.rec_x3 = (i + 1 < n_layers) && (s.ndir * s.hidden) % 8 == 0 && (!big || big_x3);
         split_fmt = s.rec_x3;
     }
     const float* whh[2] = {L.w[1], s.ndir == 2 ? L.w[5] : nullptr};

@@ -256,6 +256,109 @@ __global__ void __launch_bounds__(64 * NW, 1) lstm_x3_kernel(const LstmX3Args a)
     }
 }
 
+// Hidden sizes 257 ... 512 in a split-bf16 plan (round 6).  The kernel above keeps the accumulators and the cell state of ALL of a wave's
+// blocks in registers (NB <= 64); above that the recurrence fell to lstm_big_kernel -- exact f32, 30 ms per layer at 512 hidden units.
+// Here a wave walks its gate-column blocks FOUR at a time (block-major: each group runs its whole K loop, then its cell updates), the
+// cell state lives in LDS ([unit][16 lines] floats: a lane only ever touches its own (unit, line)), the weight fragments of the next K
+// block are requested while this one's twelve MFMAs run.  Same arithmetic per accumulator as lstm_x3_loop (x, then K blocks ascending,
+// hi.hi + hi.lo + lo.hi per block), same LDS rows of h, same output pass: the next layer's projection reads split planes as before.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 1) lstm_x3b_kernel(const LstmX3Args a) {
+    constexpr int M = 16, NA = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    unsigned char* hs = smem8;                                        // [2 buffers][2 planes][M][hrow]
+    float* cs = reinterpret_cast<float*>(smem8 + 4 * M * a.hrow);    // [NB * 4 units][16 lines]
+    int* lens_s = reinterpret_cast<int*>(cs + (size_t)a.NB * 4 * M);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.x % a.ndir;
+    const bool rev = (a.dirmode == 1) || (a.dirmode == 2 && dir == 1);
+    const int n0 = (blockIdx.x / a.ndir) * M;
+    if (tid < M) {
+        const int n = n0 + tid;
+        int l = 0;
+        if (n < a.N) l = a.lens ? min(max(a.lens[n], 0), a.T) : a.T;
+        lens_s[tid] = l;
+    }
+    for (int e = tid; e < M * a.hrow + a.NB * 4 * M; e += 64 * NW) reinterpret_cast<unsigned int*>(hs)[e] = 0u;   // h (both buffers) and c
+    __syncthreads();
+    int Lmax = 0;
+    for (int i = 0; i < M; ++i) Lmax = max(Lmax, lens_s[i]);
+
+    const int line = lane & 15, us = lane >> 4;
+    const int RS = a.hrow, plane = M * RS, buf = 2 * plane;
+    const int mylen = lens_s[line];
+    const __bf16* wbase = a.wp + ((size_t)dir * a.NKB * a.NB * 2 * 64 + lane) * 8;
+    const size_t kstride = (size_t)a.NB * 1024;
+    const float* xrow0 = a.xp + (a.xtiled ? ((size_t)n0 * a.T + line) : (size_t)(n0 + line) * a.T) * a.xstride + (size_t)dir * a.G + us * 4;
+    const size_t xg_step = a.xtiled ? 16 : 1;
+    int cur = 0;
+    for (int s = 0; s < Lmax; ++s) {
+        const bool on = s < mylen;
+        const int t = on ? (rev ? (mylen - 1 - s) : s) : 0;
+        const float* xr = xrow0 + (size_t)t * xg_step * a.xstride;
+        const unsigned char* hcur = hs + cur * buf;
+        unsigned char* hnext = hs + (cur ^ 1) * buf;
+        const unsigned char* hp0 = hcur + line * RS + us * 16;
+        for (int b0 = wave; b0 < a.NB; b0 += NW * NA) {
+            f32x4 acc[NA];
+            const __bf16* wb[NA];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int b = min(b0 + NW * j, a.NB - 1);            // (a block past the end recomputes the last one; never stored)
+                wb[j] = wbase + (size_t)b * 1024;
+                acc[j] = on ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + b * 16)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            WPair wa[NA], wn[NA];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                wa[j].hi = *reinterpret_cast<const bf16x8*>(wb[j]);
+                wa[j].lo = *reinterpret_cast<const bf16x8*>(wb[j] + 512);
+            }
+            for (int kb = 0; kb < a.NKB; ++kb) {
+                const int kn = min(kb + 1, a.NKB - 1);
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    wn[j].hi = *reinterpret_cast<const bf16x8*>(wb[j] + (size_t)kn * kstride);
+                    wn[j].lo = *reinterpret_cast<const bf16x8*>(wb[j] + (size_t)kn * kstride + 512);
+                }
+                const bf16x8 hh = *reinterpret_cast<const bf16x8*>(hp0 + kb * 64);
+                const bf16x8 hl = *reinterpret_cast<const bf16x8*>(hp0 + kb * 64 + plane);
+#pragma unroll
+                for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j].hi, hh, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j].hi, hl, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j].lo, hh, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NA; ++j) wa[j] = wn[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int b = b0 + NW * j;
+                if (b >= a.NB) break;
+                const int unit = b * 4 + us;
+                const float gi = krk_sigmoid(acc[j][0]);
+                const float gf = krk_sigmoid(acc[j][1]);
+                const float gg = krk_tanh(acc[j][2]);
+                const float go = krk_sigmoid(acc[j][3]);
+                const float c = gf * cs[unit * M + line] + gi * gg;
+                cs[unit * M + line] = c;
+                const float h = go * krk_tanh(c);
+                const __bf16 hh = (__bf16)h;
+                __bf16* dst = reinterpret_cast<__bf16*>(hnext + line * RS) + unit;
+                dst[0] = hh;
+                *reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(dst) + plane) = (__bf16)(h - (float)hh);
+            }
+        }
+        __syncthreads();
+        lstm_x3_store<NW, M>(a, hnext, lens_s, s, wave, lane, dir, rev, n0);
+        cur ^= 1;
+    }
+}
+
 template <int NW, int G, int MAXB, bool XPRE>
 int launch_one(const LstmX3Args& a, hipStream_t s) {
     constexpr int M = 16 * G;
@@ -278,6 +381,14 @@ int launch_one(const LstmX3Args& a, hipStream_t s) {
 // stream is then paid once per 32 lines and the kernel holds half as many CUs (chip time per line -33 %), but a
 // launch takes 1.9 instead of 1.36 ms and the pipelined engine loses more to the longer per-batch chain.
 int krk_launch_lstm_x3(const LstmX3Args& a, hipStream_t s) {
+    if (a.NB > 64) {                       // 257 ... 512 hidden units: the block-major kernel with the cell state in LDS
+        if (a.NB > 128 || a.N <= 0) return a.N <= 0 ? 0 : -4;
+        dim3 grid((unsigned)((a.N + 15) / 16 * a.ndir));
+        const size_t lds = (size_t)4 * 16 * a.hrow + (size_t)a.NB * 4 * 16 * sizeof(float) + 16 * sizeof(int);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_x3b_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(lstm_x3b_kernel<8>, grid, dim3(512), lds, s, a);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     int nw = a.NB > 16 && a.NB <= 64 ? 8 : 4;
     if (const char* e = getenv("KRK_LSTM_STREAM_NW")) nw = atoi(e) == 8 && a.NB <= 64 ? 8 : 4;
     int g = 1;   // 32-line tiles are opt-in: measured 80 k vs 91 k lines/s on the pipelined bench (longer per-batch chain)

@@ -1201,7 +1201,7 @@ def test_recurrent_kernel_variants_agree(bench_a_x3, monkeypatch):
         assert _max_conf_diff(got, base) < 1e-5, env
 
 
-@pytest.mark.parametrize('hidden', [232, 256])
+@pytest.mark.parametrize('hidden', [240, 256])
 def test_cluster_kernel_at_hidden_sizes_up_to_256(hidden, monkeypatch):
     """Round 6: lstm_ws.hip covers eight K blocks (hidden sizes 225 ... 256; Lbx256 is a common size and took the streaming kernel: 3.3 ms
     per layer where the cluster kernel needs 0.6).  Its K-major instantiation against the streaming kernel (same arithmetic per
@@ -1228,6 +1228,44 @@ def test_cluster_kernel_at_hidden_sizes_up_to_256(hidden, monkeypatch):
     want, _ = ref.forward(x.cpu(), lens.tolist())
     for i, l in enumerate((lens // 8).tolist()):
         assert float((y[i, ..., :l].cpu() - torch.as_tensor(want)[i, ..., :l]).abs().max()) < X3_TOL, i
+
+
+@pytest.mark.parametrize('hidden', [320, 512])
+def test_block_major_streaming_kernel_at_hidden_sizes_257_to_512(hidden, monkeypatch):
+    """Round 6: 257 ... 512 hidden units in a split-bf16 plan run on lstm_x3b_kernel (lstm_x3.hip: block-major, cell state in LDS) and
+    hand split planes to the next projection; before, the exact-f32 lstm_big_kernel took them (30 ms per layer at 512).  Against the
+    same network with that kernel switched off (exact-f32 recurrence) and against the CPU oracle; 40 ragged lines = three 16-line tiles."""
+    import kraken_amd
+    spec = f'[1,48,0,1 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,64 Mp2,2 Cr3,9,64 S1(1x0)1,3 Lbx{hidden} Lfx{hidden} O1c40]'
+
+    def model():
+        torch.manual_seed(0)
+        m = kraken_amd.TorchVGSLModel(vgsl=spec, codec={chr(0x100 + i): [i + 1] for i in range(39)})
+        m.nn.set_precision('bf16x3')
+        return m.to('cuda')
+    x = synth_input(40, 320).cuda()
+    lens = torch.tensor([320 - 5 * i for i in range(40)])
+    m = model()
+    y, _ = m.nn(x, lens)
+    lib = kraken_amd._lib.load()
+    plan = m.nn.plan(0)
+    lib.krk_plan_set_profiling(plan.handle, 1)
+    m.nn(x, lens)
+    names = [lib.krk_plan_layer_name(plan.handle, i).decode() for i in range(lib.krk_plan_num_steps(plan.handle))]
+    assert names.count('lstm_rec_x3') == 2, names                        # both layers feed a split-bf16 projection: both on the new kernel
+    monkeypatch.setenv('KRK_NO_LSTM_X3B', '1')
+    m2 = model()
+    y2, _ = m2.nn(x, lens)
+    monkeypatch.delenv('KRK_NO_LSTM_X3B')
+    p2 = m2.nn.plan(0)
+    assert 'lstm_rec_x3' not in [lib.krk_plan_layer_name(p2.handle, i).decode() for i in range(lib.krk_plan_num_steps(p2.handle))]
+    assert float((y - y2).abs().max()) < 5e-5
+    ref = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()})
+    want, _ = ref.forward(x.cpu(), lens.tolist())
+    for i, l in enumerate((lens // 8).tolist()):
+        assert float((y[i, ..., :l].cpu() - torch.as_tensor(want)[i, ..., :l]).abs().max()) < X3_TOL, i
+    one, _ = m.nn(x[7:8, ..., :int(lens[7])].contiguous())
+    assert float((one - y[7:8, ..., :int(lens[7]) // 8]).abs().max()) == 0.0      # a line's result does not depend on its batch
 
 
 @pytest.mark.parametrize('forced', [None, '3'])
