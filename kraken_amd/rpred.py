@@ -444,6 +444,13 @@ class LinePipeline:
         use = ok & ink
         h = self.engine.in_height
         widths, host, keys = {}, set(), []
+        if bool(use.all()):
+            # the common batch -- every line has ink and a full band -- without a per-line branch (same double arithmetic as below)
+            keys = [k for k, _ in items]
+            w = np.fromiter((a.shape[1] for _, a in items), dtype=np.float64, count=len(items))
+            wd = ((h * 1.0 / (2 * r.astype(np.int64))) * w).astype(np.int64) + 2 * pad
+            widths = dict(zip(keys, wd.tolist()))
+            items = ()
         for (k, a), rr, o, i in zip(items, r, ok, ink):
             # a UNIFORM crop (ink False: max == min) is the reference's flat line only when it is white: any other value becomes a
             # non-flat tensor once the white padding is added (kraken/rpred.py:221 tests the PADDED tensor) and is recognised --
@@ -530,7 +537,17 @@ class _RecognitionRun:
 
     # -- device-side preparation (krk_prep_lines): rectangular crops of a fixed-height model, no dewarp ------------
     def _transform_on_device_ok(self, net, ts) -> bool:
-        """The transform is crop -> fixed-height LANCZOS resize -> white padding -> scale -> invert: what the device kernels do."""
+        """The transform is crop -> fixed-height LANCZOS resize -> white padding -> scale -> invert: what the device kernels do.
+        (Asked once per LINE: the answer for a (recogniser, transform) pair is kept for the run -- walking the network's layer list
+        2048 times was 10 % of a warm page's host time.)"""
+        memo = self.__dict__.setdefault('_device_ok_memo', {})
+        key = (id(net), id(ts), DEVICE_PREP, DEVICE_DEWARP)
+        ok = memo.get(key)
+        if ok is None:
+            ok = memo[key] = self._transform_on_device_ok_uncached(net, ts)
+        return ok
+
+    def _transform_on_device_ok_uncached(self, net, ts) -> bool:
         if not DEVICE_PREP:
             return self._host_path('device preparation is switched off (rpred.DEVICE_PREP)')
         pad = ts.pad
@@ -815,13 +832,19 @@ class _RecognitionRun:
             idxs = range(self._prepared, min(self._prepared + chunk, self.len))
             if self._gray_wanted():
                 self._ensure_gray(idxs)
-            if self._pool and len(idxs) > 1:
+            # Lines the DEVICE cuts out of the uploaded page are a crop descriptor each (a few microseconds of interpreter time, all of it
+            # under the GIL): the worker pool only adds hand-offs there -- a warm 2048-line page took 36.7 ms with six workers and 31.4 ms
+            # on the main thread.  The pool is for lines whose pixels the host touches (PIL crops, conversions, resizes).
+            first = self._prepare(idxs[0])
+            light = isinstance(first, _Pending) and first.tensor is None and first.box is not None and first.image is None
+            if self._pool and len(idxs) > 1 and not light:
                 # a future per line costs more than a crop descriptor does: hand the pool a few slices per worker instead
-                k = max(1, len(idxs) // (4 * self._workers))
-                parts = self._pool.map(lambda lo: [self._prepare(i) for i in idxs[lo:lo + k]], range(0, len(idxs), k))
-                items = [it for part in parts for it in part]
+                rest = idxs[1:]
+                k = max(1, len(rest) // (4 * self._workers))
+                parts = self._pool.map(lambda lo: [self._prepare(i) for i in rest[lo:lo + k]], range(0, len(rest), k))
+                items = [first] + [it for part in parts for it in part]
             else:
-                items = [self._prepare(i) for i in idxs]
+                items = [first] + [self._prepare(i) for i in idxs[1:]]
             self._prepared = idxs[-1] + 1
             groups: dict = {}
             for i, item in zip(idxs, items):

@@ -25,6 +25,7 @@ ap.add_argument('--width', type=int, default=1200)
 ap.add_argument('--height', type=int, default=48, help='48: BENCH-A; 120: kraken\'s default recognition spec')
 ap.add_argument('--workers', type=int, default=8, help='num_line_workers (1: everything on the main thread, so that --cprofile sees the line preparation)')
 ap.add_argument('--cprofile', type=int, default=0, help='print the top N functions (cumulative) of every pass')
+ap.add_argument('--sort', default='cumulative', help='cProfile order: cumulative | tottime')
 a = ap.parse_args()
 print('import %.0f ms' % (1e3 * (time.perf_counter() - t_import)))
 
@@ -97,5 +98,5 @@ for p in range(a.passes):
         import io
         import pstats
         buf = io.StringIO()
-        pstats.Stats(prof, stream=buf).sort_stats('cumulative').print_stats(a.cprofile)
+        pstats.Stats(prof, stream=buf).sort_stats(a.sort).print_stats(a.cprofile)
         print('\n'.join(ln for ln in buf.getvalue().splitlines()[6:] if ln.strip()))
