@@ -828,15 +828,18 @@ class _RecognitionRun:
             # the first chunk is ONE batch: the device starts after a third of the page band has been copied and uploaded (a page is
             # a handful of batches: its first result waits for all the host work in front of the first submission)
             # (not for dewarped lines: their batches are pipelined in pairs inside a chunk, _submit_dewarp)
-            chunk = self._batch if self._prepared == 0 and not self._dewarps() else self._chunk
-            idxs = range(self._prepared, min(self._prepared + chunk, self.len))
+            # Lines the DEVICE cuts out of the uploaded page are a crop descriptor each: their chunks are ONE batch too -- prepared,
+            # submitted, and the oldest batch in flight decoded, batch by batch (the dewarp's two halves are pipelined across calls)
+            start = self._prepared
             if self._gray_wanted():
-                self._ensure_gray(idxs)
+                self._ensure_gray(range(start, min(start + self._chunk, self.len)))
+            first = self._prepare(start)
+            light = isinstance(first, _Pending) and first.tensor is None and first.box is not None and first.image is None
+            chunk = self._batch if light or (start == 0 and not self._dewarps()) else self._chunk
+            idxs = range(start, min(start + chunk, self.len))
             # Lines the DEVICE cuts out of the uploaded page are a crop descriptor each (a few microseconds of interpreter time, all of it
             # under the GIL): the worker pool only adds hand-offs there -- a warm 2048-line page took 36.7 ms with six workers and 31.4 ms
             # on the main thread.  The pool is for lines whose pixels the host touches (PIL crops, conversions, resizes).
-            first = self._prepare(idxs[0])
-            light = isinstance(first, _Pending) and first.tensor is None and first.box is not None and first.image is None
             if self._pool and len(idxs) > 1 and not light:
                 # a future per line costs more than a crop descriptor does: hand the pool a few slices per worker instead
                 rest = idxs[1:]
@@ -858,7 +861,9 @@ class _RecognitionRun:
             for (_, shape), group in groups.items():     # one (recogniser, line height) per batch: heights are never padded
                 if shape[0] == 'crop' and shape[1] == 'dewarp':
                     self._submit_dewarp(group)
-                elif shape[0] == 'crop':
+                    continue
+                self._dewarp_flush()                     # (nothing may be submitted between the two halves of a dewarp batch)
+                if shape[0] == 'crop':
                     self._pipe(group[0].net).submit_crops([(p.idx, p.crop) for p in group], self.pad)
                 elif shape[0] == 'dev':
                     net = group[0].net
@@ -867,8 +872,11 @@ class _RecognitionRun:
                                                             for p in group], self.pad)
                 else:
                     self._pipe(group[0].net).submit([(p.idx, p.tensor) for p in group])
+            if self._prepared >= self.len:
+                self._dewarp_flush()
             self._absorb()
             return
+        self._dewarp_flush()
         busiest = max(self._pipes.values(), key=lambda p: p.pending(), default=None)
         self._absorb(block_pipe=busiest)
 
@@ -909,28 +917,46 @@ class _RecognitionRun:
             px += n
         if cur:
             parts.append(cur)
-        # software pipeline over the batches: the measurement of batch k + 1 is enqueued (next slot but one) before the host
-        # waits for batch k's -- the read-back between krk_dewarp_measure and krk_dewarp_apply costs the host no idle time.
-        # Lines that take the host transform are submitted after the last batch (no other submission may come between a
-        # batch's two halves).
-        to_host, begun = [], None
+        # software pipeline over the batches, ACROSS chunks: the measurement of batch k + 1 is enqueued (next slot but one) before the
+        # host waits for batch k's -- the read-back between krk_dewarp_measure and krk_dewarp_apply costs the host no idle time -- and
+        # the last batch of this call stays begun until the next call (or the end of the page, or a submission of another kind:
+        # _dewarp_flush) finishes it.  Lines that take the host transform are submitted when no batch is begun (no other submission
+        # may come between a batch's two halves).
+        begun = self.__dict__.get('_dw_begun')
+        if begun is not None and begun[0] is not pipe:
+            self._dewarp_flush()
         two = len(pipe.engine.slots) >= 2
-        for part in parts + [None]:
-            nxt = None
-            if part is not None and not two and begun is None:       # a one-slot engine: both halves of a batch back to back
-                begun = (part, pipe.dewarp_begin([(p.idx, p.crop) for p in part], page=page, top=top))
-                part = None
-            if part is not None:
-                nxt = (part, pipe.dewarp_begin([(p.idx, p.crop) for p in part], ahead=1 if begun else 0, page=page, top=top))
-            if begun is not None:
-                bpart, handle = begun
-                widths, host = pipe.dewarp_finish([(p.idx, p.crop) for p in bpart], handle, self.pad)
-                for p in bpart:
-                    if p.idx in widths:
-                        p.width = widths[p.idx]
-                to_host += [p for p in bpart if p.idx in host]
-            begun = nxt
-        for p in to_host:
+        for part in parts:
+            items = [(p.idx, p.crop) for p in part]
+            ahead = 1 if (two and self.__dict__.get('_dw_begun') is not None) else 0
+            if not two:
+                self._dewarp_flush()                                   # a one-slot engine: both halves of a batch back to back
+            handle = pipe.dewarp_begin(items, ahead=ahead, page=page, top=top)
+            self._dewarp_finish_begun()
+            self._dw_begun = (pipe, part, items, handle, ts)
+        if not two or self.__dict__.get('_dw_to_host'):
+            self._dewarp_flush()                                       # (lines for the host transform do not wait for the end of the page)
+
+    def _dewarp_finish_begun(self):
+        """Second half (apply + recognition) of the batch whose measurement is in flight."""
+        begun = self.__dict__.get('_dw_begun')
+        if begun is None:
+            return
+        self._dw_begun = None
+        pipe, part, items, handle, ts = begun
+        widths, host = pipe.dewarp_finish(items, handle, self.pad)
+        for p in part:
+            if p.idx in widths:
+                p.width = widths[p.idx]
+        if host:
+            self.__dict__.setdefault('_dw_to_host', []).extend((p, pipe, ts) for p in part if p.idx in host)
+
+    def _dewarp_flush(self):
+        """Finishes the begun batch and submits the lines that took the host transform: before a submission of another kind, at the
+        end of the page."""
+        self._dewarp_finish_begun()
+        to_host, self._dw_to_host = self.__dict__.get('_dw_to_host') or [], []
+        for p, pipe, ts in to_host:
             del self._pending[p.idx]
             if isinstance(p.crop, _PageCrop):
                 box = self.im.crop(p.crop.box[:4])
@@ -966,6 +992,7 @@ class _RecognitionRun:
 
     def close(self):
         """Ends the run: engines go back to their models (batches still in flight are abandoned), the thread pool stops."""
+        self._dw_begun, self._dw_to_host = None, []
         for pipe in self.__dict__.get('_pipes', {}).values():
             pipe.close()
         self.__dict__.get('_pipes', {}).clear()

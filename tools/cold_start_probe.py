@@ -61,6 +61,16 @@ timed(E.RecognitionEngine, 'measure_dewarp_begin', 'engine.measure_dewarp_begin'
 timed(E.RecognitionEngine, 'submit_dewarped', 'engine.submit_dewarped')
 timed(E.RecognitionEngine, 'collect', 'engine.collect')
 timed(V.HipSequential, 'plan', 'HipSequential.plan (krk_plan_create per slot)')
+timed(R._RecognitionRun, '_advance', 'run._advance (everything below + line descriptors)')
+timed(R._RecognitionRun, '_submit_dewarp', 'run._submit_dewarp')
+timed(R._RecognitionRun, '_dewarp_finish_begun', 'run._dewarp_finish_begun')
+timed(R._RecognitionRun, '_absorb', 'run._absorb (records)')
+timed(R._RecognitionRun, '_strip_on_device', 'run._strip_on_device (page band upload)')
+timed(R.LinePipeline, '_collect_one', 'pipe._collect_one (collect + decode)')
+timed(R.LinePipeline, 'dewarp_begin', 'pipe.dewarp_begin')
+timed(R.LinePipeline, 'dewarp_finish', 'pipe.dewarp_finish (waits for the measurement)')
+timed(R.LinePipeline, 'submit_boxes', 'pipe.submit_boxes')
+timed(R, '_decode_lines', 'rpred._decode_lines')
 
 torch.manual_seed(0)
 t0 = time.perf_counter()
