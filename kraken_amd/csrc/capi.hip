@@ -484,7 +484,8 @@ int pack_gemm_x3_weights(const ConvGeom& g, const float* w, const std::vector<in
 // Round 6: K % 16 == 8 (2 x 100 hidden units: kraken's classic recognisers) -- the K-blocked rows get one more octet, zeroed per call,
 // and the weights a zero column block; before, such a network lost its whole split-bf16 plan.
 int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
-    if (g.Cin % 8) return fail(KRK_E_UNSUPPORTED, "bf16x3: input features must be a multiple of 8");
+    // (any K since round 6: a row's last octet may be partly real -- 2 x 150 hidden units = 37.5 octets -- the rest of it and, for
+    // K % 16 in 1 .. 8, one more octet are zeroed per call; such a network had lost its whole split-bf16 plan too)
     g.xK = (g.Cin + 15) / 16 * 16;
     if (g.xK == g.Cin) return pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3);
     int nrows = g.Cout;
@@ -1276,7 +1277,7 @@ int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
         // ... up to 256 hidden units on the cluster / streaming kernels, 257 ... 512 on the block-major streaming kernel (lstm_x3.hip,
         // round 6: they fell to the exact-f32 lstm_big_kernel, 30 ms per layer at 512); the peephole cell and wider layers stay there
         const bool big_x3 = big && !peep && s.Hp <= 512 && !getenv("KRK_NO_LSTM_X3B");
-        s.rec_x3 = (i + 1 < n_layers) && (s.ndir * s.hidden) % 8 == 0 && (!big || big_x3);
+        s.rec_x3 = (i + 1 < n_layers) && (!big || big_x3);
         split_fmt = s.rec_x3;
     }
     const float* whh[2] = {L.w[1], s.ndir == 2 ? L.w[5] : nullptr};
@@ -2216,8 +2217,11 @@ int Pass::split_input(Step& s, const float* cur, size_t in_elems, const void** x
     if (s.aux2.ensure(in_elems * sizeof(float))) return nomem();
     if (mark("split", 0)) return kFailed;
     const int kx = s.cg.xK ? s.cg.xK : s.cg.Cin, rows = (int)(in_elems / kx);
-    if (kx != s.cg.Cin)           // the pad octet of both planes (the kernel writes Cin / 8 octets of kx / 8)
-        if (int r = hip(hipMemset2DAsync((char*)s.aux2.p + (size_t)(s.cg.Cin / 8) * rows * 16, in_elems * 2, 0, (size_t)rows * 16, 2, stream), "hipMemset2DAsync")) return r;
+    if (kx != s.cg.Cin) {         // the pad octets of both planes (the kernel writes ceil(Cin / 8) octets of kx / 8, the last one zero-filled)
+        const int done = (s.cg.Cin + 7) / 8, pad = kx / 8 - done;
+        if (pad > 0)
+            if (int r = hip(hipMemset2DAsync((char*)s.aux2.p + (size_t)done * rows * 16, in_elems * 2, 0, (size_t)pad * rows * 16, 2, stream), "hipMemset2DAsync")) return r;
+    }
     if (int rc = krk_launch_split_rows(cur, s.aux2.p, rows, s.cg.Cin, in_elems, stream)) return rc;
     *xin = s.aux2.p;
     return 0;
@@ -2457,7 +2461,9 @@ int run_plan(krk_plan* p, const float* x_dev, const int* lens_host, int N, int W
         }
         if (s.seq_kpad && !s.skip) {
             const size_t rows = out_elems / s.seq_kpad;
-            HIPCHK(hipMemset2DAsync((char*)outp + (seq_feat / 8) * rows * 16, out_elems * 2, 0, rows * 16, 2, stream));
+            // the octets behind the last full one: a partly real octet (features not a multiple of 8: the recurrence writes its real
+            // elements afterwards) and the pad octet
+            HIPCHK(hipMemset2DAsync((char*)outp + (seq_feat / 8) * rows * 16, out_elems * 2, 0, (s.seq_kpad / 8 - seq_feat / 8) * rows * 16, 2, stream));
         }
         if (s.skip) { outs[si] = cur; continue; }   // recomputed inside the next step (c1gn.hip): `cur` stays the step's input
         int rc;

@@ -336,14 +336,28 @@ __global__ void __launch_bounds__(256) split_kernel(const float* __restrict__ x,
     }
 }
 
-// fp32 rows [M][K] -> K-blocked split planes [K/8][M][8]: one 16-byte piece per thread, rows fastest
+// fp32 rows [M][K] -> K-blocked split planes [ceil(K/8)][M][8]: one 16-byte piece per thread, rows fastest.  ANY = false: K % 8 == 0
+// (rows are 32-byte aligned: two 16-byte loads); ANY = true: any K, element loads, the last octet zero-filled.
+template <bool ANY>
 __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ x, __bf16* __restrict__ hi,
-                                                         __bf16* __restrict__ lo, int M, int K8) {
+                                                         __bf16* __restrict__ lo, int M, int K) {
+    const int K8 = (K + 7) / 8;
     const size_t total = (size_t)M * K8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int pc = (int)(i / M), row = (int)(i - (size_t)pc * M);
-        const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)row * K8 * 8 + pc * 8);
-        const f32x4 a = src[0], b = src[1];
+        f32x4 a, b;
+        if constexpr (ANY) {
+            const float* src = x + (size_t)row * K + pc * 8;
+            const int n = K - pc * 8;                               // real elements of this octet (>= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = j < n ? src[j] : 0.f;
+                b[j] = 4 + j < n ? src[4 + j] : 0.f;
+            }
+        } else {
+            const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)row * K + pc * 8);
+            a = src[0]; b = src[1];
+        }
         bf16x8 h, l;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -362,12 +376,17 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
 #ifndef KRK_BF16_ONE
 // `plane`: elements between the hi and the lo plane (M x K, or more when the consumer's K is padded: capi.hip seq_kpad)
 int krk_launch_split_rows(const float* x, void* hi, int M, int K, size_t plane, hipStream_t s) {
-    if (K % 8 || plane < (size_t)M * K) return -1;
-    const size_t total = (size_t)M * (K / 8);
+    const int K8 = (K + 7) / 8;
+    if (plane < (size_t)M * K8 * 8) return -1;
+    const size_t total = (size_t)M * K8;
     if (!total) return 0;
     const unsigned blocks = (unsigned)min((size_t)8192, (total + 255) / 256);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(blocks), dim3(256), 0, s, x, reinterpret_cast<__bf16*>(hi),
-                       reinterpret_cast<__bf16*>(hi) + plane, M, K / 8);
+    if (K % 8)
+        hipLaunchKernelGGL(split_rows_kernel<true>, dim3(blocks), dim3(256), 0, s, x, reinterpret_cast<__bf16*>(hi),
+                           reinterpret_cast<__bf16*>(hi) + plane, M, K);
+    else
+        hipLaunchKernelGGL(split_rows_kernel<false>, dim3(blocks), dim3(256), 0, s, x, reinterpret_cast<__bf16*>(hi),
+                           reinterpret_cast<__bf16*>(hi) + plane, M, K);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

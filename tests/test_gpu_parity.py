@@ -1230,6 +1230,37 @@ def test_cluster_kernel_at_hidden_sizes_up_to_256(hidden, monkeypatch):
         assert float((y[i, ..., :l].cpu() - torch.as_tensor(want)[i, ..., :l]).abs().max()) < X3_TOL, i
 
 
+@pytest.mark.parametrize('tail', ['Lbx150 Lbx150', 'Lfx75 Lbx50', 'Lbx300 Lbx27', 'Lbx100 Lbx150 Lfx99', 'Lbx6 Lfx5 Lrx3'])
+def test_hidden_sizes_that_are_not_a_multiple_of_8_keep_the_split_plan(tail):
+    """Round 6: a recurrent layer whose output features are not a multiple of 8 (2 x 150, 75, 2 x 27 ...) no longer costs the network
+    its whole split-bf16 plan: the K-blocked rows' last octet is partly real (the recurrence stores element by element), the rest of
+    it and the octet that rounds K up to 16 are zeroed per call.  Against the CPU oracle, ragged, and line by line (batch of one)."""
+    import kraken_amd
+    spec = f'[1,48,0,1 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,64 Mp2,2 Cr3,9,64 S1(1x0)1,3 {tail} O1c40]'
+    torch.manual_seed(0)
+    m = kraken_amd.TorchVGSLModel(vgsl=spec, codec={chr(0x100 + i): [i + 1] for i in range(39)})
+    m.nn.set_precision('bf16x3')
+    m.to('cuda')
+    x = synth_input(40, 320).cuda()
+    lens = torch.tensor([320 - 5 * i for i in range(40)])
+    y, _ = m.nn(x, lens)
+    assert m.nn.precision == kraken_amd._lib.PREC_BF16X3                  # the plan did not fall back to exact f32
+    lib = kraken_amd._lib.load()
+    plan = m.nn.plan(0)
+    lib.krk_plan_set_profiling(plan.handle, 1)
+    m.nn(x, lens)
+    names = [lib.krk_plan_layer_name(plan.handle, i).decode() for i in range(lib.krk_plan_num_steps(plan.handle))]
+    lib.krk_plan_set_profiling(plan.handle, 0)
+    assert names.count('lstm_rec_x3') == len(tail.split()), names         # every recurrence on the bf16 cores, split planes handed on
+    ref = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()})
+    want, _ = ref.forward(x.cpu(), lens.tolist())
+    for i, l in enumerate((lens // 8).tolist()):
+        assert float((y[i, ..., :l].cpu() - torch.as_tensor(want)[i, ..., :l]).abs().max()) < X3_TOL, i
+    for i in (0, 7, 39):
+        one, _ = m.nn(x[i:i + 1, ..., :int(lens[i])].contiguous())
+        assert float((one - y[i:i + 1, ..., :int(lens[i]) // 8]).abs().max()) == 0.0, i
+
+
 @pytest.mark.parametrize('hidden', [320, 512])
 def test_block_major_streaming_kernel_at_hidden_sizes_257_to_512(hidden, monkeypatch):
     """Round 6: 257 ... 512 hidden units in a split-bf16 plan run on lstm_x3b_kernel (lstm_x3.hip: block-major, cell state in LDS) and
@@ -1952,7 +1983,9 @@ def test_legacy_recogniser_runs_the_32_true_plan_unless_told_otherwise():
     exact.nn.set_precision('f32')
     TorchSeqRecognizer(exact, device='cuda')
     assert exact.nn.precision == kraken_amd._lib.PREC_F32
-    odd = build_model('[1,48,0,1 Cr3,3,12 Mp2,2 S1(1x0)1,3 Lbx6 O1c5]', codec={'a': [1], 'b': [2], 'c': [3], 'd': [4]}, seed=0)
+    # (a convolution with 6 output channels between two split-bf16 ones: "bf16x3 needs a multiple of 4 output channels".  Until round 6
+    # the example here was 'Cr3,3,12 Mp2,2 ... Lbx6 O1c5' -- 12 features, not a multiple of 8 -- which the split plan now takes)
+    odd = build_model('[1,48,0,1 Cr3,3,16 Cr3,3,6 Cr3,3,16 S1(1x0)1,3 Lbx8 O1c5]', codec={'a': [1], 'b': [2], 'c': [3], 'd': [4]}, seed=0)
     net = TorchSeqRecognizer(odd, device='cuda')            # a network the split kernels do not cover keeps the exact plan (with a warning)
     net.predict_labels(synth_input(2, 64).cuda())
     assert odd.nn.precision == kraken_amd._lib.PREC_F32
