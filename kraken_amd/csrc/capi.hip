@@ -483,16 +483,21 @@ int pack_gemm_x3_weights(const ConvGeom& g, const float* w, const std::vector<in
 
 // Round 6: K % 16 == 8 (2 x 100 hidden units: kraken's classic recognisers) -- the K-blocked rows get one more octet, zeroed per call,
 // and the weights a zero column block; before, such a network lost its whole split-bf16 plan.
-int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap) {
-    // (any K since round 6: a row's last octet may be partly real -- 2 x 150 hidden units = 37.5 octets -- the rest of it and, for
-    // K % 16 in 1 .. 8, one more octet are zeroed per call; such a network had lost its whole split-bf16 plan too)
-    g.xK = (g.Cin + 15) / 16 * 16;
-    if (g.xK == g.Cin) return pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3);
+// `colmap` (+ `kphys` physical features): input feature c of the torch weights lies at column colmap[c] of the rows the producer
+// writes (a recurrent layer whose directions are padded to Hp units each, Step::opad); the other columns are zero.
+int upload_gemm_x3_weights(ConvGeom& g, const float* w, const std::vector<int>* rowmap, const std::vector<int>* colmap = nullptr, int kphys = 0) {
+    // (any K since round 6: a row's last octet may be partly real -- a convolution stack's C x H that is not a multiple of 8 --
+    // the rest of it and, for K % 16 in 1 .. 8, one more octet are zeroed per call; such a network had lost its whole split-bf16 plan)
+    g.xK = ((colmap ? kphys : g.Cin) + 15) / 16 * 16;
+    if (g.xK == g.Cin && !colmap) return pack_gemm_x3_weights(g, w, rowmap, 128, &g.d_wx3);
     int nrows = g.Cout;
     if (rowmap)
         for (int v : *rowmap) nrows = std::max(nrows, v + 1);
     std::vector<float> wp((size_t)nrows * g.xK, 0.f);
-    for (int r = 0; r < nrows; ++r) std::memcpy(&wp[(size_t)r * g.xK], w + (size_t)r * g.Cin, (size_t)g.Cin * sizeof(float));
+    for (int r = 0; r < nrows; ++r) {
+        if (!colmap) { std::memcpy(&wp[(size_t)r * g.xK], w + (size_t)r * g.Cin, (size_t)g.Cin * sizeof(float)); continue; }
+        for (int c = 0; c < g.Cin; ++c) wp[(size_t)r * g.xK + (*colmap)[c]] = w[(size_t)r * g.Cin + c];
+    }
     ConvGeom gp = g;
     gp.Cin = g.xK;
     const int rc = pack_gemm_x3_weights(gp, wp.data(), rowmap, 128, &g.d_wx3);
@@ -532,6 +537,7 @@ struct Step {
     float* d_peep = nullptr;    // ocropy peephole cell: [ndir][3 (i, f, o)][Hp] peephole weights (lstm_big_kernel)
     void* d_wrecsmx = nullptr;  // ... split bf16 for its bf16x3 variant (plans whose arithmetic is split-bf16)
     bool rec_x3 = false;        // run the recurrence on the bf16 cores and emit split planes
+    bool opad = false;          // ... with every direction's units padded to Hp (hidden % 8 != 0): the stores stay 16-byte pieces, the cluster kernel takes the layer; the consumer's weights get zero columns at the pad units (which are exactly 0: zero weights, zero bias)
     bool on_split = false;      // MAXPOOL / GN / TOSEQ working on split-bf16 NHWC planes (norm_x3.hip)
     bool split_rows = false;    // TOSEQ: fp32 NCHW in, K-blocked split sequence rows out (toseq_split_f32)
     int img_axis = 0;           // LSTM over image rows (1) or columns (2): sequences = N*H (N*W), steps = W (H); 0 = plain sequence
@@ -749,7 +755,7 @@ int upload_lstm_x3(Step& st, const float* const* whh) {
                     }
     HIPCHK(hipMalloc(&st.d_wrecx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(st.d_wrecx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    if (krk_lstm_ws_supported(H, Hp)) {
+    if (krk_lstm_ws_supported(st.opad ? Hp : H, Hp)) {
         // lstm_ws.hip: [dir][slice 4][wave 8][i][kb][plane][lane][8]; slice r owns blocks [r*BPC, (r+1)*BPC), wave w of it the
         // blocks r*BPC + w + 8i; fragments of blocks that do not exist stay zero (they compute h = 0 and publish nothing)
         const int BPC = (NB + 3) / 4, BPW = (BPC + 7) / 8;
@@ -882,6 +888,8 @@ struct PlanBuilder {
     int C, H;
     bool seq = false;
     bool split_fmt = false;   // bf16x3: the current activation is held as split bf16 planes
+    std::vector<int> seq_colmap;   // non-empty: the split sequence rows in front hold every direction's units padded to Hp (Step::opad): feature -> column
+    int seq_kphys = 0;
     int stage = 0;
     int i = 0;
     bool want_x3 = false;     // the plan's arithmetic is split-bf16 (KRK_PREC_BF16X3 / KRK_PREC_BF16)
@@ -1226,8 +1234,10 @@ int PlanBuilder::linear(const krk_layer& L, const std::string& where, Step& s) {
     if (x3) {
         g.x3 = true;
         s.in_split = split_fmt;
-        if (upload_gemm_x3_weights(g, L.w[0], nullptr) != KRK_OK) return KRK_E_UNSUPPORTED;
+        const bool padded = s.in_split && !seq_colmap.empty();
+        if (upload_gemm_x3_weights(g, L.w[0], nullptr, padded ? &seq_colmap : nullptr, seq_kphys) != KRK_OK) return KRK_E_UNSUPPORTED;
         if (s.in_split && g.xK != g.Cin && !p->steps.empty()) p->steps.back().seq_kpad = g.xK;      // the producer leaves room for the pad octet
+        seq_colmap.clear();
         split_fmt = false;   // fp32 rows out
     }
     s.outC = L.cout;
@@ -1271,14 +1281,24 @@ int PlanBuilder::lstm(const krk_layer& L, const std::string& where, Step& s) {
     if (x3) {
         g.x3 = true;
         s.in_split = split_fmt;
-        if (upload_gemm_x3_weights(g, wih.data(), &rowmap) != KRK_OK) return KRK_E_UNSUPPORTED;
+        const bool padded = s.in_split && !seq_colmap.empty();
+        if (upload_gemm_x3_weights(g, wih.data(), &rowmap, padded ? &seq_colmap : nullptr, seq_kphys) != KRK_OK) return KRK_E_UNSUPPORTED;
         if (s.in_split && g.xK != g.Cin && !p->steps.empty()) p->steps.back().seq_kpad = g.xK;      // the producer leaves room for the pad octet
+        seq_colmap.clear();
         // all but a final LSTM run the recurrence on the bf16 cores and hand over split planes
         // ... up to 256 hidden units on the cluster / streaming kernels, 257 ... 512 on the block-major streaming kernel (lstm_x3.hip,
         // round 6: they fell to the exact-f32 lstm_big_kernel, 30 ms per layer at 512); the peephole cell and wider layers stay there
         const bool big_x3 = big && !peep && s.Hp <= 512 && !getenv("KRK_NO_LSTM_X3B");
         s.rec_x3 = (i + 1 < n_layers) && (!big || big_x3);
         split_fmt = s.rec_x3;
+        // hidden sizes that are not a multiple of 8 (kraken's classic Lbx100; 150, 75 ...): every direction is written Hp units wide
+        s.opad = s.rec_x3 && (s.hidden % 8) != 0 && !getenv("KRK_NO_OPAD");
+        if (s.opad) {
+            seq_colmap.resize((size_t)s.ndir * s.hidden);
+            for (int d = 0; d < s.ndir; ++d)
+                for (int k = 0; k < s.hidden; ++k) seq_colmap[(size_t)d * s.hidden + k] = d * s.Hp + k;
+            seq_kphys = s.ndir * s.Hp;
+        }
     }
     const float* whh[2] = {L.w[1], s.ndir == 2 ? L.w[5] : nullptr};
     std::vector<float> pk;
@@ -2306,11 +2326,11 @@ int Pass::recurrence_x3(Step& s, float* outp, size_t out_elems, int Ns, int T, i
     l.out = (__bf16*)outp;
     l.out_plane = out_elems;
     l.lens = lens_at(s.len_in);
-    l.N = Ns; l.T = T; l.H = s.hidden; l.Hp = s.Hp; l.G = G;
+    l.N = Ns; l.T = T; l.H = s.opad ? s.Hp : s.hidden; l.Hp = s.Hp; l.G = G;     // (H only shapes the stores: Step::opad)
     l.NB = G / 16; l.NKB = (s.Hp + 31) / 32;
     l.ndir = s.ndir; l.dirmode = s.dirmode;
     l.xstride = s.ndir * G;
-    l.ostride = s.ndir * s.hidden;
+    l.ostride = s.ndir * (s.opad ? s.Hp : s.hidden);
     l.hrow = l.NKB * 64 + 16;
     l.xtiled = 1;
     l.otiled = s.out_tiled ? 1 : 0;

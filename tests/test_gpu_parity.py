@@ -1231,7 +1231,7 @@ def test_cluster_kernel_at_hidden_sizes_up_to_256(hidden, monkeypatch):
 
 
 @pytest.mark.parametrize('tail', ['Lbx150 Lbx150', 'Lfx75 Lbx50', 'Lbx300 Lbx27', 'Lbx100 Lbx150 Lfx99', 'Lbx6 Lfx5 Lrx3'])
-def test_hidden_sizes_that_are_not_a_multiple_of_8_keep_the_split_plan(tail):
+def test_hidden_sizes_that_are_not_a_multiple_of_8_keep_the_split_plan(tail, monkeypatch):
     """Round 6: a recurrent layer whose output features are not a multiple of 8 (2 x 150, 75, 2 x 27 ...) no longer costs the network
     its whole split-bf16 plan: the K-blocked rows' last octet is partly real (the recurrence stores element by element), the rest of
     it and the octet that rounds K up to 16 are zeroed per call.  Against the CPU oracle, ragged, and line by line (batch of one)."""
@@ -1259,6 +1259,20 @@ def test_hidden_sizes_that_are_not_a_multiple_of_8_keep_the_split_plan(tail):
     for i in (0, 7, 39):
         one, _ = m.nn(x[i:i + 1, ..., :int(lens[i])].contiguous())
         assert float((one - y[i:i + 1, ..., :int(lens[i]) // 8]).abs().max()) == 0.0, i
+    # the layers above 64 units run on the cluster kernel (every direction written Hp units wide: 16-byte stores; the consumer's
+    # weights have zero columns at the pad units) -- against the element-wise layout of the streaming kernel (KRK_NO_OPAD)
+    if any(int(t[3:]) > 64 and int(t[3:]) <= 256 for t in tail.split()):
+        assert lib.krk_plan_has_exchange(plan.handle)
+    monkeypatch.setenv('KRK_NO_OPAD', '1')
+    torch.manual_seed(0)
+    m2 = kraken_amd.TorchVGSLModel(vgsl=spec, codec={chr(0x100 + i): [i + 1] for i in range(39)})
+    m2.nn.set_precision('bf16x3')
+    m2.to('cuda')
+    y2, _ = m2.nn(x, lens)
+    monkeypatch.delenv('KRK_NO_OPAD')
+    assert not lib.krk_plan_has_exchange(m2.nn.plan(0).handle) or 'Lbx8' in tail
+    for i, l in enumerate((lens // 8).tolist()):
+        assert float((y[i, ..., :l] - y2[i, ..., :l]).abs().max()) < 2e-5, i
 
 
 @pytest.mark.parametrize('hidden', [320, 512])
