@@ -202,7 +202,48 @@ class RecognitionEngine:
         dev._krk_ready = ev
         return dev
 
-    def upload_rows(self, table, y0: int, y1: int) -> torch.Tensor:
+    @staticmethod
+    def pin_blocks(table, pins: dict, y0: int, y1: int) -> bool:
+        """
+        hipHostRegister of the Pillow blocks that hold rows [y0, y1) (once per block: ``pins`` maps block address -> bytes and belongs
+        to the caller, who calls ``unpin_blocks`` before the image may go away).  True: every one of those blocks is page-locked, the
+        band can be copied asynchronously.
+        """
+        blocks = pins.get('blocks')
+        if blocks is None:
+            rows, ls = table.rows, table.linesize
+            cuts = np.flatnonzero(np.diff(rows) != ls) + 1
+            st = np.concatenate(([0], cuts))
+            en = np.concatenate((cuts, [len(rows)]))
+            blocks = pins['blocks'] = [(int(a), int(b), int(rows[a]), int((b - a) * ls)) for a, b in zip(st, en)]
+            pins['done'] = {}
+        rt = torch.cuda.cudart()
+        ok = True
+        for a, b, addr, nbytes in blocks:
+            if b <= y0 or a >= y1:
+                continue
+            state = pins['done'].get(addr)
+            if state is None:
+                try:
+                    state = int(rt.cudaHostRegister(addr, nbytes, 0)) == 0
+                except Exception:
+                    state = False
+                pins['done'][addr] = state
+            ok = ok and state
+        return ok
+
+    @staticmethod
+    def unpin_blocks(pins: dict):
+        rt = torch.cuda.cudart()
+        for addr, state in (pins.get('done') or {}).items():
+            if state:
+                try:
+                    rt.cudaHostUnregister(addr)
+                except Exception:
+                    pass
+        pins.clear()
+
+    def upload_rows(self, table, y0: int, y1: int, pins: Optional[dict] = None) -> torch.Tensor:
         """
         Rows [y0, y1) of an image whose rows lie in Pillow's memory (``pilmem.RowTable``) -> device tensor (rows, width[, 4]), copied
         STRAIGHT from Pillow's blocks: one pageable host -> device copy per run of rows that are contiguous there (a block holds
@@ -218,12 +259,14 @@ class RecognitionEngine:
         cuts = np.flatnonzero(np.diff(rows) != ls) + 1
         starts = np.concatenate(([0], cuts)).tolist()
         ends = np.concatenate((cuts, [y1 - y0])).tolist()
+        # ``pins``: the caller's registry of page-locked Pillow blocks (pin_blocks): the band's copies are then asynchronous
+        locked = pins is not None and self.pin_blocks(table, pins, y0, y1)
         self._pg_stream.wait_stream(torch.cuda.current_stream(self.device))      # `dev` may recycle a block still in use there
         with torch.cuda.stream(self._pg_stream):
             for a, b in zip(starts, ends):
                 n = (b - a) * ls
                 src = np.frombuffer((C.c_ubyte * n).from_address(int(rows[a])), dtype=np.uint8)
-                flat[a * ls:b * ls].copy_(torch.from_numpy(src))               # pageable: returns when the bytes have left the host
+                flat[a * ls:b * ls].copy_(torch.from_numpy(src), non_blocking=locked)   # pageable: returns when the bytes have left the host
             ev = torch.cuda.Event()
             ev.record(self._pg_stream)
         dev.record_stream(self._pg_stream)

@@ -57,6 +57,7 @@ DEVICE_PREP = True     # crop / resize / pad / invert eligible lines on the devi
 DEVICE_DEWARP = True   # ... and the CenterNormalizer dewarp of 1-channel bbox lines (krk_dewarp_measure / krk_dewarp_apply) instead of scipy
 PAGE_ROWS = True       # upload the page's rows straight from Pillow's memory (kraken_amd.pilmem) instead of through np.asarray(im)
 DEWARP_BATCH_PIXELS = 32 * 1024 * 1024   # pixels per device dewarp batch (krk_dewarp_measure: 24 bytes of fp64 scratch per pixel, 32-bit offsets)
+PIN_PAGES = os.environ.get('KRK_PIN_PAGES', '1') == '1'     # page-lock Pillow's blocks in place for the run (hipHostRegister): the band copies are asynchronous (KRK_PIN_PAGES=0: pageable copies)
 PREP_THREADS = 4       # host threads preparing line images when the caller does not say (``num_line_workers``); PIL holds the GIL in its
                        # conversions: 2..6 threads give the same throughput, 16 and more lose 40 % to contention
 
@@ -703,7 +704,7 @@ class _RecognitionRun:
             # for a 1-channel model, Pillow's 'L' conversion (krk_prep_lines_fmt / krk_dewarp_*_page).
             # The band goes up straight from Pillow's blocks, one pageable copy per contiguous run of rows (engine.upload_rows: on these
             # hosts as fast as memmove + pinned DMA, and a fresh process pays no first-use cost of a pinned page buffer)
-            dev = eng.upload_rows(rows, y0, y1)
+            dev = eng.upload_rows(rows, y0, y1, pins=self.__dict__.setdefault('_pins', {}) if PIN_PAGES else None)
             if whole:
                 self._pages[mode] = dev
             return dev, y0
@@ -994,7 +995,12 @@ class _RecognitionRun:
         """Ends the run: engines go back to their models (batches still in flight are abandoned), the thread pool stops."""
         self._dw_begun, self._dw_to_host = None, []
         for pipe in self.__dict__.get('_pipes', {}).values():
-            pipe.close()
+            pipe.close()                                   # (engine.reset() waits for the streams: no copy out of a pinned block is in flight)
+        pins = self.__dict__.get('_pins')
+        if pins:
+            torch.cuda.synchronize()
+            from .engine import RecognitionEngine
+            RecognitionEngine.unpin_blocks(pins)
         self.__dict__.get('_pipes', {}).clear()
         pool, self._pool = self.__dict__.get('_pool'), None
         if pool:

@@ -1689,7 +1689,7 @@ def test_rpred_reads_the_page_from_pillows_rows_and_gives_the_same_records(page_
     from kraken_amd.engine import RecognitionEngine
     real = RecognitionEngine.upload_rows          # (round 6: the band goes up straight from Pillow's blocks, no staging copy)
     monkeypatch.setattr(RecognitionEngine, 'upload_rows',
-                        lambda self, t, y0, y1: (moved.append((y1 - y0) * t.linesize), real(self, t, y0, y1))[1])
+                        lambda self, t, y0, y1, pins=None: (moved.append((y1 - y0) * t.linesize), real(self, t, y0, y1, pins))[1])
 
     def records():
         with warnings.catch_warnings():
@@ -1697,6 +1697,15 @@ def test_rpred_reads_the_page_from_pillows_rows_and_gives_the_same_records(page_
             return list(R.rpred(net, page, seg, bidi_reordering=False))
     fast = records()
     assert sum(moved) >= page.size[0] * page.size[1] * (1 if page_mode in ('1', 'L') else 4) * 0.9
+    # (round 6: the run page-locks Pillow's blocks in place for its lifetime -- asynchronous band copies -- and lets go of them when it
+    # ends: a second run can lock them again; with the switch off the bands go up as pageable copies: the same records)
+    monkeypatch.setattr(R, 'PIN_PAGES', False)
+    pageable = records()
+    monkeypatch.setattr(R, 'PIN_PAGES', True)
+    assert [(r.prediction, list(r.cuts)) for r in pageable] == [(r.prediction, list(r.cuts)) for r in fast]
+    moved.clear()
+    again = records()
+    assert [(r.prediction, list(r.cuts)) for r in again] == [(r.prediction, list(r.cuts)) for r in fast]
     monkeypatch.setattr(R, 'PAGE_ROWS', False)
     n = len(moved)
     slow = records()
