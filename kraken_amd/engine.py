@@ -31,6 +31,29 @@ from . import _lib
 from .vgsl import DecodedBatch, TorchVGSLModel
 
 
+_HIP = None
+
+
+def _hip_runtime():
+    """ctypes handle of the HIP runtime THIS process already uses (torch ships its own copy: a dlopen by name could load a second one)."""
+    global _HIP
+    if _HIP is None:
+        path = None
+        try:
+            with open('/proc/self/maps') as f:
+                for ln in f:
+                    if 'libamdhip64' in ln:
+                        path = ln.split()[-1]
+                        break
+        except OSError:
+            pass
+        try:
+            _HIP = C.CDLL(path) if path else False
+        except OSError:
+            _HIP = False
+    return _HIP
+
+
 class _Slot:
     def __init__(self, model: TorchVGSLModel, dev: int, twin: Optional['_Slot'] = None):
         # the first slot builds a plan (same f32 fallback -- and warning -- as a direct nn(x) call); the others share its packed
@@ -224,10 +247,20 @@ class RecognitionEngine:
                 continue
             state = pins['done'].get(addr)
             if state is None:
-                try:
-                    state = int(rt.cudaHostRegister(addr, nbytes, 0)) == 0
-                except Exception:
-                    state = False
+                probe = torch.from_numpy(np.frombuffer((C.c_ubyte * 1).from_address(addr), dtype=np.uint8))
+                if probe.is_pinned():
+                    state = False              # locked by someone else (another live run on this page): theirs to release, not ours
+                else:
+                    try:
+                        state = int(rt.cudaHostRegister(addr, nbytes, 0)) == 0
+                    except Exception:
+                        state = False
+                    if not state:
+                        # (read-only mapping, memlock limit ...)  HIP keeps the failure as this thread's "last error" and the library's
+                        # launch wrappers read that after every launch: take it off, or the next kernel is reported as failed
+                        hip = _hip_runtime()
+                        if hip:
+                            hip.hipGetLastError()
                 pins['done'][addr] = state
             ok = ok and state
         return ok
@@ -238,9 +271,11 @@ class RecognitionEngine:
         for addr, state in (pins.get('done') or {}).items():
             if state:
                 try:
-                    rt.cudaHostUnregister(addr)
+                    bad = int(rt.cudaHostUnregister(addr)) != 0
                 except Exception:
-                    pass
+                    bad = True
+                if bad and _hip_runtime():                 # (see pin_blocks: a refusal must not stay behind as the thread's last error)
+                    _hip_runtime().hipGetLastError()
         pins.clear()
 
     def upload_rows(self, table, y0: int, y1: int, pins: Optional[dict] = None) -> torch.Tensor:

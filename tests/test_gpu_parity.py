@@ -7,6 +7,7 @@ Parity tests proper: the HIP path (through the C ABI of libkraken_amd.so) agains
 Tolerances (fp32 plan): logits |d| <= 1e-3 (BASELINE.json north_star; observed ~2e-6), decode
 tuples (label, start, end) identical, confidences |d| <= 1e-4.
 """
+import ctypes
 import json
 
 import numpy as np
@@ -1706,6 +1707,16 @@ def test_rpred_reads_the_page_from_pillows_rows_and_gives_the_same_records(page_
     moved.clear()
     again = records()
     assert [(r.prediction, list(r.cuts)) for r in again] == [(r.prediction, list(r.cuts)) for r in fast]
+    # two live runs on ONE page: the second cannot lock blocks the first holds -- it copies them pageable, and the failed
+    # hipHostRegister must not be taken for a failed launch
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        first = R.rpred(net, page, seg, bidi_reordering=False)
+        head = next(first)
+        second = list(R.rpred(net, page, seg, bidi_reordering=False))
+        rest = list(first)
+    assert [(r.prediction, list(r.cuts)) for r in second] == [(r.prediction, list(r.cuts)) for r in fast]
+    assert [(r.prediction, list(r.cuts)) for r in [head] + rest] == [(r.prediction, list(r.cuts)) for r in fast]
     monkeypatch.setattr(R, 'PAGE_ROWS', False)
     n = len(moved)
     slow = records()
@@ -1714,6 +1725,40 @@ def test_rpred_reads_the_page_from_pillows_rows_and_gives_the_same_records(page_
     for i, (a, b) in enumerate(zip(fast, slow)):
         assert a.prediction == b.prediction and list(a.cuts) == list(b.cuts), i
         np.testing.assert_allclose(a.confidences, b.confidences, atol=1e-6)
+
+
+def test_page_locking_in_place_and_a_refusal_that_poisons_nothing(bench_a_x3):
+    """RecognitionEngine.pin_blocks / upload_rows / unpin_blocks on a block of host memory: the band arrives byte for byte whether
+    the block could be locked, was locked by somebody else (then it is theirs to release) or not at all; and a refusal of the HIP
+    runtime (here: releasing a block that is not locked) is not left behind as the thread's "last error" -- the library's launch
+    wrappers read that after every launch and would report the next kernel as failed."""
+    from kraken_amd import pilmem
+    from kraken_amd.engine import RecognitionEngine
+    ls, nrows = 4096, 256
+    buf = np.random.RandomState(3).randint(0, 255, size=nrows * ls + 8192, dtype=np.uint8)
+    base = (buf.ctypes.data + 4095) & ~4095                               # page-aligned start inside the buffer
+    view = np.frombuffer((ctypes.c_ubyte * (nrows * ls)).from_address(base), dtype=np.uint8)
+    table = pilmem.RowTable(rows=np.arange(nrows, dtype=np.int64) * ls + base, linesize=ls, pixelsize=1, width=ls, height=nrows, keep=buf)
+    eng = RecognitionEngine(bench_a_x3, device=0, max_batch=8, max_width=256, slots=1)
+    rt = torch.cuda.cudart()
+    pins = {}
+    assert RecognitionEngine.pin_blocks(table, pins, 0, nrows) is True and pins['done'] == {base: True}
+    dev = eng.upload_rows(table, 0, nrows, pins)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy().reshape(-1), view)
+    theirs = {}
+    assert RecognitionEngine.pin_blocks(table, theirs, 0, nrows) is False and theirs['done'] == {base: False}     # locked already: not ours
+    dev2 = eng.upload_rows(table, 0, nrows, theirs)
+    torch.cuda.synchronize()
+    assert torch.equal(dev2, dev)
+    RecognitionEngine.unpin_blocks(theirs)                                 # releases nothing
+    assert torch.from_numpy(view[:1]).is_pinned()
+    RecognitionEngine.unpin_blocks(pins)
+    assert not torch.from_numpy(view[:1]).is_pinned() and pins == {}
+    RecognitionEngine.unpin_blocks({'done': {base: True}})                 # a release the runtime refuses ...
+    y, _ = bench_a_x3.nn(synth_input(2, 64).cuda())                        # ... and a launch right behind it
+    assert torch.isfinite(y).all()
+    eng.close()
 
 
 @pytest.mark.parametrize('mode', ['L', 'RGB'])
