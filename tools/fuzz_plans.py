@@ -35,6 +35,14 @@ SPECS = [
     '[1,16,0,1 Cr3,3,8 Mp2,2 CTr3,3,8,2,2 Cr3,5,16 S1(1x0)1,3 Lbx24 O1c9]',
     '[1,12,0,1 Cr3,3,16 S3(2x8)1,3 Cr3,3,16 Mp2,2 S1(1x0)1,3 Lbx32 Lbx16 O1c11]',
     '[1,16,0,1 Cr3,7,16 Mp2,2 Cr3,3,8 S1(1x0)1,3 Lbxo12 Lbx24 O1c13]',
+    # round 6: hidden sizes that are not a multiple of 8 (every direction written Hp units wide: the cluster kernel above 64 units, the
+    # streaming one below), 257 ... 512 units (block-major streaming kernel), a convolution stack whose C x H is not a multiple of 8
+    # (zero-filled last octet of the projection's rows), kraken's classic recogniser
+    '[1,24,0,1 Cr3,7,16 Mp2,2 Cr3,5,32 Mp2,2 Cr3,3,32 S1(1x0)1,3 Lbx100 Lbx150 Lfx75 O1c31]',
+    '[1,16,0,1 Cr3,5,16 Mp2,2 Cr3,3,32 Cr3,3,16 S1(1x0)1,3 Lfx27 Lbx6 Lrx99 O1c17]',
+    '[1,16,0,1 Cr3,5,16 Mp2,2 Cr3,3,32 Cr3,3,16 S1(1x0)1,3 Lbx300 Lbx100 O1c14]',
+    '[1,12,0,1 Cr3,5,16 Mp2,2 Cr3,3,16 Cr3,3,12 S1(1x0)1,3 Lbx20 O1c9]',
+    '[1,48,0,1 Cr3,3,32 Mp2,2 Cr3,3,64 Mp2,2 S1(1x12)1,3 Lbx100 O1c50]',
 ]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()) if '--time-seed' in sys.argv else 0)
