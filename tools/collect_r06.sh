@@ -38,6 +38,7 @@ PREFLIGHT_OUT=$O/preflight bash tools/scale_preflight.sh 20 > $O/${TAG}_prefligh
 (timeout 120 python tools/blla_forward.py --x3 2>&1 | grep -v amdgpu.ids | tail -30 > $O/${TAG}_blla.txt)
 for i in 3 4; do (KRK_LSTM_V=3 timeout 200 python tools/ws_flake.py 1500 $i --slots 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_exchange_timeouts_three_in_flight.txt); done
 (timeout 260 python tools/fuzz_plans.py ${FUZZ:-150} --time-seed 2>&1 | grep -v amdgpu.ids | tail -30 > $O/${TAG}_fuzz.txt)
-for n in 40 2048; do (timeout 120 python tools/cold_start_probe.py --lines $n --mode L --passes 3 2>&1 | grep -v amdgpu.ids > $O/${TAG}_cold_L_$n.txt); done
+for n in 40 2048; do for md in L RGB; do (timeout 120 python tools/cold_start_probe.py --lines $n --mode $md --passes 6 2>&1 | grep -v amdgpu.ids > $O/${TAG}_cold_${md}_$n.txt); done; done
+(timeout 200 bash tools/prep_kernels.sh 2>&1 | grep -v amdgpu.ids > $O/${TAG}_prep_kernels_final.txt)
 for f in $O/${TAG}_*bench*.json $O/${TAG}_two_ranks*.json; do echo $(basename $f) $(tail -1 $f | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['unit'], d.get('steps'), d.get('parity_checked'))" 2>&1 | tail -1 | cut -c1-400); done
 tail -3 $O/${TAG}_fuzz.txt; head -8 $O/${TAG}_preflight_summary.txt; cat $O/${TAG}_exchange_timeouts_three_in_flight.txt; cat $O/${TAG}_height120.txt | cut -c1-400; grep "pass 0" $O/${TAG}_cold_*.txt
