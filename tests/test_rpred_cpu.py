@@ -157,6 +157,15 @@ def test_decode_lines_table_path_equals_the_codec():
         assert g.text == ''.join(x[0] for x in w) and g.out_width == ol
         assert g.starts.tolist() == [x[1] for x in w] and g.ends.tolist() == [x[2] for x in w]
         np.testing.assert_allclose(g.confs, [x[3] for x in w], rtol=0, atol=0)
+    # every label decodable: the batch-wide path (one utf-32 decode, a line's string a slice of it), garbage behind the counts
+    clean = rng.integers(1, 200, size=(n, t)).astype(np.int32)
+    for i, k in enumerate(counts):
+        clean[i, k:] = rng.integers(-5, 5000, size=t - k)
+    batch2 = DecodedBatch(clean, starts, ends, confs, counts)
+    got2, want2 = R._decode_lines(single, batch2, olens), single.decode_batch(batch2)
+    for g, w in zip(got2, want2):
+        assert g.text == ''.join(x[0] for x in w) and len(g.text) == len(g.starts) == len(w)
+        assert g.starts.tolist() == [x[1] for x in w] and g.confs.tolist() == [np.float32(x[3]) for x in w]
     multi = PytorchCodec({'a': [1], 'bc': [2], 'd': [3, 4]})
     small = DecodedBatch(np.array([[1, 2, 3, 4], [3, 1, 0, 0]], np.int32), np.array([[0, 2, 4, 6], [1, 3, 0, 0]], np.int32),
                          np.array([[1, 3, 5, 7], [2, 4, 0, 0]], np.int32), np.full((2, 4), 0.5, np.float32), np.array([4, 2], np.int32))
