@@ -643,16 +643,24 @@ class _RecognitionRun:
         (pixel for pixel `im.crop(box).convert('L')`: the conversion is point-wise).  None: the general path decides (boxes
         touching the page border are padded by PIL, invalid ones give the reference's empty records).
         """
-        on_page = self._rows is not None and DEVICE_DEWARP and self.bounds.type != 'baselines' and \
-            self.bounds.text_direction.startswith('horizontal') and extract_polygons is _EXTRACT_POLYGONS
+        # (asked once per line: what does not depend on the line is worked out once per run and switch setting)
+        memo = self.__dict__.get('_on_page_memo')
+        if memo is None or memo[0] != (DEVICE_DEWARP, extract_polygons):
+            on_page = self._rows is not None and DEVICE_DEWARP and self.bounds.type != 'baselines' and \
+                self.bounds.text_direction.startswith('horizontal') and extract_polygons is _EXTRACT_POLYGONS
+            memo = self._on_page_memo = ((DEVICE_DEWARP, extract_polygons), on_page, self.im.size)
+        on_page, (W, H) = memo[1], memo[2]
         if (self._gray is None and not on_page) or not ts._center_norm or not self._transform_on_device_ok(net, ts):
             return None
         box = line.bbox
         if box is None or len(box) != 4:
             return None
-        x0, y0, x1, y1 = (int(v) for v in box)
-        W, H = self.im.size
-        if not (0 <= x0 < x1 <= W and 0 <= y0 < y1 <= H) or list(box) != [x0, y0, x1, y1]:
+        x0, y0, x1, y1 = box
+        if not (type(x0) is int and type(y0) is int and type(x1) is int and type(y1) is int):
+            x0, y0, x1, y1 = (int(v) for v in box)
+            if list(box) != [x0, y0, x1, y1]:
+                return None
+        if not (0 <= x0 < x1 <= W and 0 <= y0 < y1 <= H):
             return None
         w, h = x1 - x0, y1 - y0
         step = self.GRAY_ROWS
@@ -1111,11 +1119,12 @@ class mm_rpred(_RecognitionRun):
             logger.info(f'Ignoring line segment with type {_line_type(line.tags)}.')
             return self._empty(line)
         tag, net = _pick_model(line.tags, self.nets, self._default)
-        if extract_polygons is _EXTRACT_POLYGONS and self._device_prep_ok(net, self.ts[tag]):
-            item = self._prepare_on_device(idx, line, tag, net, self.ts[tag])
+        ts = self.ts[tag]
+        if not ts._center_norm and extract_polygons is _EXTRACT_POLYGONS and self._device_prep_ok(net, ts):
+            item = self._prepare_on_device(idx, line, tag, net, ts)
             if item is not None:
                 return item
-        item = self._dewarp_crop_from_page(idx, line, tag, net, self.ts[tag])
+        item = self._dewarp_crop_from_page(idx, line, tag, net, ts)
         if item is not None:
             return item
         legacy = self._use_legacy_extractor(net)
