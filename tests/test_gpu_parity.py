@@ -2088,6 +2088,45 @@ def test_mm_rpred_tag_routing_on_the_engine(bench_b):
     assert ignored == ['', only_a[1], '', only_a[3]]
 
 
+def test_two_dewarping_models_interleaved_on_one_page_keep_the_pipeline_straight(bench_b):
+    """Round 6: a dewarp batch's measurement stays in flight across _advance calls (its second half is submitted when the next batch
+    has begun).  Two 1-channel models sharing a page line by line (tags), flat lines and lines whose band leaves the padded stack in
+    between (they take the host transform, submitted when no batch is begun): the records of the interleaved run are the records of
+    each model on its own, in input order."""
+    import warnings
+    from collections import defaultdict
+    from PIL import Image
+    from kraken_amd import rpred as R
+    from kraken_amd.containers import BBoxLine, Segmentation
+    from kraken_amd.models import TorchSeqRecognizer
+    other = build_model(BENCH_A, codec=bench_codec(), seed=5)
+    for mm in (bench_b, other):
+        mm.seg_type, mm.model_type = 'bbox', ['recognition']
+    a, b = TorchSeqRecognizer(bench_b, device='cuda'), TorchSeqRecognizer(other, device='cuda')
+    rng = np.random.RandomState(13)
+    rows, boxes, y = [], [], 0
+    for i in range(150):
+        h, w = int(rng.randint(30, 80)), int(rng.randint(200, 900))
+        line = _wavy_line(rng, h, w) if i % 37 != 5 else np.full((h, w), 255 if i % 2 else 0, np.uint8)     # flat white / solid black lines
+        rows.append(np.pad(line, ((0, 0), (0, 900 - w)), constant_values=255))
+        boxes.append((0, y, w, y + h))
+        y += h
+    page = Image.fromarray(np.vstack(rows), 'L')
+    tags = [{'type': [{'type': 'foo' if (i // 3) % 2 else 'default'}]} for i in range(150)]
+    seg = Segmentation(type='bbox', imagename='p', text_direction='horizontal-lr', script_detection=True,
+                       lines=[BBoxLine(id=f'l{i}', bbox=list(bx), tags=tags[i]) for i, bx in enumerate(boxes)])
+
+    def run(nets):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return [(r.prediction, list(r.cuts)) for r in R.mm_rpred(nets, page, seg, bidi_reordering=False)]
+    both = run({'default': a, 'foo': b})
+    only_a, only_b = run(defaultdict(lambda: a)), run(defaultdict(lambda: b))
+    assert len(both) == 150 and sum(bool(t) for t, _ in both) >= 140
+    for i in range(150):
+        assert both[i] == (only_b if (i // 3) % 2 else only_a)[i], i
+
+
 def test_predict_api_precision_logits_and_line_images(bench_a, monkeypatch):
     """TorchVGSLModel.prepare_for_inference / predict (lib/vgsl/rpred.py:56-208): config.precision -> plan,
     return_logits (baseline records: the probability slice, :200; bbox records: the decoded tuples, :157),
