@@ -58,7 +58,10 @@ class _Slot:
     def __init__(self, model: TorchVGSLModel, dev: int, twin: Optional['_Slot'] = None):
         # the first slot builds a plan (same f32 fallback -- and warning -- as a direct nn(x) call); the others share its packed
         # weights (krk_plan_clone: 7 ms of repack + upload per slot of kraken's default recogniser otherwise)
-        self.plan = model.nn.new_plan(dev) if twin is None else twin.plan.clone()
+        # Round 6, later: the first slot is a clone too -- of the plan the MODEL keeps for this device and arithmetic (HipSequential.plan:
+        # built when a recogniser is put on the device, TorchSeqRecognizer.to / prepare_for_inference, or by the first nn(x) call), so a
+        # page's first pass does not pack and upload the weights again (12-15 ms of kraken's default recogniser).
+        self.plan = model.nn.plan(dev).clone() if twin is None else twin.plan.clone()
         self.dev = dev
         self.stream = torch.cuda.Stream(device=dev)
         self.event = torch.cuda.Event()

@@ -86,6 +86,14 @@ class TorchSeqRecognizer(object):
             raise ValueError('kraken_amd.TorchSeqRecognizer runs on HIP devices only (got device="cpu")')
         self.device = device
         self.nn.to(device)
+        # the plan of a fixed-height model (packed weights on the device) is made now, not inside the first page: engines clone it
+        hs = getattr(self.nn, 'nn', None)
+        if hs is not None and hasattr(hs, 'plan') and self.nn.input[2] > 0 and torch.cuda.is_available():
+            try:
+                p = next(self.nn.parameters())
+                hs.plan(p.device.index if p.device.index is not None else torch.cuda.current_device())
+            except Exception:
+                pass                                   # (said where the plan is needed: the first call raises or warns as before)
 
     # ``outputs``: (N, C, T) float32 numpy array of softmax probabilities, like the reference.
     @property

@@ -30,6 +30,20 @@ a = ap.parse_args()
 print('import %.0f ms' % (1e3 * (time.perf_counter() - t_import)))
 
 acc = {}
+import gc  # noqa: E402
+_gc_t0 = [0.0]
+
+
+def _gc_cb(phase, info):          # how long the cyclic collector ran inside a pass, per generation
+    if phase == 'start':
+        _gc_t0[0] = time.perf_counter()
+    else:
+        e = acc.setdefault(f'gc generation {info["generation"]} ({info["collected"]} collected)', [0, 0.0])
+        e[0] += 1
+        e[1] += time.perf_counter() - _gc_t0[0]
+
+
+gc.callbacks.append(_gc_cb)
 
 
 def timed(obj, name, label=None):
