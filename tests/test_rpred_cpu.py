@@ -365,3 +365,112 @@ def test_width_buckets_cover_every_line_once_widest_first_and_respect_both_limit
                 assert widths[idx].min() >= widths[b[i + 1]].max()      # buckets partition the sorted order
     assert width_buckets([], 8) == []
     assert [x.tolist() for x in width_buckets([5, 5, 5], 2)] == [[2], [0, 1]]
+
+
+# ------------------------------------------------------------------ the dewarp pipeline's state machine on the host (round 6)
+class _DewarpStubEngine(_StubEngine):
+    """The dewarp surface of RecognitionEngine with the RULES of the real one as assertions: a batch's second half goes into the slot
+    its measurement was begun on, nothing else is submitted in between, `ahead=1` only behind a begun batch, never more batches in
+    flight than slots.  Every 11th line's band "leaves the padded stack" (ok False: host transform), every 17th line is flat."""
+    in_height, in_channels, device = 48, 1, 0
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.begun = None          # [n] of the batch whose measurement is in flight
+        self.log = []
+        self.uploads = 0
+
+    def upload_rows(self, table, y0, y1, pins=None):
+        self.uploads += 1
+        return types.SimpleNamespace(rows=(y0, y1))
+
+    def measure_dewarp_begin(self, crops, pool=None, ahead=0, page=None):
+        assert page is not None, 'the lines of this test are boxes of the uploaded page'
+        assert (ahead == 1) == (self.begun is not None), ('ahead', ahead, self.begun)
+        assert self.free_slots() >= 1 + ahead, 'no slot for the measurement'
+        n = len(crops)
+        r = np.full(n, 12, np.int32)
+        idx = (np.asarray(crops)[:, 1] + page.rows[0]) // 40    # line index: the boxes are 40 rows apart, relative to the band's first row
+        ok, ink = idx % 61 != 3, idx % 17 != 5
+        prev, self.begun_next = self.begun, [n, ok, ink]
+        self.log.append(('begin', n, ahead))
+        stub = self
+
+        class H:
+            def result(_):
+                return r, ok, ink
+        if prev is None:
+            self.begun = self.begun_next
+        else:
+            self.pending_begin = self.begun_next
+        return H()
+
+    def submit_dewarped(self, r, use, pad, want_probs=False):
+        assert self.begun is not None, 'second half without a first'
+        n = self.begun[0]
+        assert len(r) == n and len(use) == n
+        self.log.append(('finish', n))
+        self.begun = self.__dict__.pop('pending_begin', None)
+        t = self.submit_staged(np.full(n, 8 * 30))
+        self.__dict__.setdefault('flags_of', {})[t] = np.asarray(use).astype(np.int32)      # krk_dewarp_apply's "holds ink" flags
+        return t
+
+    def collect(self, ticket):
+        self.last_flags = self.__dict__.get('flags_of', {}).pop(ticket, None)
+        return super().collect(ticket)
+
+    def submit_staged(self, lens=None, want_probs=False):
+        self.log.append(('staged', len(lens)))
+        return super().submit_staged(lens, want_probs)
+
+
+@pytest.mark.parametrize('two_models', [False, True])
+def test_dewarp_batches_are_pipelined_across_chunks_without_breaking_the_engines_rules(monkeypatch, two_models):
+    """Descriptor-only lines go batch by batch; a dewarp batch's measurement stays in flight until the next batch has begun
+    (_dw_begun), the end of the page or a submission of another kind: the stub engine asserts the real engine's rules on every call.
+    Lines for the host transform are submitted when no batch is begun; flat lines give empty records; every line gets its record,
+    in input order, with one or two recognisers sharing the page."""
+    import kraken_amd.engine as E
+    monkeypatch.setattr(E, 'RecognitionEngine', _DewarpStubEngine)
+    monkeypatch.setattr(R, '_fused_ok', lambda net: True)
+    monkeypatch.setattr(R, 'PIN_PAGES', False)
+    _StubEngine.made.clear()
+
+    def recogniser(ch):
+        w = torch.nn.Parameter(torch.zeros(1))
+        hs = types.SimpleNamespace(precision=2, _weights_version=lambda: (w.data_ptr(), w._version))
+        hs.__dict__['_engines'] = {}
+        vgsl = types.SimpleNamespace(nn=hs, input=(1, 1, 48, 0), one_channel_mode='L', use_legacy_polygons=False,
+                                     parameters=lambda: iter([types.SimpleNamespace(is_cuda=True, device=types.SimpleNamespace(index=0))]))
+        return types.SimpleNamespace(nn=vgsl, seg_type='bbox', codec=PytorchCodec({ch: [1]}), temperature=1.0)
+    a, b = recogniser('a'), recogniser('b')
+    n = 230
+    rng = np.random.default_rng(2)
+    px = rng.integers(0, 255, (40 * n, 300), dtype=np.uint8)
+    for i in range(5, n, 17):
+        px[40 * i:40 * i + 40] = 255                                         # the flat lines are white (any other uniform value is recognised)
+    im = Image.fromarray(px, 'L')
+    boxes = [(0, 40 * i, 200 + i % 50, 40 * i + 36) for i in range(n)]
+    tags = [{'type': [{'type': 'foo' if two_models and (i // 40) % 2 else 'default'}]} for i in range(n)]
+    nets = {'default': a, 'foo': b} if two_models else defaultdict(lambda: a)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        recs = list(R.mm_rpred(nets, im, seg(boxes, tags=tags, script_detection=True), bidi_reordering=False, batch_size=32))
+    assert len(recs) == n
+    engines = _StubEngine.made
+    assert len(engines) == (2 if two_models else 1)
+    for e in engines:
+        assert e.begun is None and not e.q and not e.in_use                  # nothing left begun or in flight
+        begins = [x for x in e.log if x[0] == 'begin']
+        assert len(begins) == sum(1 for x in e.log if x[0] == 'finish') >= 2
+        # batches are begun behind their predecessor (ahead = 1) except the first and those behind a batch with lines for the host
+        # transform (the pipeline is drained for them)
+        assert sum(x[2] for x in begins) >= (2 if not two_models else 1), begins
+    for i, r in enumerate(recs):
+        want = 'b' if two_models and (i // 40) % 2 else 'a'
+        if i % 17 == 5 and i % 61 != 3:
+            assert r.prediction == '', i                                      # flat line: empty record
+        elif i % 61 == 3:
+            assert r.prediction in ('', want), i                              # host transform (random pixels: recognised by the stub or flat)
+        else:
+            assert r.prediction == want, i
