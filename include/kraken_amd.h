@@ -290,6 +290,7 @@ int krk_prep_crops(const unsigned char* crops_dev, int channels, const int* desc
  *                   exp(-x^2 / 2 sigma^2) / sum (computed by the caller with the host's exp: kraken_amd/transforms.py)
  *       scratch_dev 3 * h * w doubles per line; work_dev int32 [2 n + 2 n max_w] (min/max, ridge, centre line: kept for apply)
  *       info_dev    int32 [n][4] out: r = int(1 + 4 mad), ok (the reference's band slices are full), has ink, 0
+ *       max_h <= 192 rows (r1 = 4 h <= 768 taps either side; KRK_E_UNSUPPORTED above: such lines take the reference's host transform)
  *   krk_dewarp_apply    band cut-out + bilinear scaling to out_h + uint8 truncation + white padding + / 255 + inversion.
  *       geo_dev     int32 [n][4]: r, out_w = int(out_h / (2 r) * w), use (0: the line's rows stay zero), 0
  *       x_dev       float (n, 1, out_h, batch_w); flags_dev int32 [n]: 1 if the line holds a non-white pixel
