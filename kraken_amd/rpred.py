@@ -695,7 +695,7 @@ class _RecognitionRun:
             return None                              # Image.resize raises on an empty target: the host path reports it
         taps = lambda n_in, n_out: math.ceil(3.0 * max(1.0, n_in / n_out)) * 2 + 1      # noqa: E731
         channels = 3 if ts._mode == 'RGB' else 1
-        max_rows = min(512, (160 * 1024 - (out_h + 64) * 98 * 4) // (channels * 64) - 2)      # (the kernel's LDS budget: _prepare_on_device)
+        max_rows = min(512, (160 * 1024 - (out_h + 64) * 99 * 4) // (channels * 64) - 2)      # (the kernel's LDS budget: _prepare_on_device)
         if h > max_rows or taps(h, out_h) > 96 or taps(w, ow) > 96:
             self._host_path(f'crop geometry outside the kernel\'s range (taller than {max_rows} px or scaled by more than 15)')
             return None
@@ -774,7 +774,7 @@ class _RecognitionRun:
         # the kernel keeps the crop's rows of a 64-column tile and its filter tables in LDS (prep_lines.hip: (out_h + 64) x 98 ints +
         # channels x (rows + 2) x 64 bytes <= 160 KB): 512 rows at height 48, 456 for a colour line of a 120-row model
         channels = 3 if ts._mode == 'RGB' else 1
-        max_rows = min(512, (160 * 1024 - (out_h + 64) * 98 * 4) // (channels * 64) - 2)
+        max_rows = min(512, (160 * 1024 - (out_h + 64) * 99 * 4) // (channels * 64) - 2)
         if h > max_rows or taps(h, out_h) > 96 or taps(w, ow) > 96:
             return None                              # outside the kernel's range
         pad = int(ts.pad[0])

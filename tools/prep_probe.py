@@ -44,10 +44,11 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-for ch, name in ((1, 'prep_L'), (3, 'prep_RGB')):
+for ch, name in ((1, 'prep_L'), (3, 'prep_RGB'), (4, 'prep_RGBX')):
     if args.case not in ('all', name):
         continue
-    page = gray if ch == 1 else np.stack([gray, np.roll(gray, 3, axis=1), np.minimum(gray, 200)], axis=2)
+    page = gray if ch == 1 else np.stack([gray, np.roll(gray, 3, axis=1), np.minimum(gray, 200)] + ([np.full_like(gray, 255)] if ch == 4 else []), axis=2)
+    ps, ch = ch, min(ch, 3)                       # 'prep_RGBX': a 3-channel model reading Pillow's own R, G, B, X rows (krk_prep_lines_fmt)
     pg = torch.from_numpy(np.ascontiguousarray(page)).to(dev)
     ow = int(W * H / sh)
     rows = [(0, i * sh, W, (i + 1) * sh, ow) for i in range(n)]
@@ -56,8 +57,12 @@ for ch, name in ((1, 'prep_L'), (3, 'prep_RGB')):
     out = torch.empty((n, ch, H, wmax), device=dev)
     flags = torch.empty((n,), dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    ms = timed(lambda: _lib.check(lib.krk_prep_lines(pg.data_ptr(), gray.shape[0], W, ch, bx.data_ptr(), n, sh, H, 16, wmax,
-                                                     out.data_ptr(), flags.data_ptr(), st)), args.reps)
+    if ps == 4:
+        ms = timed(lambda: _lib.check(lib.krk_prep_lines_fmt(pg.data_ptr(), gray.shape[0], W, W * ps, ps, ch, bx.data_ptr(), n, sh, H, 16, wmax,
+                                                             out.data_ptr(), flags.data_ptr(), st)), args.reps)
+    else:
+        ms = timed(lambda: _lib.check(lib.krk_prep_lines(pg.data_ptr(), gray.shape[0], W, ch, bx.data_ptr(), n, sh, H, 16, wmax,
+                                                         out.data_ptr(), flags.data_ptr(), st)), args.reps)
     print(f'{name}: {n} lines {sh} x {W} -> {H} x {ow}: {ms:.3f} ms per batch ({n / ms:.1f} k lines/s); bytes in {page.nbytes / 1e6:.1f} MB, out {out.numel() * 4 / 1e6:.1f} MB')
 
 if args.case in ('all', 'dewarp'):
