@@ -1545,7 +1545,11 @@ int PlanBuilder::build() {
     for (i = 0; i < n_layers; ++i) {
         const krk_layer& L = layers[i];
         const std::string where = "layer " + std::to_string(i);
-        x3 = want_x3 && !left_x3 && i > last_f32_only;
+        // (round 6: a convolution stack that left the split-bf16 kernels -- 24 / 40 / 48 channels: no 16-channel K blocks -- no longer takes
+        // the sequence part with it: recurrent and linear layers over the width axis split their fp32 rows on the way in, like behind a
+        // GroupNorm part; BENCH-A's layers on 20 / 40 channels ran their recurrences on the exact-f32 kernel, 2.9 ms each)
+        const bool seq_layer = seq && (L.op == KRK_OP_LSTM || L.op == KRK_OP_LINEAR) && !(L.kh == 1 && L.kw == 0);
+        x3 = want_x3 && i > last_f32_only && (!left_x3 || seq_layer);
         // a convolution that would be the first split-bf16 layer AND carry the height collapse has no split-plane hand-over
         // (the f32 kernel writes split NHWC planes, not sequence rows): it stays f32, the sequence layers behind it split their rows
         if (x3 && !split_fmt && !seq && L.op == KRK_OP_CONV) {

@@ -1276,6 +1276,36 @@ def test_hidden_sizes_that_are_not_a_multiple_of_8_keep_the_split_plan(tail, mon
         assert float((y[i, ..., :l] - y2[i, ..., :l]).abs().max()) < 2e-5, i
 
 
+@pytest.mark.parametrize('convs', ['Cr3,3,24 Mp2,2 Cr3,3,48 Mp2,2 Cr3,3,40', 'Cr3,13,20 Mp2,2 Cr3,13,20 Mp2,2 Cr3,9,40 Mp2,2 Cr3,9,40'])
+def test_a_convolution_stack_that_leaves_the_split_kernels_keeps_the_sequence_part_on_them(convs):
+    """Round 6: channel counts without 16-channel K blocks (24, 20, 40 ...) send the rest of the CONVOLUTION stack to the exact-f32
+    kernels -- and used to take the recurrent layers with them (2.9 ms per layer instead of 0.46 on BENCH-A's layers with 20 / 40
+    channels).  The sequence part splits its fp32 rows on the way in, like behind a GroupNorm part.  Against the CPU oracle, ragged."""
+    import kraken_amd
+    spec = f'[1,48,0,1 {convs} S1(1x0)1,3 Lbx64 Lbx100 O1c40]'
+    torch.manual_seed(0)
+    m = kraken_amd.TorchVGSLModel(vgsl=spec, codec={chr(0x100 + i): [i + 1] for i in range(39)})
+    m.nn.set_precision('bf16x3')
+    m.to('cuda')
+    x = synth_input(24, 320).cuda()
+    lens = torch.tensor([320 - 9 * i for i in range(24)])
+    y, _ = m.nn(x, lens)
+    assert m.nn.precision == kraken_amd._lib.PREC_BF16X3
+    lib = kraken_amd._lib.load()
+    plan = m.nn.plan(0)
+    lib.krk_plan_set_profiling(plan.handle, 1)
+    m.nn(x, lens)
+    names = [lib.krk_plan_layer_name(plan.handle, i).decode() for i in range(lib.krk_plan_num_steps(plan.handle))]
+    lib.krk_plan_set_profiling(plan.handle, 0)
+    assert 'conv' in names and names.count('lstm_rec_x3') == 2 and 'linear_x3' in names, names       # f32 convolutions, split-bf16 sequence part
+    ref = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()})
+    want, _ = ref.forward(x.cpu(), lens.tolist())
+    T = y.shape[-1]
+    for i, l in enumerate(lens.tolist()):
+        lo = l * T // 320
+        assert float((y[i, ..., :lo].cpu() - torch.as_tensor(want)[i, ..., :lo]).abs().max()) < X3_TOL, i
+
+
 @pytest.mark.parametrize('hidden', [320, 512])
 def test_block_major_streaming_kernel_at_hidden_sizes_257_to_512(hidden, monkeypatch):
     """Round 6: 257 ... 512 hidden units in a split-bf16 plan run on lstm_x3b_kernel (lstm_x3.hip: block-major, cell state in LDS) and
