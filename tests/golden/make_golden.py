@@ -240,6 +240,18 @@ BREADTH_CASES = {
 }
 
 
+SIZES_R6_CASES = {
+    # round 6: sizes the split-bf16 plan had refused or sent to the exact-f32 kernels.  Hidden sizes that are not a multiple of 8 (every
+    # direction is written Hp units wide; above 64 units the cluster kernel), feature counts that are not a multiple of 8 or 16, a
+    # convolution stack without 16-channel K blocks in front of recurrent layers (f32 convolutions, split-bf16 sequence part)
+    'odd_h70':     ('[1,2,0,1 Cr3,3,8 Cr3,3,16 S1(1x0)1,3 Lbx70 Lbx70 O1c12]', 3, 40, [40, 27, 9]),
+    'odd_h75_99':  ('[1,2,0,1 Cr3,3,8 Cr3,3,16 S1(1x0)1,3 Lfx75 Lrx99 O1c9]', 3, 33, [33, 20, 7]),
+    'odd_tiny':    ('[1,2,0,1 Cr3,3,8 Cr3,3,16 S1(1x0)1,3 Lbx6 Lfx5 Lrx3 O1c5]', 2, 25, None),
+    'feat36':      ('[1,6,0,1 Cr3,5,16 Mp2,2 Cr3,3,16 Cr3,3,12 S1(1x0)1,3 Lbx20 O1c9]', 3, 44, [44, 30, 21]),
+    'ch24':        ('[1,16,0,1 Cr3,3,24 Mp2,2 Cr3,3,48 Cr3,3,40 S1(1x0)1,3 Lbx20 Lfx12 O1c9]', 3, 50, [50, 33, 17]),
+}
+
+
 FORMS_R5_CASES = {
     # round 5: the VGSL forms that were still refused.  ocropy's peephole cell (layers.py:72-186, 'o'): always bidirectional, no
     # biases, a constant 1 in front of the input; ragged batches against the reference's per-line result (it has no batched form)
@@ -873,7 +885,7 @@ def reshape_random_fixture(path, n=240, seed=11):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms', 'bench_lines', 'bench_lines_r6', 'big_lstm', 'forms_r5', 'reshape_random', 'forms_random']
+    which = sys.argv[1:] or ['overfit', 'overfit_models', 'bench_a', 'bench_b', 'layers', 'image_lstm', 'x3_networks', 'breadth', 'groups', 'groups_random', 'spec_names', 'codec', 'transforms', 'bench_lines', 'bench_lines_r6', 'big_lstm', 'forms_r5', 'reshape_random', 'forms_random', 'sizes_r6']
     if 'overfit' in which:
         overfit_fixture(os.path.join(HERE, 'overfit.npz'))
     if 'overfit_models' in which:
@@ -897,6 +909,8 @@ if __name__ == '__main__':
         layer_fixture(os.path.join(HERE, 'x3_networks.npz'), X3_NETWORK_CASES)
     if 'breadth' in which:
         layer_fixture(os.path.join(HERE, 'breadth.npz'), BREADTH_CASES)
+    if 'sizes_r6' in which:
+        layer_fixture(os.path.join(HERE, 'sizes_r6.npz'), SIZES_R6_CASES)
     if 'groups' in which:
         layer_fixture(os.path.join(HERE, 'groups.npz'), GROUP_CASES)
     if 'forms_r5' in which:

@@ -85,6 +85,7 @@ def test_layers_against_reference_golden(name):
 
 
 X3_NETS = layer_cases('x3_networks.npz')
+X3_NETS.update(layer_cases('sizes_r6.npz'))      # round 6: odd hidden sizes, feature counts off 8 / 16, a stack without 16-channel K blocks
 
 
 @pytest.mark.parametrize('name', sorted(X3_NETS))

@@ -18,6 +18,7 @@ LAYER_TOL = 2e-5
 CASES = layer_cases()
 CASES.update(layer_cases('image_lstm.npz'))   # LSTMs over image rows/columns, scaled-down BLLA segmenter
 CASES.update(layer_cases('breadth.npz'))      # round 4: 'G' cells, hidden sizes above 256, ...
+CASES.update(layer_cases('sizes_r6.npz'))     # round 6: odd hidden sizes, feature counts off 8 / 16, channel counts off 16
 CASES.update(layer_cases('groups.npz'))       # round 4: nested [ ] / ( ) groups, Addition, x-axis summarising LSTMs
 CASES.update(layer_cases('groups_random.npz'))   # ... and 14 randomly nested networks (identity members, groups inside groups inside groups)
 CASES.update(layer_cases('forms_r5.npz'))        # round 5: the forms that were still refused (ocropy peephole cell, ...)
