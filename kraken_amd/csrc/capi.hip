@@ -381,19 +381,23 @@ int upload_x6_weights(ConvGeom& g, const float* w) {
 
 // conv1_x3.hip weight order: [channel][kernel row dy][plane][lane][8]; lane = filter + 32*half holds taps 8*half..+7.  `w` is
 // (Cout, Cin, kh, kw), Cin = 1 or 3.
+// Round 6: more than 32 filters (a first layer of 64: kraken specs that open with Cr3,3,64) = one such pack per 32 filters, one launch each.
 int upload_conv1_x3_weights(ConvGeom& g, const float* w) {
-    std::vector<uint16_t> pack((size_t)g.Cin * g.kh * 2 * 64 * 8, 0);
+    const int halves = (g.Cout + 31) / 32;
+    const size_t per_half = (size_t)g.Cin * g.kh * 2 * 64 * 8;
+    std::vector<uint16_t> pack(per_half * halves, 0);
+    for (int hf = 0; hf < halves; ++hf)
     for (int ch = 0; ch < g.Cin; ++ch)
         for (int dy = 0; dy < g.kh; ++dy)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                    const int f = lane & 31, dx = 8 * (lane >> 5) + e;
+                    const int f = 32 * hf + (lane & 31), dx = 8 * (lane >> 5) + e;
                     if (f >= g.Cout || dx >= g.kw) continue;
                     const float v = w[(((size_t)f * g.Cin + ch) * g.kh + dy) * g.kw + dx];
                     const uint16_t hi = f2bf(v);
                     const size_t row = (size_t)(ch * g.kh + dy) * 2;
-                    pack[((row + 0) * 64 + lane) * 8 + e] = hi;
-                    pack[((row + 1) * 64 + lane) * 8 + e] = f2bf(v - bf2f(hi));
+                    pack[hf * per_half + ((row + 0) * 64 + lane) * 8 + e] = hi;
+                    pack[hf * per_half + ((row + 1) * 64 + lane) * 8 + e] = f2bf(v - bf2f(hi));
                 }
     HIPCHK(hipMalloc(&g.d_wx3, pack.size() * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(g.d_wx3, pack.data(), pack.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -978,7 +982,7 @@ struct PlanBuilder {
 // layers outside conv1_x3's geometry (round 4: their second convolution ran on the generic channel-as-K kernel, 1.8 ms per
 // 256-line batch where the tap kernel takes 0.5).  KRK_NO_F32_NHCW keeps the round-3 routing.
 bool feeds_taps(const ConvGeom& g) {
-    if (g.c1x3) return true;
+    if (g.c1x3) return g.Cout <= 32;          // (a first layer of more than 32 filters is two launches on channels-last planes)
     return g.split_out && !g.x3 && !g.taps && !g.x6 && !g.out_seq && !getenv("KRK_NO_F32_NHCW");
 }
 
@@ -2069,7 +2073,15 @@ int Pass::conv(Step& s, const float* cur, float* outp, size_t out_elems, int Win
         a.dbg = probe.x3_dbg;
         s.flops = 2.0 * N * (double)g.Ho * a.Wo * g.Cout * g.Cin * g.kh * g.kw;
         if (mark("conv1_x3", s.flops)) return kFailed;
-        return one ? krk_launch_conv1_x3_b1(a, g.pool, stream) : krk_launch_conv1_x3(a, g.pool, stream);
+        for (int hf = 0; 32 * hf < g.Cout; ++hf) {             // 32 filters per launch: the halves of the channels-last output
+            Conv1Args h = a;
+            h.wpack = a.wpack + (size_t)hf * g.Cin * g.kh * 2 * 64 * 8;
+            h.bias = a.bias + 32 * hf;
+            h.y = a.y + 32 * hf;
+            h.Cout = std::min(32, g.Cout - 32 * hf);
+            if (int rc = one ? krk_launch_conv1_x3_b1(h, g.pool, stream) : krk_launch_conv1_x3(h, g.pool, stream)) return rc;
+        }
+        return 0;
     }
     if (g.x6 && probe.conv_x6) {
         // fp32 NCHW -> three bf16 planes NHWC (h + m + l = x to 2^-24), then the six-term convolution; fp32 NCHW out

@@ -332,7 +332,8 @@ int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
 #ifndef KRK_BF16_ONE
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw) {
     // three channels (colour models): kernel rows 1 and 3 (tile + fragments of kh = 5 would not fit the 64 KB of static LDS)
-    return (Cin == 1 || (Cin == 3 && kh <= 3)) && Cout <= 32 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5) && kw >= 1 &&
+    // (a launch computes up to 32 filters; up to 64 are two launches on the two halves of the channels-last output: capi.hip)
+    return (Cin == 1 || (Cin == 3 && kh <= 3)) && Cout <= 64 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5) && kw >= 1 &&
            kw <= 16 && sh == 1 && sw == 1 && dh == 1 && dw == 1;
 }
 

@@ -1307,6 +1307,34 @@ def test_a_convolution_stack_that_leaves_the_split_kernels_keeps_the_sequence_pa
         assert float((y[i, ..., :lo].cpu() - torch.as_tensor(want)[i, ..., :lo]).abs().max()) < X3_TOL, i
 
 
+@pytest.mark.parametrize('first', ['Cr3,3,64', 'Cr3,13,48', 'Cr5,5,64 Mp2,2'])
+def test_a_first_convolution_of_more_than_32_filters_runs_on_the_bf16_cores(first):
+    """Round 6: conv1_x3.hip computes 32 filters per launch; a first layer of up to 64 (specs that open with Cr3,3,64) is two launches
+    on the two halves of the channels-last planes instead of the exact-f32 kernel (0.88 ms per 256 lines).  Against the CPU oracle."""
+    import kraken_amd
+    spec = f'[1,48,0,1 {first} Mp2,2 Cr3,3,64 Mp2,2 S1(1x0)1,3 Lbx64 O1c40]'
+    torch.manual_seed(0)
+    m = kraken_amd.TorchVGSLModel(vgsl=spec, codec={chr(0x100 + i): [i + 1] for i in range(39)})
+    m.nn.set_precision('bf16x3')
+    m.to('cuda')
+    x = synth_input(12, 256).cuda()
+    lens = torch.tensor([256 - 13 * i for i in range(12)])
+    y, _ = m.nn(x, lens)
+    lib = kraken_amd._lib.load()
+    plan = m.nn.plan(0)
+    lib.krk_plan_set_profiling(plan.handle, 1)
+    m.nn(x, lens)
+    names = [lib.krk_plan_layer_name(plan.handle, i).decode() for i in range(lib.krk_plan_num_steps(plan.handle))]
+    lib.krk_plan_set_profiling(plan.handle, 0)
+    assert names[0] == 'conv1_x3' and 'conv' not in names, names
+    ref = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()})
+    want, _ = ref.forward(x.cpu(), lens.tolist())
+    T = y.shape[-1]
+    for i, l in enumerate(lens.tolist()):
+        lo = l * T // 256
+        assert float((y[i, ..., :lo].cpu() - torch.as_tensor(want)[i, ..., :lo]).abs().max()) < X3_TOL, i
+
+
 @pytest.mark.parametrize('hidden', [320, 512])
 def test_block_major_streaming_kernel_at_hidden_sizes_257_to_512(hidden, monkeypatch):
     """Round 6: 257 ... 512 hidden units in a split-bf16 plan run on lstm_x3b_kernel (lstm_x3.hip: block-major, cell state in LDS) and
