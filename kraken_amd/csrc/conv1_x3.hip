@@ -333,7 +333,7 @@ int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw) {
     // three channels (colour models): kernel rows 1 and 3 (tile + fragments of kh = 5 would not fit the 64 KB of static LDS)
     // (a launch computes up to 32 filters; up to 64 are two launches on the two halves of the channels-last output: capi.hip)
-    return (Cin == 1 || (Cin == 3 && kh <= 3)) && Cout <= 64 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5) && kw >= 1 &&
+    return (Cin == 1 || (Cin == 3 && kh <= 3)) && Cout <= 64 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5 || (kh == 7 && Cin == 1)) && kw >= 1 &&
            kw <= 16 && sh == 1 && sw == 1 && dh == 1 && dw == 1;
 }
 
@@ -352,6 +352,7 @@ int KRK_FN(krk_launch_conv1_x3)(const Conv1Args& a, bool pool, hipStream_t s) {
         case 1: return launch_kh<1, 1>(a, pool, s);
         case 3: return launch_kh<3, 1>(a, pool, s);
         case 5: return launch_kh<5, 1>(a, pool, s);
+        case 7: return launch_kh<7, 1>(a, pool, s);       // (round 6: specs that open with Cr7,7,32 ran their first layer on the exact-f32 kernel)
         default: return -1;
     }
 }

@@ -1307,10 +1307,11 @@ def test_a_convolution_stack_that_leaves_the_split_kernels_keeps_the_sequence_pa
         assert float((y[i, ..., :lo].cpu() - torch.as_tensor(want)[i, ..., :lo]).abs().max()) < X3_TOL, i
 
 
-@pytest.mark.parametrize('first', ['Cr3,3,64', 'Cr3,13,48', 'Cr5,5,64 Mp2,2'])
+@pytest.mark.parametrize('first', ['Cr3,3,64', 'Cr3,13,48', 'Cr5,5,64 Mp2,2', 'Cr7,7,32', 'Cr7,11,48'])
 def test_a_first_convolution_of_more_than_32_filters_runs_on_the_bf16_cores(first):
     """Round 6: conv1_x3.hip computes 32 filters per launch; a first layer of up to 64 (specs that open with Cr3,3,64) is two launches
-    on the two halves of the channels-last planes instead of the exact-f32 kernel (0.88 ms per 256 lines).  Against the CPU oracle."""
+    on the two halves of the channels-last planes instead of the exact-f32 kernel (0.88 ms per 256 lines); kernel heights up to 7.
+    Against the CPU oracle."""
     import kraken_amd
     spec = f'[1,48,0,1 {first} Mp2,2 Cr3,3,64 Mp2,2 S1(1x0)1,3 Lbx64 O1c40]'
     torch.manual_seed(0)
