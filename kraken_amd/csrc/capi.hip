@@ -2609,7 +2609,7 @@ int krk_dewarp_measure_page(const unsigned char* crops_dev, long row_stride, int
     int* centre = ridge + (size_t)n * max_w;
     const int rc = krk_launch_dewarp_measure(crops_dev, (size_t)row_stride, pix_stride, desc_dev, n, max_w, max_h, weights_dev, scratch_dev, mm,
                                              ridge, centre, info_dev, (hipStream_t)stream);
-    if (rc == -4) return fail(KRK_E_UNSUPPORTED, "krk_dewarp_measure: pixel stride must be 1, 3 or 4");
+    if (rc == -4) return fail(KRK_E_UNSUPPORTED, "krk_dewarp_measure: pixel stride must be 1, 3 or 4, lines at most 192 rows high");
     if (rc) return fail(KRK_E_HIP, std::string("krk_dewarp_measure: launch failed: ") + hipGetErrorString(hipGetLastError()));
     return KRK_OK;
 }
