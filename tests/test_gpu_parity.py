@@ -762,8 +762,10 @@ def test_x3_plan_continues_on_f32_kernels_where_it_has_to():
     ('[1,48,0,3 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,64 S1(1x0)1,3 Lbx32 O1c19]', 301, 'conv1_x3'),
     # three channels and five kernel rows: outside the first-layer kernel's colour geometry, the exact-f32 kernel hands over
     ('[1,24,0,3 Cr5,9,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 150, 'conv'),
-    # one channel, but a first layer outside conv1_x3's geometry (7 kernel rows): same hand-over, no pool in between, width 203
-    ('[1,20,0,1 Cr7,5,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 203, 'conv'),
+    # one channel, but a first layer outside conv1_x3's geometry (9 kernel rows; 7 until round 6): same hand-over, no pool in between, width 203
+    ('[1,20,0,1 Cr9,5,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 203, 'conv'),
+    # ... and seven kernel rows on the first-layer kernel itself
+    ('[1,20,0,1 Cr7,5,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 203, 'conv1_x3'),
     # a GroupNorm part in front: the first split-bf16 layer reads fp32 NCHW from the GroupNorm
     ('[1,16,0,1 Cr3,3,8 Gn4 Cr3,5,16 Cr3,12,20 Cr3,3,16 S1(1x0)1,3 Lbx16 O1c7]', 77, None),
 ])
