@@ -43,6 +43,10 @@ SPECS = [
     '[1,16,0,1 Cr3,5,16 Mp2,2 Cr3,3,32 Cr3,3,16 S1(1x0)1,3 Lbx300 Lbx100 O1c14]',
     '[1,12,0,1 Cr3,5,16 Mp2,2 Cr3,3,16 Cr3,3,12 S1(1x0)1,3 Lbx20 O1c9]',
     '[1,48,0,1 Cr3,3,32 Mp2,2 Cr3,3,64 Mp2,2 S1(1x12)1,3 Lbx100 O1c50]',
+    # ... a first layer of 64 filters / 7 kernel rows (conv1_x3), a convolution stack without 16-channel K blocks in front of recurrent layers
+    '[1,24,0,1 Cr3,3,64 Mp2,2 Cr3,3,32 Mp2,2 S1(1x0)1,3 Lbx40 O1c21]',
+    '[1,24,0,1 Cr7,9,48 Mp2,2 Cr3,5,32 Mp2,2 S1(1x0)1,3 Lfx72 Lrx30 O1c21]',
+    '[1,16,0,1 Cr3,3,24 Mp2,2 Cr3,3,48 Cr3,3,40 S1(1x0)1,3 Lbx100 Lfx12 O1c9]',
 ]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()) if '--time-seed' in sys.argv else 0)
