@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <memory>
 #include <vector>
@@ -884,6 +885,9 @@ namespace {
 // Compiles a layer table into a plan's schedule.  State that travels from layer to layer: the activation's shape and
 // format (image / sequence, fp32 / split-bf16 planes), the length stage, and the lookahead index `i` (a convolution
 // swallows a directly following 2x2 max-pool and the height->channel reshape).
+constexpr int kRetryPlan = -100;   // PlanBuilder -> krk_plan_create: a zero-filter request was filed, compile again
+constexpr int kNoPadPlan = -101;   // ... a padded activation met a layer that cannot take it: compile again without padding
+
 struct PlanBuilder {
     krk_plan* p;
     const krk_layer* layers;
@@ -892,6 +896,14 @@ struct PlanBuilder {
     int C, H;
     bool seq = false;
     bool split_fmt = false;   // bf16x3: the current activation is held as split bf16 planes
+    // Round 6: a split-bf16 convolution needs input channels in blocks of 16.  A producer with 20 / 24 / 40 filters is compiled with ZERO
+    // filters appended (weights and biases 0; whatever the activation makes of 0 meets zero weights in the consumer) when its consumer
+    // asks for it: the request is filed under the producer's layer index and the plan compiled again (krk_plan_create's loop) -- the
+    // rest of such a stack no longer runs on the exact-f32 kernels.
+    std::map<int, int>* cpad = nullptr;   // layer index -> number of filters incl. the zero ones (survives the retries)
+    int c_log = 0;                        // > 0: the current activation holds c_log real channels in front of zero ones (C = all of them)
+    bool pad_conflict = false;            // a padded activation reached a layer that cannot take it: compile again without padding
+    int last_split_conv = -1;             // layer index of the convolution that wrote the current split planes
     std::vector<int> seq_colmap;   // non-empty: the split sequence rows in front hold every direction's units padded to Hp (Step::opad): feature -> column
     int seq_kphys = 0;
     int stage = 0;
@@ -960,6 +972,7 @@ struct PlanBuilder {
             u.len_in = u.len_out = stage;
             p->steps.push_back(std::move(u));
         }
+        if (c_log > 0) pad_conflict = true;   // fp32 NCHW with zero channels in it: nobody behind expects them
         x3 = false;
         left_x3 = true;
         split_fmt = false;
@@ -1000,7 +1013,36 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where, int ph_force
         const bool taps_ok = !p->steps.empty() && p->steps.back().kind == S_CONV && feeds_taps(p->steps.back().cg) &&
                              krk_conv_taps_supported(C, L.cout, L.kh, L.kw, L.sh, L.sw, L.dh, L.dw) &&
                              !(i + 1 < n_layers && layers[i + 1].op == KRK_OP_RESHAPE_HC);
-        if (!taps_ok) leave_x3();
+        if (!taps_ok) {
+            if (cpad && c_log == 0 && last_split_conv >= 0 && !cpad->count(last_split_conv)) {
+                (*cpad)[last_split_conv] = (C + 15) / 16 * 16;      // the producer again, with zero filters: compile the plan anew
+                return kRetryPlan;
+            }
+            leave_x3();
+        }
+    }
+    const int li = i;                                   // (i moves on when a pool / the reshape is fused below)
+    const int Cin_log = c_log > 0 ? c_log : C;          // input channels of the torch weights
+    int Cout_eff = L.cout;
+    if (cpad && x3) {
+        const auto it = cpad->find(li);
+        if (it != cpad->end()) Cout_eff = it->second;
+    }
+    std::vector<float> wpad, bpad;
+    const float* w_eff = L.w[0];
+    const float* b_eff = L.w[1];
+    if (Cout_eff != L.cout || Cin_log != C) {
+        const size_t kk = (size_t)L.kh * L.kw;
+        wpad.assign((size_t)Cout_eff * C * kk, 0.f);
+        bpad.assign((size_t)Cout_eff, 0.f);
+        for (int f = 0; f < L.cout; ++f) {
+            for (int c = 0; c < Cin_log; ++c)
+                std::memcpy(&wpad[((size_t)f * C + c) * kk], L.w[0] + ((size_t)f * Cin_log + c) * kk, kk * sizeof(float));
+            bpad[f] = L.w[1][f];
+        }
+        w_eff = wpad.data();
+        b_eff = bpad.data();
+        if (!x3) pad_conflict = true;                   // (an exact-f32 layer behind a padded one: not planned for)
     }
     Step s;
     StepGuard guard{s};
@@ -1010,7 +1052,7 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where, int ph_force
     ConvGeom& g = s.cg;
     g.Cin = C;
     g.H = H;
-    g.Cout = L.cout;
+    g.Cout = Cout_eff;
     g.kh = L.kh; g.kw = L.kw; g.sh = L.sh; g.sw = L.sw; g.dh = L.dh; g.dw = L.dw;
     g.ph = ph_force >= 0 ? ph_force : (L.dh * (L.kh - 1)) / 2;
     g.pw = pw_force >= 0 ? pw_force : (L.dw * (L.kw - 1)) / 2;
@@ -1036,19 +1078,20 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where, int ph_force
         ++i;
     }
     plan_conv_geom(g);
-    if (upload_conv_weights(g, L.w[0], L.w[1], nullptr, nullptr) != KRK_OK) return KRK_E_HIP;
+    if (upload_conv_weights(g, w_eff, b_eff, nullptr, nullptr) != KRK_OK) return KRK_E_HIP;
     // A convolution of a split-bf16 plan that must keep fp32-class operands (it feeds a GroupNorm, directly or through later
     // layers: i <= last_gn) takes the three-plane kernel (conv_x6.hip) when its geometry fits: fp32 NCHW in and out like the f32
     // kernel it replaces, 6/16 of its matrix time.  KRK_NO_CONV_X6 keeps the exact-f32 kernel.
     if (want_x3 && !left_x3 && !x3 && !g.out_seq && g.Cin % 16 == 0 && !getenv("KRK_NO_CONV_X6") && plan_x6_geom(g) == 0) {
-        if (upload_x6_weights(g, L.w[0]) != KRK_OK) return KRK_E_HIP;
+        if (upload_x6_weights(g, w_eff) != KRK_OK) return KRK_E_HIP;
         g.x6 = true;
     }
     if (x3) {
         // the first convolution reads the caller's fp32 NCHW image on the f32 cores and hands
         // over split channels-last planes; every later one runs on the bf16 cores
         const bool first = !split_fmt;
-        const int feat = g.out_seq ? g.Hy * L.cout : L.cout;
+        const int feat = g.out_seq ? g.Hy * Cout_eff : Cout_eff;
+        if (g.out_seq && Cout_eff != L.cout) pad_conflict = true;      // (nobody asks a collapsing convolution for zero filters)
         if (feat % 4) return fail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs a multiple of 4 output channels");   // the consumer checks its own K granule
         if (first && g.out_seq) return fail(KRK_E_UNSUPPORTED, where + ": bf16x3 needs >= 2 convolutions before the reshape");
         g.split_out = true;
@@ -1057,17 +1100,19 @@ int PlanBuilder::conv(const krk_layer& L, const std::string& where, int ph_force
             krk_conv_taps_supported(g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw) && !getenv("KRK_NO_CONV_TAPS")) {
             g.taps = true;
             p->steps.back().cg.out_nhcw = true;
-            if (upload_conv_taps_weights(g, L.w[0]) != KRK_OK) return KRK_E_HIP;
+            if (upload_conv_taps_weights(g, w_eff) != KRK_OK) return KRK_E_HIP;
         } else if (!first) {
             g.x3 = true;
-            if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, L.w[0], nullptr) != KRK_OK) return KRK_E_UNSUPPORTED;
+            if (plan_x3_geom(g) != KRK_OK || upload_x3_weights(g, w_eff, nullptr) != KRK_OK) return KRK_E_UNSUPPORTED;
         } else if (!g.out_seq && krk_conv1_x3_supported(g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw) &&
                    !getenv("KRK_NO_CONV1_X3")) {
             g.c1x3 = true;
-            if (upload_conv1_x3_weights(g, L.w[0]) != KRK_OK) return KRK_E_HIP;
+            if (upload_conv1_x3_weights(g, w_eff) != KRK_OK) return KRK_E_HIP;
         }
         split_fmt = true;
+        last_split_conv = li;
     }
+    c_log = (Cout_eff != L.cout) ? L.cout : 0;
     s.len_out = stage;
     if (g.out_seq) {
         s.out_is_seq = true;
@@ -1578,10 +1623,12 @@ int PlanBuilder::build() {
             default: rc = fail(KRK_E_UNSUPPORTED, where + ": unknown op " + std::to_string(L.op));
         }
         if (rc) return rc;
+        if (pad_conflict) return kNoPadPlan;
     }
     if (!forks.empty()) return fail(KRK_E_INVALID, "parallel group not closed");
     // a network that ENDS in a split-bf16 convolution (no sequence part): the caller gets fp32 NCHW like from every other plan
     if (split_fmt && !seq) leave_x3();
+    if (pad_conflict) return kNoPadPlan;
     p->nstages = (int)p->lenops.size() + 1;
     p->out_stage = stage;
     return KRK_OK;
@@ -1655,20 +1702,35 @@ int krk_plan_create(const krk_layer* layers, int n_layers, int in_channels, int 
         return fail(KRK_E_HIP, "krk_plan_create: no HIP device " + std::to_string(device));
     HIPCHK(hipSetDevice(device));
 
-    krk_plan* p = new krk_plan();
-    p->device = device;
-    p->in_c = in_channels;
-    p->in_h = in_height;
-    p->precision = precision;
+    krk_plan* p = nullptr;
     auto bail = [&](int code, const std::string& msg) {
         krk_plan_destroy(p);
         return fail(code, msg);
     };
-    // KRK_PREC_BF16 = the split-bf16 plan with the cross terms dropped (one MFMA per product): same layouts, same kernels
-    PlanBuilder b{p, layers, n_layers, precision == KRK_PREC_BF16X3 || precision == KRK_PREC_BF16, in_channels, in_height};
-    if (int rc = b.build()) {
+    // zero-filter requests (PlanBuilder::cpad): every retry compiles the whole plan again with one more producer padded; a padded plan
+    // that fails for ANY reason is compiled once more without padding (what rounds 1-5 did)
+    std::map<int, int> cpad;
+    bool allow_pad = !getenv("KRK_NO_CPAD");
+    for (int attempt = 0;; ++attempt) {
+        p = new krk_plan();
+        p->device = device;
+        p->in_c = in_channels;
+        p->in_h = in_height;
+        p->precision = precision;
+        // KRK_PREC_BF16 = the split-bf16 plan with the cross terms dropped (one MFMA per product): same layouts, same kernels
+        PlanBuilder b{p, layers, n_layers, precision == KRK_PREC_BF16X3 || precision == KRK_PREC_BF16, in_channels, in_height};
+        b.cpad = allow_pad ? &cpad : nullptr;
+        const int rc = b.build();
+        if (!rc) break;
         krk_plan_destroy(p);
-        return rc;
+        p = nullptr;
+        if (rc == kRetryPlan && attempt < n_layers + 2) continue;
+        if (allow_pad && !cpad.empty()) {          // (kNoPadPlan, or any failure of a padded plan)
+            cpad.clear();
+            allow_pad = false;
+            continue;
+        }
+        return rc == kRetryPlan || rc == kNoPadPlan ? fail(KRK_E_UNSUPPORTED, "krk_plan_create: channel padding did not converge") : rc;
     }
     {
         const int dev = device;

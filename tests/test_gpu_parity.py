@@ -732,11 +732,15 @@ def test_x3_matches_cpu_oracle_on_small_networks(spec, n, w, lens):
             assert gl.tolist() == wl.tolist()
 
 
-def test_x3_plan_continues_on_f32_kernels_where_it_has_to():
+@pytest.mark.parametrize('padded', [True, False])
+def test_x3_plan_continues_on_f32_kernels_where_it_has_to(padded, monkeypatch):
     """A bf16x3 plan does not reject layers that only exist in the f32 plan: it converts the activations once (split NHWC
     -> fp32 NCHW, `unsplit`) and runs the rest on the f32 kernels.  Here: a convolution on 24 input channels (the split kernels
-    take multiples of 16)."""
+    take multiples of 16) -- with round 6's zero filters switched off (KRK_NO_CPAD); with them (the default) the producer is compiled
+    with 32 filters, eight of them zero, and the whole stack stays on the split kernels.  Both against the CPU oracle."""
     from kraken_amd.engine import RecognitionEngine
+    if not padded:
+        monkeypatch.setenv('KRK_NO_CPAD', '1')
     spec = '[1,8,0,1 Cr3,13,32 Cr3,3,24 Cr3,3,16 S1(1x0)1,3 Lbx8 O1c5]'
     m = build_model(spec, seed=0)
     x = synth_input(3, 64, h=8)
@@ -751,7 +755,10 @@ def test_x3_plan_continues_on_f32_kernels_where_it_has_to():
     eng.collect()
     names = [n_ for n_, _, _ in eng.layer_times()[0]]
     eng.close()
-    assert names[0] == 'conv1_x3' and 'unsplit' in names and names[names.index('unsplit') + 1] == 'conv', names
+    if padded:
+        assert names[0] == 'conv1_x3' and 'unsplit' not in names and 'conv' not in names, names
+    else:
+        assert names[0] == 'conv1_x3' and 'unsplit' in names and names[names.index('unsplit') + 1] == 'conv', names
     with pytest.raises(ValueError):
         m.nn.set_precision('fp8')
 
@@ -1280,11 +1287,12 @@ def test_hidden_sizes_that_are_not_a_multiple_of_8_keep_the_split_plan(tail, mon
 
 
 @pytest.mark.parametrize('convs', ['Cr3,3,24 Mp2,2 Cr3,3,48 Mp2,2 Cr3,3,40', 'Cr3,13,20 Mp2,2 Cr3,13,20 Mp2,2 Cr3,9,40 Mp2,2 Cr3,9,40'])
-def test_a_convolution_stack_that_leaves_the_split_kernels_keeps_the_sequence_part_on_them(convs):
+def test_a_convolution_stack_that_leaves_the_split_kernels_keeps_the_sequence_part_on_them(convs, monkeypatch):
     """Round 6: channel counts without 16-channel K blocks (24, 20, 40 ...) send the rest of the CONVOLUTION stack to the exact-f32
     kernels -- and used to take the recurrent layers with them (2.9 ms per layer instead of 0.46 on BENCH-A's layers with 20 / 40
     channels).  The sequence part splits its fp32 rows on the way in, like behind a GroupNorm part.  Against the CPU oracle, ragged."""
     import kraken_amd
+    monkeypatch.setenv('KRK_NO_CPAD', '1')          # (with zero filters -- the default since -- such a stack does not leave them at all: next test)
     spec = f'[1,48,0,1 {convs} S1(1x0)1,3 Lbx64 Lbx100 O1c40]'
     torch.manual_seed(0)
     m = kraken_amd.TorchVGSLModel(vgsl=spec, codec={chr(0x100 + i): [i + 1] for i in range(39)})
@@ -1307,6 +1315,40 @@ def test_a_convolution_stack_that_leaves_the_split_kernels_keeps_the_sequence_pa
     for i, l in enumerate(lens.tolist()):
         lo = l * T // 320
         assert float((y[i, ..., :lo].cpu() - torch.as_tensor(want)[i, ..., :lo]).abs().max()) < X3_TOL, i
+
+
+@pytest.mark.parametrize('convs', ['Cr3,3,24 Mp2,2 Cr3,3,48 Mp2,2 Cr3,3,40', 'Cr3,13,20 Mp2,2 Cr3,13,20 Mp2,2 Cr3,9,40 Mp2,2 Cr3,9,40',
+                                   'Cr3,3,36 Cr3,3,20 Mp2,2 Cr5,5,44 Mp2,2 Cr3,3,12'])
+def test_channel_counts_without_16_channel_blocks_stay_on_the_split_kernels(convs):
+    """Round 6: a split-bf16 convolution reads its input channels in blocks of 16.  A producer with 20 / 24 / 36 / 40 / 44 filters is
+    compiled with zero filters appended (the consumer's weights are zero there) when its consumer asks for it -- krk_plan_create
+    compiles the plan again per request -- instead of the rest of the stack falling to the exact-f32 kernels (BENCH-A on 20 / 40
+    channels: 121 -> 174 k lines/s).  Against the CPU oracle, ragged, and line by line (batch of one)."""
+    import kraken_amd
+    spec = f'[1,48,0,1 {convs} S1(1x0)1,3 Lbx64 Lbx100 O1c40]'
+    torch.manual_seed(0)
+    m = kraken_amd.TorchVGSLModel(vgsl=spec, codec={chr(0x100 + i): [i + 1] for i in range(39)})
+    m.nn.set_precision('bf16x3')
+    m.to('cuda')
+    x = synth_input(24, 320).cuda()
+    lens = torch.tensor([320 - 9 * i for i in range(24)])
+    y, _ = m.nn(x, lens)
+    lib = kraken_amd._lib.load()
+    plan = m.nn.plan(0)
+    lib.krk_plan_set_profiling(plan.handle, 1)
+    m.nn(x, lens)
+    names = [lib.krk_plan_layer_name(plan.handle, i).decode() for i in range(lib.krk_plan_num_steps(plan.handle))]
+    lib.krk_plan_set_profiling(plan.handle, 0)
+    assert 'conv' not in names and 'unsplit' not in names and names.count('lstm_rec_x3') == 2, names
+    ref = CpuRecognizer(m.layer_specs, {k: v.cpu() for k, v in m.state_dict().items()})
+    want, _ = ref.forward(x.cpu(), lens.tolist())
+    T = y.shape[-1]
+    for i, l in enumerate(lens.tolist()):
+        lo = l * T // 320
+        assert float((y[i, ..., :lo].cpu() - torch.as_tensor(want)[i, ..., :lo]).abs().max()) < X3_TOL, i
+    for i in (0, 11, 23):
+        one, _ = m.nn(x[i:i + 1, ..., :int(lens[i])].contiguous())
+        assert float((one - y[i:i + 1, ..., :one.shape[-1]]).abs().max()) == 0.0, i
 
 
 @pytest.mark.parametrize('first', ['Cr3,3,64', 'Cr3,13,48', 'Cr5,5,64 Mp2,2', 'Cr7,7,32', 'Cr7,11,48'])
