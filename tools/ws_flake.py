@@ -16,7 +16,10 @@ specs = [('[1,9,0,1 Cr3,13,28 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,16 S1(1x0)1,3 Lbx8 O1c
          # the sizes lstm_ws.hip is the default for (H > 128), small and ragged batches
          ('[1,10,0,1 Cr1,16,32 Mp2,2 Cr3,11,32 Cr3,13,16 S1(1x0)1,3 Lbx136 Lbx160 O1c11]', 4, 517, [517, 516, 260, 31]),
          ('[1,10,0,1 Cr1,16,32 Mp2,2 Cr3,11,32 Cr3,13,16 S1(1x0)1,3 Lbx192 Lfx200 Lrx224 O1c11]', 7, 301, [301, 300, 155, 154, 40, 3, 1]),
-         ('[1,10,0,1 Cr1,16,32 Mp2,2 Cr3,11,32 Cr3,13,16 S1(1x0)1,3 Lbx200 Lbx200 O1c11]', 40, 260, [260 - 5 * i for i in range(40)])]
+         ('[1,10,0,1 Cr1,16,32 Mp2,2 Cr3,11,32 Cr3,13,16 S1(1x0)1,3 Lbx200 Lbx200 O1c11]', 40, 260, [260 - 5 * i for i in range(40)]),
+         # round 6: hidden sizes that are not a multiple of 8 on the cluster kernel (directions written Hp units wide), eight K blocks (256)
+         ('[1,10,0,1 Cr1,16,32 Mp2,2 Cr3,11,32 Cr3,13,16 S1(1x0)1,3 Lbx100 Lbx150 Lfx75 O1c11]', 7, 301, [301, 300, 155, 154, 40, 3, 1]),
+         ('[1,10,0,1 Cr1,16,32 Mp2,2 Cr3,11,32 Cr3,13,16 S1(1x0)1,3 Lbx256 Lbx250 O1c11]', 20, 260, [260 - 11 * i for i in range(20)])]
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 reps = int(args[0]) if args else 200
 if len(args) > 1:
