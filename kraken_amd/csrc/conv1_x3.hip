@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256, 2) conv1_x3_kernel(const Conv1Args a) {
     __shared__ __attribute__((aligned(16))) __bf16 tile[2][2][CIN][IH][LW];   // [buffer][plane][channel][row][column]
     __shared__ __attribute__((aligned(16))) float bias_s[32];
     // CIN > 1: the A fragments [channel][kernel row][plane][lane][8] (the order of a.wpack) in LDS
-    __shared__ __attribute__((aligned(16))) __bf16 wlds[CIN > 1 ? CIN * KH * 2 * 64 * 8 : 8];
+    // (dynamic: with three channels and five kernel rows the tile and these fragments are 72 KB together -- more than static LDS may be)
+    extern __shared__ __attribute__((aligned(16))) __bf16 wlds[];        // [CIN * KH * 2 * 64 * 8] when CIN > 1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -318,12 +319,17 @@ int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
     dim3 grid((unsigned)(a.N * a.tiles_h));
     const bool nhcw = a.y_pitch > 0;
     const bool relu = a.act == ACT_RELU;
-    if (pool && nhcw && relu) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true, true, CIN>), grid, dim3(256), 0, s, a);
-    else if (pool && nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, true, false, CIN>), grid, dim3(256), 0, s, a);
-    else if (pool) hipLaunchKernelGGL((conv1_x3_kernel<KH, true, false, false, CIN>), grid, dim3(256), 0, s, a);
-    else if (nhcw && relu) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true, true, CIN>), grid, dim3(256), 0, s, a);
-    else if (nhcw) hipLaunchKernelGGL((conv1_x3_kernel<KH, false, true, false, CIN>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv1_x3_kernel<KH, false, false, false, CIN>), grid, dim3(256), 0, s, a);
+    constexpr size_t dyn = CIN > 1 ? (size_t)CIN * KH * 2 * 64 * 8 * sizeof(__bf16) : 0;       // the weight fragments in LDS
+#define KRK_C1(P_, N_, R_) do { \
+        if (dyn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_x3_kernel<KH, P_, N_, R_, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+        hipLaunchKernelGGL((conv1_x3_kernel<KH, P_, N_, R_, CIN>), grid, dim3(256), dyn, s, a); } while (0)
+    if (pool && nhcw && relu) KRK_C1(true, true, true);
+    else if (pool && nhcw) KRK_C1(true, true, false);
+    else if (pool) KRK_C1(true, false, false);
+    else if (nhcw && relu) KRK_C1(false, true, true);
+    else if (nhcw) KRK_C1(false, true, false);
+    else KRK_C1(false, false, false);
+#undef KRK_C1
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -331,9 +337,9 @@ int launch_kh(const Conv1Args& a, bool pool, hipStream_t s) {
 
 #ifndef KRK_BF16_ONE
 bool krk_conv1_x3_supported(int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw) {
-    // three channels (colour models): kernel rows 1 and 3 (tile + fragments of kh = 5 would not fit the 64 KB of static LDS)
+    // three channels (colour models): kernel rows 1, 3 and 5 (round 6: the fragments moved to dynamic LDS; 7 rows would need 97 KB: one workgroup per CU)
     // (a launch computes up to 32 filters; up to 64 are two launches on the two halves of the channels-last output: capi.hip)
-    return (Cin == 1 || (Cin == 3 && kh <= 3)) && Cout <= 64 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5 || (kh == 7 && Cin == 1)) && kw >= 1 &&
+    return (Cin == 1 || (Cin == 3 && kh <= 5)) && Cout <= 64 && Cout % 4 == 0 && (kh == 1 || kh == 3 || kh == 5 || (kh == 7 && Cin == 1)) && kw >= 1 &&
            kw <= 16 && sh == 1 && sw == 1 && dh == 1 && dw == 1;
 }
 
@@ -345,6 +351,7 @@ int KRK_FN(krk_launch_conv1_x3)(const Conv1Args& a, bool pool, hipStream_t s) {
         switch (a.kh) {
             case 1: return launch_kh<1, 3>(a, pool, s);
             case 3: return launch_kh<3, 3>(a, pool, s);
+            case 5: return launch_kh<5, 3>(a, pool, s);
             default: return -1;
         }
     }

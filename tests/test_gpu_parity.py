@@ -767,8 +767,10 @@ def test_x3_plan_continues_on_f32_kernels_where_it_has_to(padded, monkeypatch):
     # an RGB recogniser: the first layer reads three channels -- on the first-layer kernel since round 5 (conv1_x3.hip, CIN = 3; the
     # exact-f32 kernel before) --, the second is BENCH-A's 3x13 tap geometry
     ('[1,48,0,3 Cr3,13,32 Mp2,2 Cr3,13,32 Mp2,2 Cr3,9,64 S1(1x0)1,3 Lbx32 O1c19]', 301, 'conv1_x3'),
-    # three channels and five kernel rows: outside the first-layer kernel's colour geometry, the exact-f32 kernel hands over
-    ('[1,24,0,3 Cr5,9,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 150, 'conv'),
+    # three channels and seven kernel rows: outside the first-layer kernel's colour geometry (five until round 6), the exact-f32 kernel hands over
+    ('[1,24,0,3 Cr7,9,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 150, 'conv'),
+    # ... five kernel rows on the first-layer kernel (its weight fragments in dynamic LDS)
+    ('[1,24,0,3 Cr5,9,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 150, 'conv1_x3'),
     # one channel, but a first layer outside conv1_x3's geometry (9 kernel rows; 7 until round 6): same hand-over, no pool in between, width 203
     ('[1,20,0,1 Cr9,5,24 Cr3,11,32 Mp2,2 Cr3,3,16 S1(1x0)1,3 Lfx32 O1c9]', 203, 'conv'),
     # ... and seven kernel rows on the first-layer kernel itself
