@@ -771,7 +771,7 @@ class _RecognitionRun:
             logger.warning(f'Conversion of line {line} failed. Emitting empty record..')
             return self._empty(line)
         taps = lambda n_in, n_out: math.ceil(3.0 * max(1.0, n_in / n_out)) * 2 + 1      # noqa: E731
-        # the kernel keeps the crop's rows of a 64-column tile and its filter tables in LDS (prep_lines.hip: (out_h + 64) x 98 ints +
+        # the kernel keeps the crop's rows of a 64-column tile and its filter tables in LDS (prep_lines.hip; since round 6 its table rows are as long as the scale needs -- this bound still assumes the longest, (out_h + 64) x 99 ints +
         # channels x (rows + 2) x 64 bytes <= 160 KB): 512 rows at height 48, 456 for a colour line of a 120-row model
         channels = 3 if ts._mode == 'RGB' else 1
         max_rows = min(512, (160 * 1024 - (out_h + 64) * 99 * 4) // (channels * 64) - 2)
