@@ -36,7 +36,15 @@ specs = [BENCH_A, BENCH_B, BENCH_A_RGB, DEFAULT_H120,
          '[1,1,0,16 Lbx1024 O1c8]', '[1,1,0,16 Lfx1280 O1c8]', '[1,1,0,16 Lbxo832 O1c8]', '[1,1,0,16 Lbx264 O1c8]',
          '[1,24,0,1 Cr3,3,8 Lbx8 Lby8 Cr1,1,4 S1(1x0)1,3 O1c5]',
          '[1,48,0,1 Cr3,3,8 CTr2,2,6,2,2 Mp2,2 Mp2,2 S1(1x0)1,3 Lbx12 O1c6]',
-         '[1,48,0,1 Cr3,3,12 A1,4 Mp2,2 S1(1x0)1,3 Lbx12 O1c6]']
+         '[1,48,0,1 Cr3,3,12 A1,4 Mp2,2 S1(1x0)1,3 Lbx12 O1c6]',
+         # round 6: zero filters appended on request (the plan is compiled again per request), odd hidden sizes (padded directions, any K),
+         # 257-512 units, a first layer of 64 filters / 7 kernel rows / colour with 5, a stack the split kernels leave with the switch off
+         '[1,48,0,1 Cr3,3,24 Mp2,2 Cr3,3,48 Mp2,2 Cr3,3,40 S1(1x0)1,3 Lbx64 O1c12]',
+         '[1,48,0,1 Cr3,13,20 Mp2,2 Cr3,13,20 Mp2,2 Cr3,9,40 Mp2,2 Cr3,9,40 S1(1x0)1,3 Lbx100 Lbx150 Lfx75 O1c12]',
+         '[1,48,0,1 Cr3,3,36 Cr3,3,20 Mp2,2 Cr5,5,44 Mp2,2 Cr3,3,12 S1(1x0)1,3 Lbx6 Lfx5 Lrx3 O1c5]',
+         '[1,48,0,1 Cr3,3,64 Mp2,2 Cr3,3,32 S1(1x0)1,3 Lbx300 Lbx8 O1c5]',
+         '[1,48,0,1 Cr7,7,32 Mp2,2 Cr3,3,64 Mp2,2 S1(1x0)1,3 Lbx200 O1c80]',
+         '[1,48,0,3 Cr5,5,32 Mp2,2 Cr3,3,64 S1(1x0)1,3 Lfx75 O1c5]']
 try:        # the 80 random specs whose state-dict names are pinned against the reference: a wide sample of nested groups
     names = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'spec_names.json')))
     specs += [c['spec'] for c in (names.values() if isinstance(names, dict) else names)][:40]
